@@ -1,0 +1,92 @@
+"""ctypes binding of libcr3dod.so (include/cr3dod.h).  The product path FAILS
+LOUDLY when the library is missing -- there is no CPU / eager fallback."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcr3dod.so")
+
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+P = c_void_p
+
+# name -> argtypes; the single source of truth for "every symbol the header declares"
+SIGNATURES = {
+    "cr_ctx_create": [c_int, P, ctypes.POINTER(P)],
+    "cr_ctx_destroy": [P],
+    "cr_ctx_set_stream": [P, P],
+    "cr_abi_version": [],
+    "cr_cuboid_corners": [P, P, P, c_int64, P],
+    "cr_cubes_project_score": [P, P, c_int64, c_int64, P, c_int, c_float, c_float, P, P, P, P,
+                               P, P, P, P, P, P, P, P],
+    "cr_propose": [P, P, c_int64, P, c_int, c_int, P, P, P, c_int64, P, c_int, P, P, P, P, P],
+    "cr_ransac_plane": [P, P, c_int64, P, c_int64, c_float, P, P, P],
+}
+
+
+class CrError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """dlopen libcr3dod.so and set signatures.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise CrError(
+                f"{LIB_PATH} not found: build it with `python 3dod_amd/build.py` "
+                "(or __graft_entry__.build()). There is no fallback path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.cr_last_error.restype = ctypes.c_char_p
+        lib.cr_last_error.argtypes = []
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cr_last_error().decode("utf-8", "replace")
+        raise CrError(f"{what} failed (rc={rc}): {msg}")
+
+
+# ---- per-device context bound to torch's current stream ---------------------
+_ctxs = {}
+
+
+def ctx_for(device):
+    """cr_ctx for a torch cuda device, re-pointed at torch's CURRENT stream on
+    every call so library launches order with surrounding torch work."""
+    import torch
+    lib = load()
+    if device.type != "cuda":
+        raise CrError(f"3dod_amd kernels run on the GPU only (got device '{device}'); there is no CPU path")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(idx).cuda_stream
+    ctx = _ctxs.get(idx)
+    if ctx is None:
+        h = P()
+        check(lib.cr_ctx_create(idx, P(stream), ctypes.byref(h)), "cr_ctx_create")
+        ctx = _ctxs[idx] = h
+    else:
+        check(lib.cr_ctx_set_stream(ctx, P(stream)), "cr_ctx_set_stream")
+    return ctx
+
+
+def ptr(t):
+    """device pointer of a contiguous tensor, or NULL for None."""
+    if t is None:
+        return P(None)
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return P(t.data_ptr())

@@ -1,0 +1,60 @@
+"""Builds libcr3dod.so (the C-ABI HIP library, include/cr3dod.h) in-tree for gfx950.
+
+    python 3dod_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  Objects are cached by source mtime.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+LIB = os.path.join(LIBDIR, "libcr3dod.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+          "-I", os.path.join(HERE, "..", "include")]
+# per-file extra flags.  geometry.hip: the float32 op order is part of the parity
+# contract with oracle/geometry.py -> no fused multiply-add contraction.
+EXTRA = {"geometry.hip": ["-ffp-contract=off"]}
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "cr3dod.h"))
+    objs, rebuilt = [], False
+    procs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJDIR, s[:-4] + ".o")
+        objs.append(obj)
+        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
+            cmd = [HIPCC] + COMMON + EXTRA.get(s, []) + ["-c", src, "-o", obj]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd)))
+            rebuilt = True
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + s)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

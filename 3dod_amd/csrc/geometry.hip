@@ -1,0 +1,671 @@
+// Geometry kernels of the 1000-cube proposal-and-scoring method (HBM-bound, no
+// MFMA): K17 project+score+argmax, K18 proposal sampler, K21 RANSAC plane, and
+// the 8-corner helper.  gfx950 only; wave = 64.
+//
+// This translation unit is compiled with -ffp-contract=off: the float32
+// operation order below is the contract shared with oracle/geometry.py, so the
+// scores (and therefore the argmax) agree bit-for-bit with the oracle.
+//
+// Reference semantics restated here (paths into the reference tree):
+//   corners      cubercnn/util/math_util.py:142-245
+//   projection   ProposalNetwork/utils/spaces.py:224-245
+//   2D boxes     ProposalNetwork/utils/conversions.py:25-48
+//   scores       ProposalNetwork/scoring/scorefunction.py:47-85,144-160
+//   argmax       cubercnn/modeling/roi_heads/roi_heads.py:492-505
+//   propose      ProposalNetwork/proposals/proposals.py:338-424
+//   RANSAC       ProposalNetwork/utils/plane.py:79-134
+#include "cr_common.h"
+#include <math.h>
+
+#define GEO_T 256          // threads per workgroup (4 waves)
+#define GEO_W (GEO_T / 64)
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float nan_f() { return __builtin_nanf(""); }
+
+// np.minimum / np.maximum: NaN-propagating
+__device__ __forceinline__ float nmin(float a, float b) { return (a != a || b != b) ? nan_f() : fminf(a, b); }
+__device__ __forceinline__ float nmax(float a, float b) { return (a != a || b != b) ? nan_f() : fmaxf(a, b); }
+
+// torch.clamp / Tensor.clamp_: NaN stays NaN
+__device__ __forceinline__ float clamp_keep_nan(float x, float lo, float hi) {
+    return (x != x) ? x : fminf(fmaxf(x, lo), hi);
+}
+
+// deterministic float32 exp (Cephes scheme), bit-identical to oracle/geometry.py:exp_f32
+__device__ __forceinline__ float cr_exp_f32(float x) {
+    if (x != x) return x;
+    if (x < -87.0f) return 0.0f;
+    float xc = fminf(x, 88.0f);
+    float k = rintf(xc * 1.4426950408889634f);
+    float r = xc - k * 0.693359375f;
+    r = r - k * -2.12194440e-4f;
+    float p = 1.9875691500e-4f;
+    p = p * r; p = p + 1.3981999507e-3f;
+    p = p * r; p = p + 8.3334519073e-3f;
+    p = p * r; p = p + 4.1665795894e-2f;
+    p = p * r; p = p + 1.6666665459e-1f;
+    p = p * r; p = p + 5.0000001201e-1f;
+    float r2 = r * r;
+    p = p * r2;
+    p = p + r;
+    p = p + 1.0f;
+    return ldexpf(p, (int)k);
+}
+
+// 8 corners of a cuboid in camera space, vertex order of math_util.py:198-207
+// (x <- l, y <- h, z <- w).  c[0..14] = cx,cy,cz,w,h,l,R row-major.
+__device__ __forceinline__ void cube_corners3d(const float* c, float* X, float* Y, float* Z) {
+    const float hw = c[3] / 2.0f, hh = c[4] / 2.0f, hl = c[5] / 2.0f;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const float vx = ((v & 3) == 1 || (v & 3) == 2) ? hl : -hl;   // +l/2 for {1,2,5,6}
+        const float vy = (v & 2) ? hh : -hh;                           // +h/2 for {2,3,6,7}
+        const float vz = (v & 4) ? hw : -hw;                           // +w/2 for {4,5,6,7}
+        float a;
+        a = c[6] * vx;  a = a + c[7] * vy;  a = a + c[8] * vz;  X[v] = a + c[0];
+        a = c[9] * vx;  a = a + c[10] * vy; a = a + c[11] * vz; Y[v] = a + c[1];
+        a = c[12] * vx; a = a + c[13] * vy; a = a + c[14] * vz; Z[v] = a + c[2];
+    }
+}
+
+struct Clamp { float lo0, hi0, lo1, hi1; };
+
+// K @ X, perspective divide (no guard on p2 <= 0), clamp.  spaces.py:233-243
+__device__ __forceinline__ void project8(const float* X, const float* Y, const float* Z, const float* K,
+                                         const Clamp cl, float* u, float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float p0 = (K[0] * X[i] + K[1] * Y[i]) + K[2] * Z[i];
+        const float p1 = (K[3] * X[i] + K[4] * Y[i]) + K[5] * Z[i];
+        const float p2 = (K[6] * X[i] + K[7] * Y[i]) + K[8] * Z[i];
+        u[i] = clamp_keep_nan(p0 / p2, cl.lo0, cl.hi0);
+        v[i] = clamp_keep_nan(p1 / p2, cl.lo1, cl.hi1);
+    }
+}
+
+__device__ __forceinline__ void minmax8(const float* a, float& mn, float& mx) {
+    float lo = a[0], hi = a[0];
+    bool nan = a[0] != a[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        nan |= a[i] != a[i];
+        lo = fminf(lo, a[i]);
+        hi = fmaxf(hi, a[i]);
+    }
+    mn = nan ? nan_f() : lo;      // torch.min/max over a dim propagate NaN
+    mx = nan ? nan_f() : hi;
+}
+
+// ---- block reductions (256 threads = 4 waves) -----------------------------
+// max with torch.max semantics: NaN if any NaN.  scratch: >= 2*GEO_W floats.
+__device__ __forceinline__ float block_max_nanprop(float val, bool valid, float* scratch) {
+    float m = valid && val == val ? val : -INFINITY;
+    int anynan = valid && (val != val);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_down(m, off, 64));
+        anynan |= __shfl_down(anynan, off, 64);
+    }
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) { scratch[w] = m; scratch[GEO_W + w] = anynan ? 1.0f : 0.0f; }
+    __syncthreads();
+    float r = scratch[0];
+    float n = scratch[GEO_W];
+#pragma unroll
+    for (int i = 1; i < GEO_W; ++i) { r = fmaxf(r, scratch[i]); n += scratch[GEO_W + i]; }
+    return n > 0.0f ? nan_f() : r;
+}
+
+__device__ __forceinline__ double block_sum_f64(double val, double* scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) scratch[w] = val;
+    __syncthreads();
+    double r = scratch[0];
+#pragma unroll
+    for (int i = 1; i < GEO_W; ++i) r += scratch[i];
+    return r;
+}
+
+// np.argmax ordering: NaN beats everything, then larger value, then smaller index
+__device__ __forceinline__ bool arg_better(float va, int ia, float vb, int ib) {
+    const bool na = va != va, nb = vb != vb;
+    if (ia < 0) return false;
+    if (ib < 0) return true;
+    if (na != nb) return na;
+    if (na) return ia < ib;
+    if (va != vb) return va > vb;
+    return ia < ib;
+}
+
+// ---------------------------------------------------------------------------
+// K17: one workgroup per object; every cube is read once from HBM (staged
+// through LDS with coalesced 16-B loads), all per-cube intermediates stay in
+// registers across the two per-object reductions (max ratio difference, max
+// chamfer), outputs are written once.
+// ---------------------------------------------------------------------------
+template <int CPT>
+__global__ __launch_bounds__(GEO_T) void k_project_score(
+    const float* __restrict__ cubes, int P, const float* __restrict__ Kmat, int k_per_object, Clamp cl,
+    const float* __restrict__ ref_boxes, const float* __restrict__ prior_mu,
+    const float* __restrict__ prior_sigma, const float* __restrict__ rect_pts,
+    float* __restrict__ out_corners, float* __restrict__ out_boxes, float* __restrict__ out_iou,
+    float* __restrict__ out_dim, float* __restrict__ out_corner, float* __restrict__ out_combined,
+    int64_t* __restrict__ out_argmax, float* __restrict__ out_best) {
+    __shared__ __attribute__((aligned(16))) float s_cubes[GEO_T * 15];
+    __shared__ double s_red64[GEO_W * 4];
+    __shared__ float s_red[GEO_W * 2];
+    __shared__ int s_redi[GEO_W];
+    __shared__ float s_rect[8];
+
+    const int obj = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* cb = cubes + (size_t)obj * P * 15;
+
+    float K[9];
+    {
+        const float* kp = Kmat + (k_per_object ? (size_t)obj * 9 : 0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) K[i] = kp[i];
+    }
+    const float r0 = ref_boxes[obj * 4 + 0], r1 = ref_boxes[obj * 4 + 1];
+    const float r2 = ref_boxes[obj * 4 + 2], r3 = ref_boxes[obj * 4 + 3];
+    const float mu0 = prior_mu[obj * 3 + 0], mu1 = prior_mu[obj * 3 + 1], mu2 = prior_mu[obj * 3 + 2];
+    const float sg0 = prior_sigma[obj * 3 + 0], sg1 = prior_sigma[obj * 3 + 1], sg2 = prior_sigma[obj * 3 + 2];
+    const float a1 = (r2 - r0) * (r3 - r1);
+    const float gt_ratio = (r2 - r0) / (r3 - r1);
+
+    const bool have_rect = rect_pts != nullptr;
+    if (have_rect && tid < 8) s_rect[tid] = rect_pts[obj * 8 + tid];
+
+    float v_iou[CPT], v_gauss[CPT], v_diff[CPT], v_s[CPT];
+    double sum_mnx = 0, sum_mxx = 0, sum_mny = 0, sum_mxy = 0;
+
+    // ---------------- pass A: corners, boxes, iou, gauss, ratio diff (+ chamfer if rect given)
+    for (int pass = 0; pass < (have_rect ? 1 : 2); ++pass) {
+        if (pass == 1) {
+            // no-contour fallback rect (scorefunction.py:69-75): mean over proposals of min/max u,v
+            const double t0 = block_sum_f64(sum_mnx, s_red64);
+            const double t1 = block_sum_f64(sum_mxx, s_red64);
+            const double t2 = block_sum_f64(sum_mny, s_red64);
+            const double t3 = block_sum_f64(sum_mxy, s_red64);
+            if (tid == 0) {
+                const float mnx = (float)(t0 / P), mxx = (float)(t1 / P);
+                const float mny = (float)(t2 / P), mxy = (float)(t3 / P);
+                s_rect[0] = mnx; s_rect[1] = mny; s_rect[2] = mxx; s_rect[3] = mny;
+                s_rect[4] = mxx; s_rect[5] = mxy; s_rect[6] = mnx; s_rect[7] = mxy;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const int base = c * GEO_T;
+            if (base < P) {                          // block-uniform
+            const int cnt = min(GEO_T, P - base);
+            // stage cnt*15 floats, coalesced
+            {
+                const float* src = cb + (size_t)base * 15;
+                const int nfl = cnt * 15;
+                if ((((uintptr_t)src) & 15) == 0) {
+                    const int n4 = nfl >> 2;
+                    const float4* s4 = reinterpret_cast<const float4*>(src);
+                    float4* d4 = reinterpret_cast<float4*>(s_cubes);
+                    for (int i = tid; i < n4; i += GEO_T) d4[i] = s4[i];
+                    for (int i = (n4 << 2) + tid; i < nfl; i += GEO_T) s_cubes[i] = src[i];
+                } else {
+                    for (int i = tid; i < nfl; i += GEO_T) s_cubes[i] = src[i];
+                }
+            }
+            __syncthreads();
+            const int p = base + tid;
+            const bool valid = tid < cnt;
+            if (valid) {
+                float cu[15];
+#pragma unroll
+                for (int j = 0; j < 15; ++j) cu[j] = s_cubes[tid * 15 + j];
+                float X[8], Y[8], Z[8], u[8], v[8];
+                cube_corners3d(cu, X, Y, Z);
+                project8(X, Y, Z, K, cl, u, v);
+                if (pass == 0) {
+                    float b0, b1, b2, b3;
+                    minmax8(u, b0, b2);
+                    minmax8(v, b1, b3);
+                    const size_t gi = (size_t)obj * P + p;
+                    if (out_corners) {
+                        float4* oc = reinterpret_cast<float4*>(out_corners + gi * 16);
+                        oc[0] = make_float4(u[0], v[0], u[1], v[1]);
+                        oc[1] = make_float4(u[2], v[2], u[3], v[3]);
+                        oc[2] = make_float4(u[4], v[4], u[5], v[5]);
+                        oc[3] = make_float4(u[6], v[6], u[7], v[7]);
+                    }
+                    if (out_boxes) reinterpret_cast<float4*>(out_boxes)[gi] = make_float4(b0, b1, b2, b3);
+                    // IoU vs the object's 2D box (detectron2 pairwise_iou definition)
+                    const float a2 = (b2 - b0) * (b3 - b1);
+                    float w = nmin(r2, b2) - nmax(r0, b0);
+                    float h = nmin(r3, b3) - nmax(r1, b1);
+                    w = (w != w) ? w : fmaxf(w, 0.0f);
+                    h = (h != h) ? h : fmaxf(h, 0.0f);
+                    const float inter = w * h;
+                    const float iou = inter / ((a1 + a2) - inter);
+                    v_iou[c] = inter > 0.0f ? iou : 0.0f;
+                    // size prior (scorefunction.py:151-152), dims are (w,h,l) = cu[3..5]
+                    const float z0 = (cu[3] - mu0) / sg0, z1 = (cu[4] - mu1) / sg1, z2 = (cu[5] - mu2) / sg2;
+                    const float e0 = cr_exp_f32(-0.5f * (z0 * z0));
+                    const float e1 = cr_exp_f32(-0.5f * (z1 * z1));
+                    const float e2 = cr_exp_f32(-0.5f * (z2 * z2));
+                    v_gauss[c] = ((e0 + e1) + e2) / 3.0f;
+                    const float pr = (b2 - b0) / (b3 - b1);
+                    v_diff[c] = fabsf(gt_ratio - pr);
+                    sum_mnx += b0; sum_mxx += b2; sum_mny += b1; sum_mxy += b3;
+                }
+                if (have_rect || pass == 1) {
+                    // modified chamfer (scorefunction.py:51-56): float64 like scipy's cKDTree
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double rx = (double)s_rect[q * 2], ry = (double)s_rect[q * 2 + 1];
+                        double best = INFINITY;
+                        bool nan = false;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const double dx = rx - (double)u[i], dy = ry - (double)v[i];
+                            const double d2 = dx * dx + dy * dy;
+                            nan |= d2 != d2;
+                            best = fmin(best, d2);
+                        }
+                        const double d = nan ? (double)nan_f() : sqrt(best);
+                        acc = (q == 0) ? d : acc + d;
+                    }
+                    v_s[c] = (float)(acc / 4.0);
+                }
+            }
+            __syncthreads();
+            }
+        }
+    }
+
+    // ---------------- per-object normalisers
+    float lmaxd = -INFINITY, lmaxs = -INFINITY;
+    bool nand = false, nans = false;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        if (c * GEO_T + tid < P) {
+            nand |= v_diff[c] != v_diff[c];
+            nans |= v_s[c] != v_s[c];
+            lmaxd = fmaxf(lmaxd, v_diff[c]);
+            lmaxs = fmaxf(lmaxs, v_s[c]);
+        }
+    }
+    const bool anyv = tid < P;
+    const float maxdiff = block_max_nanprop(nand ? nan_f() : lmaxd, anyv, s_red);
+    const float maxs = block_max_nanprop(nans ? nan_f() : lmaxs, anyv, s_red);
+
+    // ---------------- pass B: final scores + argmax
+    float bestv = 0.0f;
+    int besti = -1;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int p = c * GEO_T + tid;
+        if (p < P) {
+            const float dim = (1.0f - v_diff[c] / maxdiff) * v_gauss[c];
+            const float cor = 1.0f - v_s[c] / maxs;
+            const float comb = (v_iou[c] * dim) * cor;
+            const size_t gi = (size_t)obj * P + p;
+            if (out_iou) out_iou[gi] = v_iou[c];
+            if (out_dim) out_dim[gi] = dim;
+            if (out_corner) out_corner[gi] = cor;
+            if (out_combined) out_combined[gi] = comb;
+            if (arg_better(comb, p, bestv, besti)) { bestv = comb; besti = p; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(bestv, off, 64);
+        const int oi = __shfl_down(besti, off, 64);
+        if (arg_better(ov, oi, bestv, besti)) { bestv = ov; besti = oi; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { s_red[tid >> 6] = bestv; s_redi[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        float bv = s_red[0];
+        int bi = s_redi[0];
+        for (int i = 1; i < GEO_W; ++i)
+            if (arg_better(s_red[i], s_redi[i], bv, bi)) { bv = s_red[i]; bi = s_redi[i]; }
+        out_argmax[obj] = bi < 0 ? 0 : bi;
+        if (out_best) out_best[obj] = bi < 0 ? 0.0f : bv;
+    }
+}
+
+extern "C" int cr_cubes_project_score(cr_ctx* ctx, const float* cubes, int64_t N, int64_t P,
+                                      const float* K, int k_per_object, float im_w, float im_h,
+                                      const float* ref_boxes, const float* prior_mu, const float* prior_sigma,
+                                      const float* rect_pts, float* out_corners, float* out_boxes,
+                                      float* out_iou, float* out_dim, float* out_corner, float* out_combined,
+                                      int64_t* out_argmax, float* out_best) {
+    CR_CHECK_ARG(ctx != nullptr, "cr_cubes_project_score: ctx is NULL");
+    CR_CHECK_ARG(N >= 0 && P >= 0, "cr_cubes_project_score: negative N/P");
+    if (N == 0) return CR_OK;
+    CR_CHECK_ARG(P >= 1 && P <= 4096, "cr_cubes_project_score: P=%lld outside [1,4096]", (long long)P);
+    CR_CHECK_ARG(N <= 0x7fffffff, "cr_cubes_project_score: N too large");
+    CR_CHECK_ARG(cubes && K && ref_boxes && prior_mu && prior_sigma && out_argmax,
+                 "cr_cubes_project_score: NULL required pointer");
+    Clamp cl;
+    // python int() truncation toward zero, spaces.py:241-242
+    cl.lo0 = (float)(int)(-(double)im_w / 2 + 1);
+    cl.hi0 = (float)(int)((double)im_w - 1 + (double)im_w);
+    cl.lo1 = (float)(int)(-(double)im_h / 2 + 1);
+    cl.hi1 = (float)(int)((double)im_h - 1 + (double)im_h);
+    dim3 grid((unsigned)N), block(GEO_T);
+    if (P <= 4 * GEO_T)
+        hipLaunchKernelGGL(k_project_score<4>, grid, block, 0, ctx->stream, cubes, (int)P, K, k_per_object, cl,
+                           ref_boxes, prior_mu, prior_sigma, rect_pts, out_corners, out_boxes, out_iou, out_dim,
+                           out_corner, out_combined, out_argmax, out_best);
+    else
+        hipLaunchKernelGGL(k_project_score<16>, grid, block, 0, ctx->stream, cubes, (int)P, K, k_per_object, cl,
+                           ref_boxes, prior_mu, prior_sigma, rect_pts, out_corners, out_boxes, out_iou, out_dim,
+                           out_corner, out_combined, out_argmax, out_best);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// get_cuboid_verts_faces (verts only)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(GEO_T) void k_cuboid_corners(const float* __restrict__ box6,
+                                                           const float* __restrict__ R, int64_t n,
+                                                           float* __restrict__ verts) {
+    const int64_t i = (int64_t)blockIdx.x * GEO_T + threadIdx.x;
+    if (i >= n) return;
+    float c[15];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) c[j] = box6[i * 6 + j];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) c[6 + j] = R[i * 9 + j];
+    float X[8], Y[8], Z[8];
+    cube_corners3d(c, X, Y, Z);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        verts[i * 24 + v * 3 + 0] = X[v];
+        verts[i * 24 + v * 3 + 1] = Y[v];
+        verts[i * 24 + v * 3 + 2] = Z[v];
+    }
+}
+
+extern "C" int cr_cuboid_corners(cr_ctx* ctx, const float* box6, const float* R, int64_t n, float* verts) {
+    CR_CHECK_ARG(ctx != nullptr, "cr_cuboid_corners: ctx is NULL");
+    CR_CHECK_ARG(n >= 0, "cr_cuboid_corners: negative n");
+    if (n == 0) return CR_OK;
+    CR_CHECK_ARG(box6 && R && verts, "cr_cuboid_corners: NULL pointer");
+    hipLaunchKernelGGL(k_cuboid_corners, dim3((unsigned)cr_cdiv(n, GEO_T)), dim3(GEO_T), 0, ctx->stream, box6, R, n,
+                       verts);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// K18: proposal sampler (one workgroup per object, P <= 1024)
+// ---------------------------------------------------------------------------
+#define PROP_MAXP 1024
+#define PROP_SLOTS (PROP_MAXP / GEO_T)
+
+// in-LDS bitonic sort of 1024 floats (ascending; padded with +inf)
+__device__ __forceinline__ void bitonic_sort_1024(float* a) {
+    for (int k = 2; k <= PROP_MAXP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < PROP_MAXP / 2; t += GEO_T) {
+                const int i = ((t / j) * 2 * j) + (t % j);
+                const int l = i + j;
+                const bool up = ((i & k) == 0);
+                const float x = a[i], y = a[l];
+                if ((x > y) == up) { a[i] = y; a[l] = x; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(GEO_T) void k_propose(
+    const float* __restrict__ boxes, const float* __restrict__ depth, int H, int W,
+    const float* __restrict__ prior_mu, const float* __restrict__ prior_sigma, const float* __restrict__ Kmat,
+    int N, int P, const float* __restrict__ dim_normals, int rounds, const float* __restrict__ ctr_normals,
+    const int32_t* __restrict__ yaw_idx, const float* __restrict__ normal, float* __restrict__ out_cubes,
+    int32_t* __restrict__ out_exhausted) {
+    __shared__ float s_sort[PROP_MAXP];
+    __shared__ double s_red64[GEO_W];
+    __shared__ float s_tab[36 * 9];
+    __shared__ float s_stat[6];       // median x,y,z ; std x,y,z
+
+    const int obj = blockIdx.x, tid = threadIdx.x;
+    const float b0 = boxes[obj * 4 + 0], b1 = boxes[obj * 4 + 1], b2 = boxes[obj * 4 + 2], b3 = boxes[obj * 4 + 3];
+    const float K00 = Kmat[0], K02 = Kmat[2], K12 = Kmat[5];
+
+    // 36-yaw table from the ground normal: utils.py:112-146, proposals.py:404-405
+    if (tid < 36) {
+        const float n0 = normal[0], n1 = normal[1], n2 = normal[2];
+        float p0, p1, p2;
+        if (n0 == 0.0f) { p0 = 0.0f; p1 = n2; p2 = -n1; }
+        else {
+            float mag = sqrtf((n1 * n1 + n0 * n0) + 0.0f);
+            mag = fmaxf(mag, 1e-8f);
+            p0 = n1 / mag; p1 = -n0 / mag; p2 = 0.0f / mag;
+        }
+        // torch.linspace(0, pi, 36): symmetric fill
+        const float endv = 3.14159274101257324f, step = endv / 35.0f;
+        const float th = tid < 18 ? 0.0f + step * (float)tid : endv - step * (float)(35 - tid);
+        const float ct = cosf(th), st = sinf(th);
+        const float k0 = n1 * p2 - n2 * p1, k1 = n2 * p0 - n0 * p2, k2 = n0 * p1 - n1 * p0;
+        const float kd = (n0 * p0 + n1 * p1) + n2 * p2;
+        const float omc = 1.0f - ct;
+        const float x0 = (p0 * ct + k0 * st) + (n0 * kd) * omc;
+        const float x1 = (p1 * ct + k1 * st) + (n1 * kd) * omc;
+        const float x2 = (p2 * ct + k2 * st) + (n2 * kd) * omc;
+        const float y0 = n1 * x2 - n2 * x1, y1 = n2 * x0 - n0 * x2, y2 = n0 * x1 - n1 * x0;
+        float* t = s_tab + tid * 9;            // columns (x, n, y)
+        t[0] = x0; t[1] = n0; t[2] = y0;
+        t[3] = x1; t[4] = n1; t[5] = y1;
+        t[6] = x2; t[7] = n2; t[8] = y2;
+    }
+
+    const float wd = b2 - b0, ht = b3 - b1;
+    const float x_lo = b0 + wd / 4.0f, x_hi = b2 - wd / 4.0f;
+    const float y_lo = b1 + ht / 4.0f, y_hi = b3 - ht / 4.0f;
+    const float x_sp = (x_hi - x_lo) / (float)(P - 1), y_sp = (y_hi - y_lo) / (float)(P - 1);
+
+    const float mu[3] = {prior_mu[obj * 3], prior_mu[obj * 3 + 1], prior_mu[obj * 3 + 2]};
+    const float sg[3] = {prior_sigma[obj * 3], prior_sigma[obj * 3 + 1] * 1.1f, prior_sigma[obj * 3 + 2]};
+    const float hi[3] = {mu[0] + 2.0f * prior_sigma[obj * 3], mu[1] + 2.2f * prior_sigma[obj * 3 + 1],
+                         mu[2] + 2.0f * prior_sigma[obj * 3 + 2]};
+
+    float vx[PROP_SLOTS], vy[PROP_SLOTS], vz[PROP_SLOTS], dims[PROP_SLOTS][3];
+    int exhausted = 0;
+#pragma unroll
+    for (int s = 0; s < PROP_SLOTS; ++s) {
+        const int p = s * GEO_T + tid;
+        vx[s] = vy[s] = vz[s] = INFINITY;
+        if (p < P) {
+            // vectorized_linspace(...).long(): trunc toward zero (utils.py:170-177, proposals.py:360-363)
+            const long xg = (long)truncf((float)p * x_sp + x_lo);
+            const long yg = (long)truncf((float)p * y_sp + y_lo);
+            long xi = xg < 0 ? xg + W : xg, yi = yg < 0 ? yg + H : yg;      // python negative-index wrap
+            xi = min(max(xi, 0L), (long)W - 1);
+            yi = min(max(yi, 0L), (long)H - 1);
+            const float d = depth[yi * W + xi];
+            const float ox = (float)xg - K02, oy = (float)yg - K12, a = K00;
+            const float ang_x = atan2f(ox, a);
+            const float dxc = sqrtf(ox * ox + a * a);
+            const float ang_d = atan2f(oy, dxc);
+            const float y = d * sinf(ang_d);
+            const float dx = sqrtf(d * d - y * y);
+            const float x = dx * sinf(ang_x);
+            const float zt = sqrtf(dx * dx - x * x);
+            // truncated normals for w,h,l with `rounds` pre-drawn rejection rounds
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float v = mu[k] + sg[k] * dim_normals[(((size_t)0 * 3 + k) * N + obj) * P + p];
+                for (int r = 1; r < rounds && (v < 0.05f || v > hi[k]); ++r)
+                    v = mu[k] + sg[k] * dim_normals[(((size_t)r * 3 + k) * N + obj) * P + p];
+                if (v < 0.05f || v > hi[k]) exhausted++;
+                dims[s][k] = v;
+            }
+            vx[s] = x; vy[s] = y; vz[s] = zt + dims[s][2] / 2.0f;
+        }
+    }
+    if (exhausted) atomicAdd(out_exhausted, exhausted);
+
+    // median (lower) + unbiased std over the P samples of x, y, z
+    for (int k = 0; k < 3; ++k) {
+        __syncthreads();
+        double lsum = 0.0;
+#pragma unroll
+        for (int s = 0; s < PROP_SLOTS; ++s) {
+            const int p = s * GEO_T + tid;
+            const float v = k == 0 ? vx[s] : (k == 1 ? vy[s] : vz[s]);
+            s_sort[p] = p < P ? v : INFINITY;
+            if (p < P) lsum += (double)v;
+        }
+        const double mean = block_sum_f64(lsum, s_red64) / (double)P;
+        double lsq = 0.0;
+#pragma unroll
+        for (int s = 0; s < PROP_SLOTS; ++s) {
+            const int p = s * GEO_T + tid;
+            if (p < P) {
+                const double dv = (double)(k == 0 ? vx[s] : (k == 1 ? vy[s] : vz[s])) - mean;
+                lsq += dv * dv;
+            }
+        }
+        const double var = block_sum_f64(lsq, s_red64) / (double)(P - 1);
+        bitonic_sort_1024(s_sort);
+        if (tid == 0) {
+            s_stat[k] = s_sort[(P - 1) / 2];
+            s_stat[3 + k] = (float)sqrt(var);
+        }
+    }
+    __syncthreads();
+    const float mx = 1.15f * s_stat[0] + 0.0f, sx = s_stat[3] * 1.2f;
+    const float my = 1.1f * s_stat[1] + 0.0f, sy = s_stat[4] * 0.8f;
+    const float mz = 0.85f * s_stat[2] + 0.35f, sz = s_stat[5] * 1.2f;
+#pragma unroll
+    for (int s = 0; s < PROP_SLOTS; ++s) {
+        const int p = s * GEO_T + tid;
+        if (p < P) {
+            const size_t gi = (size_t)obj * P + p;
+            float* o = out_cubes + gi * 15;
+            o[0] = mx + sx * ctr_normals[((size_t)0 * N + obj) * P + p];
+            o[1] = my + sy * ctr_normals[((size_t)1 * N + obj) * P + p];
+            o[2] = mz + sz * ctr_normals[((size_t)2 * N + obj) * P + p];
+            o[3] = dims[s][0]; o[4] = dims[s][1]; o[5] = dims[s][2];
+            int yi = yaw_idx[gi];
+            yi = min(max(yi, 0), 35);
+            const float* t = s_tab + yi * 9;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) o[6 + j] = t[j];
+        }
+    }
+}
+
+extern "C" int cr_propose(cr_ctx* ctx, const float* boxes, int64_t N, const float* depth, int H, int W,
+                          const float* prior_mu, const float* prior_sigma, const float* K, int64_t P,
+                          const float* dim_normals, int rounds, const float* ctr_normals,
+                          const int32_t* yaw_idx, const float* normal, float* out_cubes,
+                          int32_t* out_exhausted) {
+    CR_CHECK_ARG(ctx != nullptr, "cr_propose: ctx is NULL");
+    CR_CHECK_ARG(N >= 0, "cr_propose: negative N");
+    if (N == 0) return CR_OK;
+    CR_CHECK_ARG(P >= 2 && P <= PROP_MAXP, "cr_propose: P=%lld outside [2,%d]", (long long)P, PROP_MAXP);
+    CR_CHECK_ARG(rounds >= 1, "cr_propose: rounds must be >= 1");
+    CR_CHECK_ARG(H > 0 && W > 0, "cr_propose: bad depth shape");
+    CR_CHECK_ARG(boxes && depth && prior_mu && prior_sigma && K && dim_normals && ctr_normals && yaw_idx &&
+                     normal && out_cubes && out_exhausted,
+                 "cr_propose: NULL pointer");
+    CR_HIP(hipMemsetAsync(out_exhausted, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(k_propose, dim3((unsigned)N), dim3(GEO_T), 0, ctx->stream, boxes, depth, H, W, prior_mu,
+                       prior_sigma, K, (int)N, (int)P, dim_normals, rounds, ctr_normals, yaw_idx, normal, out_cubes,
+                       out_exhausted);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// K21: parallel RANSAC plane.  One workgroup per candidate triple counts its
+// inliers over all points (points stay L2-resident: Q*12 B ~ 126 KB at 512^2).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(GEO_T) void k_ransac_count(const float* __restrict__ pts, int Q,
+                                                         const int32_t* __restrict__ triples, float thresh,
+                                                         float* __restrict__ eqs, int32_t* __restrict__ counts) {
+    __shared__ int s_cnt[GEO_W];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int i0 = triples[t * 3], i1 = triples[t * 3 + 1], i2 = triples[t * 3 + 2];
+    const float ax = pts[i1 * 3] - pts[i0 * 3], ay = pts[i1 * 3 + 1] - pts[i0 * 3 + 1], az = pts[i1 * 3 + 2] - pts[i0 * 3 + 2];
+    const float bx = pts[i2 * 3] - pts[i0 * 3], by = pts[i2 * 3 + 1] - pts[i0 * 3 + 1], bz = pts[i2 * 3 + 2] - pts[i0 * 3 + 2];
+    float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+    const float nrm = sqrtf((cx * cx + cy * cy) + cz * cz);
+    cx = cx / nrm; cy = cy / nrm; cz = cz / nrm;
+    const float k = -((cx * pts[i1 * 3] + cy * pts[i1 * 3 + 1]) + cz * pts[i1 * 3 + 2]);
+    const float den = sqrtf((cx * cx + cy * cy) + cz * cz);
+    int cnt = 0;
+    for (int q = tid; q < Q; q += GEO_T) {
+        const float d = (((cx * pts[q * 3] + cy * pts[q * 3 + 1]) + cz * pts[q * 3 + 2]) + k) / den;
+        cnt += fabsf(d) <= thresh ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        for (int i = 0; i < GEO_W; ++i) c += s_cnt[i];
+        counts[t] = c;
+        eqs[t * 4] = cx; eqs[t * 4 + 1] = cy; eqs[t * 4 + 2] = cz; eqs[t * 4 + 3] = k;
+    }
+}
+
+__global__ __launch_bounds__(GEO_T) void k_ransac_pick(const float* __restrict__ eqs,
+                                                        const int32_t* __restrict__ counts, int T,
+                                                        float* __restrict__ out_neg_eq, int32_t* __restrict__ out_best) {
+    __shared__ int s_c[GEO_W], s_i[GEO_W];
+    const int tid = threadIdx.x;
+    int bc = -1, bi = 0x7fffffff;
+    for (int t = tid; t < T; t += GEO_T) {
+        const int c = counts[t];
+        if (c > bc || (c == bc && t < bi)) { bc = c; bi = t; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int oc = __shfl_down(bc, off, 64), oi = __shfl_down(bi, off, 64);
+        if (oc > bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_c[tid >> 6] = bc; s_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < GEO_W; ++i)
+            if (s_c[i] > bc || (s_c[i] == bc && s_i[i] < bi)) { bc = s_c[i]; bi = s_i[i]; }
+        // torch.argmax = first maximal index; reference returns -equation (plane.py:134)
+        for (int j = 0; j < 4; ++j) out_neg_eq[j] = -eqs[bi * 4 + j];
+        out_best[0] = bi;
+        out_best[1] = bc;
+    }
+}
+
+extern "C" int cr_ransac_plane(cr_ctx* ctx, const float* pts, int64_t Q, const int32_t* triples, int64_t T,
+                               float thresh, float* out_neg_eq, int32_t* out_counts, int32_t* out_best) {
+    CR_CHECK_ARG(ctx != nullptr, "cr_ransac_plane: ctx is NULL");
+    CR_CHECK_ARG(Q >= 3 && T >= 1, "cr_ransac_plane: need Q>=3 points and T>=1 triples");
+    CR_CHECK_ARG(Q <= 0x7fffffff / 3 && T <= (int64_t)(ctx->ws_bytes / 16), "cr_ransac_plane: too large");
+    CR_CHECK_ARG(pts && triples && out_neg_eq && out_counts && out_best, "cr_ransac_plane: NULL pointer");
+    float* eqs = (float*)ctx->ws;
+    hipLaunchKernelGGL(k_ransac_count, dim3((unsigned)T), dim3(GEO_T), 0, ctx->stream, pts, (int)Q, triples, thresh,
+                       eqs, out_counts);
+    CR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(GEO_T), 0, ctx->stream, eqs, out_counts, (int)T, out_neg_eq,
+                       out_best);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

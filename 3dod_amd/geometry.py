@@ -1,0 +1,118 @@
+"""Python entry points of the geometry kernels (thin: argument checking, output
+allocation, one C-ABI call each).  Semantics documented in include/cr3dod.h."""
+import torch
+
+from . import _lib
+
+f32 = torch.float32
+
+
+def _f32c(t, name, shape=None):
+    if t.dtype != f32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_cuda:
+        raise _lib.CrError(f"{name} must be a CUDA(HIP) tensor; 3dod_amd has no CPU path")
+    if shape is not None:
+        if t.dim() != len(shape) or any(s is not None and s != d for s, d in zip(shape, t.shape)):
+            raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {shape}")
+    return t.contiguous()
+
+
+def cuboid_corners(box6, R):
+    """get_cuboid_verts_faces (verts) -- cubercnn/util/math_util.py:142-245."""
+    box6 = _f32c(box6, "box6", (None, 6))
+    n = box6.shape[0]
+    R = _f32c(R, "R", (n, 3, 3))
+    verts = torch.empty((n, 8, 3), dtype=f32, device=box6.device)
+    lib = _lib.load()
+    _lib.check(lib.cr_cuboid_corners(_lib.ctx_for(box6.device), _lib.ptr(box6), _lib.ptr(R), n, _lib.ptr(verts)),
+               "cr_cuboid_corners")
+    return verts
+
+
+def cubes_project_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_pts=None,
+                        want=("corners", "boxes", "iou", "dim", "corner", "combined")):
+    """Fused K17 (see cr_cubes_project_score).  Returns a dict with the requested
+    planes plus `argmax` (N,) int64 and `best` (N,)."""
+    cubes = _f32c(cubes, "cubes", (None, None, 15))
+    N, Pn = cubes.shape[:2]
+    dev = cubes.device
+    K = _f32c(K, "K")
+    if K.shape == (3, 3):
+        kpo = 0
+    elif K.shape == (N, 3, 3):
+        kpo = 1
+    else:
+        raise ValueError(f"K must be (3,3) or ({N},3,3), got {tuple(K.shape)}")
+    ref_boxes = _f32c(ref_boxes, "ref_boxes", (N, 4))
+    prior_mu = _f32c(prior_mu, "prior_mu", (N, 3))
+    prior_sigma = _f32c(prior_sigma, "prior_sigma", (N, 3))
+    if rect_pts is not None:
+        rect_pts = _f32c(rect_pts, "rect_pts", (N, 4, 2))
+    shapes = {"corners": (N, Pn, 8, 2), "boxes": (N, Pn, 4), "iou": (N, Pn), "dim": (N, Pn),
+              "corner": (N, Pn), "combined": (N, Pn)}
+    out = {k: (torch.empty(shapes[k], dtype=f32, device=dev) if k in want else None) for k in shapes}
+    out["argmax"] = torch.zeros((N,), dtype=torch.int64, device=dev)
+    out["best"] = torch.zeros((N,), dtype=f32, device=dev)
+    if N == 0:
+        return out
+    lib = _lib.load()
+    rc = lib.cr_cubes_project_score(
+        _lib.ctx_for(dev), _lib.ptr(cubes), N, Pn, _lib.ptr(K), kpo, float(im_wh[0]), float(im_wh[1]),
+        _lib.ptr(ref_boxes), _lib.ptr(prior_mu), _lib.ptr(prior_sigma), _lib.ptr(rect_pts),
+        _lib.ptr(out["corners"]), _lib.ptr(out["boxes"]), _lib.ptr(out["iou"]), _lib.ptr(out["dim"]),
+        _lib.ptr(out["corner"]), _lib.ptr(out["combined"]), _lib.ptr(out["argmax"]), _lib.ptr(out["best"]))
+    _lib.check(rc, "cr_cubes_project_score")
+    return out
+
+
+def propose_from_draws(boxes, depth, prior_mu, prior_sigma, K, P, dim_normals, ctr_normals, yaw_idx, normal):
+    """K18 with caller-supplied variates (see cr_propose).  Returns (cubes (N,P,15), exhausted int tensor)."""
+    boxes = _f32c(boxes, "boxes", (None, 4))
+    N = boxes.shape[0]
+    dev = boxes.device
+    depth = _f32c(depth, "depth", (None, None))
+    H, W = depth.shape
+    prior_mu = _f32c(prior_mu, "prior_mu", (N, 3))
+    prior_sigma = _f32c(prior_sigma, "prior_sigma", (N, 3))
+    K = _f32c(K, "K", (3, 3))
+    dim_normals = _f32c(dim_normals, "dim_normals", (None, 3, N, P))
+    ctr_normals = _f32c(ctr_normals, "ctr_normals", (3, N, P))
+    if yaw_idx.dtype != torch.int32:
+        yaw_idx = yaw_idx.to(torch.int32)
+    yaw_idx = yaw_idx.contiguous()
+    assert tuple(yaw_idx.shape) == (N, P)
+    normal = _f32c(normal, "normal", (3,))
+    cubes = torch.empty((N, P, 15), dtype=f32, device=dev)
+    exhausted = torch.zeros((1,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    rc = lib.cr_propose(_lib.ctx_for(dev), _lib.ptr(boxes), N, _lib.ptr(depth), H, W, _lib.ptr(prior_mu),
+                        _lib.ptr(prior_sigma), _lib.ptr(K), P, _lib.ptr(dim_normals), dim_normals.shape[0],
+                        _lib.ptr(ctr_normals), _lib.ptr(yaw_idx), _lib.ptr(normal), _lib.ptr(cubes),
+                        _lib.ptr(exhausted))
+    _lib.check(rc, "cr_propose")
+    return cubes, exhausted
+
+
+def ransac_plane(pts, triples, thresh=0.05, validate=True):
+    """K21 Plane.fit_parallel with given triples.  Returns (-equation (4,), counts (T,), best (2,) = idx,count)."""
+    pts = _f32c(pts, "pts", (None, 3))
+    Q = pts.shape[0]
+    if triples.dtype != torch.int32:
+        triples = triples.to(torch.int32)
+    triples = triples.contiguous()
+    T = triples.shape[0]
+    assert triples.shape == (T, 3) and triples.is_cuda
+    if validate:      # an out-of-range index would be an out-of-bounds device read
+        mn, mx = int(triples.min()), int(triples.max())
+        if mn < 0 or mx >= Q:
+            raise ValueError(f"triples index outside [0,{Q})")
+    dev = pts.device
+    neg_eq = torch.empty((4,), dtype=f32, device=dev)
+    counts = torch.empty((T,), dtype=torch.int32, device=dev)
+    best = torch.empty((2,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    rc = lib.cr_ransac_plane(_lib.ctx_for(dev), _lib.ptr(pts), Q, _lib.ptr(triples), T, float(thresh),
+                             _lib.ptr(neg_eq), _lib.ptr(counts), _lib.ptr(best))
+    _lib.check(rc, "cr_ransac_plane")
+    return neg_eq, counts, best

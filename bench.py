@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py -- measures the hot path on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|geometry]
+
+N>1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+Workloads
+  geometry  BASELINE.json configs[2]: ProposalNetwork 1000-cube/object project + IoU/size/corner
+            scoring + argmax, 64 images x 16 objects x 1000 cubes per GPU, ONE launch per step.
+  train     BASELINE.json metric: Cube R-CNN DLA34-FPN train step (see bench_train.py).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def dist_setup(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return rank, world, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world, dev):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+# ---------------------------------------------------------------------------
+def geometry_inputs(n_obj, P, seed, dev):
+    """Synthetic Omni3D-shaped scoring inputs: K f~U(400,800), pp (256,256);
+    cubes around plausible depths; 2D boxes; priors mu~U(0.3,1.1), sigma=0.2mu; a rect per object."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    f = float(torch.empty(1).uniform_(400, 800, generator=g))
+    K = torch.tensor([[f, 0, 256], [0, f, 256], [0, 0, 1]], dtype=torch.float32)
+    z = torch.empty(n_obj, P).uniform_(1, 8, generator=g)
+    u = torch.empty(n_obj, P).uniform_(0, 512, generator=g)
+    v = torch.empty(n_obj, P).uniform_(0, 512, generator=g)
+    x = (u - 256) * z / f
+    y = (v - 256) * z / f
+    dims = torch.empty(n_obj, P, 3).uniform_(0.05, 1.5, generator=g)
+    yaw = torch.empty(n_obj, P).uniform_(0, 3.14159, generator=g)
+    c, s = yaw.cos(), yaw.sin()
+    zeros, ones = torch.zeros_like(c), torch.ones_like(c)
+    R = torch.stack([c, zeros, s, zeros, ones, zeros, -s, zeros, c], -1)
+    cubes = torch.cat([x[..., None], y[..., None], z[..., None], dims, R], -1).float()
+    ctr = torch.empty(n_obj, 2).uniform_(64, 448, generator=g)
+    wh = torch.empty(n_obj, 2).uniform_(32, 256, generator=g)
+    ref = torch.cat([ctr - wh / 2, ctr + wh / 2], 1).clamp(0, 511)
+    mu = torch.empty(n_obj, 3).uniform_(0.3, 1.1, generator=g)
+    sg = 0.2 * mu
+    rect = torch.stack([ref[:, [0, 1]], ref[:, [2, 1]], ref[:, [2, 3]], ref[:, [0, 3]]], 1).contiguous()
+    to = lambda t: t.to(dev).contiguous()
+    return dict(cubes=to(cubes), K=to(K), im_wh=(512, 512), ref=to(ref), mu=to(mu), sg=to(sg), rect=to(rect))
+
+
+def bench_geometry(args, rank, world, dev):
+    geo = importlib.import_module("3dod_amd.geometry")
+    n_img, n_obj_img, P = 64, 16, 1000
+    n_obj = n_img * n_obj_img
+    inp = geometry_inputs(n_obj, P, 1234 + rank, dev)
+
+    def step():
+        return geo.cubes_project_score(inp["cubes"], inp["K"], inp["im_wh"], inp["ref"], inp["mu"], inp["sg"],
+                                       inp["rect"])
+    for _ in range(args.warmup):
+        step()
+    barrier(world)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        out = step()
+    ev1.record()
+    barrier(world)
+    dt = time.perf_counter() - t0
+    dt = max_over_ranks(dt, world, dev)
+    kern_ms = ev0.elapsed_time(ev1) / args.steps       # events on the stream the kernel is launched on
+    cubes_total = n_obj * P * world
+    value = cubes_total * args.steps / dt
+    bytes_per_cube = 60 + 64 + 16 + 16               # read 60 B + corners 64 + box 16 + 4 score planes
+    achieved = bytes_per_cube * n_obj * P / (kern_ms * 1e-3) / 1e9
+    res = {
+        "metric": "cubes/sec ProposalNetwork 1000-cube project+score+argmax (BASELINE configs[2])",
+        "value": value, "unit": "cubes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "geometry: 64 images x 16 objects x 1000 cubes per GPU, full outputs (156 B/cube), one launch",
+                   "objects_per_gpu": n_obj, "proposals": P, "parallelism": f"objects sharded x{world}, no collective"},
+        "roofline": {"bound": "hbm", "kernel": "k_project_score<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": bytes_per_cube * n_obj * P, "kernel_ms": kern_ms},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_geometry(inp, P)
+    return res
+
+
+def cpu_baseline_geometry(inp, P):
+    """oracle (numpy restatement of the reference's per-object loop, roi_heads.py:494-505) on a bounded sample."""
+    from oracle import geometry as og
+    n = 48
+    c = {k: (v[:n].cpu().numpy() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] > 3 else v) for k, v in inp.items()}
+    K = inp["K"].cpu().numpy()
+    og.project_and_score(c["cubes"][:2], K, inp["im_wh"], c["ref"][:2], c["mu"][:2], c["sg"][:2], c["rect"][:2])
+    t0 = time.perf_counter()
+    og.project_and_score(c["cubes"], K, inp["im_wh"], c["ref"], c["mu"], c["sg"], c["rect"])
+    dt = time.perf_counter() - t0
+    return {"value": n * P / dt, "unit": "cubes/s", "cores": 1, "kind": "port",
+            "sample": f"{n} objects x {P} cubes, numpy float32 oracle, per-object loop, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="geometry", choices=["train", "geometry"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.workload == "geometry" else 20
+    if args.warmup is None:
+        args.warmup = 20 if args.workload == "geometry" else 5
+    rank, world, local = dist_setup(args.gpus)
+    dev = torch.device("cuda", local)
+    if args.workload == "geometry":
+        res = bench_geometry(args, rank, world, dev)
+    else:
+        bt = importlib.import_module("bench_train")
+        res = bt.bench_train(args, rank, world, dev)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
