@@ -21,6 +21,23 @@ SIGNATURES = {
                                P, P, P, P, P, P, P, P],
     "cr_propose": [P, P, c_int64, P, c_int, c_int, P, P, P, c_int64, P, c_int, P, P, P, P, P],
     "cr_ransac_plane": [P, P, c_int64, P, c_int64, c_float, P, P, P],
+    "cr_conv2d_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int],
+    "cr_conv2d_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "cr_conv2d_bwd_weight": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "cr_cast_f32_to_bf16": [P, P, P, c_int64],
+    "cr_weight_transpose": [P, P, P, c_int, c_int, c_int],
+    "cr_bn_fwd": [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, P],
+    "cr_bn_bwd": [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int],
+    "cr_pool2x_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int],
+    "cr_pool2x_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int],
+    "cr_upsample2x_add": [P, P, P, P, c_int, c_int, c_int, c_int],
+    "cr_sum2x2": [P, P, P, c_int, c_int, c_int, c_int],
+    "cr_preprocess": [P, P, P, c_int, c_int, c_int, P, P],
+    "cr_roi_align_fwd": [P, P, P, P, P, c_int, c_int, P, c_int64, c_int, c_int, P],
+    "cr_roi_align_bwd": [P, P, P, P, P, c_int, c_int, P, c_int64, c_int, c_int, P],
+    "cr_nms_grouped": [P, P, P, c_int, c_int, c_float, P, P],
+    "cr_nonfinite_flag": [P, P, c_int64, P],
+    "cr_sgd_step": [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P],
 }
 
 

@@ -1,0 +1,936 @@
+// Convolution stack of the Cube R-CNN DLA34/ResNet34 + FPN + RPN-head path as
+// implicit GEMMs on the CDNA4 matrix cores (bf16 in, f32 accumulate), NHWC.
+//
+//   k_conv_igemm   forward conv and backward-data (transposed gather) in one
+//                  template: out[pixel][ch] = sum_k  W[ch][k] * X_gather[pixel][k]
+//                  with fused bias / residual add / ReLU / BatchNorm statistics.
+//   k_conv_wgrad   backward-weight: dW[ch][k] = sum_pixels dY[pixel][ch] * X_gather[pixel][k]
+//                  (both operands read column-wise from LDS with ds_read_b64_tr_b16),
+//                  split over pixel ranges, f32 atomics.
+//
+// Reference modules covered (paths into the reference tree):
+//   cubercnn/modeling/backbone/dla.py:40-68,156-174,233-321  (conv3x3/1x1/7x7 + BN + ReLU + residual)
+//   detectron2 FPN / StandardRPNHead [third-party], wired at dla.py:484-507, configs/Base.yaml:41-60
+//
+// MFMA operand maps used (cdna_hip_programming.md section 3), v_mfma_f32_16x16x32_bf16:
+//   A: lane l holds A[row l&15][k = 8(l>>4)+j]   B: lane l holds B[k = 8(l>>4)+j][col l&15]
+//   D: col = l&15, row = 4(l>>4)+reg.
+// We feed WEIGHTS as A (rows = output channels) and PIXELS as B (cols = pixels), so a lane
+// ends up with 4 consecutive output channels of one pixel = one 8-byte NHWC store.
+#include "cr_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+#define CONV_T 256
+#define STAT_REPL 32        // replicas of the BN statistics accumulators (atomic contention)
+
+__device__ __forceinline__ float bf2f(u16 b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ u16 f2bf(float f) {
+    __bf16 b = (__bf16)f;                      // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(u16, b);
+}
+
+struct ConvP {
+    const u16* x;        // gather source, NHWC bf16 (fwd: input; bwd-data: dY)
+    const u16* w;        // [Cout][Kdim] bf16, k = (r*KS + s)*Cin + c
+    void* y;             // [M][Cout] bf16 or f32
+    const u16* res;      // optional residual [M][Cout] bf16 (added before ReLU)
+    const float* bias;   // optional [Cout]
+    float* stats;        // optional [STAT_REPL][2][Cout]: sum and sum of squares of the conv output
+    int N, Hin, Win, Cin, Hout, Wout, Cout;
+    int stride, pad, Kdim, M, cshift, relu;
+};
+
+// LDS image of a [rows][32] bf16 tile (64-B rows, four 16-B chunks): chunk' = chunk ^ ((-(row>>2)) & 3)
+// makes the 16x16x32 fragment read (lane -> row l&15, chunk l>>4) conflict-free per ds_read_b128 lane group.
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * 32 + ((chunk ^ ((-(row >> 2)) & 3)) << 3);
+}
+
+template <int BN, int KS, int MODE, typename OutT>
+__global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
+    constexpr int BM = 128;
+    constexpr int TP = (BN == 128) ? 4 : 2;          // pixel tiles (16) per wave
+    constexpr int TC = (BN == 128) ? 4 : BN / 16;    // channel tiles per wave
+    constexpr int NB = (BN * 4 + CONV_T - 1) / CONV_T;   // weight chunks per thread
+    __shared__ __attribute__((aligned(16))) u16 sX[BM * 32];
+    __shared__ __attribute__((aligned(16))) u16 sW[BN * 32];
+    __shared__ float sStat[2 * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = p.Cout / BN;
+    const int nt = blockIdx.x % n_tiles, mt = blockIdx.x / n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- per-thread gather bookkeeping (2 pixel rows, one 16-B k-chunk each)
+    const int cA = tid & 3;
+    int nimg[2], hb[2], wb[2];
+    bool rv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + (tid >> 2) + 64 * i;
+        rv[i] = m < p.M;
+        const int mm = rv[i] ? m : 0;
+        const int hw = p.Hout * p.Wout;
+        const int n = mm / hw;
+        const int rem = mm - n * hw;
+        const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+        nimg[i] = n;
+        if (MODE == 0) { hb[i] = ho * p.stride - p.pad; wb[i] = wo * p.stride - p.pad; }
+        else           { hb[i] = ho + p.pad;            wb[i] = wo + p.pad; }
+    }
+    uint4 ra[2], rb[NB];
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * 32 + cA * 8;
+        int r = 0, s = 0, c0 = k0;
+        if (KS > 1) {
+            const int tap = k0 >> p.cshift;
+            c0 = k0 & (p.Cin - 1);
+            r = tap / KS;
+            s = tap - r * KS;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int hi, wi;
+            bool ok = rv[i] && (k0 < p.Kdim);
+            if (MODE == 0) { hi = hb[i] + r; wi = wb[i] + s; }
+            else {
+                const int th = hb[i] - r, tw = wb[i] - s;
+                if (p.stride == 2) { ok = ok && (((th | tw) & 1) == 0); hi = th >> 1; wi = tw >> 1; }
+                else { hi = th; wi = tw; }
+            }
+            ok = ok && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(nimg[i] * p.Hin + hi) * p.Win + wi) * p.Cin + c0);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + CONV_T * i;
+            const int row = idx >> 2, kb = kt * 32 + (idx & 3) * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < BN * 4 && kb < p.Kdim) v = *reinterpret_cast<const uint4*>(p.w + (size_t)(n0 + row) * p.Kdim + kb);
+            rb[i] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<uint4*>(&sX[lds_off((tid >> 2) + 64 * i, cA)]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + CONV_T * i;
+            if (idx < BN * 4) *reinterpret_cast<uint4*>(&sW[lds_off(idx >> 2, idx & 3)]) = rb[i];
+        }
+    };
+
+    const int poff = (BN == 128) ? (wave >> 1) * 64 : wave * 32;    // pixel offset of this wave in the tile
+    const int coff = (BN == 128) ? (wave & 1) * 64 : 0;             // channel offset
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.Kdim + 31) >> 5;
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tiles(kt + 1);        // global loads in flight under the MFMAs
+        bf16x8 xf[TP], wf[TC];
+        const int fr = lane & 15, fc = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+            xf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sX[lds_off(poff + j * 16 + fr, fc)]));
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+            wf[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sW[lds_off(coff + i * 16 + fr, fc)]));
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias, BN statistics, residual, ReLU, store (4 consecutive channels per lane)
+    const bool do_stats = p.stats != nullptr;
+    if (do_stats) {
+        for (int i = tid; i < 2 * BN; i += CONV_T) sStat[i] = 0.f;
+        __syncthreads();
+    }
+    const int g = lane >> 4, pl = lane & 15;
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        const int chl = coff + i * 16 + 4 * g;     // channel within the block tile
+        const int ch = n0 + chl;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b4[e] = p.bias[ch + e];
+        }
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int m = m0 + poff + j * 16 + pl;
+            if (m < p.M) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[e];
+                if (do_stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+                }
+                const size_t o = (size_t)m * p.Cout + ch;
+                if (p.res) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + o);
+                    v[0] += bf2f((u16)(rr.x & 0xffff)); v[1] += bf2f((u16)(rr.x >> 16));
+                    v[2] += bf2f((u16)(rr.y & 0xffff)); v[3] += bf2f((u16)(rr.y >> 16));
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (sizeof(OutT) == 4) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(p.y) + o) = pk;
+                }
+            }
+        }
+        if (do_stats) {
+            // reduce over the 16 pixel lanes that share this lane's channel group
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    ssum[e] += __shfl_xor(ssum[e], off, 64);
+                    ssq[e] += __shfl_xor(ssq[e], off, 64);
+                }
+            }
+            if (pl == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(&sStat[chl + e], ssum[e]);
+                    atomicAdd(&sStat[BN + chl + e], ssq[e]);
+                }
+            }
+        }
+    }
+    if (do_stats) {
+        __syncthreads();
+        float* dst = p.stats + (size_t)(blockIdx.x % STAT_REPL) * 2 * p.Cout;
+        for (int i = tid; i < BN; i += CONV_T) {
+            atomicAdd(&dst[n0 + i], sStat[i]);
+            atomicAdd(&dst[p.Cout + n0 + i], sStat[BN + i]);
+        }
+    }
+}
+
+template <int BN, int KS, int MODE>
+static int launch_igemm_t(cr_ctx* ctx, const ConvP& p, int out_f32) {
+    const int grid = (int)(cr_cdiv(p.M, 128) * (p.Cout / BN));
+    if (out_f32)
+        hipLaunchKernelGGL((k_conv_igemm<BN, KS, MODE, float>), dim3(grid), dim3(CONV_T), 0, ctx->stream, p);
+    else
+        hipLaunchKernelGGL((k_conv_igemm<BN, KS, MODE, u16>), dim3(grid), dim3(CONV_T), 0, ctx->stream, p);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+template <int KS, int MODE>
+static int launch_igemm_ks(cr_ctx* ctx, const ConvP& p, int out_f32) {
+    if (p.Cout % 128 == 0) return launch_igemm_t<128, KS, MODE>(ctx, p, out_f32);
+    if (p.Cout % 64 == 0) return launch_igemm_t<64, KS, MODE>(ctx, p, out_f32);
+    if (p.Cout % 32 == 0) return launch_igemm_t<32, KS, MODE>(ctx, p, out_f32);
+    return launch_igemm_t<16, KS, MODE>(ctx, p, out_f32);
+}
+
+static int ilog2_exact(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return ((1 << s) == v) ? s : -1;
+}
+
+static int conv_common_checks(const char* who, int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad) {
+    CR_CHECK_ARG(N > 0 && H > 0 && W > 0, "%s: bad input dims", who);
+    CR_CHECK_ARG(Cin % 8 == 0 && Cin >= 8, "%s: Cin=%d must be a multiple of 8 (NHWC 16-B chunks)", who, Cin);
+    CR_CHECK_ARG(Cout % 16 == 0, "%s: Cout=%d must be a multiple of 16", who, Cout);
+    CR_CHECK_ARG(ks == 1 || ks == 3 || ks == 7, "%s: kernel size %d not supported (1,3,7)", who, ks);
+    CR_CHECK_ARG(stride == 1 || stride == 2, "%s: stride %d not supported (1,2)", who, stride);
+    CR_CHECK_ARG(ks == 1 || ilog2_exact(Cin) >= 0, "%s: Cin=%d must be a power of two for %dx%d kernels", who, Cin, ks, ks);
+    CR_CHECK_ARG(pad >= 0 && pad <= ks / 2, "%s: pad %d", who, pad);
+    CR_CHECK_ARG((int64_t)N * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < (int64_t)0x7fffffff,
+                 "%s: tensor too large for 32-bit pixel indexing", who);
+    return CR_OK;
+}
+
+extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y, int N, int H, int W, int Cin,
+                             int Cout, int ks, int stride, int pad, const float* bias, const void* residual,
+                             int relu, float* stats, int out_f32) {
+    CR_CHECK_ARG(ctx && x && w && y, "cr_conv2d_fwd: NULL pointer");
+    int rc = conv_common_checks("cr_conv2d_fwd", N, H, W, Cin, Cout, ks, stride, pad);
+    if (rc) return rc;
+    ConvP p;
+    p.x = (const u16*)x; p.w = (const u16*)w; p.y = y; p.res = (const u16*)residual; p.bias = bias; p.stats = stats;
+    p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Cout = Cout;
+    p.Hout = (H + 2 * pad - ks) / stride + 1;
+    p.Wout = (W + 2 * pad - ks) / stride + 1;
+    p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = N * p.Hout * p.Wout;
+    p.cshift = ks == 1 ? 0 : ilog2_exact(Cin); p.relu = relu;
+    if (stats) CR_HIP(hipMemsetAsync(stats, 0, sizeof(float) * STAT_REPL * 2 * Cout, ctx->stream));
+    if (ks == 1) return launch_igemm_ks<1, 0>(ctx, p, out_f32);
+    if (ks == 3) return launch_igemm_ks<3, 0>(ctx, p, out_f32);
+    return launch_igemm_ks<7, 0>(ctx, p, out_f32);
+}
+
+// dX[n,h,w,c] = sum_{r,s,k} dY[n,(h+pad-r)/stride,(w+pad-s)/stride,k] * W[k,r,s,c]
+// wt = weights re-laid as [Cin][(r*KS+s)*Cout + k]  (cr_weight_transpose)
+extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int N, int H, int W,
+                                  int Cin, int Cout, int ks, int stride, int pad) {
+    CR_CHECK_ARG(ctx && dy && wt && dx, "cr_conv2d_bwd_data: NULL pointer");
+    int rc = conv_common_checks("cr_conv2d_bwd_data", N, H, W, Cout, Cin, ks, stride, pad);
+    if (rc) return rc;
+    CR_CHECK_ARG(Cin % 16 == 0, "cr_conv2d_bwd_data: Cin=%d must be a multiple of 16", Cin);
+    ConvP p;
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+    p.x = (const u16*)dy; p.w = (const u16*)wt; p.y = dx; p.res = nullptr; p.bias = nullptr; p.stats = nullptr;
+    p.N = N; p.Hin = Ho; p.Win = Wo; p.Cin = Cout;      // gather source = dY
+    p.Hout = H; p.Wout = W; p.Cout = Cin;               // GEMM output = dX
+    p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cout; p.M = N * H * W;
+    p.cshift = ks == 1 ? 0 : ilog2_exact(Cout); p.relu = 0;
+    if (ks == 1) return launch_igemm_ks<1, 1>(ctx, p, 0);
+    if (ks == 3) return launch_igemm_ks<3, 1>(ctx, p, 0);
+    return launch_igemm_ks<7, 1>(ctx, p, 0);
+}
+
+// ---------------------------------------------------------------------------
+// backward-weight
+// ---------------------------------------------------------------------------
+struct WgP {
+    const u16* dy;   // [M][Cout]
+    const u16* x;    // NHWC
+    float* dw;       // [Cout][Kdim] f32, accumulated with atomics
+    int N, Hin, Win, Cin, Hout, Wout, Cout, stride, pad, Kdim, M, cshift;
+    int steps_per_split;    // 32-pixel steps handled by one blockIdx.z
+};
+
+// transposing LDS read: 16-lane group reads a 4(row) x 16(col) block of 16-bit elements and
+// returns it column-major: lane i gets column i, rows 0..3 (cdna_hip_programming.md T10).
+__device__ __forceinline__ s16x4 lds_tr16(const u16* ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ptr));
+}
+
+template <int TM, int KS>
+__global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
+    constexpr int TN = 128;
+    constexpr int WM = (TM == 128) ? 2 : 1, WN = 4 / WM;
+    constexpr int WTM = TM / WM, WTN = TN / WN;          // wave tile
+    constexpr int TI = WTM / 16, TJ = WTN / 16;
+    constexpr int PP = TM + 8, PQ = TN + 8;              // padded row pitches (elements)
+    constexpr int NP = (32 * TM / 8 + CONV_T - 1) / CONV_T;   // dy chunks per thread
+    __shared__ __attribute__((aligned(16))) u16 sP[32 * PP];
+    __shared__ __attribute__((aligned(16))) u16 sQ[32 * PQ];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * TM;        // output-channel tile
+    const int q0 = blockIdx.y * TN;        // k (r,s,c) tile
+    const int step0 = blockIdx.z * p.steps_per_split;
+    const int nsteps_total = (p.M + 31) >> 5;
+    const int step1 = min(step0 + p.steps_per_split, nsteps_total);
+    if (step0 >= step1) return;
+
+    // Q-gather bookkeeping: 32 pixels x 16 chunks = 512 chunks, 2 per thread; the k-chunk is fixed per thread
+    const int qc = tid & 15;                   // chunk within the 128-wide k tile
+    const int qk = q0 + qc * 8;
+    int qr = 0, qs = 0, qch = qk;
+    const bool qvalid = qk < p.Kdim;
+    if (KS > 1) {
+        const int tap = qk >> p.cshift;
+        qch = qk & (p.Cin - 1);
+        qr = tap / KS;
+        qs = tap - qr * KS;
+    }
+    const int hw = p.Hout * p.Wout;
+    uint4 rq[2], rp[NP];
+
+    auto load_step = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int prow = (tid >> 4) + 16 * i;
+            const int m = st * 32 + prow;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (qvalid && m < p.M) {
+                const int n = m / hw;
+                const int rem = m - n * hw;
+                const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+                const int hi = ho * p.stride - p.pad + qr, wi = wo * p.stride - p.pad + qs;
+                if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
+                    v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(n * p.Hin + hi) * p.Win + wi) * p.Cin + qch);
+            }
+            rq[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + CONV_T * i;
+            constexpr int CPR = TM / 8;           // chunks per pixel row
+            const int prow = idx / CPR, pc = idx - prow * CPR;
+            const int m = st * 32 + prow;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < 32 * CPR && m < p.M && c0 + pc * 8 < p.Cout)
+                v = *reinterpret_cast<const uint4*>(p.dy + (size_t)m * p.Cout + c0 + pc * 8);
+            rp[i] = v;
+        }
+    };
+    auto store_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<uint4*>(&sQ[((tid >> 4) + 16 * i) * PQ + qc * 8]) = rq[i];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + CONV_T * i;
+            constexpr int CPR = TM / 8;
+            const int prow = idx / CPR, pc = idx - prow * CPR;
+            if (idx < 32 * CPR) *reinterpret_cast<uint4*>(&sP[prow * PP + pc * 8]) = rp[i];
+        }
+    };
+
+    const int wm = (WM == 2) ? (wave >> 1) : 0, wn = (WM == 2) ? (wave & 1) : wave;
+    const int moff = wm * WTM, noff = wn * WTN;
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read addressing: 16-lane group g covers pixel rows 8g..8g+7; lane 4q+pp supplies row q, cols 4pp..
+    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    load_step(step0);
+    store_step();
+    __syncthreads();
+    for (int st = step0; st < step1; ++st) {
+        if (st + 1 < step1) load_step(st + 1);
+        bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const u16* b0 = &sP[(8 * g + tq) * PP + moff + i * 16 + 4 * tp];
+            const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b0 + 4 * PP);
+            af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const u16* b0 = &sQ[(8 * g + tq) * PQ + noff + j * 16 + 4 * tp];
+            const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b0 + 4 * PQ);
+            bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+        if (st + 1 < step1) {
+            store_step();
+            __syncthreads();
+        }
+    }
+    // D: col (lane&15) = k index, row 4(lane>>4)+reg = channel
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int kk = q0 + noff + j * 16 + li;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = c0 + moff + i * 16 + 4 * g + e;
+                if (kk < p.Kdim && ch < p.Cout) atomicAdd(&p.dw[(size_t)ch * p.Kdim + kk], acc[i][j][e]);
+            }
+        }
+}
+
+template <int KS>
+static int launch_wgrad_ks(cr_ctx* ctx, WgP& p) {
+    const int nsteps = (p.M + 31) >> 5;
+    const int tn = (int)cr_cdiv(p.Kdim, 128);
+    int TM = p.Cout >= 128 ? 128 : (p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16));
+    const int tm = (int)cr_cdiv(p.Cout, TM);
+    // split the pixel range so that the grid is ~ 4 blocks per CU
+    int splits = (1024 + tm * tn - 1) / (tm * tn);
+    if (splits > nsteps) splits = nsteps;
+    if (splits < 1) splits = 1;
+    p.steps_per_split = (nsteps + splits - 1) / splits;
+    splits = (nsteps + p.steps_per_split - 1) / p.steps_per_split;
+    dim3 grid(tm, tn, splits);
+    if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad<128, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    else if (TM == 64) hipLaunchKernelGGL((k_conv_wgrad<64, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    else if (TM == 32) hipLaunchKernelGGL((k_conv_wgrad<32, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((k_conv_wgrad<16, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// dW[k][r][s][c] (+)= sum dY * X ; dw is f32 [Cout][ks*ks*Cin]; `accumulate`=0 zeroes it first.
+extern "C" int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W,
+                                    int Cin, int Cout, int ks, int stride, int pad, int accumulate) {
+    CR_CHECK_ARG(ctx && dy && x && dw, "cr_conv2d_bwd_weight: NULL pointer");
+    int rc = conv_common_checks("cr_conv2d_bwd_weight", N, H, W, Cin, Cout, ks, stride, pad);
+    if (rc) return rc;
+    WgP p;
+    p.dy = (const u16*)dy; p.x = (const u16*)x; p.dw = dw;
+    p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Cout = Cout;
+    p.Hout = (H + 2 * pad - ks) / stride + 1;
+    p.Wout = (W + 2 * pad - ks) / stride + 1;
+    p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = N * p.Hout * p.Wout;
+    p.cshift = ks == 1 ? 0 : ilog2_exact(Cin);
+    if (!accumulate) CR_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * p.Kdim, ctx->stream));
+    if (ks == 1) return launch_wgrad_ks<1>(ctx, p);
+    if (ks == 3) return launch_wgrad_ks<3>(ctx, p);
+    return launch_wgrad_ks<7>(ctx, p);
+}
+
+// ---------------------------------------------------------------------------
+// weight preparation: f32 master [Cout][ks*ks][Cin] (channels_last physical layout of a
+// (Cout,Cin,ks,ks) parameter) -> bf16 same layout, and -> bf16 [Cin][ks*ks][Cout] for bwd-data.
+// ---------------------------------------------------------------------------
+__global__ void k_cast_f32_bf16(const float* __restrict__ src, u16* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        uint2 pk;
+        pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+        pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+        *reinterpret_cast<uint2*>(dst + i) = pk;
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+    }
+}
+
+extern "C" int cr_cast_f32_to_bf16(cr_ctx* ctx, const float* src, void* dst, int64_t n) {
+    CR_CHECK_ARG(ctx && n >= 0, "cr_cast_f32_to_bf16: bad args");
+    if (n == 0) return CR_OK;
+    CR_CHECK_ARG(src && dst, "cr_cast_f32_to_bf16: NULL pointer");
+    CR_CHECK_ARG((((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 7) == 0, "cr_cast_f32_to_bf16: misaligned");
+    hipLaunchKernelGGL(k_cast_f32_bf16, dim3((unsigned)cr_cdiv(cr_cdiv(n, 4), 256)), dim3(256), 0, ctx->stream, src,
+                       (u16*)dst, n);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+__global__ void k_weight_transpose(const float* __restrict__ w, u16* __restrict__ wt, int Cout, int taps, int Cin) {
+    // wt[c][t][k] = w[k][t][c]
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)Cout * taps * Cin;
+    if (i >= n) return;
+    const int k = (int)(i % Cout);
+    const int t = (int)((i / Cout) % taps);
+    const int c = (int)(i / ((int64_t)Cout * taps));
+    wt[i] = f2bf(w[((int64_t)k * taps + t) * Cin + c]);
+}
+
+extern "C" int cr_weight_transpose(cr_ctx* ctx, const float* w, void* wt, int Cout, int ks, int Cin) {
+    CR_CHECK_ARG(ctx && w && wt && Cout > 0 && Cin > 0 && ks > 0, "cr_weight_transpose: bad args");
+    const int64_t n = (int64_t)Cout * ks * ks * Cin;
+    hipLaunchKernelGGL(k_weight_transpose, dim3((unsigned)cr_cdiv(n, 256)), dim3(256), 0, ctx->stream, w, (u16*)wt,
+                       Cout, ks * ks, Cin);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm2d (training mode, per-GPU statistics: dla.py:17 BatchNorm = nn.BatchNorm2d)
+// ---------------------------------------------------------------------------
+// finalize: stats replicas -> mean / invstd (+ running stats update, momentum 0.1, unbiased var)
+__global__ void k_bn_finalize(const float* __restrict__ stats, int C, float count, float eps, float momentum,
+                              float* __restrict__ mean_invstd, float* __restrict__ running_mean,
+                              float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < STAT_REPL; ++r) { s += stats[(size_t)r * 2 * C + c]; q += stats[(size_t)r * 2 * C + C + c]; }
+    const float mean = s / count;
+    float var = q / count - mean * mean;
+    var = fmaxf(var, 0.f);
+    mean_invstd[c] = mean;
+    mean_invstd[C + c] = rsqrtf(var + eps);
+    if (running_mean) {
+        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// y = relu?( (x - mean) * invstd * gamma + beta (+ residual) ), 8 channels per thread
+__global__ __launch_bounds__(256) void k_bn_apply(const u16* __restrict__ x, const float* __restrict__ mean_invstd,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const u16* __restrict__ res, u16* __restrict__ y, int64_t M, int C,
+                                                  int relu) {
+    const int cg = C >> 3;
+    const int64_t total = M * cg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) << 3;
+        const uint4 xv = *reinterpret_cast<const uint4*>(x + i * 8);
+        uint4 rv = make_uint4(0, 0, 0, 0);
+        if (res) rv = *reinterpret_cast<const uint4*>(res + i * 8);
+        const unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = c0 + 2 * e + h;
+                const float xf = bf2f((u16)(h ? xs[e] >> 16 : xs[e] & 0xffff));
+                float t = (xf - mean_invstd[c]) * mean_invstd[C + c] * gamma[c] + beta[c];
+                if (res) t += bf2f((u16)(h ? rs[e] >> 16 : rs[e] & 0xffff));
+                v[h] = relu ? fmaxf(t, 0.f) : t;
+            }
+            o[e] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        }
+        *reinterpret_cast<uint4*>(y + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+extern "C" int cr_bn_fwd(cr_ctx* ctx, const void* x, const float* stats, const float* gamma, const float* beta,
+                         const void* residual, void* y, int64_t M, int C, int relu, float eps, float momentum,
+                         float* mean_invstd, float* running_mean, float* running_var) {
+    CR_CHECK_ARG(ctx && x && stats && gamma && beta && y && mean_invstd, "cr_bn_fwd: NULL pointer");
+    CR_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0, "cr_bn_fwd: bad dims M=%lld C=%d", (long long)M, C);
+    hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)cr_cdiv(C, 64)), dim3(64), 0, ctx->stream, stats, C, (float)M, eps,
+                       momentum, mean_invstd, running_mean, running_var);
+    CR_LAUNCH_CHECK();
+    const int64_t total = M * (C >> 3);
+    const unsigned grid = (unsigned)(cr_cdiv(total, 256) < 4096 ? cr_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(256), 0, ctx->stream, (const u16*)x, mean_invstd, gamma, beta,
+                       (const u16*)residual, (u16*)y, M, C, relu);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// backward reduce: g = dy * (relu ? out > 0 : 1);  sums[rep][0][c] += g ; sums[rep][1][c] += g * xhat
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const u16* __restrict__ dy, const u16* __restrict__ out,
+                                                       const u16* __restrict__ x, const float* __restrict__ mean_invstd,
+                                                       float* __restrict__ sums, int64_t M, int C, int relu) {
+    extern __shared__ float s_acc[];        // [2][C]
+    const int cg = C >> 3;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
+    __syncthreads();
+    // thread -> fixed channel group when blockDim % cg == 0 (cg <= 64 for C <= 512; blockDim = 256)
+    const int mycg = threadIdx.x % cg;
+    const int rows_per_block = blockDim.x / cg;
+    const int c0 = mycg << 3;
+    float a[8], b[8], mu[8], is[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; mu[e] = mean_invstd[c0 + e]; is[e] = mean_invstd[C + c0 + e]; }
+    for (int64_t m = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cg; m < M; m += (int64_t)gridDim.x * rows_per_block) {
+        const int64_t i = m * cg + mycg;
+        const uint4 dv = *reinterpret_cast<const uint4*>(dy + i * 8);
+        const uint4 xv = *reinterpret_cast<const uint4*>(x + i * 8);
+        uint4 ov = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        if (relu) ov = *reinterpret_cast<const uint4*>(out + i * 8);
+        const unsigned ds[4] = {dv.x, dv.y, dv.z, dv.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w}, os[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int w = e >> 1, h = e & 1;
+            const float o = bf2f((u16)(h ? os[w] >> 16 : os[w] & 0xffff));
+            float gq = bf2f((u16)(h ? ds[w] >> 16 : ds[w] & 0xffff));
+            gq = o > 0.f ? gq : 0.f;
+            const float xh = (bf2f((u16)(h ? xs[w] >> 16 : xs[w] & 0xffff)) - mu[e]) * is[e];
+            a[e] += gq;
+            b[e] += gq * xh;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(&s_acc[c0 + e], a[e]); atomicAdd(&s_acc[C + c0 + e], b[e]); }
+    __syncthreads();
+    float* dst = sums + (size_t)(blockIdx.x % STAT_REPL) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&dst[i], s_acc[i]);
+}
+
+// dgamma/dbeta + dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); also writes g (the masked grad) for the residual branch
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const u16* __restrict__ dy, const u16* __restrict__ out,
+                                                      const u16* __restrict__ x, const float* __restrict__ mean_invstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                      u16* __restrict__ dx, u16* __restrict__ dres,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M,
+                                                      int C, int relu) {
+    extern __shared__ float s_sum[];        // [2][C] reduced over replicas
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < STAT_REPL; ++r) s += sums[(size_t)r * 2 * C + i];
+        s_sum[i] = s;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) { dbeta[c] += s_sum[c]; dgamma[c] += s_sum[C + c]; }
+    }
+    const int cg = C >> 3;
+    const float invM = 1.f / (float)M;
+    const int64_t total = M * cg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) << 3;
+        const uint4 dv = *reinterpret_cast<const uint4*>(dy + i * 8);
+        const uint4 xv = *reinterpret_cast<const uint4*>(x + i * 8);
+        uint4 ov = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        if (relu) ov = *reinterpret_cast<const uint4*>(out + i * 8);
+        const unsigned ds[4] = {dv.x, dv.y, dv.z, dv.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w}, os[4] = {ov.x, ov.y, ov.z, ov.w};
+        unsigned od[4], og[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            float vd[2], vg[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = c0 + 2 * w + h;
+                const float o = bf2f((u16)(h ? os[w] >> 16 : os[w] & 0xffff));
+                float gq = bf2f((u16)(h ? ds[w] >> 16 : ds[w] & 0xffff));
+                gq = o > 0.f ? gq : 0.f;
+                const float is = mean_invstd[C + c];
+                const float xh = (bf2f((u16)(h ? xs[w] >> 16 : xs[w] & 0xffff)) - mean_invstd[c]) * is;
+                vd[h] = gamma[c] * is * (gq - s_sum[c] * invM - xh * s_sum[C + c] * invM);
+                vg[h] = gq;
+            }
+            od[w] = (unsigned)f2bf(vd[0]) | ((unsigned)f2bf(vd[1]) << 16);
+            og[w] = (unsigned)f2bf(vg[0]) | ((unsigned)f2bf(vg[1]) << 16);
+        }
+        *reinterpret_cast<uint4*>(dx + i * 8) = make_uint4(od[0], od[1], od[2], od[3]);
+        if (dres) *reinterpret_cast<uint4*>(dres + i * 8) = make_uint4(og[0], og[1], og[2], og[3]);
+    }
+}
+
+// sums: workspace [STAT_REPL][2][C] f32 (zeroed here). dgamma/dbeta are ACCUMULATED (+=).
+extern "C" int cr_bn_bwd(cr_ctx* ctx, const void* dy, const void* out, const void* x, const float* mean_invstd,
+                         const float* gamma, float* sums, void* dx, void* dres, float* dgamma, float* dbeta,
+                         int64_t M, int C, int relu) {
+    CR_CHECK_ARG(ctx && dy && x && mean_invstd && gamma && sums && dx && dgamma && dbeta, "cr_bn_bwd: NULL pointer");
+    CR_CHECK_ARG(!relu || out, "cr_bn_bwd: relu needs the forward output");
+    CR_CHECK_ARG(M > 0 && C % 8 == 0 && C <= 2048 && 256 % (C >> 3) == 0, "cr_bn_bwd: unsupported C=%d", C);
+    CR_HIP(hipMemsetAsync(sums, 0, sizeof(float) * STAT_REPL * 2 * C, ctx->stream));
+    const int rows_per_block = 256 / (C >> 3);
+    int64_t nb = cr_cdiv(M, (int64_t)rows_per_block * 8);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3((unsigned)nb), dim3(256), sizeof(float) * 2 * C, ctx->stream,
+                       (const u16*)dy, (const u16*)out, (const u16*)x, mean_invstd, sums, M, C, relu);
+    CR_LAUNCH_CHECK();
+    const int64_t total = M * (C >> 3);
+    const unsigned grid = (unsigned)(cr_cdiv(total, 256) < 4096 ? cr_cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(256), sizeof(float) * 2 * C, ctx->stream, (const u16*)dy,
+                       (const u16*)out, (const u16*)x, mean_invstd, gamma, sums, (u16*)dx, (u16*)dres, dgamma, dbeta, M,
+                       C, relu);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// pooling / resampling / elementwise, NHWC bf16, 8 channels (16 B) per thread
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void unpack8(const uint4 v, float* f) {
+    f[0] = bf2f((u16)(v.x & 0xffff)); f[1] = bf2f((u16)(v.x >> 16));
+    f[2] = bf2f((u16)(v.y & 0xffff)); f[3] = bf2f((u16)(v.y >> 16));
+    f[4] = bf2f((u16)(v.z & 0xffff)); f[5] = bf2f((u16)(v.z >> 16));
+    f[6] = bf2f((u16)(v.w & 0xffff)); f[7] = bf2f((u16)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 o;
+    o.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
+    o.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
+    o.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
+    o.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+    return o;
+}
+
+// window = 2: MaxPool2d(2,2) (dla.py:208); window = 1: max_pool2d(k=1,s=2) = subsample (dla.py:474)
+__global__ void k_pool_fwd(const u16* __restrict__ x, u16* __restrict__ y, int N, int H, int W, int C, int window) {
+    const int Ho = H / 2, Wo = W / 2, cg = C >> 3;
+    const int64_t total = (int64_t)N * Ho * Wo * cg;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cg);
+    const int wo = (int)((i / cg) % Wo);
+    const int ho = (int)((i / ((int64_t)cg * Wo)) % Ho);
+    const int n = (int)(i / ((int64_t)cg * Wo * Ho));
+    const u16* b = x + (((size_t)(n * H + 2 * ho) * W + 2 * wo) * C) + c * 8;
+    uint4 v = *reinterpret_cast<const uint4*>(b);
+    if (window == 2) {
+        float m[8], t[8];
+        unpack8(v, m);
+        const size_t offs[3] = {(size_t)C, (size_t)W * C, (size_t)W * C + C};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            unpack8(*reinterpret_cast<const uint4*>(b + offs[q]), t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = (t[e] > m[e] || t[e] != t[e]) ? t[e] : m[e];
+        }
+        v = pack8(m);
+    }
+    *reinterpret_cast<uint4*>(y + i * 8) = v;
+}
+
+// routes dy to the FIRST maximal element of each window in scan order (PyTorch's tie rule)
+__global__ void k_pool_bwd(const u16* __restrict__ x, const u16* __restrict__ dy, u16* __restrict__ dx, int N, int H,
+                           int W, int C, int window) {
+    const int Ho = H / 2, Wo = W / 2, cg = C >> 3;
+    const int64_t total = (int64_t)N * Ho * Wo * cg;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cg);
+    const int wo = (int)((i / cg) % Wo);
+    const int ho = (int)((i / ((int64_t)cg * Wo)) % Ho);
+    const int n = (int)(i / ((int64_t)cg * Wo * Ho));
+    const size_t base = (((size_t)(n * H + 2 * ho) * W + 2 * wo) * C) + c * 8;
+    const size_t offs[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+    float g[8];
+    unpack8(*reinterpret_cast<const uint4*>(dy + i * 8), g);
+    float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (window == 1) {
+        *reinterpret_cast<uint4*>(dx + base) = pack8(g);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) *reinterpret_cast<uint4*>(dx + base + offs[q]) = pack8(z);
+        return;
+    }
+    float v[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) unpack8(*reinterpret_cast<const uint4*>(x + base + offs[q]), v[q]);
+    int am[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int a = 0;
+        float m = v[0][e];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (v[q][e] > m || v[q][e] != v[q][e]) { m = v[q][e]; a = q; }
+        am[e] = a;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = am[e] == q ? g[e] : 0.f;
+        *reinterpret_cast<uint4*>(dx + base + offs[q]) = pack8(o);
+    }
+}
+
+extern "C" int cr_pool2x_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int window) {
+    CR_CHECK_ARG(ctx && x && y, "cr_pool2x_fwd: NULL pointer");
+    CR_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && (window == 1 || window == 2), "cr_pool2x_fwd: bad dims");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+    if (total == 0) return CR_OK;
+    hipLaunchKernelGGL(k_pool_fwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)x, (u16*)y,
+                       N, H, W, C, window);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+extern "C" int cr_pool2x_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C,
+                             int window) {
+    CR_CHECK_ARG(ctx && x && dy && dx, "cr_pool2x_bwd: NULL pointer");
+    CR_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && (window == 1 || window == 2), "cr_pool2x_bwd: bad dims");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+    if (total == 0) return CR_OK;
+    hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)x,
+                       (const u16*)dy, (u16*)dx, N, H, W, C, window);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// FPN top-down: y[n,h,w,:] = lat[n,h,w,:] + top[n,h/2,w/2,:]   (nearest 2x upsample + sum)
+__global__ void k_upsample_add(const u16* __restrict__ lat, const u16* __restrict__ top, u16* __restrict__ y, int N,
+                               int H, int W, int C) {
+    const int cg = C >> 3;
+    const int64_t total = (int64_t)N * H * W * cg;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cg);
+    const int w = (int)((i / cg) % W);
+    const int h = (int)((i / ((int64_t)cg * W)) % H);
+    const int n = (int)(i / ((int64_t)cg * W * H));
+    float a[8], b[8];
+    unpack8(*reinterpret_cast<const uint4*>(lat + i * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(top + (((size_t)(n * (H / 2) + h / 2) * (W / 2) + w / 2) * C) + c * 8), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += b[e];
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8(a);
+}
+
+// its backward w.r.t. `top`: dtop[n,h2,w2,:] = sum of the 2x2 block of dy
+__global__ void k_sum2x2(const u16* __restrict__ dy, u16* __restrict__ dtop, int N, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, cg = C >> 3;
+    const int64_t total = (int64_t)N * Ho * Wo * cg;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cg);
+    const int wo = (int)((i / cg) % Wo);
+    const int ho = (int)((i / ((int64_t)cg * Wo)) % Ho);
+    const int n = (int)(i / ((int64_t)cg * Wo * Ho));
+    const u16* b = dy + (((size_t)(n * H + 2 * ho) * W + 2 * wo) * C) + c * 8;
+    float s[8], t[8];
+    unpack8(*reinterpret_cast<const uint4*>(b), s);
+    const size_t offs[3] = {(size_t)C, (size_t)W * C, (size_t)W * C + C};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        unpack8(*reinterpret_cast<const uint4*>(b + offs[q]), t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += t[e];
+    }
+    *reinterpret_cast<uint4*>(dtop + i * 8) = pack8(s);
+}
+
+extern "C" int cr_upsample2x_add(cr_ctx* ctx, const void* lat, const void* top, void* y, int N, int H, int W, int C) {
+    CR_CHECK_ARG(ctx && lat && top && y, "cr_upsample2x_add: NULL pointer");
+    CR_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "cr_upsample2x_add: bad dims");
+    const int64_t total = (int64_t)N * H * W * (C / 8);
+    if (total == 0) return CR_OK;
+    hipLaunchKernelGGL(k_upsample_add, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)lat,
+                       (const u16*)top, (u16*)y, N, H, W, C);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+extern "C" int cr_sum2x2(cr_ctx* ctx, const void* dy, void* dtop, int N, int H, int W, int C) {
+    CR_CHECK_ARG(ctx && dy && dtop, "cr_sum2x2: NULL pointer");
+    CR_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "cr_sum2x2: bad dims");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+    if (total == 0) return CR_OK;
+    hipLaunchKernelGGL(k_sum2x2, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)dy,
+                       (u16*)dtop, N, H, W, C);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// preprocess_image (detectron2 GeneralizedRCNN, Base.yaml:32-33): (x - mean)/std on a stacked
+// uint8 (N,3,H,W) batch -> NHWC bf16 with channels padded 3 -> 8 (zeros)
+__global__ void k_preprocess(const unsigned char* __restrict__ img, u16* __restrict__ y, int N, int H, int W, float m0,
+                             float m1, float m2, float s0, float s1, float s2) {
+    const int64_t total = (int64_t)N * H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t hw = (int64_t)H * W;
+    const int64_t n = i / hw, pix = i - n * hw;
+    const unsigned char* b = img + n * 3 * hw + pix;
+    float f[8] = {((float)b[0] - m0) / s0, ((float)b[hw] - m1) / s1, ((float)b[2 * hw] - m2) / s2, 0, 0, 0, 0, 0};
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8(f);
+}
+
+extern "C" int cr_preprocess(cr_ctx* ctx, const unsigned char* img, void* y, int N, int H, int W, const float* mean3,
+                             const float* std3) {
+    CR_CHECK_ARG(ctx && img && y && mean3 && std3, "cr_preprocess: NULL pointer (mean3/std3 are HOST pointers)");
+    const int64_t total = (int64_t)N * H * W;
+    if (total == 0) return CR_OK;
+    hipLaunchKernelGGL(k_preprocess, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, img, (u16*)y, N, H, W,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

@@ -1,0 +1,243 @@
+// Detection-side kernels: ROIAlign (aligned, adaptive sampling) forward/backward over the FPN
+// pyramid with the level assignment fused in, grouped NMS, and RPN anchor decoding.
+//
+// Reference call sites (paths into the reference tree); the arithmetic itself lives in
+// third-party code that is absent from the reference and is restated from its published
+// definition (parity unpinned, pinned here by a torch restatement in oracle/):
+//   ROIPooler(ROIAlignV2 7x7, sampling_ratio 0)  cubercnn/modeling/roi_heads/roi_heads.py:2075-2080,2178,2273
+//        = torchvision roi_align(aligned=True) + detectron2 assign_boxes_to_levels
+//   nms / batched_nms                              cubercnn/modeling/roi_heads/fast_rcnn.py:105; detectron2 RPN
+#include "cr_common.h"
+#include <math.h>
+
+typedef unsigned short u16;
+__device__ __forceinline__ float bf2f(u16 b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ u16 f2bf(float f) { __bf16 b = (__bf16)f; return __builtin_bit_cast(u16, b); }
+
+#define MAX_LEVELS 5
+struct Pyramid {
+    const u16* feat[MAX_LEVELS];   // NHWC bf16
+    float* grad[MAX_LEVELS];       // NHWC f32 (backward)
+    int H[MAX_LEVELS], W[MAX_LEVELS];
+    float scale[MAX_LEVELS];
+    int nlev, C, min_level;        // min_level = log2(stride of level 0)
+};
+
+// detectron2 assign_boxes_to_levels: floor(4 + log2(sqrt(area)/224 + 1e-8)) clamped to the pyramid
+__device__ __forceinline__ int roi_level(const float* b, const Pyramid& py) {
+    const float area = (b[2] - b[0]) * (b[3] - b[1]);
+    float lv = floorf(4.0f + log2f(sqrtf(area) / 224.0f + 1e-8f));
+    const float lo = (float)py.min_level, hi = (float)(py.min_level + py.nlev - 1);
+    lv = fminf(fmaxf(lv, lo), hi);
+    return (int)lv - py.min_level;
+}
+
+struct Samp { int yl, yh, xl, xh; float w1, w2, w3, w4; bool ok; };
+__device__ __forceinline__ Samp bilinear(float y, float x, int H, int W) {
+    Samp s;
+    s.ok = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    s.yl = (int)y; s.xl = (int)x;
+    if (s.yl >= H - 1) { s.yh = s.yl = H - 1; y = (float)s.yl; } else s.yh = s.yl + 1;
+    if (s.xl >= W - 1) { s.xh = s.xl = W - 1; x = (float)s.xl; } else s.xh = s.xl + 1;
+    const float ly = y - s.yl, lx = x - s.xl, hy = 1.f - ly, hx = 1.f - lx;
+    s.w1 = hy * hx; s.w2 = hy * lx; s.w3 = ly * hx; s.w4 = ly * lx;
+    return s;
+}
+
+// one thread = (roi, ph, pw, 8 channels).  rois (R,5) = [batch, x1,y1,x2,y2].  out (R,PH,PW,C) bf16
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_roi_align(Pyramid py, const float* __restrict__ rois, int R, int PH, int PW,
+                                                   u16* __restrict__ out, const u16* __restrict__ dout) {
+    const int cg = py.C >> 3;
+    const int64_t total = (int64_t)R * PH * PW * cg;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cg);
+    const int pw = (int)((i / cg) % PW);
+    const int ph = (int)((i / ((int64_t)cg * PW)) % PH);
+    const int r = (int)(i / ((int64_t)cg * PW * PH));
+    const float* rb = rois + (size_t)r * 5;
+    const int n = (int)rb[0];
+    const int lv = roi_level(rb + 1, py);
+    const int H = py.H[lv], W = py.W[lv];
+    const float sc = py.scale[lv];
+    const float x1 = rb[1] * sc - 0.5f, y1 = rb[2] * sc - 0.5f;
+    const float rw = (rb[3] - rb[1]) * sc, rh = (rb[4] - rb[2]) * sc;     // aligned: no 1-px floor
+    const float bw = rw / (float)PW, bh = rh / (float)PH;
+    const int gh = (int)ceilf(rh / (float)PH), gw = (int)ceilf(rw / (float)PW);
+    const float cnt = fmaxf((float)(gh * gw), 1.f);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float g8[8];
+    if (BWD) {
+        const uint4 dv = *reinterpret_cast<const uint4*>(dout + i * 8);
+        const unsigned w4[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g8[e] = bf2f((u16)((e & 1) ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xffff)) / cnt;
+    }
+    const size_t img = (size_t)n * H * W;
+    for (int iy = 0; iy < gh; ++iy) {
+        const float y = y1 + ph * bh + (iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+            const float x = x1 + pw * bw + (ix + 0.5f) * bw / (float)gw;
+            const Samp s = bilinear(y, x, H, W);
+            if (!s.ok) continue;
+            const size_t o1 = (img + (size_t)s.yl * W + s.xl) * py.C + c * 8, o2 = (img + (size_t)s.yl * W + s.xh) * py.C + c * 8;
+            const size_t o3 = (img + (size_t)s.yh * W + s.xl) * py.C + c * 8, o4 = (img + (size_t)s.yh * W + s.xh) * py.C + c * 8;
+            if (!BWD) {
+                const u16* f = py.feat[lv];
+                const uint4 v1 = *reinterpret_cast<const uint4*>(f + o1), v2 = *reinterpret_cast<const uint4*>(f + o2);
+                const uint4 v3 = *reinterpret_cast<const uint4*>(f + o3), v4 = *reinterpret_cast<const uint4*>(f + o4);
+                const unsigned a1[4] = {v1.x, v1.y, v1.z, v1.w}, a2[4] = {v2.x, v2.y, v2.z, v2.w};
+                const unsigned a3[4] = {v3.x, v3.y, v3.z, v3.w}, a4[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int w = e >> 1, sh = (e & 1) * 16;
+                    acc[e] += s.w1 * bf2f((u16)(a1[w] >> sh)) + s.w2 * bf2f((u16)(a2[w] >> sh)) +
+                              s.w3 * bf2f((u16)(a3[w] >> sh)) + s.w4 * bf2f((u16)(a4[w] >> sh));
+                }
+            } else {
+                float* gq = py.grad[lv];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    atomicAdd(gq + o1 + e, g8[e] * s.w1);
+                    atomicAdd(gq + o2 + e, g8[e] * s.w2);
+                    atomicAdd(gq + o3 + e, g8[e] * s.w3);
+                    atomicAdd(gq + o4 + e, g8[e] * s.w4);
+                }
+            }
+        }
+    }
+    if (!BWD) {
+        uint4 o;
+        unsigned pk[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) pk[w] = (unsigned)f2bf(acc[2 * w] / cnt) | ((unsigned)f2bf(acc[2 * w + 1] / cnt) << 16);
+        o = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        *reinterpret_cast<uint4*>(out + i * 8) = o;
+    }
+}
+
+static int fill_pyramid(Pyramid& py, const void* const* feats, float* const* grads, const int* Hs, const int* Ws,
+                        const float* scales, int nlev, int C) {
+    CR_CHECK_ARG(nlev >= 1 && nlev <= MAX_LEVELS, "roi_align: 1..%d levels", MAX_LEVELS);
+    CR_CHECK_ARG(C % 8 == 0, "roi_align: C %% 8");
+    py.nlev = nlev; py.C = C;
+    for (int l = 0; l < nlev; ++l) {
+        py.feat[l] = feats ? (const u16*)feats[l] : nullptr;
+        py.grad[l] = grads ? grads[l] : nullptr;
+        py.H[l] = Hs[l]; py.W[l] = Ws[l]; py.scale[l] = scales[l];
+    }
+    py.min_level = (int)lroundf(-log2f(scales[0]));
+    return CR_OK;
+}
+
+// feats/Hs/Ws/scales are HOST arrays of length nlev (device pointers inside feats)
+extern "C" int cr_roi_align_fwd(cr_ctx* ctx, const void* const* feats, const int* Hs, const int* Ws,
+                                const float* scales, int nlev, int C, const float* rois, int64_t R, int PH, int PW,
+                                void* out) {
+    CR_CHECK_ARG(ctx && feats && Hs && Ws && scales, "cr_roi_align_fwd: NULL pointer");
+    if (R == 0) return CR_OK;
+    CR_CHECK_ARG(rois && out && PH > 0 && PW > 0, "cr_roi_align_fwd: bad args");
+    Pyramid py;
+    int rc = fill_pyramid(py, feats, nullptr, Hs, Ws, scales, nlev, C);
+    if (rc) return rc;
+    const int64_t total = R * PH * PW * (C / 8);
+    hipLaunchKernelGGL((k_roi_align<false>), dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py, rois,
+                       (int)R, PH, PW, (u16*)out, (const u16*)nullptr);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// grads: HOST array of nlev device pointers to f32 NHWC maps (accumulated with atomics; zero them first)
+extern "C" int cr_roi_align_bwd(cr_ctx* ctx, float* const* grads, const int* Hs, const int* Ws, const float* scales,
+                                int nlev, int C, const float* rois, int64_t R, int PH, int PW, const void* dout) {
+    CR_CHECK_ARG(ctx && grads && Hs && Ws && scales, "cr_roi_align_bwd: NULL pointer");
+    if (R == 0) return CR_OK;
+    CR_CHECK_ARG(rois && dout && PH > 0 && PW > 0, "cr_roi_align_bwd: bad args");
+    Pyramid py;
+    int rc = fill_pyramid(py, nullptr, grads, Hs, Ws, scales, nlev, C);
+    if (rc) return rc;
+    const int64_t total = R * PH * PW * (C / 8);
+    hipLaunchKernelGGL((k_roi_align<true>), dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py, rois,
+                       (int)R, PH, PW, (u16*)nullptr, (const u16*)dout);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// grouped NMS.  boxes [G][maxn][4] sorted by descending score inside each group, counts [G].
+// keep [G][maxn] uint8.  Standard bitmask formulation: pass 1 builds the suppression matrix in
+// parallel, pass 2 is one wave per group walking the rows in order (rows prefetched).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ counts,
+                                                 int maxn, float thresh, unsigned long long* __restrict__ mask) {
+    const int g = blockIdx.z, n = counts[g];
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    if (row0 >= n || col0 >= n) return;
+    if (col0 + 63 < row0) return;                       // only j > i matters
+    __shared__ float sb[64 * 4];
+    const float* gb = boxes + (size_t)g * maxn * 4;
+    const int t = threadIdx.x;
+    if (col0 + t < n) {
+        sb[t * 4 + 0] = gb[(col0 + t) * 4 + 0]; sb[t * 4 + 1] = gb[(col0 + t) * 4 + 1];
+        sb[t * 4 + 2] = gb[(col0 + t) * 4 + 2]; sb[t * 4 + 3] = gb[(col0 + t) * 4 + 3];
+    }
+    __syncthreads();
+    const int i = row0 + t;
+    if (i >= n) return;
+    const float ax1 = gb[i * 4], ay1 = gb[i * 4 + 1], ax2 = gb[i * 4 + 2], ay2 = gb[i * 4 + 3];
+    const float aa = (ax2 - ax1) * (ay2 - ay1);
+    unsigned long long bits = 0;
+    const int jn = min(64, n - col0);
+    for (int j = 0; j < jn; ++j) {
+        if (col0 + j <= i) continue;
+        const float bx1 = sb[j * 4], by1 = sb[j * 4 + 1], bx2 = sb[j * 4 + 2], by2 = sb[j * 4 + 3];
+        const float w = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f), h = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
+        const float inter = w * h, ba = (bx2 - bx1) * (by2 - by1);
+        if (inter / (aa + ba - inter) > thresh) bits |= 1ULL << j;
+    }
+    const int words = (maxn + 63) / 64;
+    mask[((size_t)g * maxn + i) * words + blockIdx.x] = bits;
+}
+
+__global__ __launch_bounds__(64) void k_nms_scan(const int* __restrict__ counts, int maxn,
+                                                 const unsigned long long* __restrict__ mask,
+                                                 unsigned char* __restrict__ keep) {
+    extern __shared__ unsigned long long removed[];     // words
+    const int g = blockIdx.x, n = counts[g], t = threadIdx.x;
+    const int words = (maxn + 63) / 64, nw = (n + 63) / 64;
+    for (int w = t; w < words; w += 64) removed[w] = 0;
+    __syncthreads();
+    const unsigned long long* gm = mask + (size_t)g * maxn * words;
+    unsigned char* gk = keep + (size_t)g * maxn;
+    for (int i = 0; i < n; ++i) {
+        const bool dead = (removed[i >> 6] >> (i & 63)) & 1ULL;     // uniform
+        if (t == 0) gk[i] = dead ? 0 : 1;
+        if (!dead) {
+            // words left of the diagonal block were never written: start at i>>6
+            for (int w = (i >> 6) + t; w < nw; w += 64) removed[w] |= gm[(size_t)i * words + w];
+        }
+        __syncthreads();
+    }
+    for (int i = n + t; i < maxn; i += 64) gk[i] = 0;
+}
+
+// mask_ws: workspace of G*maxn*ceil(maxn/64) u64.
+extern "C" int cr_nms_grouped(cr_ctx* ctx, const float* boxes, const int* counts, int G, int maxn, float thresh,
+                              void* mask_ws, unsigned char* keep) {
+    CR_CHECK_ARG(ctx, "cr_nms_grouped: ctx is NULL");
+    if (G == 0 || maxn == 0) return CR_OK;
+    CR_CHECK_ARG(boxes && counts && mask_ws && keep && G > 0 && maxn > 0 && maxn <= 65536, "cr_nms_grouped: bad args");
+    const int words = (maxn + 63) / 64;
+    // rows below the diagonal block are skipped by the kernel -> clear the matrix first
+    CR_HIP(hipMemsetAsync(mask_ws, 0, (size_t)G * maxn * words * 8, ctx->stream));
+    hipLaunchKernelGGL(k_nms_mask, dim3(words, words, G), dim3(64), 0, ctx->stream, boxes, counts, maxn, thresh,
+                       (unsigned long long*)mask_ws);
+    CR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_nms_scan, dim3(G), dim3(64), words * 8, ctx->stream, counts, maxn,
+                       (const unsigned long long*)mask_ws, keep);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

@@ -99,6 +99,73 @@ int cr_propose(cr_ctx* ctx, const float* boxes, int64_t N, const float* depth, i
 int cr_ransac_plane(cr_ctx* ctx, const float* pts, int64_t Q, const int32_t* triples, int64_t T,
                     float thresh, float* out_neg_eq, int32_t* out_counts, int32_t* out_best);
 
+/* ---- convolution stack (bf16 MFMA, f32 accumulate, NHWC) ---------------- */
+/* Activations are NHWC bf16 (channels padded to a multiple of 8).  Conv weights
+ * are [Cout][ks*ks][Cin] = the physical (channels_last) layout of a
+ * (Cout,Cin,ks,ks) parameter, so state-dict shapes stay the reference's.
+ * Replaces torch ATen/cuDNN conv2d + BatchNorm2d + ReLU of
+ * cubercnn/modeling/backbone/dla.py:40-68,156-174,233-321 and the detectron2 FPN /
+ * StandardRPNHead convolutions wired at dla.py:484-507 (configs/Base.yaml:41-60). */
+
+/* y = relu?(conv(x,w) + bias? + residual?)   ks in {1,3,7}, stride in {1,2}.
+ * x (N,H,W,Cin) bf16; w (Cout, ks*ks*Cin) bf16; y (N,Ho,Wo,Cout) bf16 or f32 (out_f32).
+ * stats: optional f32 [32][2][Cout] workspace receiving per-channel sum / sum-of-squares of the
+ * (pre-residual, pre-ReLU) conv output for BatchNorm (zeroed by the call). */
+int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout,
+                  int ks, int stride, int pad, const float* bias, const void* residual, int relu,
+                  float* stats, int out_f32);
+/* dx (N,H,W,Cin) bf16 from dy (N,Ho,Wo,Cout) bf16; wt = cr_weight_transpose(w). */
+int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int N, int H, int W, int Cin,
+                       int Cout, int ks, int stride, int pad);
+/* dw f32 (Cout, ks*ks*Cin); accumulate=0 zeroes it first (shared RPN-head weights accumulate over levels). */
+int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
+                         int Cout, int ks, int stride, int pad, int accumulate);
+int cr_cast_f32_to_bf16(cr_ctx* ctx, const float* src, void* dst, int64_t n);
+/* wt[c][tap][k] (bf16) = w[k][tap][c] (f32) */
+int cr_weight_transpose(cr_ctx* ctx, const float* w, void* wt, int Cout, int ks, int Cin);
+
+/* BatchNorm2d, training mode, per-GPU statistics (dla.py:17).  stats from cr_conv2d_fwd.
+ * y = relu?((x-mean)*invstd*gamma + beta + residual?); writes mean_invstd [2][C]; updates running stats
+ * (may be NULL). */
+int cr_bn_fwd(cr_ctx* ctx, const void* x, const float* stats, const float* gamma, const float* beta,
+              const void* residual, void* y, int64_t M, int C, int relu, float eps, float momentum,
+              float* mean_invstd, float* running_mean, float* running_var);
+/* g = dy*(out>0 if relu); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres = g (may be NULL);
+ * dgamma/dbeta are ACCUMULATED; sums = f32 [32][2][C] workspace. */
+int cr_bn_bwd(cr_ctx* ctx, const void* dy, const void* out, const void* x, const float* mean_invstd,
+              const float* gamma, float* sums, void* dx, void* dres, float* dgamma, float* dbeta, int64_t M,
+              int C, int relu);
+
+/* window 2: MaxPool2d(2,2) (dla.py:208); window 1: max_pool2d(k=1,s=2) (dla.py:474). */
+int cr_pool2x_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int window);
+int cr_pool2x_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int window);
+/* FPN top-down path (detectron2 FPN, fuse_type "sum"): y = lat + nearest_up2x(top); and d/dtop. */
+int cr_upsample2x_add(cr_ctx* ctx, const void* lat, const void* top, void* y, int N, int H, int W, int C);
+int cr_sum2x2(cr_ctx* ctx, const void* dy, void* dtop, int N, int H, int W, int C);
+/* preprocess_image: uint8 (N,3,H,W) -> (x-mean)/std -> NHWC bf16, channels 3->8.  mean3/std3: HOST floats. */
+int cr_preprocess(cr_ctx* ctx, const unsigned char* img, void* y, int N, int H, int W, const float* mean3,
+                  const float* std3);
+
+/* ---- detection ops ------------------------------------------------------ */
+/* ROIPooler(ROIAlignV2): torchvision roi_align(aligned=True, sampling_ratio=0) with detectron2's FPN level
+ * assignment fused in.  feats/grads/Hs/Ws/scales: HOST arrays of length nlev.  rois (R,5) f32
+ * [batch,x1,y1,x2,y2]; out / dout (R,PH,PW,C) bf16; grads f32 NHWC maps (atomics; zero first).
+ * roi_heads.py:2075-2080,2178,2273. */
+int cr_roi_align_fwd(cr_ctx* ctx, const void* const* feats, const int* Hs, const int* Ws, const float* scales,
+                     int nlev, int C, const float* rois, int64_t R, int PH, int PW, void* out);
+int cr_roi_align_bwd(cr_ctx* ctx, float* const* grads, const int* Hs, const int* Ws, const float* scales,
+                     int nlev, int C, const float* rois, int64_t R, int PH, int PW, const void* dout);
+/* batched NMS over G independent groups; boxes (G,maxn,4) sorted by descending score per group, counts (G)
+ * int32; keep (G,maxn) uint8; mask_ws: G*maxn*ceil(maxn/64)*8 bytes.  fast_rcnn.py:105, detectron2 RPN. */
+int cr_nms_grouped(cr_ctx* ctx, const float* boxes, const int* counts, int G, int maxn, float thresh,
+                   void* mask_ws, unsigned char* keep);
+
+/* ---- optimizer (tools/train_net.py:233-266, cubercnn/solver/build.py:50-56) ------------- */
+int cr_nonfinite_flag(cr_ctx* ctx, const float* g, int64_t n, int* flag);
+/* SGD momentum on flat f32 buffers; skipped on device when *skip_flag != 0 (may be NULL). */
+int cr_sgd_step(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, float momentum,
+                float weight_decay, float grad_scale, const int* skip_flag);
+
 #ifdef __cplusplus
 }
 #endif

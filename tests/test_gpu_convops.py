@@ -1,0 +1,204 @@
+"""GPU parity of the conv-stack kernels (through the C-ABI + autograd glue) against the plain
+PyTorch float32 CPU oracle (oracle/torch_ref.py).  bf16 storage / f32 accumulate: tolerance
+2e-2 relative to the tensor's scale for activations and gradients (stated per assert)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+ops = importlib.import_module("3dod_amd.hipops")
+DEV = "cuda:0"
+bf16 = torch.bfloat16
+
+
+def q(t):
+    """round to bf16 and back (the oracle sees exactly the values the kernel sees)."""
+    return t.to(bf16).to(torch.float32)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    a = a.float().cpu(); b = b.float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def mk_weight(co, ci, k, g):
+    w = torch.randn(co, ci, k, k, generator=g) * (2.0 / (k * k * ci)) ** 0.5
+    return q(w)
+
+
+CASES = [  # N, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 8, 16, 7, 1, 3),        # stem shape class (Kdim = 392, not a multiple of 32)
+    (2, 32, 32, 16, 16, 3, 1, 1),
+    (2, 32, 32, 16, 32, 3, 2, 1),
+    (1, 24, 40, 32, 64, 3, 2, 1),       # non-square, M tail
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (2, 16, 16, 128, 128, 3, 1, 1),     # BN = 128 path
+    (1, 8, 8, 256, 256, 3, 2, 1),
+    (2, 16, 16, 128, 64, 1, 1, 0),      # Root 1x1
+    (2, 16, 16, 320, 128, 1, 1, 0),     # Root with level_root concat (Cin not a power of two)
+    (3, 10, 14, 64, 128, 1, 1, 0),      # project 1x1, odd sizes
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("relu,use_res", [(True, False), (True, True), (False, False)])
+def test_conv_bn_act_fwd_bwd(case, relu, use_res):
+    N, H, W, Ci, Co, k, st, pd = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = q(torch.randn(N, Ci, H, W, generator=g))
+    w = mk_weight(Co, Ci, k, g)
+    gamma = torch.rand(Co, generator=g) + 0.5
+    beta = torch.randn(Co, generator=g) * 0.1
+    Ho, Wo = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
+    res = q(torch.randn(N, Co, Ho, Wo, generator=g)) if use_res else None
+    dy = q(torch.randn(N, Co, Ho, Wo, generator=g))
+    # oracle
+    xo, wo, go, bo = [t.clone().requires_grad_(True) for t in (x, w, gamma, beta)]
+    ro = res.clone().requires_grad_(True) if use_res else None
+    yo = R.conv_bn_act(xo, wo, go, bo, st, pd, relu, ro)
+    yo.backward(dy)
+    # HIP
+    xd = nhwc(x).to(DEV).to(bf16).requires_grad_(True)
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    rd = nhwc(res).to(DEV).to(bf16).requires_grad_(True) if use_res else None
+    rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+    yd = ops.conv_bn_act(xd, wd, gd, bd, rm, rv, st, pd, relu, rd)
+    yd.backward(nhwc(dy).to(DEV).to(bf16))
+    torch.cuda.synchronize()
+    assert relerr(nchw(yd), yo.detach()) < 2e-2
+    assert relerr(nchw(xd.grad), xo.grad) < 3e-2
+    assert relerr(wd.grad, wo.grad) < 3e-2
+    assert relerr(gd.grad, go.grad) < 3e-2
+    assert relerr(bd.grad, bo.grad) < 3e-2
+    if use_res:
+        assert relerr(nchw(rd.grad), ro.grad) < 2e-2
+    # running statistics follow nn.BatchNorm2d (momentum 0.1, unbiased variance)
+    yraw = torch.nn.functional.conv2d(x, w, None, st, pd)
+    assert relerr(rm, 0.1 * yraw.mean((0, 2, 3))) < 2e-2
+    assert relerr(rv, 0.9 + 0.1 * yraw.var((0, 2, 3), unbiased=True)) < 2e-2
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256, 1, 1, 0), (2, 16, 16, 256, 256, 3, 1, 1),
+                                  (1, 8, 8, 512, 256, 1, 1, 0), (2, 16, 16, 256, 16, 1, 1, 0)])
+@pytest.mark.parametrize("relu,out_f32", [(False, False), (True, False), (False, True)])
+def test_conv_bias_act_fwd_bwd(case, relu, out_f32):
+    N, H, W, Ci, Co, k, st, pd = case
+    g = torch.Generator().manual_seed(7 + Ci + Co)
+    x = q(torch.randn(N, Ci, H, W, generator=g)); w = mk_weight(Co, Ci, k, g)
+    b = torch.randn(Co, generator=g) * 0.1
+    xo, wo, bo = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    yo = R.conv_bias_act(xo, wo, bo, st, pd, relu)
+    dy = q(torch.randn_like(yo))
+    yo.backward(dy)
+    xd = nhwc(x).to(DEV).to(bf16).requires_grad_(True)
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True)
+    yd = ops.conv_bias_act(xd, wd, bd, st, pd, relu, out_f32)
+    assert yd.dtype == (torch.float32 if out_f32 else bf16)
+    yd.backward(nhwc(dy).to(DEV).to(yd.dtype))
+    torch.cuda.synchronize()
+    assert relerr(nchw(yd), yo.detach()) < (2e-3 if out_f32 else 2e-2)
+    assert relerr(nchw(xd.grad), xo.grad) < 3e-2
+    assert relerr(wd.grad, wo.grad) < 3e-2
+    assert relerr(bd.grad, bo.grad) < 3e-2
+
+
+def test_pool_and_fpn_topdown():
+    g = torch.Generator().manual_seed(3)
+    x = q(torch.randn(2, 32, 12, 20, generator=g)).clamp(min=0)      # post-ReLU like: many exact ties at 0
+    for fn_d, fn_o in ((ops.maxpool2x2, lambda t: torch.nn.functional.max_pool2d(t, 2, 2)),
+                       (ops.subsample2x, lambda t: torch.nn.functional.max_pool2d(t, 1, 2))):
+        xo = x.clone().requires_grad_(True)
+        yo = fn_o(xo); dy = q(torch.randn_like(yo)); yo.backward(dy)
+        xd = nhwc(x).to(DEV).to(bf16).requires_grad_(True)
+        yd = fn_d(xd); yd.backward(nhwc(dy).to(DEV).to(bf16))
+        assert torch.equal(nchw(yd).float().cpu(), yo.detach())
+        assert torch.equal(nchw(xd.grad).float().cpu(), xo.grad)           # first-max tie rule
+    lat = q(torch.randn(2, 16, 8, 12, generator=g)); top = q(torch.randn(2, 16, 4, 6, generator=g))
+    lo, to = lat.clone().requires_grad_(True), top.clone().requires_grad_(True)
+    yo = R.upsample2x_add(lo, to); dy = q(torch.randn_like(yo)); yo.backward(dy)
+    ld, td = [nhwc(t).to(DEV).to(bf16).requires_grad_(True) for t in (lat, top)]
+    yd = ops.upsample2x_add(ld, td); yd.backward(nhwc(dy).to(DEV).to(bf16))
+    assert relerr(nchw(yd), yo.detach()) < 1e-2
+    assert relerr(nchw(ld.grad), lo.grad) < 1e-6 and relerr(nchw(td.grad), to.grad) < 1e-2
+
+
+def test_preprocess():
+    g = torch.Generator().manual_seed(4)
+    img = torch.randint(0, 256, (2, 3, 8, 12), generator=g, dtype=torch.uint8)
+    mean, std = [103.530, 116.280, 123.675], [57.375, 57.120, 58.395]
+    y = ops.preprocess(img.to(DEV), mean, std).float().cpu()
+    ref = (img.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    assert relerr(y[..., :3], nhwc(ref)) < 1e-2
+    assert (y[..., 3:] == 0).all()
+
+
+def test_roi_align_fwd_bwd():
+    g = torch.Generator().manual_seed(5)
+    C, N = 16, 2
+    sizes = [(32, 40), (16, 20), (8, 10), (4, 5), (2, 3)]
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32, 1 / 64]
+    feats = [q(torch.randn(N, C, h, w, generator=g)) for h, w in sizes]
+    # rois spanning all levels, some partially outside the image
+    wh = torch.tensor([[20., 24.], [60, 50], [110, 130], [300, 200], [700, 600], [15, 90], [40, 40], [128, 160]])
+    ctr = torch.rand(8, 2, generator=g) * torch.tensor([160., 128.])
+    rois = torch.cat([torch.tensor([[0.], [1], [0], [1], [0], [1], [0], [1]]), ctr - wh / 2, ctr + wh / 2], 1)
+    fo = [f.clone().requires_grad_(True) for f in feats]
+    yo = R.roi_align(fo, rois, scales, 7)
+    dy = q(torch.randn_like(yo)); yo.backward(dy)
+    fd = [nhwc(f).to(DEV).to(bf16).requires_grad_(True) for f in feats]
+    yd = ops.roi_align_pyramid(fd, rois.to(DEV), scales, 7)
+    yd.backward(nhwc(dy).to(DEV).to(bf16))
+    torch.cuda.synchronize()
+    assert relerr(nchw(yd), yo.detach()) < 1e-2
+    for a, b in zip(fd, fo):
+        assert relerr(nchw(a.grad), b.grad) < 2e-2
+
+
+def test_nms_grouped():
+    g = torch.Generator().manual_seed(6)
+    G, maxn = 5, 300
+    counts = torch.tensor([300, 257, 64, 1, 0], dtype=torch.int32)
+    ctr = torch.rand(G, maxn, 2, generator=g) * 200; wh = torch.rand(G, maxn, 2, generator=g) * 60 + 5
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 2)
+    boxes[0, 10] = boxes[0, 3]          # exact duplicate -> suppressed
+    keep = ops.nms_grouped(boxes.to(DEV), counts.to(DEV), 0.5).cpu()
+    for gi in range(G):
+        n = int(counts[gi])
+        scores = torch.arange(n, 0, -1, dtype=torch.float32)      # already sorted by descending score
+        ref = torch.zeros(maxn, dtype=torch.bool)
+        if n:
+            ref[R.nms(boxes[gi, :n], scores, 0.5)] = True
+        assert torch.equal(keep[gi], ref), gi
+
+
+def test_sgd_and_nonfinite():
+    g = torch.Generator().manual_seed(8)
+    n = 100003
+    p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g); m = torch.randn(n, generator=g)
+    pn, mn = R.sgd_step(p, gr, m, 0.02, 0.9, 1e-4)
+    pd, gd, md = p.to(DEV), gr.to(DEV), m.to(DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.nonfinite_flag(gd, flag)
+    ops.sgd_step(pd, gd, md, 0.02, 0.9, 1e-4, 1.0, flag)
+    assert int(flag.item()) == 0
+    np.testing.assert_allclose(pd.cpu().numpy(), pn.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(md.cpu().numpy(), mn.numpy(), rtol=1e-6, atol=1e-7)
+    gd[777] = float("nan")
+    ops.nonfinite_flag(gd, flag)
+    before = pd.clone()
+    ops.sgd_step(pd, gd, md, 0.02, 0.9, 1e-4, 1.0, flag)       # skipped on device
+    assert int(flag.item()) == 1 and torch.equal(pd, before)
