@@ -105,5 +105,8 @@ def ptr(t):
     """device pointer of a contiguous tensor, or NULL for None."""
     if t is None:
         return P(None)
-    assert t.is_contiguous(), "tensor must be contiguous"
+    if not t.is_contiguous():
+        import torch
+        if not (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)):
+            raise CrError("tensor must be dense (contiguous or channels_last)")
     return P(t.data_ptr())

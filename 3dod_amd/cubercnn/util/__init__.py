@@ -1,0 +1,1 @@
+from .math_util import *  # noqa: F401,F403
