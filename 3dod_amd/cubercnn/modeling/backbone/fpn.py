@@ -1,0 +1,98 @@
+"""detectron2 Backbone / FPN stand-ins on the HIP conv kernels [third-party behaviour restated;
+wired by the reference at cubercnn/modeling/backbone/dla.py:484-507].  Features are NHWC bf16."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ....d2lite import ShapeSpec
+from .... import hipops as ops
+
+
+def c2_xavier_fill(module):
+    """fvcore c2_xavier_fill: kaiming_uniform_(a=1), zero bias."""
+    nn.init.kaiming_uniform_(module.weight, a=1)
+    if module.bias is not None:
+        nn.init.constant_(module.bias, 0)
+
+
+def to_channels_last(module):
+    """conv weights live in channels_last storage = the [Cout][k*k][Cin] layout the kernels read; the
+    logical (Cout,Cin,k,k) shape (and so the state dict) is unchanged."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return module
+
+
+class Backbone(nn.Module):
+    def output_shape(self):
+        return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])
+                for name in self._out_features}
+
+    @property
+    def size_divisibility(self):
+        return 0
+
+    @property
+    def padding_constraints(self):
+        return {}
+
+
+class FPN(Backbone):
+    """lateral 1x1 + top-down nearest-2x sum + output 3x3, no norm, no top block."""
+
+    def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
+        super().__init__()
+        assert norm == "" and top_block is None, "only the configuration used by the reference is built"
+        assert fuse_type in ("sum", "avg")
+        input_shapes = bottom_up.output_shape()
+        strides = [input_shapes[f].stride for f in in_features]
+        in_channels_per_feature = [input_shapes[f].channels for f in in_features]
+        lateral_convs, output_convs = [], []
+        for idx, in_channels in enumerate(in_channels_per_feature):
+            lateral_conv = nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=True)
+            output_conv = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True)
+            c2_xavier_fill(lateral_conv)
+            c2_xavier_fill(output_conv)
+            stage = int(math.log2(strides[idx]))
+            self.add_module("fpn_lateral{}".format(stage), lateral_conv)
+            self.add_module("fpn_output{}".format(stage), output_conv)
+            lateral_convs.append(lateral_conv)
+            output_convs.append(output_conv)
+        self.lateral_convs = lateral_convs[::-1]
+        self.output_convs = output_convs[::-1]
+        self.in_features = tuple(in_features)
+        self.bottom_up = bottom_up
+        self._out_feature_strides = {"p{}".format(int(math.log2(s))): s for s in strides}
+        self._out_features = list(self._out_feature_strides.keys())
+        self._out_feature_channels = {k: out_channels for k in self._out_features}
+        self._size_divisibility = strides[-1]
+        self._fuse_type = fuse_type
+        to_channels_last(self)
+
+    @property
+    def size_divisibility(self):
+        return self._size_divisibility
+
+    @property
+    def padding_constraints(self):
+        return {"square_size": 0}
+
+    def forward(self, x):
+        """x: NHWC bf16 image batch (channels padded to 8) -> dict name -> NHWC bf16 feature map."""
+        bottom_up_features = self.bottom_up(x)
+        results = []
+        lat0, out0 = self.lateral_convs[0], self.output_convs[0]
+        prev = ops.conv_bias_act(bottom_up_features[self.in_features[-1]], lat0.weight, lat0.bias, 1, 0)
+        results.append(ops.conv_bias_act(prev, out0.weight, out0.bias, 1, 1))
+        for idx, (lateral_conv, output_conv) in enumerate(zip(self.lateral_convs, self.output_convs)):
+            if idx > 0:
+                features = bottom_up_features[self.in_features[-idx - 1]]
+                lateral = ops.conv_bias_act(features, lateral_conv.weight, lateral_conv.bias, 1, 0)
+                prev = ops.upsample2x_add(lateral, prev)
+                if self._fuse_type == "avg":
+                    prev = prev / 2
+                results.insert(0, ops.conv_bias_act(prev, output_conv.weight, output_conv.bias, 1, 1))
+        assert len(self._out_features) == len(results)
+        return {f: res for f, res in zip(self._out_features, results)}

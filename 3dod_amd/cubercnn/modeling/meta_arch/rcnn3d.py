@@ -1,0 +1,125 @@
+"""RCNN3D meta-architecture -- cubercnn/modeling/meta_arch/rcnn3d.py:34-124,894-918 of the reference on a
+detectron2 GeneralizedRCNN stand-in [third-party: preprocess_image, _postprocess].
+model(list[dict]) -> dict of scalar losses (training) or list[{"instances": Instances}] (eval)."""
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ....d2lite import META_ARCH_REGISTRY, BACKBONE_REGISTRY, ImageList, Instances, ShapeSpec, Boxes, get_event_storage
+from .... import hipops as ops
+from ..proposal_generator import build_proposal_generator
+from ..roi_heads import build_roi_heads
+
+
+def detector_postprocess(results: Instances, output_height: int, output_width: int):
+    """detectron2 detector_postprocess [third-party]: rescale 2D boxes to the requested output size."""
+    scale_x, scale_y = output_width / results.image_size[1], output_height / results.image_size[0]
+    out = Instances((output_height, output_width), **results.get_fields())
+    if out.has("pred_boxes"):
+        b = out.pred_boxes.clone()
+        b.scale(scale_x, scale_y)
+        b.tensor = torch.stack((b.tensor[:, 0].clamp(0, output_width), b.tensor[:, 1].clamp(0, output_height),
+                                b.tensor[:, 2].clamp(0, output_width), b.tensor[:, 3].clamp(0, output_height)), -1)
+        out.pred_boxes = b
+        out = out[b.nonempty()]
+    return out
+
+
+@META_ARCH_REGISTRY.register()
+class RCNN3D(nn.Module):
+    def __init__(self, cfg, priors=None):
+        super().__init__()
+        self.backbone = build_backbone(cfg, priors=priors)
+        self.proposal_generator = build_proposal_generator(cfg, self.backbone.output_shape())
+        self.roi_heads = build_roi_heads(cfg, self.backbone.output_shape(), priors=priors)
+        self.input_format = cfg.INPUT.FORMAT
+        self.vis_period = cfg.VIS_PERIOD
+        self.pixel_mean_list = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
+        self.pixel_std_list = [float(v) for v in cfg.MODEL.PIXEL_STD]
+        self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess_image(self, batched_inputs):
+        """(x - mean)/std, pad to the backbone's size divisibility, stack.  Returns (ImageList of the uint8 batch
+        sizes, NHWC bf16 tensor with 8 channels)."""
+        images = [x["image"].to(self.device) for x in batched_inputs]
+        il = ImageList.from_tensors(images, self.backbone.size_divisibility,
+                                    padding_constraints=self.backbone.padding_constraints)
+        batch = il.tensor
+        if batch.dtype != torch.uint8:
+            batch = batch.clamp(0, 255).to(torch.uint8)
+        x = ops.preprocess(batch.contiguous(), self.pixel_mean_list, self.pixel_std_list)
+        H, W = batch.shape[-2:]
+        if any(tuple(s) != (H, W) for s in il.image_sizes):
+            # detectron2 pads AFTER normalisation (zeros in normalised space)
+            mask = torch.zeros((len(images), H, W, 1), dtype=x.dtype, device=x.device)
+            for i, (h, w) in enumerate(il.image_sizes):
+                mask[i, :h, :w] = 1
+            x = x * mask
+        return il, x
+
+    def forward(self, batched_inputs: List[Dict[str, torch.Tensor]]):
+        if not self.training:
+            return self.inference(batched_inputs)
+        images, x = self.preprocess_image(batched_inputs)
+        im_scales_ratio = [info['height'] / im_size[0] for (info, im_size) in zip(batched_inputs, images.image_sizes)]
+        Ks = [torch.FloatTensor(info['K']) for info in batched_inputs]
+        if "instances" in batched_inputs[0]:
+            gt_instances = [b["instances"].to(self.device) for b in batched_inputs]
+        else:
+            gt_instances = None
+        features = self.backbone(x)
+        proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
+        instances, detector_losses = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, gt_instances)
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        return losses
+
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess: bool = True):
+        assert not self.training
+        images, x = self.preprocess_image(batched_inputs)
+        im_scales_ratio = [info['height'] / im_size[0] for (info, im_size) in zip(batched_inputs, images.image_sizes)]
+        Ks = [torch.FloatTensor(info['K']) for info in batched_inputs]
+        features = self.backbone(x)
+        if type(batched_inputs == list) and np.any(['oracle2D' in b for b in batched_inputs]):
+            oracles = [b['oracle2D'] for b in batched_inputs]
+            results, _ = self.roi_heads(images, features, oracles, Ks, im_scales_ratio, None)
+        else:
+            proposals, _ = self.proposal_generator(images, features, None)
+            results, _ = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, None)
+        if do_postprocess:
+            return RCNN3D._postprocess(results, batched_inputs, images.image_sizes)
+        return results
+
+    @staticmethod
+    def _postprocess(instances, batched_inputs, image_sizes):
+        processed_results = []
+        for results_per_image, input_per_image, image_size in zip(instances, batched_inputs, image_sizes):
+            height = input_per_image.get("height", image_size[0])
+            width = input_per_image.get("width", image_size[1])
+            processed_results.append({"instances": detector_postprocess(results_per_image, height, width)})
+        return processed_results
+
+
+def build_model(cfg, priors=None):
+    """rcnn3d.py:894-903."""
+    meta_arch = cfg.MODEL.META_ARCHITECTURE
+    model = META_ARCH_REGISTRY.get(meta_arch)(cfg, priors=priors)
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    # .to() keeps channels_last storage of the conv weights
+    return model
+
+
+def build_backbone(cfg, input_shape=None, priors=None):
+    """rcnn3d.py:905-918."""
+    if input_shape is None:
+        input_shape = ShapeSpec(channels=len(cfg.MODEL.PIXEL_MEAN))
+    backbone_name = cfg.MODEL.BACKBONE.NAME
+    return BACKBONE_REGISTRY.get(backbone_name)(cfg, input_shape, priors)

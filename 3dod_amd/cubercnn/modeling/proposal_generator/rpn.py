@@ -1,0 +1,333 @@
+"""RPN with ignore regions and the "IoUness" objectness loss.
+
+RPNWithIgnore restates cubercnn/modeling/proposal_generator/rpn.py:19-354 of the reference; the base RPN
+(head, anchors, decode, per-level top-k, NMS) restates detectron2's RPN / StandardRPNHead [third-party].
+The head convolutions run on cr_conv2d_* (shared weights over the 5 levels; the objectness and delta 1x1
+predictors are evaluated as ONE 16-channel conv), NMS on cr_nms_grouped."""
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ....d2lite import (PROPOSAL_GENERATOR_REGISTRY, RPN_HEAD_REGISTRY, Boxes, Instances, ShapeSpec, Box2BoxTransform,
+                        Matcher, DefaultAnchorGenerator, cat, pairwise_iou, pairwise_ioa, get_event_storage)
+from .... import hipops as ops
+from ..backbone.fpn import to_channels_last
+
+
+@RPN_HEAD_REGISTRY.register()
+class StandardRPNHead(nn.Module):
+    def __init__(self, in_channels, num_anchors, box_dim=4):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        self.objectness_logits = nn.Conv2d(in_channels, num_anchors, kernel_size=1, stride=1)
+        self.anchor_deltas = nn.Conv2d(in_channels, num_anchors * box_dim, kernel_size=1, stride=1)
+        for layer in (self.conv, self.objectness_logits, self.anchor_deltas):
+            nn.init.normal_(layer.weight, std=0.01)
+            nn.init.constant_(layer.bias, 0)
+        self.num_anchors, self.box_dim = num_anchors, box_dim
+        to_channels_last(self)
+
+    def forward(self, features: List[torch.Tensor]):
+        A, D = self.num_anchors, self.box_dim
+        n_out = A + A * D
+        pad = (-n_out) % 16
+        w = torch.cat([self.objectness_logits.weight, self.anchor_deltas.weight,
+                       self.conv.weight.new_zeros((pad,) + tuple(self.anchor_deltas.weight.shape[1:]))], 0)
+        b = torch.cat([self.objectness_logits.bias, self.anchor_deltas.bias, self.conv.bias.new_zeros(pad)])
+        pred_objectness_logits, pred_anchor_deltas = [], []
+        for x in features:
+            t = ops.conv_bias_act(x, self.conv.weight, self.conv.bias, 1, 1, relu=True)
+            y = ops.conv_bias_act(t, w, b, 1, 0, relu=False, out_f32=True)             # (N,H,W,16) f32
+            N = y.shape[0]
+            pred_objectness_logits.append(y[..., :A].reshape(N, -1))                    # (N, H*W*A)
+            pred_anchor_deltas.append(y[..., A:n_out].reshape(N, -1, D))                # (N, H*W*A, 4)
+        return pred_objectness_logits, pred_anchor_deltas
+
+
+def find_top_rpn_proposals(proposals, pred_objectness_logits, image_sizes, nms_thresh, pre_nms_topk, post_nms_topk,
+                           min_box_size, training):
+    """detectron2 find_top_rpn_proposals [third-party, restated]: per level top-k, clip, drop empty boxes,
+    per-level NMS, then the post_nms_topk best per image."""
+    num_images = len(image_sizes)
+    device = proposals[0].device
+    L = len(proposals)
+    ks = [min(p.shape[1], pre_nms_topk) for p in proposals]
+    maxn = max(ks)
+    boxes_pad = proposals[0].new_zeros((num_images, L, maxn, 4))
+    scores_pad = proposals[0].new_full((num_images, L, maxn), float("-inf"))
+    for l, (props, logits, k) in enumerate(zip(proposals, pred_objectness_logits, ks)):
+        topk_scores, topk_idx = logits.topk(k, dim=1)
+        boxes_pad[:, l, :k] = torch.gather(props, 1, topk_idx[:, :, None].expand(-1, -1, 4))
+        scores_pad[:, l, :k] = topk_scores
+    hw = torch.tensor([[s[1], s[0], s[1], s[0]] for s in image_sizes], dtype=boxes_pad.dtype, device=device)
+    finite = torch.isfinite(boxes_pad).all(dim=3) & torch.isfinite(scores_pad)
+    boxes_pad = torch.where(finite[..., None], boxes_pad, torch.zeros((), device=device))
+    boxes_pad = torch.minimum(boxes_pad.clamp(min=0), hw[:, None, None, :])              # Boxes.clip
+    valid = finite & ((boxes_pad[..., 2] - boxes_pad[..., 0]) > min_box_size) & \
+        ((boxes_pad[..., 3] - boxes_pad[..., 1]) > min_box_size)
+    # invalid boxes become zero-area: they neither suppress nor survive
+    nms_boxes = torch.where(valid[..., None], boxes_pad, torch.zeros((), device=device))
+    counts = torch.tensor(ks, dtype=torch.int32, device=device).repeat(num_images)
+    keep = ops.nms_grouped(nms_boxes.view(num_images * L, maxn, 4), counts, nms_thresh).view(num_images, L, maxn)
+    keep = keep & valid
+    flat_scores = torch.where(keep, scores_pad, torch.full((), float("-inf"), device=device)).view(num_images, -1)
+    flat_boxes = boxes_pad.view(num_images, -1, 4)
+    k_post = min(post_nms_topk, flat_scores.shape[1])
+    top_scores, top_idx = flat_scores.topk(k_post, dim=1)
+    n_keep = keep.view(num_images, -1).sum(1).clamp(max=k_post).tolist()                 # one host sync per step
+    results = []
+    for i in range(num_images):
+        res = Instances(image_sizes[i])
+        idx = top_idx[i, :n_keep[i]]
+        res.proposal_boxes = Boxes(flat_boxes[i][idx])
+        res.objectness_logits = top_scores[i, :n_keep[i]]
+        results.append(res)
+    return results
+
+
+class RPN(nn.Module):
+    """detectron2 RPN [third-party, restated]."""
+
+    def __init__(self, *, in_features, head, anchor_generator, anchor_matcher, box2box_transform, batch_size_per_image,
+                 positive_fraction, pre_nms_topk, post_nms_topk, nms_thresh=0.7, min_box_size=0.0,
+                 anchor_boundary_thresh=-1.0, loss_weight=1.0, box_reg_loss_type="smooth_l1", smooth_l1_beta=0.0):
+        super().__init__()
+        self.in_features = in_features
+        self.rpn_head = head
+        self.anchor_generator = anchor_generator
+        self.anchor_matcher = anchor_matcher
+        self.box2box_transform = box2box_transform
+        self.batch_size_per_image = batch_size_per_image
+        self.positive_fraction = positive_fraction
+        self.pre_nms_topk = {True: pre_nms_topk[0], False: pre_nms_topk[1]}
+        self.post_nms_topk = {True: post_nms_topk[0], False: post_nms_topk[1]}
+        self.nms_thresh = nms_thresh
+        self.min_box_size = float(min_box_size)
+        self.anchor_boundary_thresh = anchor_boundary_thresh
+        if isinstance(loss_weight, float):
+            loss_weight = {"loss_rpn_cls": loss_weight, "loss_rpn_loc": loss_weight}
+        self.loss_weight = loss_weight
+        self.box_reg_loss_type = box_reg_loss_type
+        self.smooth_l1_beta = smooth_l1_beta
+
+    @classmethod
+    def from_config(cls, cfg, input_shape: Dict[str, ShapeSpec]):
+        in_features = cfg.MODEL.RPN.IN_FEATURES
+        shapes = [input_shape[f] for f in in_features]
+        anchor_generator = DefaultAnchorGenerator.from_config(cfg, shapes)
+        num_anchors = anchor_generator.num_anchors
+        assert len(set(num_anchors)) == 1
+        in_channels = shapes[0].channels
+        head = RPN_HEAD_REGISTRY.get(cfg.MODEL.RPN.HEAD_NAME)(in_channels, num_anchors[0], 4)
+        return {
+            "in_features": in_features,
+            "min_box_size": cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE,
+            "nms_thresh": cfg.MODEL.RPN.NMS_THRESH,
+            "batch_size_per_image": cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE,
+            "positive_fraction": cfg.MODEL.RPN.POSITIVE_FRACTION,
+            "loss_weight": {"loss_rpn_cls": cfg.MODEL.RPN.LOSS_WEIGHT,
+                            "loss_rpn_loc": cfg.MODEL.RPN.BBOX_REG_LOSS_WEIGHT * cfg.MODEL.RPN.LOSS_WEIGHT},
+            "anchor_boundary_thresh": cfg.MODEL.RPN.BOUNDARY_THRESH,
+            "box2box_transform": Box2BoxTransform(weights=cfg.MODEL.RPN.BBOX_REG_WEIGHTS),
+            "box_reg_loss_type": cfg.MODEL.RPN.BBOX_REG_LOSS_TYPE,
+            "smooth_l1_beta": cfg.MODEL.RPN.SMOOTH_L1_BETA,
+            "pre_nms_topk": (cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, cfg.MODEL.RPN.PRE_NMS_TOPK_TEST),
+            "post_nms_topk": (cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN, cfg.MODEL.RPN.POST_NMS_TOPK_TEST),
+            "anchor_generator": anchor_generator,
+            "anchor_matcher": Matcher(cfg.MODEL.RPN.IOU_THRESHOLDS, cfg.MODEL.RPN.IOU_LABELS,
+                                      allow_low_quality_matches=True),
+            "head": head,
+        }
+
+    def forward(self, images, features: Dict[str, torch.Tensor], gt_instances=None):
+        feats = [features[f] for f in self.in_features]
+        grid_sizes = [(f.shape[1], f.shape[2]) for f in feats]                     # NHWC
+        anchors = self.anchor_generator(grid_sizes, feats[0].device)
+        pred_objectness_logits, pred_anchor_deltas = self.rpn_head(feats)
+        if self.training:
+            assert gt_instances is not None, "RPN requires gt_instances in training!"
+            gt_labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances)
+            losses = self.losses(anchors, pred_objectness_logits, gt_labels, pred_anchor_deltas, gt_boxes)
+        else:
+            losses = {}
+        proposals = self.predict_proposals(anchors, pred_objectness_logits, pred_anchor_deltas, images.image_sizes)
+        return proposals, losses
+
+    @torch.no_grad()
+    def predict_proposals(self, anchors, pred_objectness_logits, pred_anchor_deltas, image_sizes):
+        pred_proposals = self._decode_proposals(anchors, pred_anchor_deltas)
+        return find_top_rpn_proposals(pred_proposals, [t.detach() for t in pred_objectness_logits], image_sizes,
+                                      self.nms_thresh, self.pre_nms_topk[self.training],
+                                      self.post_nms_topk[self.training], self.min_box_size, self.training)
+
+    def _decode_proposals(self, anchors, pred_anchor_deltas):
+        N = pred_anchor_deltas[0].shape[0]
+        proposals = []
+        for anchors_i, pred_anchor_deltas_i in zip(anchors, pred_anchor_deltas):
+            B = anchors_i.tensor.size(1)
+            pred_anchor_deltas_i = pred_anchor_deltas_i.detach().reshape(-1, B)
+            anchors_e = anchors_i.tensor.unsqueeze(0).expand(N, -1, -1).reshape(-1, B)
+            proposals_i = self.box2box_transform.apply_deltas(pred_anchor_deltas_i, anchors_e)
+            proposals.append(proposals_i.view(N, -1, B))
+        return proposals
+
+
+def subsample_labels(labels, num_samples, positive_fraction, bg_label, matched_ious=None, eps=1e-4):
+    """rpn.py:275-328: IoU-weighted multinomial sampling of positives / negatives."""
+    positive = ((labels != -1) & (labels != bg_label)).nonzero(as_tuple=True)[0]
+    negative = (labels == bg_label).nonzero(as_tuple=True)[0]
+    num_pos = int(num_samples * positive_fraction)
+    num_pos = min(positive.numel(), num_pos)
+    num_neg = num_samples - num_pos
+    num_neg = min(negative.numel(), num_neg)
+    if num_pos > 0 and matched_ious is not None:
+        perm1 = torch.multinomial(matched_ious[positive] + eps, num_pos)
+    else:
+        perm1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
+    if num_neg > 0 and matched_ious is not None:
+        perm2 = torch.multinomial(matched_ious[negative] + eps, num_neg)
+    else:
+        perm2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
+    return positive[perm1], negative[perm2]
+
+
+def matched_pairwise_iou(boxes1: Boxes, boxes2: Boxes) -> torch.Tensor:
+    """rpn.py:330-354."""
+    assert len(boxes1) == len(boxes2)
+    area1, area2 = boxes1.area(), boxes2.area()
+    box1, box2 = boxes1.tensor, boxes2.tensor
+    lt = torch.max(box1[:, :2], box2[:, :2])
+    rb = torch.min(box1[:, 2:], box2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, 0] * wh[:, 1]
+    return inter / (area1 + area2 - inter)
+
+
+def _dense_box_regression_loss_with_uncertainty(anchors, box2box_transform, pred_anchor_deltas, pred_objectness_logits,
+                                                gt_boxes, fg_mask, box_reg_loss_type="smooth_l1", smooth_l1_beta=0.0,
+                                                uncertainty_type="centerness"):
+    """rpn.py:206-273: objectness target = IoU(anchor, matched GT); both losses weighted by that IoU."""
+    anchors = Boxes.cat(anchors).tensor if isinstance(anchors[0], Boxes) else cat(anchors)
+    n = len(gt_boxes)
+    boxes_fg = Boxes(anchors.unsqueeze(0).repeat([n, 1, 1])[fg_mask])
+    gt_boxes_fg = Boxes(torch.stack(gt_boxes)[fg_mask].detach())
+    objectness_targets_anchors = matched_pairwise_iou(boxes_fg, gt_boxes_fg).detach()
+    objectness_logits = torch.cat(pred_objectness_logits, dim=1)
+    loss_box_conf = F.binary_cross_entropy_with_logits(objectness_logits[fg_mask], objectness_targets_anchors,
+                                                       reduction="none")
+    loss_box_conf = (loss_box_conf * objectness_targets_anchors).sum()
+    storage = get_event_storage()
+    with torch.no_grad():
+        sig = torch.sigmoid(objectness_logits)
+        storage.put_scalar("rpn/conf_pos_anchors", sig[fg_mask].mean())
+        storage.put_scalar("rpn/conf_neg_anchors", sig[~fg_mask].mean())
+    if box_reg_loss_type != "smooth_l1":
+        raise ValueError(f"Invalid dense box regression loss type '{box_reg_loss_type}'")
+    gt_anchor_deltas = torch.stack([box2box_transform.get_deltas(anchors, k) for k in gt_boxes])
+    pred = cat(pred_anchor_deltas, dim=1)[fg_mask]
+    tgt = gt_anchor_deltas[fg_mask]
+    if smooth_l1_beta < 1e-5:
+        loss_box_reg = torch.abs(pred - tgt)
+    else:
+        nd = torch.abs(pred - tgt)
+        loss_box_reg = torch.where(nd < smooth_l1_beta, 0.5 * nd ** 2 / smooth_l1_beta, nd - 0.5 * smooth_l1_beta)
+    loss_box_reg = (loss_box_reg.sum(dim=1) * objectness_targets_anchors).sum()
+    return loss_box_reg, loss_box_conf
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class RPNWithIgnore(RPN):
+    def __init__(self, *, ignore_thresh: float = 0.5, objectness_uncertainty: str = "none", **kwargs):
+        super().__init__(**kwargs)
+        self.ignore_thresh = ignore_thresh
+        self.objectness_uncertainty = objectness_uncertainty
+
+    @classmethod
+    def from_config(cls, cfg, input_shape: Dict[str, ShapeSpec]):
+        ret = super().from_config(cfg, input_shape)
+        ret["ignore_thresh"] = cfg.MODEL.RPN.IGNORE_THRESHOLD
+        ret["objectness_uncertainty"] = cfg.MODEL.RPN.OBJECTNESS_UNCERTAINTY
+        return ret
+
+    @torch.no_grad()
+    def label_and_sample_anchors(self, anchors: List[Boxes], gt_instances: List[Instances]):
+        """rpn.py:41-110."""
+        anchors = Boxes.cat(anchors)
+        gt_boxes_ign = [x.gt_boxes[x.gt_classes < 0] for x in gt_instances]
+        gt_boxes = [x.gt_boxes[x.gt_classes >= 0] for x in gt_instances]
+        gt_labels, matched_gt_boxes = [], []
+        for gt_boxes_i, gt_boxes_ign_i in zip(gt_boxes, gt_boxes_ign):
+            match_quality_matrix = pairwise_iou(gt_boxes_i, anchors)
+            matched_idxs, gt_labels_i = self.anchor_matcher(match_quality_matrix)
+            gt_labels_i = gt_labels_i.to(device=gt_boxes_i.device)
+            if len(gt_boxes_i) > 0:
+                gt_arange = torch.arange(match_quality_matrix.shape[1], device=matched_idxs.device)
+                matched_ious = match_quality_matrix[matched_idxs, gt_arange]
+                best_ious_gt_ind = match_quality_matrix.max(dim=1)[1]
+                # set(best per GT) & set(labelled foreground), rpn.py:75 (tensor form, no host round trip)
+                best_inds = best_ious_gt_ind[gt_labels_i[best_ious_gt_ind] == 1]
+            else:
+                matched_ious = match_quality_matrix.new_zeros(len(anchors))
+                best_inds = matched_idxs.new_zeros(0)
+            del match_quality_matrix
+            gt_labels_i = self._subsample_labels(gt_labels_i, matched_ious=matched_ious)
+            if best_inds.numel() > 0:
+                gt_labels_i[best_inds] = 1
+            if len(gt_boxes_i) == 0:
+                matched_gt_boxes_i = torch.zeros_like(anchors.tensor)
+            else:
+                matched_gt_boxes_i = gt_boxes_i[matched_idxs].tensor
+            if len(gt_boxes_ign_i) > 0:
+                background_inds = (gt_labels_i == 0).nonzero().squeeze()
+                if background_inds.numel() > 1:
+                    match_quality_matrix_ign = pairwise_ioa(gt_boxes_ign_i, anchors[background_inds])
+                    gt_labels_i[background_inds[match_quality_matrix_ign.max(0)[0] >= self.ignore_thresh]] = -1
+            gt_labels.append(gt_labels_i)
+            matched_gt_boxes.append(matched_gt_boxes_i)
+        return gt_labels, matched_gt_boxes
+
+    def _subsample_labels(self, label, matched_ious=None):
+        pos_idx, neg_idx = subsample_labels(label, self.batch_size_per_image, self.positive_fraction, 0,
+                                            matched_ious=matched_ious)
+        label.fill_(-1)
+        label.scatter_(0, pos_idx, 1)
+        label.scatter_(0, neg_idx, 0)
+        return label
+
+    def losses(self, anchors, pred_objectness_logits, gt_labels, pred_anchor_deltas, gt_boxes):
+        """rpn.py:129-204."""
+        num_images = len(gt_labels)
+        gt_labels = torch.stack(gt_labels)
+        pos_mask = gt_labels == 1
+        storage = get_event_storage()
+        storage.put_scalar("rpn/num_pos_anchors", pos_mask.sum() / num_images)
+        storage.put_scalar("rpn/num_neg_anchors", (gt_labels == 0).sum() / num_images)
+        if self.objectness_uncertainty.lower() not in ["none"]:
+            localization_loss, objectness_loss = _dense_box_regression_loss_with_uncertainty(
+                anchors, self.box2box_transform, pred_anchor_deltas, pred_objectness_logits, gt_boxes, pos_mask,
+                box_reg_loss_type=self.box_reg_loss_type, smooth_l1_beta=self.smooth_l1_beta,
+                uncertainty_type=self.objectness_uncertainty)
+        else:
+            anchors_t = Boxes.cat(anchors).tensor
+            gt_anchor_deltas = torch.stack([self.box2box_transform.get_deltas(anchors_t, k) for k in gt_boxes])
+            localization_loss = torch.abs(cat(pred_anchor_deltas, dim=1)[pos_mask] - gt_anchor_deltas[pos_mask]).sum()
+            valid_mask = gt_labels >= 0
+            objectness_loss = F.binary_cross_entropy_with_logits(cat(pred_objectness_logits, dim=1)[valid_mask],
+                                                                 gt_labels[valid_mask].to(torch.float32),
+                                                                 reduction="sum")
+        normalizer = self.batch_size_per_image * num_images
+        losses = {"rpn/cls": objectness_loss / normalizer, "rpn/loc": localization_loss / normalizer}
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+
+
+def _construct(cls, cfg, *args, **kwargs):
+    return cls(**cls.from_config(cfg, *args, **kwargs))
+
+
+def build_proposal_generator(cfg, input_shape):
+    name = cfg.MODEL.PROPOSAL_GENERATOR.NAME
+    if name == "PrecomputedProposals":
+        return None
+    return _construct(PROPOSAL_GENERATOR_REGISTRY.get(name), cfg, input_shape)

@@ -1,0 +1,94 @@
+"""CubeHead -- cubercnn/modeling/roi_heads/cube_head.py:24-202 (same parameter names / init).
+Input is the NHWC-flattened ROIAlign output (n, 7*7*256) bf16; the first FC's weight keeps the
+reference's (c,y,x) column order in the state dict and is permuted to (y,x,c) when cast to bf16.
+FC layers are plain library GEMMs (hipBLASLt through torch.nn.functional.linear, bf16 in / f32 acc)."""
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ....d2lite import Registry, ShapeSpec
+from ...util.math_util import rotation_6d_to_matrix
+from ..backbone.fpn import c2_xavier_fill
+
+ROI_CUBE_HEAD_REGISTRY = Registry("ROI_CUBE_HEAD")
+bf16 = torch.bfloat16
+
+
+def fc_nhwc(x_nhwc_flat, fc, chw):
+    """Linear whose weight columns are in (c,h,w) order applied to an (h,w,c)-flattened bf16 input."""
+    C, H, W = chw
+    w = fc.weight.view(fc.out_features, C, H, W).permute(0, 2, 3, 1).reshape(fc.out_features, -1)
+    return F.linear(x_nhwc_flat, w.to(bf16), fc.bias.to(bf16))
+
+
+@ROI_CUBE_HEAD_REGISTRY.register()
+class CubeHead(nn.Module):
+    def __init__(self, cfg, input_shape: ShapeSpec):
+        super().__init__()
+        self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        self.use_conf = cfg.MODEL.ROI_CUBE_HEAD.USE_CONFIDENCE
+        self.z_type = cfg.MODEL.ROI_CUBE_HEAD.Z_TYPE
+        self.pose_type = cfg.MODEL.ROI_CUBE_HEAD.POSE_TYPE
+        self.cluster_bins = cfg.MODEL.ROI_CUBE_HEAD.CLUSTER_BINS
+        self.shared_fc = cfg.MODEL.ROI_CUBE_HEAD.SHARED_FC
+        if not self.shared_fc or self.cluster_bins > 1 or cfg.MODEL.ROI_CUBE_HEAD.NUM_CONV > 0:
+            raise ValueError("only the shared-FC, single-bin cube head of configs/Base.yaml is built")
+        num_fc = cfg.MODEL.ROI_CUBE_HEAD.NUM_FC
+        fc_dim = cfg.MODEL.ROI_CUBE_HEAD.FC_DIM
+        self._in_chw = (input_shape.channels, input_shape.height, input_shape.width)
+        self._output_size = self._in_chw
+        self.feature_generator = nn.Sequential()
+        for k in range(num_fc):
+            fc_dim_in = int(np.prod(self._output_size))
+            self._output_size = fc_dim
+            fc = nn.Linear(fc_dim_in, fc_dim)
+            c2_xavier_fill(fc)
+            self.feature_generator.add_module("fc{}".format(k + 1), fc)
+            self.feature_generator.add_module("fc_relu{}".format(k + 1), nn.ReLU())
+        self.bbox_3D_dims = nn.Linear(self._output_size, self.num_classes * 3)
+        nn.init.normal_(self.bbox_3D_dims.weight, std=0.001)
+        nn.init.constant_(self.bbox_3D_dims.bias, 0)
+        self.bbox_3D_center_deltas = nn.Linear(self._output_size, self.num_classes * 2)
+        nn.init.normal_(self.bbox_3D_center_deltas.weight, std=0.001)
+        nn.init.constant_(self.bbox_3D_center_deltas.bias, 0)
+        if self.pose_type == '6d':
+            self.bbox_3D_pose = nn.Linear(self._output_size, self.num_classes * 6)
+        else:
+            raise ValueError('Cuboid pose type {} is not recognized'.format(self.pose_type))
+        nn.init.normal_(self.bbox_3D_pose.weight, std=0.001)
+        nn.init.constant_(self.bbox_3D_pose.bias, 0)
+        self.bbox_3D_center_depth = nn.Linear(self._output_size, self.num_classes * 1)
+        nn.init.normal_(self.bbox_3D_center_depth.weight, std=0.001)
+        nn.init.constant_(self.bbox_3D_center_depth.bias, 1)
+        if self.use_conf:
+            self.bbox_3D_uncertainty = nn.Linear(self._output_size, self.num_classes * 1)
+            nn.init.normal_(self.bbox_3D_uncertainty.weight, std=0.001)
+            nn.init.constant_(self.bbox_3D_uncertainty.bias, 5)
+
+    def forward(self, x):
+        """x (n, H*W*C) bf16 in (h,w,c) order -> (deltas (n,K,2), z (n,K,1), dims (n,K,3), pose (n,K,3,3), uncert (n,K))."""
+        n = x.shape[0]
+        fcs = [m for m in self.feature_generator if isinstance(m, nn.Linear)]
+        h = F.relu(fc_nhwc(x, fcs[0], self._in_chw))
+        for fc in fcs[1:]:
+            h = F.relu(F.linear(h, fc.weight.to(bf16), fc.bias.to(bf16)))
+        lin = lambda m: F.linear(h, m.weight.to(bf16), m.bias.to(bf16)).float()
+        box_2d_deltas = lin(self.bbox_3D_center_deltas)
+        box_dims = lin(self.bbox_3D_dims)
+        box_pose = lin(self.bbox_3D_pose)
+        box_z = lin(self.bbox_3D_center_depth)
+        box_uncert = lin(self.bbox_3D_uncertainty).clip(0.01) if self.use_conf else None
+        box_pose = rotation_6d_to_matrix(box_pose.view(-1, 6))
+        box_2d_deltas = box_2d_deltas.view(n, self.num_classes, 2)
+        box_dims = box_dims.view(n, self.num_classes, 3)
+        box_pose = box_pose.view(n, self.num_classes, 3, 3)
+        box_z = box_z.view(n, self.num_classes, -1)
+        return box_2d_deltas, box_z, box_dims, box_pose, box_uncert
+
+
+def build_cube_head(cfg, input_shape: ShapeSpec):
+    name = cfg.MODEL.ROI_CUBE_HEAD.NAME
+    return ROI_CUBE_HEAD_REGISTRY.get(name)(cfg, input_shape)

@@ -1,0 +1,1 @@
+from .build import build_optimizer, freeze_bn, FlatSGD, TrainStep

@@ -1,0 +1,189 @@
+"""Optimizer + training step of the reference (cubercnn/solver/build.py:6-76, tools/train_net.py:184-304) for
+one process per GPU:
+
+  * all parameters / gradients / momentum live in three flat float32 buffers (parameters are views), ordered
+    so that the weight-decayed group is one contiguous range and the no-decay group (BatchNorm affine with
+    WEIGHT_DECAY_NORM, priors) another -> the SGD-momentum update is two fused kernel launches;
+  * the gradient all-reduce (DistributedDataParallel in train_net.py:477-480) is a bucketed RCCL all-reduce
+    of the flat gradient, issued on a side stream so buckets overlap; the loss dict, the divergence flag and
+    the non-finite flag (three collectives + three barriers in the reference) ride in ONE small all-reduce;
+  * the loss-divergence guard (rolling mean x4, train_net.py:202-220) and the non-finite gradient scan
+    (:233-244) are evaluated on the device; the update is skipped on the device (no host sync in the step).
+"""
+from typing import Any, Dict, List
+
+import torch
+import torch.distributed as dist
+
+from ... import hipops as ops
+
+NORM_TYPES = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.SyncBatchNorm,
+              torch.nn.GroupNorm, torch.nn.InstanceNorm1d, torch.nn.InstanceNorm2d, torch.nn.InstanceNorm3d,
+              torch.nn.LayerNorm, torch.nn.LocalResponseNorm)
+NO_DECAY_KEYS = ('priors_dims_per_cat', 'priors_z_scales', 'priors_z_stats')
+
+
+def freeze_bn(network):
+    """solver/build.py:71-76."""
+    for _, module in network.named_modules():
+        if isinstance(module, torch.nn.BatchNorm2d):
+            module.eval()
+            module.track_running_stats = False
+
+
+def _param_groups(cfg, model):
+    """same per-parameter (lr, weight_decay) rule as solver/build.py:21-47."""
+    memo, groups = set(), []
+    for module in model.modules():
+        for key, value in module.named_parameters(recurse=False):
+            if not value.requires_grad or value in memo:
+                continue
+            memo.add(value)
+            lr, wd = cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY
+            if isinstance(module, NORM_TYPES) and cfg.SOLVER.WEIGHT_DECAY_NORM is not None:
+                wd = cfg.SOLVER.WEIGHT_DECAY_NORM
+            elif key == "bias":
+                if cfg.SOLVER.BIAS_LR_FACTOR is not None:
+                    lr = cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR
+                if cfg.SOLVER.WEIGHT_DECAY_BIAS is not None:
+                    wd = cfg.SOLVER.WEIGHT_DECAY_BIAS
+            if key in NO_DECAY_KEYS:
+                wd = 0.0
+            groups.append((value, float(lr), float(wd)))
+    return groups
+
+
+class FlatSGD:
+    """torch.optim.SGD(momentum) semantics on flat buffers + fused kernels (cr_sgd_step)."""
+
+    def __init__(self, groups, momentum, nesterov=False):
+        assert not nesterov, "nesterov is not built"
+        self.momentum = float(momentum)
+        # order by (lr, wd) so that equal-hyperparameter parameters are contiguous
+        keys = sorted({(lr, wd) for _, lr, wd in groups})
+        ordered = [(p, lr, wd) for k in keys for (p, lr, wd) in groups if (lr, wd) == k]
+        dev = ordered[0][0].device
+        pad = lambda n: (n + 3) // 4 * 4                       # 16-B aligned segments
+        total = sum(pad(p.numel()) for p, _, _ in ordered)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.segments = []                                      # (start, end, lr, wd)
+        self.params = []
+        off = 0
+        cur = None
+        for p, lr, wd in ordered:
+            n = p.numel()
+            cl = p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous()
+            src = p.data.permute(0, 2, 3, 1).contiguous().view(-1) if cl else p.data.contiguous().view(-1)
+            self.flat_p[off:off + n].copy_(src)
+
+            def view_of(buf):
+                v = buf[off:off + n]
+                if cl:
+                    K, C, R, S = p.shape
+                    return v.view(K, R, S, C).permute(0, 3, 1, 2)       # logical KCRS over physical KRSC
+                return v.view(p.shape)
+            p.data = view_of(self.flat_p)
+            p.grad = view_of(self.flat_g)
+            self.params.append(p)
+            if cur is not None and cur[2:] == (lr, wd):
+                cur[1] = off + pad(n)
+            else:
+                cur = [off, off + pad(n), lr, wd]
+                self.segments.append(cur)
+            off += pad(n)
+        self.param_groups = [{"lr": s[2], "weight_decay": s[3], "range": (s[0], s[1])} for s in self.segments]
+        self.lr_scale = 1.0
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def step(self, skip_flag=None, grad_scale=1.0):
+        for (a, b, lr, wd) in self.segments:
+            ops.sgd_step(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], lr * self.lr_scale, self.momentum, wd,
+                         grad_scale, skip_flag)
+        ops.bump_weight_epoch()
+
+    def state_dict(self):
+        return {"momentum_buffer": self.flat_m, "lr_scale": self.lr_scale}
+
+    def load_state_dict(self, sd):
+        self.flat_m.copy_(sd["momentum_buffer"])
+        self.lr_scale = sd.get("lr_scale", 1.0)
+
+
+def build_optimizer(cfg, model):
+    """solver/build.py:6-69; only the SGD type is built (the reference's default and BASELINE config)."""
+    if cfg.SOLVER.TYPE != 'sgd':
+        raise ValueError('{} is not supported as an optimizer.'.format(cfg.SOLVER.TYPE))
+    return FlatSGD(_param_groups(cfg, model), cfg.SOLVER.MOMENTUM, cfg.SOLVER.NESTEROV)
+
+
+class TrainStep:
+    """One iteration of do_train (tools/train_net.py:184-304) without host round trips."""
+    TOLERANCE = 4.0
+    GAMMA = 0.02
+
+    def __init__(self, cfg, model, optimizer, world_size=1, bucket_mb=32):
+        self.model, self.opt = model, optimizer
+        self.world = world_size
+        self.stabilize = cfg.MODEL.STABILIZE > 0
+        dev = optimizer.flat_p.device
+        self.recent_loss = torch.full((), float("nan"), device=dev)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.iterations_success = torch.zeros((), device=dev)
+        self.iterations_explode = torch.zeros((), device=dev)
+        n = optimizer.flat_g.numel()
+        be = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets = [(i, min(i + be, n)) for i in range(0, n, be)][::-1]     # last-used params first
+        self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        self.last = {}
+
+    def __call__(self, data):
+        opt, world = self.opt, self.world
+        loss_dict = self.model(data)
+        keys = sorted(loss_dict.keys())
+        vals = torch.stack([loss_dict[k].float() for k in keys])
+        losses = vals.sum()
+        # ---- fused small all-reduce: loss terms (train_net.py:196 allreduce_dict)
+        red = vals.detach().clone()
+        if world > 1:
+            dist.all_reduce(red)
+            red /= world
+        losses_reduced = red.sum()
+        first = torch.isnan(self.recent_loss)
+        recent = torch.where(first, losses_reduced * 2.0, self.recent_loss)
+        diverging = (losses_reduced > recent * self.TOLERANCE) | ~torch.isfinite(losses_reduced)
+        if not self.stabilize:
+            diverging = torch.zeros_like(diverging)
+        # loss clip when diverging (train_net.py:212), rolling mean otherwise (:218)
+        losses = torch.where(diverging, losses.clip(0, 1), losses)
+        self.recent_loss = torch.where(diverging, recent, recent * (1 - self.GAMMA) + losses_reduced * self.GAMMA)
+        opt.zero_grad()
+        losses.backward()
+        # ---- gradient all-reduce (DDP, train_net.py:477-480), bucketed, overlapped on a side stream
+        if world > 1:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                for a, b in self.buckets:
+                    dist.all_reduce(opt.flat_g[a:b])
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        # ---- non-finite scan of the (averaged) gradient + skip flag, all on device
+        self.flag.copy_(diverging.to(torch.int32).view(1))
+        if self.stabilize:
+            ops.nonfinite_flag(opt.flat_g, self.flag)
+        opt.step(skip_flag=self.flag, grad_scale=1.0 / world)
+        bad = (self.flag[0] != 0).float()
+        self.iterations_explode += bad
+        self.iterations_success += 1 - bad
+        self.last = {"keys": keys, "values": red, "total": losses_reduced, "skipped": self.flag}
+        return self.last
+
+    def report(self):
+        """host-side view (one sync) for logging / the retry rule of train_net.py:268-302."""
+        d = {k: float(v) for k, v in zip(self.last["keys"], self.last["values"].tolist())}
+        d["total_loss"] = float(self.last["total"])
+        d["iterations_explode"] = float(self.iterations_explode)
+        d["iterations_success"] = float(self.iterations_success)
+        return d

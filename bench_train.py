@@ -1,0 +1,64 @@
+"""Cube R-CNN DLA34-FPN train step benchmark (BASELINE.json metric): 4 synthetic 512x512 images per GPU,
+forward + losses + backward + gradient all-reduce + SGD-momentum update, every step."""
+import importlib
+import os
+import time
+
+import torch
+
+MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 dense ~2.5 PFLOP/s
+IMS_PER_GPU = 4
+TRAIN_GFLOP_PER_IMAGE = 309.0  # BASELINE.md section 2 (fwd 51.5 GMAC x 2 x 3)
+
+
+def build(dev, seed=0):
+    syn = importlib.import_module("3dod_amd.synthetic")
+    modeling = importlib.import_module("3dod_amd.cubercnn.modeling")
+    solver = importlib.import_module("3dod_amd.cubercnn.solver")
+    cfg = syn.make_cfg(overrides=["MODEL.DEVICE", str(dev), "VIS_PERIOD", 0, "log", False,
+                                  "SOLVER.IMS_PER_BATCH", 32, "SOLVER.BASE_LR", 0.02])
+    torch.manual_seed(seed)
+    model = modeling.build_model(cfg)
+    model.train()
+    opt = solver.build_optimizer(cfg, model)
+    return cfg, model, opt, syn, solver
+
+
+def bench_train(args, rank, world, dev):
+    import bench as B
+    cfg, model, opt, syn, solver = build(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast(opt.flat_p, 0)                 # DDP wrap-time parameter broadcast
+    step = solver.TrainStep(cfg, model, opt, world_size=world)
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    batches = [syn.make_batch(IMS_PER_GPU, 1234 + rank * 1000 + i) for i in range(4)]
+    for b in batches:                                   # inputs resident in HBM before the timed region
+        for d in b:
+            d["image"] = d["image"].to(dev)
+            d["instances"] = d["instances"].to(dev)
+    with d2.EventStorage(0):
+        for i in range(args.warmup):
+            step(batches[i % len(batches)])
+        B.barrier(world)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(batches[i % len(batches)])
+        B.barrier(world)
+        dt = B.max_over_ranks(time.perf_counter() - t0, world, dev)
+        rep = step.report()
+    ims = IMS_PER_GPU * world * args.steps / dt
+    achieved_tf = TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU / (dt / args.steps) / 1e3
+    res = {
+        "metric": "images/sec Cube R-CNN DLA34-FPN train step", "value": ims, "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "Cube R-CNN DLA34+FPN train step (fwd+loss+bwd+allreduce+SGD), 4 img/GPU 512x512, "
+                               "Base_Omni3D.yaml semantics (BASELINE configs[3] per-GPU shard)",
+                   "global_batch": IMS_PER_GPU * world, "parallelism": f"dp{world}",
+                   "final_loss": rep.get("total_loss"), "skipped_steps": rep.get("iterations_explode")},
+        "roofline": {"bound": "mfma", "kernel": "whole step (conv igemm/wgrad dominate)", "achieved": achieved_tf,
+                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / MFMA_PEAK_TFLOPS,
+                     "traffic": None, "algorithmic_gflop_per_step": TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU},
+    }
+    return res
