@@ -119,6 +119,44 @@ __global__ __launch_bounds__(256) void k_roi_align(Pyramid py, const float* __re
     }
 }
 
+// backward: one thread = (roi, ph, pw, ONE channel), channel fastest, so every atomic wave-instruction adds
+// 64 consecutive floats (256 contiguous bytes: the full-rate shape of MI355X_MICROARCH.md "Global float atomics").
+__global__ __launch_bounds__(256) void k_roi_align_bwd(Pyramid py, const float* __restrict__ rois, int R, int PH,
+                                                       int PW, const u16* __restrict__ dout) {
+    const int C = py.C;
+    const int64_t total = (int64_t)R * PH * PW * C;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int pw = (int)((i / C) % PW);
+    const int ph = (int)((i / ((int64_t)C * PW)) % PH);
+    const int r = (int)(i / ((int64_t)C * PW * PH));
+    const float* rb = rois + (size_t)r * 5;
+    const int n = (int)rb[0];
+    const int lv = roi_level(rb + 1, py);
+    const int H = py.H[lv], W = py.W[lv];
+    const float sc = py.scale[lv];
+    const float x1 = rb[1] * sc - 0.5f, y1 = rb[2] * sc - 0.5f;
+    const float rw = (rb[3] - rb[1]) * sc, rh = (rb[4] - rb[2]) * sc;
+    const float bw = rw / (float)PW, bh = rh / (float)PH;
+    const int gh = (int)ceilf(rh / (float)PH), gw = (int)ceilf(rw / (float)PW);
+    const float cnt = fmaxf((float)(gh * gw), 1.f);
+    const float g = bf2f(dout[i]) / cnt;
+    float* gq = py.grad[lv] + (size_t)n * H * W * C + c;
+    for (int iy = 0; iy < gh; ++iy) {
+        const float y = y1 + ph * bh + (iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+            const float x = x1 + pw * bw + (ix + 0.5f) * bw / (float)gw;
+            const Samp s = bilinear(y, x, H, W);
+            if (!s.ok) continue;
+            atomicAdd(gq + ((size_t)s.yl * W + s.xl) * C, g * s.w1);
+            atomicAdd(gq + ((size_t)s.yl * W + s.xh) * C, g * s.w2);
+            atomicAdd(gq + ((size_t)s.yh * W + s.xl) * C, g * s.w3);
+            atomicAdd(gq + ((size_t)s.yh * W + s.xh) * C, g * s.w4);
+        }
+    }
+}
+
 static int fill_pyramid(Pyramid& py, const void* const* feats, float* const* grads, const int* Hs, const int* Ws,
                         const float* scales, int nlev, int C) {
     CR_CHECK_ARG(nlev >= 1 && nlev <= MAX_LEVELS, "roi_align: 1..%d levels", MAX_LEVELS);
@@ -159,9 +197,10 @@ extern "C" int cr_roi_align_bwd(cr_ctx* ctx, float* const* grads, const int* Hs,
     Pyramid py;
     int rc = fill_pyramid(py, nullptr, grads, Hs, Ws, scales, nlev, C);
     if (rc) return rc;
-    const int64_t total = R * PH * PW * (C / 8);
-    hipLaunchKernelGGL((k_roi_align<true>), dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py, rois,
-                       (int)R, PH, PW, (u16*)nullptr, (const u16*)dout);
+    const int64_t total = R * PH * PW * (int64_t)C;
+    CR_CHECK_ARG(cr_cdiv(total, 256) < 0x7fffffff, "cr_roi_align_bwd: too many RoIs");
+    hipLaunchKernelGGL(k_roi_align_bwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py, rois, (int)R,
+                       PH, PW, (const u16*)dout);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -85,9 +85,10 @@ class FlatSGD:
                     return v.view(K, R, S, C).permute(0, 3, 1, 2)       # logical KCRS over physical KRSC
                 return v.view(p.shape)
             p.data = view_of(self.flat_p)
-            p.grad = view_of(self.flat_g)
+            p.grad = None
+            p._cr_grad = view_of(self.flat_g)      # kernels accumulate straight into the flat gradient
             self.params.append(p)
-            if cur is not None and cur[2:] == (lr, wd):
+            if cur is not None and tuple(cur[2:]) == (lr, wd):
                 cur[1] = off + pad(n)
             else:
                 cur = [off, off + pad(n), lr, wd]
@@ -98,6 +99,21 @@ class FlatSGD:
 
     def zero_grad(self):
         self.flat_g.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def collect_grads(self):
+        """gradients that arrived through plain autograd (Linear layers, biases) are added into the flat buffer
+        with one multi-tensor launch; those written by the conv/BN kernels are already there."""
+        views, grads = [], []
+        for p in self.params:
+            if p.grad is not None:
+                views.append(p._cr_grad)
+                grads.append(p.grad)
+        if views:
+            torch._foreach_add_(views, grads)
+        for p in self.params:
+            p.grad = None
 
     def step(self, skip_flag=None, grad_scale=1.0):
         for (a, b, lr, wd) in self.segments:
@@ -162,6 +178,7 @@ class TrainStep:
         self.recent_loss = torch.where(diverging, recent, recent * (1 - self.GAMMA) + losses_reduced * self.GAMMA)
         opt.zero_grad()
         losses.backward()
+        opt.collect_grads()
         # ---- gradient all-reduce (DDP, train_net.py:477-480), bucketed, overlapped on a side stream
         if world > 1:
             self.comm_stream.wait_stream(torch.cuda.current_stream())

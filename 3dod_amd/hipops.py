@@ -103,11 +103,21 @@ def conv_bwd_data_raw(dy, wt, in_shape, k, stride, pad):
     return dx
 
 
-def conv_bwd_weight_raw(dy, x, k, stride, pad):
+def grad_sink(t):
+    """a persistent f32 gradient buffer attached to a parameter by the optimizer (FlatSGD): kernels accumulate
+    straight into it (no per-parameter zero-fill / add kernels); the autograd grad for that input is None."""
+    return getattr(t, "_cr_grad", None)
+
+
+def conv_bwd_weight_raw(dy, x, k, stride, pad, sink=None):
     N, H, W, Cin = x.shape
     Cout = dy.shape[3]
-    dw = torch.empty((Cout, Cin, k, k), dtype=f32, device=x.device).contiguous(memory_format=torch.channels_last)
     lib = _lib.load()
+    if sink is not None:
+        _chk(lib.cr_conv2d_bwd_weight(_ctx(x), _p(dy), _p(x), _p(sink), N, H, W, Cin, Cout, k, stride, pad, 1),
+             "cr_conv2d_bwd_weight")
+        return None
+    dw = torch.empty((Cout, Cin, k, k), dtype=f32, device=x.device).contiguous(memory_format=torch.channels_last)
     _chk(lib.cr_conv2d_bwd_weight(_ctx(x), _p(dy), _p(x), _p(dw), N, H, W, Cin, Cout, k, stride, pad, 0),
          "cr_conv2d_bwd_weight")
     return dw
@@ -149,6 +159,7 @@ class _ConvBN(torch.autograd.Function):
             _chk(lib.cr_bn_fwd(_ctx(x), _p(y_raw), _p(zstats), _p(gamma.detach()), _p(beta.detach()), _p(residual),
                                _p(out), M, Cout, int(relu), float(eps), 0.0, _p(mi), _p(None), _p(None)), "cr_bn_fwd")
         ctx.cfg = (k, stride, pad, relu, training, residual is not None)
+        ctx.beta_ref = beta
         ctx.save_for_backward(x, weight, gamma, y_raw, out if relu else None, mi)
         return out
 
@@ -166,16 +177,21 @@ class _ConvBN(torch.autograd.Function):
         sums = torch.empty((STAT_REPL, 2, Cout), dtype=f32, device=dev)
         dx_raw = torch.empty_like(y_raw)
         dres = torch.empty_like(y_raw) if has_res else None
-        dgamma = torch.zeros((Cout,), dtype=f32, device=dev)
-        dbeta = torch.zeros((Cout,), dtype=f32, device=dev)
+        gs, bs = grad_sink(gamma), grad_sink(ctx.beta_ref)
+        if gs is not None and bs is not None:
+            dgamma, dbeta, ret_g, ret_b = gs, bs, None, None
+        else:
+            dgamma = torch.zeros((Cout,), dtype=f32, device=dev)
+            dbeta = torch.zeros((Cout,), dtype=f32, device=dev)
+            ret_g, ret_b = dgamma, dbeta
         _chk(lib.cr_bn_bwd(_ctx(x), _p(dout), _p(out), _p(y_raw), _p(mi), _p(gamma.detach()), _p(sums), _p(dx_raw),
                            _p(dres), _p(dgamma), _p(dbeta), M, Cout, int(relu)), "cr_bn_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
             _, wt = prepared_weights(weight, need_transposed=True)
             dx = conv_bwd_data_raw(dx_raw, wt, x.shape, k, stride, pad)
-        dw = conv_bwd_weight_raw(dx_raw, x, k, stride, pad) if ctx.needs_input_grad[1] else None
-        return dx, dw, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        dw = conv_bwd_weight_raw(dx_raw, x, k, stride, pad, grad_sink(weight)) if ctx.needs_input_grad[1] else None
+        return dx, dw, ret_g, ret_b, dres, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride=1, pad=0, relu=True, residual=None,
@@ -211,7 +227,7 @@ class _ConvBias(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, wt = prepared_weights(weight, need_transposed=True)
             dx = conv_bwd_data_raw(g, wt, x.shape, k, stride, pad)
-        dw = conv_bwd_weight_raw(g, x, k, stride, pad) if ctx.needs_input_grad[1] else None
+        dw = conv_bwd_weight_raw(g, x, k, stride, pad, grad_sink(weight)) if ctx.needs_input_grad[1] else None
         return dx, dw, db, None, None, None, None
 
 

@@ -23,7 +23,11 @@ STUB = ('cv2', 'detectron2', 'pytorch3d', 'fvcore', 'iopath', 'torchvision', 'py
 
 class _D:
     def __init__(s, *a, **k): pass
-    def __call__(s, *a, **k): return _D()
+    def __call__(s, *a, **k):
+        # used as a decorator (@REGISTRY.register(), @configurable): hand the class / function back untouched
+        if len(a) == 1 and not k and (isinstance(a[0], type) or callable(a[0])) and not isinstance(a[0], _D):
+            return a[0]
+        return _D()
     def __getattr__(s, n):
         if n.startswith('__'):
             raise AttributeError(n)

@@ -38,14 +38,20 @@ def test_train_steps_run_and_learn(built):
 def test_inference_runs(built):
     cfg, model, opt, syn, solver = built
     model.eval()
+    thr = model.roi_heads.box_predictor.test_score_thresh
+    model.roi_heads.box_predictor.test_score_thresh = -1.0     # barely-trained weights: keep detections alive
     try:
         with torch.no_grad():
             out = model(syn.make_batch(2, 9, with_gt=False))
     finally:
+        model.roi_heads.box_predictor.test_score_thresh = thr
         model.train()
     assert len(out) == 2
     for o in out:
         inst = o["instances"]
         n = len(inst)
+        assert 0 < n <= cfg.TEST.DETECTIONS_PER_IMAGE
         assert inst.pred_bbox3D.shape == (n, 8, 3) and inst.pred_pose.shape == (n, 3, 3)
-        assert n <= cfg.TEST.DETECTIONS_PER_IMAGE
+        assert inst.pred_dimensions.shape == (n, 3) and inst.pred_center_cam.shape == (n, 3)
+        assert inst.scores_full.shape == (n, cfg.MODEL.ROI_HEADS.NUM_CLASSES)
+        assert torch.isfinite(inst.pred_bbox3D).all()
