@@ -21,7 +21,7 @@ def fc_nhwc(x_nhwc_flat, fc, chw):
     """Linear whose weight columns are in (c,h,w) order applied to an (h,w,c)-flattened bf16 input."""
     C, H, W = chw
     w = fc.weight.view(fc.out_features, C, H, W).permute(0, 2, 3, 1).reshape(fc.out_features, -1)
-    return F.linear(x_nhwc_flat, w.to(bf16), fc.bias.to(bf16))
+    return F.linear(x_nhwc_flat, w.to(x_nhwc_flat.dtype), fc.bias.to(x_nhwc_flat.dtype))
 
 
 @ROI_CUBE_HEAD_REGISTRY.register()
@@ -74,8 +74,8 @@ class CubeHead(nn.Module):
         fcs = [m for m in self.feature_generator if isinstance(m, nn.Linear)]
         h = F.relu(fc_nhwc(x, fcs[0], self._in_chw))
         for fc in fcs[1:]:
-            h = F.relu(F.linear(h, fc.weight.to(bf16), fc.bias.to(bf16)))
-        lin = lambda m: F.linear(h, m.weight.to(bf16), m.bias.to(bf16)).float()
+            h = F.relu(F.linear(h, fc.weight.to(h.dtype), fc.bias.to(h.dtype)))
+        lin = lambda m: F.linear(h, m.weight.to(h.dtype), m.bias.to(h.dtype)).float()
         box_2d_deltas = lin(self.bbox_3D_center_deltas)
         box_dims = lin(self.bbox_3D_dims)
         box_pose = lin(self.bbox_3D_pose)

@@ -129,7 +129,7 @@ def bench_geometry(args, rank, world, dev):
 def cpu_baseline_geometry(inp, P):
     """oracle (numpy restatement of the reference's per-object loop, roi_heads.py:494-505) on a bounded sample."""
     from oracle import geometry as og
-    n = 48
+    n = 1024
     c = {k: (v[:n].cpu().numpy() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] > 3 else v) for k, v in inp.items()}
     K = inp["K"].cpu().numpy()
     og.project_and_score(c["cubes"][:2], K, inp["im_wh"], c["ref"][:2], c["mu"][:2], c["sg"][:2], c["rect"][:2])
@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="geometry", choices=["train", "geometry"])
+    ap.add_argument("--workload", default="train", choices=["train", "geometry"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
@@ -159,6 +159,8 @@ def main():
     else:
         bt = importlib.import_module("bench_train")
         res = bt.bench_train(args, rank, world, dev)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = bt.cpu_baseline_train()
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

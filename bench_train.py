@@ -62,3 +62,21 @@ def bench_train(args, rank, world, dev):
                      "traffic": None, "algorithmic_gflop_per_step": TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU},
     }
     return res
+
+
+def cpu_baseline_train():
+    """the oracle's float32 torch-CPU train step (oracle/cpu_train_step.py) on the box's host cores, in a separate
+    process, on a bounded sample (1 warm-up + 1 timed step of 2 images)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, os.path.join(here, "oracle", "cpu_train_step.py"), "--images", "2", "--steps", "1",
+           "--warmup", "1", "--threads", str(os.cpu_count())]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:      # the baseline is a report, never a reason to lose the GPU number
+        return {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}

@@ -1,0 +1,169 @@
+"""ORACLE (test infrastructure, NOT product code) -- plain PyTorch float32 CPU implementations of the
+3dod_amd.hipops API (same function names and NHWC tensor contract), so that the host-side model of
+3dod_amd/cubercnn can be executed on the host cores as the "port" CPU baseline of bench.py and as a
+float32 reference for GPU parity tests.
+
+Used ONLY from tests/, bench.py's cpu_baseline leg (in a separate process: oracle/cpu_train_step.py) and
+__graft_entry__.smoke().  `install()` swaps the `ops` symbol inside the product's modules IN THAT PROCESS;
+the product itself never imports this file and has no CPU path.
+"""
+import importlib
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import torch_ref as R
+
+f32 = torch.float32
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def bump_weight_epoch():
+    pass
+
+
+def grad_sink(t):
+    return None
+
+
+def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride=1, pad=0, relu=True, residual=None,
+                eps=1e-5, momentum=0.1, training=True):
+    if weight.shape[1] != x.shape[3]:
+        raise ValueError("channel mismatch")
+    y = F.conv2d(_nchw(x), weight, None, stride, pad)
+    y = F.batch_norm(y, running_mean, running_var, gamma, beta, training, momentum, eps)
+    if residual is not None:
+        y = y + _nchw(residual)
+    if relu:
+        y = F.relu(y)
+    return _nhwc(y)
+
+
+def conv_bias_act(x, weight, bias, stride=1, pad=0, relu=False, out_f32=False):
+    y = F.conv2d(_nchw(x), weight, bias, stride, pad)
+    if relu:
+        y = F.relu(y)
+    return _nhwc(y)
+
+
+def maxpool2x2(x):
+    return _nhwc(F.max_pool2d(_nchw(x), 2, 2))
+
+
+def subsample2x(x):
+    return _nhwc(F.max_pool2d(_nchw(x), 1, 2))
+
+
+def upsample2x_add(lat, top):
+    return _nhwc(_nchw(lat) + F.interpolate(_nchw(top), scale_factor=2.0, mode="nearest"))
+
+
+def preprocess(images_u8, mean, std):
+    x = (images_u8.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    x = _nhwc(x)
+    return torch.cat([x, x.new_zeros(x.shape[:3] + (5,))], 3)
+
+
+def roi_align_pyramid(feats, rois, scales, out_size):
+    """vectorised torch restatement of roi_align(aligned=True, sampling_ratio=0) + level assignment
+    (same arithmetic as oracle/torch_ref.roi_align; RoIs are grouped by (level, grid))."""
+    R_ = rois.shape[0]
+    C = feats[0].shape[3]
+    out = feats[0].new_zeros((R_, out_size, out_size, C))
+    if R_ == 0:
+        return out
+    min_level = int(round(-math.log2(scales[0])))
+    lv = R.assign_levels(rois[:, 1:], min_level, min_level + len(feats) - 1)
+    for l, (f, s) in enumerate(zip(feats, scales)):
+        idx = (lv == l).nonzero(as_tuple=True)[0]
+        if idx.numel() == 0:
+            continue
+        rb = rois[idx]
+        H, W = f.shape[1], f.shape[2]
+        x1, y1 = rb[:, 1] * s - 0.5, rb[:, 2] * s - 0.5
+        rw, rh = (rb[:, 3] - rb[:, 1]) * s, (rb[:, 4] - rb[:, 2]) * s
+        gh = torch.ceil(rh / out_size).clamp(min=0).long()
+        gw = torch.ceil(rw / out_size).clamp(min=0).long()
+        for g_h, g_w in set(zip(gh.tolist(), gw.tolist())):
+            sel = ((gh == g_h) & (gw == g_w)).nonzero(as_tuple=True)[0]
+            ii = idx[sel]
+            if g_h == 0 or g_w == 0:
+                continue
+            n = sel.numel()
+            bh, bw = (rh[sel] / out_size), (rw[sel] / out_size)
+            ph = torch.arange(out_size, dtype=f32)
+            iy = torch.arange(g_h, dtype=f32)
+            ix = torch.arange(g_w, dtype=f32)
+            yy = y1[sel, None, None] + ph[None, :, None] * bh[:, None, None] + (iy[None, None, :] + 0.5) * bh[:, None, None] / g_h
+            xx = x1[sel, None, None] + ph[None, :, None] * bw[:, None, None] + (ix[None, None, :] + 0.5) * bw[:, None, None] / g_w
+            Y = yy[:, :, None, :, None].expand(n, out_size, out_size, g_h, g_w)
+            X = xx[:, None, :, None, :].expand(n, out_size, out_size, g_h, g_w)
+            ok = ~((Y < -1.0) | (Y > H) | (X < -1.0) | (X > W))
+            Yc, Xc = Y.clamp(min=0), X.clamp(min=0)
+            yl, xl = Yc.floor().long(), Xc.floor().long()
+            ytop, xtop = yl >= H - 1, xl >= W - 1
+            yl = torch.where(ytop, torch.full_like(yl, H - 1), yl)
+            xl = torch.where(xtop, torch.full_like(xl, W - 1), xl)
+            yh = torch.where(ytop, yl, yl + 1)
+            xh = torch.where(xtop, xl, xl + 1)
+            Yc = torch.where(ytop, yl.float(), Yc)
+            Xc = torch.where(xtop, xl.float(), Xc)
+            ly, lx = Yc - yl, Xc - xl
+            hy, hx = 1 - ly, 1 - lx
+            b = rb[sel, 0].long()[:, None, None, None, None].expand_as(yl)
+            val = (hy * hx)[..., None] * f[b, yl, xl] + (hy * lx)[..., None] * f[b, yl, xh] + \
+                (ly * hx)[..., None] * f[b, yh, xl] + (ly * lx)[..., None] * f[b, yh, xh]
+            val = val * ok[..., None]
+            out = out.index_put((ii,), val.sum((3, 4)) / max(g_h * g_w, 1))
+    return out
+
+
+def nms_grouped(boxes, counts, thresh):
+    G, maxn, _ = boxes.shape
+    keep = torch.zeros((G, maxn), dtype=torch.bool)
+    for g in range(G):
+        n = int(counts[g])
+        if n:
+            scores = torch.arange(n, 0, -1, dtype=f32)
+            keep[g, R.nms(boxes[g, :n], scores, thresh)] = True
+    return keep
+
+
+def nonfinite_flag(flat_grad, flag):
+    if not bool(torch.isfinite(flat_grad).all()):
+        flag.fill_(1)
+
+
+def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None):
+    if skip_flag is not None and int(skip_flag.view(-1)[0]) != 0:
+        return
+    gg = g * grad_scale + weight_decay * p
+    m.mul_(momentum).add_(gg)
+    p.sub_(lr * m)
+
+
+PATCHED = ("3dod_amd.cubercnn.modeling.backbone.dla", "3dod_amd.cubercnn.modeling.backbone.fpn",
+           "3dod_amd.cubercnn.modeling.proposal_generator.rpn", "3dod_amd.cubercnn.modeling.roi_heads.roi_heads",
+           "3dod_amd.cubercnn.modeling.roi_heads.fast_rcnn", "3dod_amd.cubercnn.modeling.meta_arch.rcnn3d",
+           "3dod_amd.cubercnn.solver.build")
+
+
+def install():
+    """point the `ops` symbol of the product's host modules at this backend (this process only)."""
+    me = importlib.import_module(__name__)
+    for name in PATCHED:
+        mod = importlib.import_module(name)
+        mod.ops = me
+    return me
+
+
+class TorchCpuOps:
+    pass
