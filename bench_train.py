@@ -49,6 +49,8 @@ def bench_train(args, rank, world, dev):
         rep = step.report()
     ims = IMS_PER_GPU * world * args.steps / dt
     achieved_tf = TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU / (dt / args.steps) / 1e3
+    import sys
+    print(f"[bench] rank {rank}: {ims:.1f} images/s, {dt / args.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
     res = {
         "metric": "images/sec Cube R-CNN DLA34-FPN train step", "value": ims, "unit": "images/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -66,16 +68,23 @@ def bench_train(args, rank, world, dev):
 
 def cpu_baseline_train():
     """the oracle's float32 torch-CPU train step (oracle/cpu_train_step.py) on the box's host cores, in a separate
-    process, on a bounded sample (1 warm-up + 1 timed step of 2 images)."""
+    process, on a bounded sample (1 warm-up + 4 timed steps of 4 images)."""
     import json
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [sys.executable, os.path.join(here, "oracle", "cpu_train_step.py"), "--images", "2", "--steps", "1",
-           "--warmup", "1", "--threads", str(os.cpu_count())]
-    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        ncpu = len(os.sched_getaffinity(0))
+    except Exception:
+        ncpu = os.cpu_count() or 1
+    threads = max(1, min(16, ncpu))          # a 1-GPU box gives this job a 16-core share
+    cmd = [sys.executable, os.path.join(here, "oracle", "cpu_train_step.py"), "--images", "4", "--steps", "4",
+           "--warmup", "1", "--threads", str(threads)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads),
+               MKL_NUM_THREADS=str(threads))
+    print(f"[bench] cpu baseline: {' '.join(cmd[1:])}", file=sys.stderr, flush=True)
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:      # the baseline is a report, never a reason to lose the GPU number

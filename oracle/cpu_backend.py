@@ -17,6 +17,15 @@ from . import torch_ref as R
 
 f32 = torch.float32
 
+# When True, every op rounds its weights and its stored outputs to bfloat16 exactly where the HIP kernels
+# store bf16 (statistics and accumulation stay float32): lets the GPU parity tests separate "bf16 storage
+# noise" (expected, grows with depth) from arithmetic errors (must be ~1e-3).
+EMULATE_BF16 = False
+
+
+def _q(t):
+    return t.to(torch.bfloat16).to(f32) if EMULATE_BF16 else t
+
 
 def _nchw(x):
     return x.permute(0, 3, 1, 2)
@@ -38,20 +47,28 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride=1, pad
                 eps=1e-5, momentum=0.1, training=True):
     if weight.shape[1] != x.shape[3]:
         raise ValueError("channel mismatch")
-    y = F.conv2d(_nchw(x), weight, None, stride, pad)
-    y = F.batch_norm(y, running_mean, running_var, gamma, beta, training, momentum, eps)
+    y = F.conv2d(_nchw(x), _q(weight), None, stride, pad)
+    if EMULATE_BF16 and training:
+        # the kernels take the statistics from the float32 accumulators and normalise the bf16-stored output
+        mean = y.mean((0, 2, 3))
+        var = y.var((0, 2, 3), unbiased=False)
+        y = (_q(y) - mean[None, :, None, None]) * torch.rsqrt(var + eps)[None, :, None, None] * \
+            gamma[None, :, None, None] + beta[None, :, None, None]
+    else:
+        y = F.batch_norm(_q(y), running_mean, running_var, gamma, beta, training, momentum, eps)
     if residual is not None:
         y = y + _nchw(residual)
     if relu:
         y = F.relu(y)
-    return _nhwc(y)
+    return _q(_nhwc(y))
 
 
 def conv_bias_act(x, weight, bias, stride=1, pad=0, relu=False, out_f32=False):
-    y = F.conv2d(_nchw(x), weight, bias, stride, pad)
+    y = F.conv2d(_nchw(x), _q(weight), bias, stride, pad)
     if relu:
         y = F.relu(y)
-    return _nhwc(y)
+    y = _nhwc(y)
+    return y if out_f32 else _q(y)
 
 
 def maxpool2x2(x):
@@ -63,12 +80,12 @@ def subsample2x(x):
 
 
 def upsample2x_add(lat, top):
-    return _nhwc(_nchw(lat) + F.interpolate(_nchw(top), scale_factor=2.0, mode="nearest"))
+    return _q(_nhwc(_nchw(lat) + F.interpolate(_nchw(top), scale_factor=2.0, mode="nearest")))
 
 
 def preprocess(images_u8, mean, std):
     x = (images_u8.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
-    x = _nhwc(x)
+    x = _q(_nhwc(x))
     return torch.cat([x, x.new_zeros(x.shape[:3] + (5,))], 3)
 
 
@@ -123,7 +140,7 @@ def roi_align_pyramid(feats, rois, scales, out_size):
                 (ly * hx)[..., None] * f[b, yh, xl] + (ly * lx)[..., None] * f[b, yh, xh]
             val = val * ok[..., None]
             out = out.index_put((ii,), val.sum((3, 4)) / max(g_h * g_w, 1))
-    return out
+    return _q(out)
 
 
 def nms_grouped(boxes, counts, thresh):
