@@ -153,7 +153,7 @@ class TrainStep:
         n = optimizer.flat_g.numel()
         be = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets = [(i, min(i + be, n)) for i in range(0, n, be)][::-1]     # last-used params first
-        self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if (world_size > 1 and dev.type == 'cuda') else None
         self.last = {}
 
     def __call__(self, data):
@@ -180,12 +180,15 @@ class TrainStep:
         losses.backward()
         opt.collect_grads()
         # ---- gradient all-reduce (DDP, train_net.py:477-480), bucketed, overlapped on a side stream
-        if world > 1:
+        if world > 1 and self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 for a, b in self.buckets:
                     dist.all_reduce(opt.flat_g[a:b])
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        elif world > 1:                      # gloo / CPU rehearsal of the same protocol
+            for a, b in self.buckets:
+                dist.all_reduce(opt.flat_g[a:b])
         # ---- non-finite scan of the (averaged) gradient + skip flag, all on device
         self.flag.copy_(diverging.to(torch.int32).view(1))
         if self.stabilize:
