@@ -40,6 +40,24 @@ class RCNN3D(nn.Module):
         self.pixel_std_list = [float(v) for v in cfg.MODEL.PIXEL_STD]
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
+        self._graphed = None
+
+    def enable_graphs(self, sample_batched_inputs):
+        """capture the static dense region (trunk + FPN + RPN head, forward and backward) as HIP graphs for the
+        image-batch shape of `sample_batched_inputs`.  Call after the optimizer (FlatSGD) has been built."""
+        from ..graphed import GraphedDense
+        il, batch = self._stack_images(sample_batched_inputs)
+        self._graphed = GraphedDense(self, batch)
+        return self._graphed
+
+    def _stack_images(self, batched_inputs):
+        images = [x["image"].to(self.device) for x in batched_inputs]
+        il = ImageList.from_tensors(images, self.backbone.size_divisibility,
+                                    padding_constraints=self.backbone.padding_constraints)
+        batch = il.tensor
+        if batch.dtype != torch.uint8:
+            batch = batch.clamp(0, 255).to(torch.uint8)
+        return il, batch.contiguous()
 
     @property
     def device(self):
@@ -48,13 +66,8 @@ class RCNN3D(nn.Module):
     def preprocess_image(self, batched_inputs):
         """(x - mean)/std, pad to the backbone's size divisibility, stack.  Returns (ImageList of the uint8 batch
         sizes, NHWC bf16 tensor with 8 channels)."""
-        images = [x["image"].to(self.device) for x in batched_inputs]
-        il = ImageList.from_tensors(images, self.backbone.size_divisibility,
-                                    padding_constraints=self.backbone.padding_constraints)
-        batch = il.tensor
-        if batch.dtype != torch.uint8:
-            batch = batch.clamp(0, 255).to(torch.uint8)
-        x = ops.preprocess(batch.contiguous(), self.pixel_mean_list, self.pixel_std_list)
+        il, batch = self._stack_images(batched_inputs)
+        x = ops.preprocess(batch, self.pixel_mean_list, self.pixel_std_list)
         H, W = batch.shape[-2:]
         if any(tuple(s) != (H, W) for s in il.image_sizes):
             # detectron2 pads AFTER normalisation (zeros in normalised space)
@@ -67,15 +80,26 @@ class RCNN3D(nn.Module):
     def forward(self, batched_inputs: List[Dict[str, torch.Tensor]]):
         if not self.training:
             return self.inference(batched_inputs)
-        images, x = self.preprocess_image(batched_inputs)
+        head_outputs = None
+        g = self._graphed
+        if g is not None:
+            images, batch = self._stack_images(batched_inputs)
+            same = all(tuple(sz) == tuple(batch.shape[-2:]) for sz in images.image_sizes)
+            if same and g.matches(batch):
+                features, logits, deltas = g(batch)
+                head_outputs = (logits, deltas)
+            else:
+                g = None
+        if g is None:
+            images, x = self.preprocess_image(batched_inputs)
+            features = self.backbone(x)
         im_scales_ratio = [info['height'] / im_size[0] for (info, im_size) in zip(batched_inputs, images.image_sizes)]
         Ks = [torch.FloatTensor(info['K']) for info in batched_inputs]
         if "instances" in batched_inputs[0]:
             gt_instances = [b["instances"].to(self.device) for b in batched_inputs]
         else:
             gt_instances = None
-        features = self.backbone(x)
-        proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
+        proposals, proposal_losses = self.proposal_generator(images, features, gt_instances, head_outputs=head_outputs)
         instances, detector_losses = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, gt_instances)
         losses = {}
         losses.update(detector_losses)

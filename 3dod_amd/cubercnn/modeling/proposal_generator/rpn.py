@@ -141,11 +141,15 @@ class RPN(nn.Module):
             "head": head,
         }
 
-    def forward(self, images, features: Dict[str, torch.Tensor], gt_instances=None):
+    def forward(self, images, features: Dict[str, torch.Tensor], gt_instances=None, head_outputs=None):
+        """head_outputs: (logits, deltas) when the head already ran inside the captured dense graph."""
         feats = [features[f] for f in self.in_features]
         grid_sizes = [(f.shape[1], f.shape[2]) for f in feats]                     # NHWC
         anchors = self.anchor_generator(grid_sizes, feats[0].device)
-        pred_objectness_logits, pred_anchor_deltas = self.rpn_head(feats)
+        if head_outputs is None:
+            pred_objectness_logits, pred_anchor_deltas = self.rpn_head(feats)
+        else:
+            pred_objectness_logits, pred_anchor_deltas = head_outputs
         if self.training:
             assert gt_instances is not None, "RPN requires gt_instances in training!"
             gt_labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances)

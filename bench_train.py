@@ -37,6 +37,9 @@ def bench_train(args, rank, world, dev):
         for d in b:
             d["image"] = d["image"].to(dev)
             d["instances"] = d["instances"].to(dev)
+    if os.environ.get("CR_NO_GRAPHS", "0") != "1":
+        model.enable_graphs(batches[0])
+        opt.zero_grad()
     with d2.EventStorage(0):
         for i in range(args.warmup):
             step(batches[i % len(batches)])
