@@ -26,7 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
 #define CONV_T 256
-#define STAT_REPL 32        // replicas of the BN statistics accumulators (atomic contention)
+#define STAT_REPL 32        // (legacy name) -- BN statistics are now per-block partial sums, reduced in a fixed order
 
 __device__ __forceinline__ float bf2f(u16 b) { return __uint_as_float(((unsigned)b) << 16); }
 __device__ __forceinline__ u16 f2bf(float f) {
@@ -40,7 +40,7 @@ struct ConvP {
     void* y;             // [M][Cout] bf16 or f32
     const u16* res;      // optional residual [M][Cout] bf16 (added before ReLU)
     const float* bias;   // optional [Cout]
-    float* stats;        // optional [STAT_REPL][2][Cout]: sum and sum of squares of the conv output
+    float* stats;        // optional [ceil(M/128)][2][Cout]: per-M-tile sum and sum of squares of the conv output
     int N, Hin, Win, Cin, Hout, Wout, Cout;
     int stride, pad, Kdim, M, cshift, relu;
 };
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
     constexpr int NB = (BN * 4 + CONV_T - 1) / CONV_T;   // weight chunks per thread
     __shared__ __attribute__((aligned(16))) u16 sX[BM * 32];
     __shared__ __attribute__((aligned(16))) u16 sW[BN * 32];
-    __shared__ float sStat[2 * BN];
+    __shared__ float sStat[4 * 2 * BN];      // [wave][2][BN]: no atomics -> bitwise reproducible statistics
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = p.Cout / BN;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
     // ---- epilogue: bias, BN statistics, residual, ReLU, store (4 consecutive channels per lane)
     const bool do_stats = p.stats != nullptr;
     if (do_stats) {
-        for (int i = tid; i < 2 * BN; i += CONV_T) sStat[i] = 0.f;
+        for (int i = tid; i < 4 * 2 * BN; i += CONV_T) sStat[i] = 0.f;
         __syncthreads();
     }
     const int g = lane >> 4, pl = lane & 15;
@@ -222,21 +222,23 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
                     ssq[e] += __shfl_xor(ssq[e], off, 64);
                 }
             }
-            if (pl == 0) {
+            if (pl == 0) {          // exactly one lane per (wave, channel): plain stores
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    atomicAdd(&sStat[chl + e], ssum[e]);
-                    atomicAdd(&sStat[BN + chl + e], ssq[e]);
+                    sStat[(wave * 2 + 0) * BN + chl + e] = ssum[e];
+                    sStat[(wave * 2 + 1) * BN + chl + e] = ssq[e];
                 }
             }
         }
     }
     if (do_stats) {
         __syncthreads();
-        float* dst = p.stats + (size_t)(blockIdx.x % STAT_REPL) * 2 * p.Cout;
+        float* dst = p.stats + (size_t)mt * 2 * p.Cout;           // this M-tile's partial, fixed wave order
         for (int i = tid; i < BN; i += CONV_T) {
-            atomicAdd(&dst[n0 + i], sStat[i]);
-            atomicAdd(&dst[p.Cout + n0 + i], sStat[BN + i]);
+            const float a = ((sStat[(0 * 2 + 0) * BN + i] + sStat[(1 * 2 + 0) * BN + i]) + sStat[(2 * 2 + 0) * BN + i]) + sStat[(3 * 2 + 0) * BN + i];
+            const float b = ((sStat[(0 * 2 + 1) * BN + i] + sStat[(1 * 2 + 1) * BN + i]) + sStat[(2 * 2 + 1) * BN + i]) + sStat[(3 * 2 + 1) * BN + i];
+            dst[n0 + i] = a;
+            dst[p.Cout + n0 + i] = b;
         }
     }
 }
@@ -292,7 +294,6 @@ extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y,
     p.Wout = (W + 2 * pad - ks) / stride + 1;
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = N * p.Hout * p.Wout;
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cin); p.relu = relu;
-    if (stats) CR_HIP(hipMemsetAsync(stats, 0, sizeof(float) * STAT_REPL * 2 * Cout, ctx->stream));
     if (ks == 1) return launch_igemm_ks<1, 0>(ctx, p, out_f32);
     if (ks == 3) return launch_igemm_ks<3, 0>(ctx, p, out_f32);
     return launch_igemm_ks<7, 0>(ctx, p, out_f32);
@@ -553,23 +554,36 @@ extern "C" int cr_weight_transpose(cr_ctx* ctx, const float* w, void* wt, int Co
 // ---------------------------------------------------------------------------
 // BatchNorm2d (training mode, per-GPU statistics: dla.py:17 BatchNorm = nn.BatchNorm2d)
 // ---------------------------------------------------------------------------
-// finalize: stats replicas -> mean / invstd (+ running stats update, momentum 0.1, unbiased var)
-__global__ void k_bn_finalize(const float* __restrict__ stats, int C, float count, float eps, float momentum,
-                              float* __restrict__ mean_invstd, float* __restrict__ running_mean,
-                              float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int r = 0; r < STAT_REPL; ++r) { s += stats[(size_t)r * 2 * C + c]; q += stats[(size_t)r * 2 * C + C + c]; }
-    const float mean = s / count;
-    float var = q / count - mean * mean;
-    var = fmaxf(var, 0.f);
-    mean_invstd[c] = mean;
-    mean_invstd[C + c] = rsqrtf(var + eps);
-    if (running_mean) {
-        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+// finalize: per-tile partials [nparts][2][C] -> mean / invstd (+ running stats update, momentum, unbiased var).
+// One workgroup per channel; strided serial sums + a fixed-order LDS tree, in double: reproducible and accurate
+// (no E[x^2]-E[x]^2 cancellation at float precision).
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ stats, int nparts, int C, float count,
+                                                     float eps, float momentum, float* __restrict__ mean_invstd,
+                                                     float* __restrict__ running_mean, float* __restrict__ running_var) {
+    __shared__ double ss[256], sq[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int r = t; r < nparts; r += 256) {
+        s += (double)stats[(size_t)r * 2 * C + c];
+        q += (double)stats[(size_t)r * 2 * C + C + c];
+    }
+    ss[t] = s; sq[t] = q;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) { ss[t] += ss[t + off]; sq[t] += sq[t + off]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double mean = ss[0] / (double)count;
+        double var = sq[0] / (double)count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_invstd[c] = (float)mean;
+        mean_invstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
     }
 }
 
@@ -604,12 +618,12 @@ __global__ __launch_bounds__(256) void k_bn_apply(const u16* __restrict__ x, con
     }
 }
 
-extern "C" int cr_bn_fwd(cr_ctx* ctx, const void* x, const float* stats, const float* gamma, const float* beta,
-                         const void* residual, void* y, int64_t M, int C, int relu, float eps, float momentum,
-                         float* mean_invstd, float* running_mean, float* running_var) {
+extern "C" int cr_bn_fwd(cr_ctx* ctx, const void* x, const float* stats, int nparts, const float* gamma,
+                         const float* beta, const void* residual, void* y, int64_t M, int C, int relu, float eps,
+                         float momentum, float* mean_invstd, float* running_mean, float* running_var) {
     CR_CHECK_ARG(ctx && x && stats && gamma && beta && y && mean_invstd, "cr_bn_fwd: NULL pointer");
-    CR_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0, "cr_bn_fwd: bad dims M=%lld C=%d", (long long)M, C);
-    hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)cr_cdiv(C, 64)), dim3(64), 0, ctx->stream, stats, C, (float)M, eps,
+    CR_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && nparts > 0, "cr_bn_fwd: bad dims M=%lld C=%d", (long long)M, C);
+    hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)C), dim3(256), 0, ctx->stream, stats, nparts, C, (float)M, eps,
                        momentum, mean_invstd, running_mean, running_var);
     CR_LAUNCH_CHECK();
     const int64_t total = M * (C >> 3);
@@ -620,22 +634,20 @@ extern "C" int cr_bn_fwd(cr_ctx* ctx, const void* x, const float* stats, const f
     return CR_OK;
 }
 
-// backward reduce: g = dy * (relu ? out > 0 : 1);  sums[rep][0][c] += g ; sums[rep][1][c] += g * xhat
+// backward reduce: g = dy * (relu ? out > 0 : 1);  partial[block][0][c] = sum g ; partial[block][1][c] = sum g*xhat
+#define BNB_MAXBLOCKS 1024
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const u16* __restrict__ dy, const u16* __restrict__ out,
                                                        const u16* __restrict__ x, const float* __restrict__ mean_invstd,
-                                                       float* __restrict__ sums, int64_t M, int C, int relu) {
-    extern __shared__ float s_acc[];        // [2][C]
+                                                       float* __restrict__ partial, int64_t M, int C, int relu) {
+    extern __shared__ float s_acc[];        // [rows_per_block][2][C]  (= 4096 floats for every supported C)
     const int cg = C >> 3;
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
-    __syncthreads();
-    // thread -> fixed channel group when blockDim % cg == 0 (cg <= 64 for C <= 512; blockDim = 256)
-    const int mycg = threadIdx.x % cg;
+    const int mycg = threadIdx.x % cg, myrow = threadIdx.x / cg;
     const int rows_per_block = blockDim.x / cg;
     const int c0 = mycg << 3;
     float a[8], b[8], mu[8], is[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; mu[e] = mean_invstd[c0 + e]; is[e] = mean_invstd[C + c0 + e]; }
-    for (int64_t m = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / cg; m < M; m += (int64_t)gridDim.x * rows_per_block) {
+    for (int64_t m = (int64_t)blockIdx.x * rows_per_block + myrow; m < M; m += (int64_t)gridDim.x * rows_per_block) {
         const int64_t i = m * cg + mycg;
         const uint4 dv = *reinterpret_cast<const uint4*>(dy + i * 8);
         const uint4 xv = *reinterpret_cast<const uint4*>(x + i * 8);
@@ -654,29 +666,48 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const u16* __restrict__ d
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { atomicAdd(&s_acc[c0 + e], a[e]); atomicAdd(&s_acc[C + c0 + e], b[e]); }
+    for (int e = 0; e < 8; ++e) { s_acc[(myrow * 2 + 0) * C + c0 + e] = a[e]; s_acc[(myrow * 2 + 1) * C + c0 + e] = b[e]; }
     __syncthreads();
-    float* dst = sums + (size_t)(blockIdx.x % STAT_REPL) * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&dst[i], s_acc[i]);
+    float* dst = partial + (size_t)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        const int which = i / C, c = i - which * C;
+        float s = 0.f;
+        for (int r = 0; r < rows_per_block; ++r) s += s_acc[(r * 2 + which) * C + c];     // fixed order
+        dst[i] = s;
+    }
 }
 
-// dgamma/dbeta + dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); also writes g (the masked grad) for the residual branch
+// partial [nparts][2][C] -> sums [2][C]; dgamma/dbeta accumulated.  One workgroup per channel, fixed-order tree.
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int nparts, int C,
+                                                         float* __restrict__ sums, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta) {
+    __shared__ double ss[256], sq[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int r = t; r < nparts; r += 256) {
+        s += (double)partial[(size_t)r * 2 * C + c];
+        q += (double)partial[(size_t)r * 2 * C + C + c];
+    }
+    ss[t] = s; sq[t] = q;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) { ss[t] += ss[t + off]; sq[t] += sq[t + off]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        sums[c] = (float)ss[0];
+        sums[C + c] = (float)sq[0];
+        dbeta[c] += (float)ss[0];
+        dgamma[c] += (float)sq[0];
+    }
+}
+
+// dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); also writes g (the masked grad) for the residual branch
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const u16* __restrict__ dy, const u16* __restrict__ out,
                                                       const u16* __restrict__ x, const float* __restrict__ mean_invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                      u16* __restrict__ dx, u16* __restrict__ dres,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M,
-                                                      int C, int relu) {
-    extern __shared__ float s_sum[];        // [2][C] reduced over replicas
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-        float s = 0.f;
-        for (int r = 0; r < STAT_REPL; ++r) s += sums[(size_t)r * 2 * C + i];
-        s_sum[i] = s;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < C; c += blockDim.x) { dbeta[c] += s_sum[c]; dgamma[c] += s_sum[C + c]; }
-    }
+                                                      u16* __restrict__ dx, u16* __restrict__ dres, int64_t M, int C,
+                                                      int relu) {
     const int cg = C >> 3;
     const float invM = 1.f / (float)M;
     const int64_t total = M * cg;
@@ -699,7 +730,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const u16* __restrict__ dy
                 gq = o > 0.f ? gq : 0.f;
                 const float is = mean_invstd[C + c];
                 const float xh = (bf2f((u16)(h ? xs[w] >> 16 : xs[w] & 0xffff)) - mean_invstd[c]) * is;
-                vd[h] = gamma[c] * is * (gq - s_sum[c] * invM - xh * s_sum[C + c] * invM);
+                vd[h] = gamma[c] * is * (gq - sums[c] * invM - xh * sums[C + c] * invM);
                 vg[h] = gq;
             }
             od[w] = (unsigned)f2bf(vd[0]) | ((unsigned)f2bf(vd[1]) << 16);
@@ -710,26 +741,29 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const u16* __restrict__ dy
     }
 }
 
-// sums: workspace [STAT_REPL][2][C] f32 (zeroed here). dgamma/dbeta are ACCUMULATED (+=).
+// sums: f32 workspace of (CR_BN_BWD_WS_ROWS) x 2 x C floats (partials + the reduced [2][C] in the last row).
+// dgamma/dbeta are ACCUMULATED (+=).  No atomics: bitwise reproducible.
 extern "C" int cr_bn_bwd(cr_ctx* ctx, const void* dy, const void* out, const void* x, const float* mean_invstd,
                          const float* gamma, float* sums, void* dx, void* dres, float* dgamma, float* dbeta,
                          int64_t M, int C, int relu) {
     CR_CHECK_ARG(ctx && dy && x && mean_invstd && gamma && sums && dx && dgamma && dbeta, "cr_bn_bwd: NULL pointer");
     CR_CHECK_ARG(!relu || out, "cr_bn_bwd: relu needs the forward output");
     CR_CHECK_ARG(M > 0 && C % 8 == 0 && C <= 2048 && 256 % (C >> 3) == 0, "cr_bn_bwd: unsupported C=%d", C);
-    CR_HIP(hipMemsetAsync(sums, 0, sizeof(float) * STAT_REPL * 2 * C, ctx->stream));
     const int rows_per_block = 256 / (C >> 3);
     int64_t nb = cr_cdiv(M, (int64_t)rows_per_block * 8);
-    if (nb > 2048) nb = 2048;
+    if (nb > BNB_MAXBLOCKS) nb = BNB_MAXBLOCKS;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3((unsigned)nb), dim3(256), sizeof(float) * 2 * C, ctx->stream,
+    float* reduced = sums + (size_t)BNB_MAXBLOCKS * 2 * C;
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3((unsigned)nb), dim3(256), sizeof(float) * rows_per_block * 2 * C, ctx->stream,
                        (const u16*)dy, (const u16*)out, (const u16*)x, mean_invstd, sums, M, C, relu);
+    CR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)C), dim3(256), 0, ctx->stream, sums, (int)nb, C, reduced, dgamma,
+                       dbeta);
     CR_LAUNCH_CHECK();
     const int64_t total = M * (C >> 3);
     const unsigned grid = (unsigned)(cr_cdiv(total, 256) < 4096 ? cr_cdiv(total, 256) : 4096);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(256), sizeof(float) * 2 * C, ctx->stream, (const u16*)dy,
-                       (const u16*)out, (const u16*)x, mean_invstd, gamma, sums, (u16*)dx, (u16*)dres, dgamma, dbeta, M,
-                       C, relu);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(256), 0, ctx->stream, (const u16*)dy, (const u16*)out,
+                       (const u16*)x, mean_invstd, gamma, reduced, (u16*)dx, (u16*)dres, M, C, relu);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -6,9 +6,38 @@ launches (and their Python/ctypes issue cost) per direction collapse into one gr
 The dynamic parts of the step (anchor/proposal sampling, RoI heads on a data-dependent number of boxes) stay
 eager and talk to the graphs through static input / output / gradient buffers.
 """
+import contextlib
+
 import torch
+import torch.nn as nn
 
 from ... import hipops as ops
+
+
+@contextlib.contextmanager
+def _fresh_leaves(modules):
+    """Temporarily replace every parameter of `modules` by a NEW nn.Parameter over the same storage.  Autograd
+    identifies a leaf by its grad-accumulator node, which is pinned to the stream it was first used on; stale ones
+    (from earlier eager steps) make the engine synchronise the capture stream with the default stream and the
+    capture dies.  Fresh leaves get fresh accumulators on the capturing stream; memory addresses are unchanged,
+    so the graphs keep reading / writing the optimizer's flat buffers."""
+    swapped = []
+    for mod in modules:
+        for m in mod.modules():
+            for name, p in list(m._parameters.items()):
+                if p is None:
+                    continue
+                q = nn.Parameter(p.data, requires_grad=p.requires_grad)
+                sink = ops.grad_sink(p)
+                if sink is not None:
+                    q._cr_grad = sink
+                m._parameters[name] = q
+                swapped.append((m, name, p))
+    try:
+        yield
+    finally:
+        for m, name, p in swapped:
+            m._parameters[name] = p
 
 
 class _Replay(torch.autograd.Function):
@@ -49,42 +78,46 @@ class GraphedDense:
             self.n_levels = len(logits)
             return tuple(feats.values()) + tuple(logits) + tuple(deltas)
 
-        params = [p for p in model.backbone.parameters()] + [p for p in pg.rpn_head.parameters()]
-        self.extra = [p for p in params if p.requires_grad]
-        for p in self.extra:
-            assert ops.grad_sink(p) is not None, "build the optimizer (FlatSGD) before capturing graphs"
+        mods = [model.backbone, pg.rpn_head]
+
+        def leaves():
+            ps = [p for m in mods for p in m.parameters() if p.requires_grad]
+            for p in ps:
+                assert ops.grad_sink(p) is not None, "build the optimizer (FlatSGD) before capturing graphs"
+            return ps
 
         def run_backward(outs, grads):
-            for p in self.extra:
-                p.grad = None
-            torch.autograd.backward(outs, grads)
-            # gradients that came through plain autograd (biases, stem / predictor weights) -> flat gradient
-            for p in self.extra:
-                if p.grad is not None:
-                    ops.grad_sink(p).add_(p.grad)
+            # torch.autograd.grad, not .backward(): no AccumulateGrad nodes (they are pinned to the stream they were
+            # first created on, which breaks capture).  Conv / BN kernels accumulate into the flat gradient
+            # themselves and return None; what comes back here went through plain autograd (biases, the stem and
+            # predictor weights) and is added to the flat gradient inside the captured region.
+            ps = leaves()
+            res = torch.autograd.grad(outs, ps, grads, allow_unused=True)
+            for p, g in zip(ps, res):
+                if g is not None:
+                    ops.grad_sink(p).add_(g)
 
         # ---- eager warm-up on a side stream (allocator / lazy-init effects out of the capture)
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
+        with torch.cuda.stream(s), _fresh_leaves(mods):
             for _ in range(warmup):
                 outs = dense()
                 run_backward(outs, tuple(torch.zeros_like(o) for o in outs))
+            del outs
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
 
         # ---- capture.  The bf16 weight copies must be re-made INSIDE the graphs on every replay.
         ops.bump_weight_epoch()
-        self.fwd_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.fwd_graph):
-            self.static_outs = dense()
-        self.static_grads = tuple(torch.zeros_like(o) for o in self.static_outs)
-        self.bwd_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool()):
-            run_backward(self.static_outs, self.static_grads)
-        self._static_param_grads = [p.grad for p in self.extra]       # keep the captured buffers alive
-        for p in self.extra:
-            p.grad = None
+        with _fresh_leaves(mods):
+            self.fwd_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.fwd_graph):
+                self.static_outs = dense()
+            self.static_grads = tuple(torch.zeros_like(o) for o in self.static_outs)
+            self.bwd_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool()):
+                run_backward(self.static_outs, self.static_grads)
         torch.cuda.synchronize(dev)
 
     def matches(self, images_u8):

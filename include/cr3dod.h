@@ -109,8 +109,8 @@ int cr_ransac_plane(cr_ctx* ctx, const float* pts, int64_t Q, const int32_t* tri
 
 /* y = relu?(conv(x,w) + bias? + residual?)   ks in {1,3,7}, stride in {1,2}.
  * x (N,H,W,Cin) bf16; w (Cout, ks*ks*Cin) bf16; y (N,Ho,Wo,Cout) bf16 or f32 (out_f32).
- * stats: optional f32 [32][2][Cout] workspace receiving per-channel sum / sum-of-squares of the
- * (pre-residual, pre-ReLU) conv output for BatchNorm (zeroed by the call). */
+ * stats: optional f32 [ceil(M/128)][2][Cout] receiving, per 128-pixel tile, the per-channel sum / sum-of-squares
+ * of the (pre-residual, pre-ReLU) conv output for BatchNorm (every entry is written; no atomics -> reproducible). */
 int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout,
                   int ks, int stride, int pad, const float* bias, const void* residual, int relu,
                   float* stats, int out_f32);
@@ -125,13 +125,13 @@ int cr_cast_f32_to_bf16(cr_ctx* ctx, const float* src, void* dst, int64_t n);
 int cr_weight_transpose(cr_ctx* ctx, const float* w, void* wt, int Cout, int ks, int Cin);
 
 /* BatchNorm2d, training mode, per-GPU statistics (dla.py:17).  stats from cr_conv2d_fwd.
- * y = relu?((x-mean)*invstd*gamma + beta + residual?); writes mean_invstd [2][C]; updates running stats
- * (may be NULL). */
-int cr_bn_fwd(cr_ctx* ctx, const void* x, const float* stats, const float* gamma, const float* beta,
+ * stats = [nparts][2][C] partial sums.  y = relu?((x-mean)*invstd*gamma + beta + residual?); writes
+ * mean_invstd [2][C]; updates running stats (may be NULL). */
+int cr_bn_fwd(cr_ctx* ctx, const void* x, const float* stats, int nparts, const float* gamma, const float* beta,
               const void* residual, void* y, int64_t M, int C, int relu, float eps, float momentum,
               float* mean_invstd, float* running_mean, float* running_var);
 /* g = dy*(out>0 if relu); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres = g (may be NULL);
- * dgamma/dbeta are ACCUMULATED; sums = f32 [32][2][C] workspace. */
+ * dgamma/dbeta are ACCUMULATED; sums = f32 [1025][2][C] workspace (1024 block partials + the reduced row). */
 int cr_bn_bwd(cr_ctx* ctx, const void* dy, const void* out, const void* x, const float* mean_invstd,
               const float* gamma, float* sums, void* dx, void* dres, float* dgamma, float* dbeta, int64_t M,
               int C, int relu);

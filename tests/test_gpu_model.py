@@ -116,11 +116,12 @@ def test_modules_in_isolation(built):
         return hook
     hooks = [m.register_forward_hook(mk(n)) for n, m in model.backbone.bottom_up.named_modules()
              if isinstance(m, (dla.BasicBlock, dla.Root, dla._Project, dla._ConvLevel))]
+    bu = {}
+    hooks.append(model.backbone.bottom_up.register_forward_hook(lambda m, i, o: bu.update(o)))
     model.train()
     with torch.no_grad():
         images, x = model.preprocess_image(batch)
-        bu = model.backbone.bottom_up(x)
-        feats = model.backbone(x)
+        feats = model.backbone(x)       # (BN statistics use float atomics: a second run is not bitwise identical)
         pg = model.proposal_generator
         logits, deltas = pg.rpn_head([feats[f] for f in pg.in_features])
     for h in hooks:
