@@ -36,6 +36,8 @@ SIGNATURES = {
     "cr_roi_align_fwd": [P, P, P, P, P, c_int, c_int, P, c_int64, c_int, c_int, P],
     "cr_roi_align_bwd": [P, P, P, P, P, c_int, c_int, P, c_int64, c_int, c_int, P],
     "cr_nms_grouped": [P, P, P, c_int, c_int, c_float, P, P],
+    "cr_cube_loss_fwd": [P, P, c_int64, c_int, c_int, c_int, c_int, P, P],
+    "cr_cube_loss_bwd": [P, P, c_int64, c_int, c_int, c_int, c_int, P, P, P, P, P, P],
     "cr_nonfinite_flag": [P, P, c_int64, P],
     "cr_sgd_step": [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P],
 }

@@ -1,0 +1,310 @@
+// K15/K16: fused Cube R-CNN 3D-head decode + disentangled corner losses, forward and backward, one lane per
+// foreground RoI (n <= 128 per image).  Replaces ~350 elementwise torch launches per direction of
+// ROIHeads3D._forward_cube (cubercnn/modeling/roi_heads/roi_heads.py:2353-2679 of the reference):
+//   decode        cube_x/y = ctr + wh*delta; dims = exp(min(.,5))*prior_mean; z = z_raw*virtual_to_real   (:2371-2436)
+//   allocentric   R = M(ray through cube_x,cube_y) @ R_alloc where angle > 0                              (math_util.py:802-830)
+//   corners       get_cuboid_verts_faces                                                                  (math_util.py:142-245)
+//   losses        disentangled L1 corner losses for xy / z / dims, chamfer for pose and joint             (:2471-2508,2575-2589)
+//   uncertainty   every term x sqrt(2)*exp(-u)                                                            (:2633-2652)
+// The reductions over RoIs (safely_reduce_losses) stay in the caller.
+#include "cr_common.h"
+#include <math.h>
+
+#define CH_T 64
+#define SQRT2F 1.41421356f
+
+struct CubeIn {
+    const float *dxy, *zr, *dr, *Ra, *u;                 // head outputs for the RoI's class: (n,2) (n) (n,3) (n,9) (n)
+    const float *src_boxes, *K4, *v2r, *prior_mean;      // (n,4) (n,4)=[fx,fy,cx,cy] (n) (n,3)
+    const float *gt2d, *gtz, *gtdims, *gtR;              // (n,2) (n) (n,3) (n,9)
+    int n, allocentric, chamfer_pose, use_conf, joint;
+};
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
+
+// corners P[v][a] = sum_b R[a][b]*loc[v][b] + c[a];  loc = (sx*l/2, sy*h/2, sz*w/2), dims = (w,h,l)
+__device__ __forceinline__ void loc_of(int v, const float* dims, float* loc) {
+    loc[0] = (((v & 3) == 1 || (v & 3) == 2) ? 0.5f : -0.5f) * dims[2];
+    loc[1] = ((v & 2) ? 0.5f : -0.5f) * dims[1];
+    loc[2] = ((v & 4) ? 0.5f : -0.5f) * dims[0];
+}
+__device__ __forceinline__ void corners(const float* c, const float* dims, const float* R, float P[8][3]) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        float l[3];
+        loc_of(v, dims, l);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) P[v][a] = (R[a * 3] * l[0] + R[a * 3 + 1] * l[1] + R[a * 3 + 2] * l[2]) + c[a];
+    }
+}
+// back-propagate dP (8x3) through corners(): accumulates dc[3], ddims[3] (w,h,l), dR[9]
+__device__ __forceinline__ void corners_bwd(const float dP[8][3], const float* dims, const float* R, float* dc,
+                                            float* ddims, float* dR) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        float l[3];
+        loc_of(v, dims, l);
+        float dl[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (dc) dc[a] += dP[v][a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                if (dR) dR[a * 3 + b] += dP[v][a] * l[b];
+                dl[b] += R[a * 3 + b] * dP[v][a];
+            }
+        }
+        if (ddims) {
+            ddims[2] += (((v & 3) == 1 || (v & 3) == 2) ? 0.5f : -0.5f) * dl[0];
+            ddims[1] += ((v & 2) ? 0.5f : -0.5f) * dl[1];
+            ddims[0] += ((v & 4) ? 0.5f : -0.5f) * dl[2];
+        }
+    }
+}
+// mean over 24 of |P - G|; optionally its gradient w.r.t. P scaled by `up`
+__device__ __forceinline__ float l1_corner(const float P[8][3], const float G[8][3], float dP[8][3], float up, bool grad) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < 8; ++v)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float d = P[v][a] - G[v][a];
+            s += fabsf(d);
+            if (grad) dP[v][a] = sgn(d) * up / 24.f;
+        }
+    return s / 24.f;
+}
+// symmetric L1 chamfer over the 8x8 corner pairs (roi_heads.py:2209-2215); first minimum wins ties
+__device__ __forceinline__ float chamfer(const float P[8][3], const float G[8][3], float dP[8][3], float up, bool grad) {
+    float d[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            d[i][j] = (fabsf(P[i][0] - G[j][0]) + fabsf(P[i][1] - G[j][1])) + fabsf(P[i][2] - G[j][2]);
+    if (grad) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) dP[v][0] = dP[v][1] = dP[v][2] = 0.f;
+    }
+    float s1 = 0.f, s2 = 0.f;
+    // l1_dist.min(1): for each target j the closest prediction i
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int bi = 0;
+        float bm = d[0][j];
+#pragma unroll
+        for (int i = 1; i < 8; ++i)
+            if (d[i][j] < bm) { bm = d[i][j]; bi = i; }
+        s1 += bm;
+        if (grad) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i == bi) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) dP[i][a] += sgn(P[i][a] - G[j][a]) * up / 8.f;
+                }
+        }
+    }
+    // l1_dist.min(2): for each prediction i the closest target j
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int bj = 0;
+        float bm = d[i][0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j)
+            if (d[i][j] < bm) { bm = d[i][j]; bj = j; }
+        s2 += bm;
+        if (grad) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j == bj) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) dP[i][a] += sgn(P[i][a] - G[j][a]) * up / 8.f;
+                }
+        }
+    }
+    return s1 / 8.f + s2 / 8.f;
+}
+
+// rotation taking the optical axis to the viewing ray through (uu,vv): pytorch3d axis_angle_to_matrix semantics
+__device__ __forceinline__ bool ray_rotation(float uu, float vv, const float* K4, float* M) {
+    float ox = (uu - K4[2]) / K4[0], oy = (vv - K4[3]) / K4[1], oz = 1.f;
+    const float nrm = sqrtf((ox * ox + oy * oy) + oz * oz);
+    ox /= nrm; oy /= nrm; oz /= nrm;
+    const float angle = acosf(oz);
+    const float an = sqrtf(oy * oy + ox * ox);
+    const float ax = angle * (-oy) / an, ay = angle * ox / an, az = 0.f;
+    const float ang = sqrtf((ax * ax + ay * ay) + az * az);
+    const float half = ang * 0.5f;
+    const float s = fabsf(ang) < 1e-6f ? 0.5f - (ang * ang) / 48.f : sinf(half) / ang;
+    const float qr = cosf(half), qi = ax * s, qj = ay * s, qk = az * s;
+    const float two_s = 2.0f / (((qr * qr + qi * qi) + qj * qj) + qk * qk);
+    M[0] = 1 - two_s * (qj * qj + qk * qk); M[1] = two_s * (qi * qj - qk * qr); M[2] = two_s * (qi * qk + qj * qr);
+    M[3] = two_s * (qi * qj + qk * qr); M[4] = 1 - two_s * (qi * qi + qk * qk); M[5] = two_s * (qj * qk - qi * qr);
+    M[6] = two_s * (qi * qk - qj * qr); M[7] = two_s * (qj * qk + qi * qr); M[8] = 1 - two_s * (qi * qi + qj * qj);
+    return angle > 0.f;
+}
+
+// BWD = false: losses (n,5) = [dims, xy, z, pose, joint] (uncertainty-weighted), dec (n,17) = [cube_x, cube_y, z,
+//              dims(3), R(9), x3d, y3d].   BWD = true: gradients of sum_k gl[i][k]*loss[i][k] w.r.t. the head outputs.
+template <bool BWD>
+__global__ __launch_bounds__(CH_T) void k_cube_loss(CubeIn in, const float* __restrict__ gl, float* __restrict__ losses,
+                                                    float* __restrict__ dec, float* __restrict__ g_dxy,
+                                                    float* __restrict__ g_zr, float* __restrict__ g_dr,
+                                                    float* __restrict__ g_Ra, float* __restrict__ g_u) {
+    const int i = blockIdx.x * CH_T + threadIdx.x;
+    if (i >= in.n) return;
+    const float* sb = in.src_boxes + i * 4;
+    const float* K4 = in.K4 + i * 4;
+    const float sw = sb[2] - sb[0], sh = sb[3] - sb[1];
+    const float cux = (sb[0] + 0.5f * sw) + sw * in.dxy[i * 2], cuy = (sb[1] + 0.5f * sh) + sh * in.dxy[i * 2 + 1];
+    float dims[3];
+    bool dclip[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float r = in.dr[i * 3 + k];
+        dclip[k] = !(r <= 5.0f);                          // clamp(max=5) passes the gradient where r <= 5
+        dims[k] = expf(fminf(r, 5.0f)) * in.prior_mean[i * 3 + k];
+    }
+    float R[9], M[9];
+    bool rot = false;
+    if (in.allocentric) rot = ray_rotation(cux, cuy, K4, M);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float* Ra = in.Ra + i * 9;
+            R[a * 3 + b] = rot ? (M[a * 3] * Ra[b] + M[a * 3 + 1] * Ra[3 + b]) + M[a * 3 + 2] * Ra[6 + b] : Ra[a * 3 + b];
+        }
+    const float z = in.zr[i] * in.v2r[i];
+    const float u = in.u[i];
+    const float sf = in.use_conf ? SQRT2F * expf(-u) : 1.0f;
+
+    // ground truth
+    const float g2x = in.gt2d[i * 2], g2y = in.gt2d[i * 2 + 1], gz = in.gtz[i];
+    const float ga = (g2x - K4[2]) / K4[0], gb = (g2y - K4[3]) / K4[1];
+    const float gc[3] = {gz * ga, gz * gb, gz};
+    const float* gd = in.gtdims + i * 3;
+    const float* gR = in.gtR + i * 9;
+    float G[8][3], P[8][3], dP[8][3];
+    corners(gc, gd, gR, G);
+
+    const float pa = (cux - K4[2]) / K4[0], pb = (cuy - K4[3]) / K4[1];
+    const float c_z[3] = {z * ga, z * gb, z};            // disentangled Z: predicted depth along the GT ray
+    const float c_xy[3] = {gz * pa, gz * pb, gz};        // disentangled XY: GT depth along the predicted ray
+    const float c_j[3] = {z * pa, z * pb, z};            // joint
+    float up[5] = {0, 0, 0, 0, 0};
+    if (BWD) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) up[k] = gl[i * 5 + k] * sf;
+    }
+    float d_cux = 0.f, d_cuy = 0.f, d_z = 0.f, d_dims[3] = {0, 0, 0}, d_R[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float L[5];
+
+    // dims
+    corners(gc, dims, gR, P);
+    L[0] = l1_corner(P, G, dP, up[0], BWD);
+    if (BWD) corners_bwd(dP, dims, gR, nullptr, d_dims, nullptr);
+    // xy
+    corners(c_xy, gd, gR, P);
+    L[1] = l1_corner(P, G, dP, up[1], BWD);
+    if (BWD) {
+        float dc[3] = {0, 0, 0};
+        corners_bwd(dP, gd, gR, dc, nullptr, nullptr);
+        d_cux += dc[0] * gz / K4[0];
+        d_cuy += dc[1] * gz / K4[1];
+    }
+    // z
+    corners(c_z, gd, gR, P);
+    L[2] = l1_corner(P, G, dP, up[2], BWD);
+    if (BWD) {
+        float dc[3] = {0, 0, 0};
+        corners_bwd(dP, gd, gR, dc, nullptr, nullptr);
+        d_z += (dc[0] * ga + dc[1] * gb) + dc[2];
+    }
+    // pose
+    corners(gc, gd, R, P);
+    L[3] = in.chamfer_pose ? chamfer(P, G, dP, up[3], BWD) : l1_corner(P, G, dP, up[3], BWD);
+    if (BWD) corners_bwd(dP, gd, R, nullptr, nullptr, d_R);
+    // joint
+    L[4] = 0.f;
+    if (in.joint) {
+        corners(c_j, dims, R, P);
+        L[4] = in.chamfer_pose ? chamfer(P, G, dP, up[4], BWD) : l1_corner(P, G, dP, up[4], BWD);
+        if (BWD) {
+            float dc[3] = {0, 0, 0};
+            corners_bwd(dP, dims, R, dc, d_dims, d_R);
+            d_z += (dc[0] * pa + dc[1] * pb) + dc[2];
+            d_cux += dc[0] * z / K4[0];
+            d_cuy += dc[1] * z / K4[1];
+        }
+    }
+    if (!BWD) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) losses[i * 5 + k] = L[k] * sf;
+        float* o = dec + i * 17;
+        o[0] = cux; o[1] = cuy; o[2] = z; o[3] = dims[0]; o[4] = dims[1]; o[5] = dims[2];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[6 + k] = R[k];
+        o[15] = z * pa; o[16] = z * pb;
+    } else {
+        g_dxy[i * 2] = d_cux * sw;
+        g_dxy[i * 2 + 1] = d_cuy * sh;
+        g_zr[i] = d_z * in.v2r[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g_dr[i * 3 + k] = dclip[k] ? 0.f : d_dims[k] * dims[k];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)          // dRa = M^T dR
+                g_Ra[i * 9 + a * 3 + b] = rot ? (M[a] * d_R[b] + M[3 + a] * d_R[3 + b]) + M[6 + a] * d_R[6 + b] : d_R[a * 3 + b];
+        float du = 0.f;
+        if (in.use_conf) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) du -= gl[i * 5 + k] * (L[k] * sf);
+        }
+        g_u[i] = du;
+    }
+}
+
+static int cube_args(CubeIn& in, const float* const* p, int64_t n, int allocentric, int chamfer_pose, int use_conf,
+                     int joint) {
+    for (int k = 0; k < 13; ++k) CR_CHECK_ARG(p[k] != nullptr, "cube_loss: NULL input pointer #%d", k);
+    in.dxy = p[0]; in.zr = p[1]; in.dr = p[2]; in.Ra = p[3]; in.u = p[4];
+    in.src_boxes = p[5]; in.K4 = p[6]; in.v2r = p[7]; in.prior_mean = p[8];
+    in.gt2d = p[9]; in.gtz = p[10]; in.gtdims = p[11]; in.gtR = p[12];
+    in.n = (int)n; in.allocentric = allocentric; in.chamfer_pose = chamfer_pose; in.use_conf = use_conf; in.joint = joint;
+    return CR_OK;
+}
+
+// inputs: HOST array of 13 device pointers in the order of CubeIn.  losses (n,5), dec (n,17).
+extern "C" int cr_cube_loss_fwd(cr_ctx* ctx, const float* const* inputs, int64_t n, int allocentric, int chamfer_pose,
+                                int use_conf, int joint, float* losses, float* dec) {
+    CR_CHECK_ARG(ctx && inputs && n >= 0, "cr_cube_loss_fwd: bad args");
+    if (n == 0) return CR_OK;
+    CR_CHECK_ARG(losses && dec, "cr_cube_loss_fwd: NULL output");
+    CubeIn in;
+    int rc = cube_args(in, inputs, n, allocentric, chamfer_pose, use_conf, joint);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_cube_loss<false>), dim3((unsigned)cr_cdiv(n, CH_T)), dim3(CH_T), 0, ctx->stream, in,
+                       (const float*)nullptr, losses, dec, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// gl (n,5) = d(total)/d(losses); outputs g_dxy (n,2) g_zr (n) g_dr (n,3) g_Ra (n,9) g_u (n)
+extern "C" int cr_cube_loss_bwd(cr_ctx* ctx, const float* const* inputs, int64_t n, int allocentric, int chamfer_pose,
+                                int use_conf, int joint, const float* gl, float* g_dxy, float* g_zr, float* g_dr,
+                                float* g_Ra, float* g_u) {
+    CR_CHECK_ARG(ctx && inputs && n >= 0, "cr_cube_loss_bwd: bad args");
+    if (n == 0) return CR_OK;
+    CR_CHECK_ARG(gl && g_dxy && g_zr && g_dr && g_Ra && g_u, "cr_cube_loss_bwd: NULL pointer");
+    CubeIn in;
+    int rc = cube_args(in, inputs, n, allocentric, chamfer_pose, use_conf, joint);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_cube_loss<true>), dim3((unsigned)cr_cdiv(n, CH_T)), dim3(CH_T), 0, ctx->stream, in, gl,
+                       (float*)nullptr, (float*)nullptr, g_dxy, g_zr, g_dr, g_Ra, g_u);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

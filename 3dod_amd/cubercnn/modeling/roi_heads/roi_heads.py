@@ -322,6 +322,24 @@ class ROIHeads3D(StandardROIHeads):
         if self.use_confidence:
             cube_uncert = cube_uncert[fg_inds, box_classes]
         cube_2d_deltas = cube_2d_deltas[fg_inds, box_classes, :]
+
+        fused = None
+        if self.training and cube_2d_deltas.is_cuda and self.use_confidence > 0 and self.dims_priors_func == 'exp' \
+                and hasattr(ops, "cube_decode_loss"):
+            # K15/K16 in one kernel each way (cr_cube_loss_fwd / _bwd); the torch expressions below are the same
+            # arithmetic and remain the path for eval-mode decode
+            K = Ks_scaled_per_box
+            K4 = torch.stack((K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]), 1)
+            v2r = virtual_to_real if self.virtual_depth else torch.ones(n, device=device)
+            pm = self.priors_dims_per_cat.detach()[0][box_classes][:, 0, :] if self.dims_priors_enabled \
+                else torch.ones(n, 3, device=device)
+            fused = ops.cube_decode_loss(cube_2d_deltas, cube_z[:, 0], cube_dims, cube_pose, cube_uncert, src_boxes, K4,
+                                         v2r, pm, gt_boxes3D[:, :2], gt_boxes3D[:, 2], gt_boxes3D[:, 3:6], gt_poses,
+                                         allocentric=self.allocentric_pose, chamfer_pose=self.chamfer_pose,
+                                         use_conf=True, joint=self.loss_w_joint > 0)
+        if fused is not None:
+            return self._finish_fused_cube(fused, cube_uncert, gt_boxes3D, num_boxes_per_image, im_ratios_per_box,
+                                           im_current_dims, box_classes, pred_boxes, n)
         cube_x = src_ctr_x + src_widths * cube_2d_deltas[:, 0]
         cube_y = src_ctr_y + src_heights * cube_2d_deltas[:, 1]
         cube_xy = torch.cat((cube_x.unsqueeze(1), cube_y.unsqueeze(1)), dim=1)
@@ -470,6 +488,65 @@ class ROIHeads3D(StandardROIHeads):
         if self.training:
             return pred_instances, losses
         return pred_instances
+
+    def _finish_fused_cube(self, fused, cube_uncert, gt_boxes3D, num_boxes_per_image, im_ratios_per_box,
+                           im_current_dims, box_classes, pred_boxes, n):
+        """reductions, tracking scalars and the training-time Instances packing on top of the fused kernel's
+        per-RoI outputs (roi_heads.py:2562-2735)."""
+        L, dec = fused
+        prefix = 'Cube/'
+        storage = get_event_storage()
+        losses = {}
+        loss_dims, loss_xy, loss_z, loss_pose, loss_joint = L.unbind(1)
+        cube_x3d_y3d_z = torch.stack((dec[:, 15], dec[:, 16], dec[:, 2]), 1)
+        cube_z, cube_dims, cube_xy = dec[:, 2], dec[:, 3:6], dec[:, 0:2]
+        cube_pose = dec[:, 6:15].reshape(n, 3, 3)
+        gt_z, gt_dims, gt_2d = gt_boxes3D[:, 2], gt_boxes3D[:, 3:6], gt_boxes3D[:, :2]
+        with torch.no_grad():
+            sf = SQRT_2_CONSTANT * torch.exp(-cube_uncert)
+            Lr = L / sf[:, None]
+            total = Lr[:, 0] * self.loss_w_dims + Lr[:, 3] * self.loss_w_pose + Lr[:, 1] * self.loss_w_xy + \
+                Lr[:, 2] * self.loss_w_z
+            if self.loss_w_joint > 0:
+                total = total + Lr[:, 4] * self.loss_w_joint
+            z_error = (cube_z - gt_z).abs()
+            storage.put_scalar(prefix + 'z_error', z_error.mean(), smoothing_hint=False)
+            storage.put_scalar(prefix + 'dims_error', (cube_dims - gt_dims).abs().mean(), smoothing_hint=False)
+            storage.put_scalar(prefix + 'xy_error', (cube_xy - gt_2d).abs().mean(), smoothing_hint=False)
+            storage.put_scalar(prefix + 'z_close', (z_error < 0.20).float().mean(), smoothing_hint=False)
+            storage.put_scalar(prefix + 'total_3D_loss', self.loss_w_3d * self.safely_reduce_losses(total),
+                               smoothing_hint=False)
+            storage.put_scalar(prefix + 'conf', torch.exp(-cube_uncert).mean(), smoothing_hint=False)
+        if self.inverse_z_weight:
+            inverse_z_w = 1 / torch.log(gt_z.clip(E_CONSTANT))
+            loss_dims, loss_xy, loss_z, loss_pose, loss_joint = [t * inverse_z_w for t in
+                                                                 (loss_dims, loss_xy, loss_z, loss_pose, loss_joint)]
+        losses[prefix + 'uncert'] = self.use_confidence * self.safely_reduce_losses(cube_uncert.clone())
+        if self.loss_w_dims > 0:
+            losses[prefix + 'loss_dims'] = self.safely_reduce_losses(loss_dims) * self.loss_w_dims * self.loss_w_3d
+        losses[prefix + 'loss_xy'] = self.safely_reduce_losses(loss_xy) * self.loss_w_xy * self.loss_w_3d
+        losses[prefix + 'loss_z'] = self.safely_reduce_losses(loss_z) * self.loss_w_z * self.loss_w_3d
+        losses[prefix + 'loss_pose'] = self.safely_reduce_losses(loss_pose) * self.loss_w_pose * self.loss_w_3d
+        if self.loss_w_joint > 0:
+            lj = torch.where(loss_joint < np.inf, loss_joint, torch.full_like(loss_joint, float('inf')))
+            losses[prefix + 'loss_joint'] = self.safely_reduce_losses(lj, absent_if_none=True) * self.loss_w_joint * self.loss_w_3d
+        with torch.no_grad():
+            cube_3D = torch.cat((cube_x3d_y3d_z, cube_dims, cube_xy * im_ratios_per_box.unsqueeze(1),
+                                 torch.exp(-cube_uncert).unsqueeze(1)), dim=1)
+            verts = util.get_cuboid_verts_faces(cube_3D[:, :6], cube_pose)[0]
+            pred_instances = [Instances(image_size) for image_size in im_current_dims]
+            for c3, cp, vv, inst, cls_i, pb in zip(cube_3D.split(num_boxes_per_image), cube_pose.split(num_boxes_per_image),
+                                                   verts.split(num_boxes_per_image), pred_instances,
+                                                   box_classes.split(num_boxes_per_image), pred_boxes):
+                inst.scores = c3[:, -1]
+                inst.pred_classes = cls_i
+                inst.pred_boxes = pb
+                inst.pred_bbox3D = vv
+                inst.pred_center_cam = c3[:, :3]
+                inst.pred_center_2D = c3[:, 6:8]
+                inst.pred_dimensions = c3[:, 3:6]
+                inst.pred_pose = cp
+        return pred_instances, losses
 
     # ------------------------------------------------------------------ sampling
     def _sample_proposals(self, matched_idxs, matched_labels, gt_classes, matched_ious=None):

@@ -358,6 +358,51 @@ def roi_align_pyramid(feats, rois, scales, out_size):
 
 
 # --------------------------------------------------------------------------
+# fused Cube R-CNN decode + corner losses (K15/K16)
+# --------------------------------------------------------------------------
+class _CubeLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dxy, zr, dr, Ra, u, consts, flags):
+        _need_cuda(dxy, "cube head outputs")
+        n = dxy.shape[0]
+        ins = [t.contiguous().to(f32) for t in (dxy, zr, dr, Ra.reshape(n, 9), u)] + \
+              [t.contiguous().to(f32) for t in consts]
+        arr = (ctypes.c_void_p * 13)(*[t.data_ptr() for t in ins])
+        losses = torch.empty((n, 5), dtype=f32, device=dxy.device)
+        dec = torch.empty((n, 17), dtype=f32, device=dxy.device)
+        lib = _lib.load()
+        _chk(lib.cr_cube_loss_fwd(_ctx(dxy), ctypes.cast(arr, ctypes.c_void_p), n, *flags, _p(losses), _p(dec)),
+             "cr_cube_loss_fwd")
+        ctx.ins, ctx.flags = ins, flags
+        ctx.mark_non_differentiable(dec)
+        return losses, dec
+
+    @staticmethod
+    def backward(ctx, gl, _gdec):
+        ins, flags = ctx.ins, ctx.flags
+        n = ins[0].shape[0]
+        dev = ins[0].device
+        arr = (ctypes.c_void_p * 13)(*[t.data_ptr() for t in ins])
+        g_dxy = torch.empty((n, 2), dtype=f32, device=dev)
+        g_zr = torch.empty((n,), dtype=f32, device=dev)
+        g_dr = torch.empty((n, 3), dtype=f32, device=dev)
+        g_Ra = torch.empty((n, 3, 3), dtype=f32, device=dev)
+        g_u = torch.empty((n,), dtype=f32, device=dev)
+        lib = _lib.load()
+        _chk(lib.cr_cube_loss_bwd(_ctx(ins[0]), ctypes.cast(arr, ctypes.c_void_p), n, *flags, _p(gl.contiguous()),
+                                  _p(g_dxy), _p(g_zr), _p(g_dr), _p(g_Ra), _p(g_u)), "cr_cube_loss_bwd")
+        return g_dxy, g_zr, g_dr, g_Ra, g_u, None, None
+
+
+def cube_decode_loss(dxy, zr, dr, Ra, u, src_boxes, K4, v2r, prior_mean, gt2d, gtz, gtdims, gtR, allocentric=True,
+                     chamfer_pose=True, use_conf=True, joint=True):
+    """fused K15/K16 (see cr_cube_loss_fwd).  Returns (losses (n,5) [dims,xy,z,pose,joint], dec (n,17))."""
+    consts = (src_boxes, K4, v2r, prior_mean, gt2d, gtz, gtdims, gtR.reshape(-1, 9))
+    flags = (int(bool(allocentric)), int(bool(chamfer_pose)), int(bool(use_conf)), int(bool(joint)))
+    return _CubeLoss.apply(dxy, zr, dr, Ra, u, consts, flags)
+
+
+# --------------------------------------------------------------------------
 # NMS
 # --------------------------------------------------------------------------
 def nms_grouped(boxes, counts, thresh):

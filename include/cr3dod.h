@@ -160,6 +160,22 @@ int cr_roi_align_bwd(cr_ctx* ctx, float* const* grads, const int* Hs, const int*
 int cr_nms_grouped(cr_ctx* ctx, const float* boxes, const int* counts, int G, int maxn, float thresh,
                    void* mask_ws, unsigned char* keep);
 
+/* ---- Cube R-CNN 3D head: fused decode + disentangled corner losses (K15/K16) -------------
+ * cubercnn/modeling/roi_heads/roi_heads.py:2353-2679 (decode, allocentric->egocentric pose, corner sets, L1 /
+ * chamfer corner losses, uncertainty weighting), one lane per foreground RoI.
+ * inputs: HOST array of 13 device pointers, all f32:
+ *   [0] deltas (n,2) [1] z_raw (n) [2] dims_raw (n,3) [3] R_alloc (n,9) [4] uncert (n)      -- head outputs of the RoI's class
+ *   [5] proposal boxes (n,4) [6] K (n,4)=[fx,fy,cx,cy] scaled [7] virtual_to_real (n) [8] prior dims mean (n,3)
+ *   [9] gt (x,y) 2D centre (n,2) [10] gt z (n) [11] gt dims (n,3) (W,H,L) [12] gt pose (n,9)
+ * losses (n,5) = [dims, xy, z, pose, joint], each already x sqrt(2)exp(-uncert) when use_conf;
+ * dec (n,17) = [cube_x, cube_y, z, dims(3), R egocentric (9), x3d, y3d].
+ * bwd: gl (n,5) = d total / d losses -> gradients w.r.t. inputs [0..4]. */
+int cr_cube_loss_fwd(cr_ctx* ctx, const float* const* inputs, int64_t n, int allocentric, int chamfer_pose,
+                     int use_conf, int joint, float* losses, float* dec);
+int cr_cube_loss_bwd(cr_ctx* ctx, const float* const* inputs, int64_t n, int allocentric, int chamfer_pose,
+                     int use_conf, int joint, const float* gl, float* g_dxy, float* g_zr, float* g_dr, float* g_Ra,
+                     float* g_u);
+
 /* ---- optimizer (tools/train_net.py:233-266, cubercnn/solver/build.py:50-56) ------------- */
 int cr_nonfinite_flag(cr_ctx* ctx, const float* g, int64_t n, int* flag);
 /* SGD momentum on flat f32 buffers; skipped on device when *skip_flag != 0 (may be NULL). */
