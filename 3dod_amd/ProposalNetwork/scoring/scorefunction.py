@@ -1,0 +1,32 @@
+"""Scoring functions of ProposalNetwork/scoring/scorefunction.py:47-85,144-160 on the fused kernel.
+score_all is the batched form used by the model; the per-object functions keep the reference's signatures."""
+import torch
+
+from ... import geometry as geo
+from ...d2lite import Boxes
+from ..utils.utils import iou_2d
+
+
+def score_all(cubes, K, im_shape, gt_boxes, prior_mean, prior_std, rect_pts=None, want=("iou", "dim", "corner", "combined")):
+    """project + IoU + size prior + corner chamfer + product + argmax for N objects x P proposals in ONE launch
+    (roi_heads.py:492-505).  gt_boxes: Boxes or (N,4) tensor.  rect_pts (N,4,2) = cv2.boxPoints(minAreaRect(mask))
+    per object, or None for the reference's no-contour fallback."""
+    ref = gt_boxes.tensor if isinstance(gt_boxes, Boxes) else gt_boxes
+    return geo.cubes_project_score(cubes.tensor.contiguous(), K, im_shape, ref.contiguous(), prior_mean.contiguous(),
+                                   prior_std.contiguous(), rect_pts, want=want)
+
+
+def score_iou(gt_box, proposal_box):
+    """scorefunction.py:47-49."""
+    return iou_2d(gt_box, proposal_box)
+
+
+def score_dimensions(category, dimensions, gt_boxes, pred_boxes):
+    """scorefunction.py:144-160 (torch form for a single object; the fused kernel computes the same)."""
+    prior_mean, prior_std = category
+    dimensions_scores = torch.exp(-1 / 2 * ((dimensions - prior_mean) / prior_std) ** 2)
+    scores = dimensions_scores.mean(1)
+    gt_ratio = (gt_boxes.tensor[0, 2] - gt_boxes.tensor[0, 0]) / (gt_boxes.tensor[0, 3] - gt_boxes.tensor[0, 1])
+    pred_ratios = (pred_boxes.tensor[:, 2] - pred_boxes.tensor[:, 0]) / (pred_boxes.tensor[:, 3] - pred_boxes.tensor[:, 1])
+    differences = torch.abs(gt_ratio - pred_ratios)
+    return (1 - differences / torch.max(differences)) * scores

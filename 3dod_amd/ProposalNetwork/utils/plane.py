@@ -1,0 +1,34 @@
+"""Plane.fit_parallel -- ProposalNetwork/utils/plane.py:79-134 on cr_ransac_plane."""
+import torch
+
+from ... import geometry as geo
+
+
+class Plane:
+    def __init__(self):
+        self.inliers = []
+        self.equation = []
+
+    @staticmethod
+    def sample_triples(n_points, n_iter, device, generator=None):
+        """three DISTINCT indices per iteration (random.sample(range(n), 3) in the reference)."""
+        i0 = torch.randint(n_points, (n_iter,), device=device, generator=generator)
+        i1 = (i0 + 1 + torch.randint(n_points - 1, (n_iter,), device=device, generator=generator)) % n_points
+        i2 = torch.randint(n_points - 2, (n_iter,), device=device, generator=generator)
+        lo, hi = torch.minimum(i0, i1), torch.maximum(i0, i1)
+        i2 = i2 + (i2 >= lo).long()
+        i2 = i2 + (i2 >= hi).long()
+        return torch.stack((i0, i1, i2), 1).to(torch.int32)
+
+    def fit_parallel(self, pts: torch.Tensor, thresh=0.05, minPoints=100, maxIteration=1000, id_samples=None,
+                     generator=None):
+        """returns (-equation (4,), inlier indices) like the reference."""
+        n_points = pts.shape[0]
+        if id_samples is None:
+            id_samples = self.sample_triples(n_points, maxIteration, pts.device, generator)
+        neg_eq, counts, best = geo.ransac_plane(pts.float().contiguous(), id_samples, thresh, validate=False)
+        eq = -neg_eq
+        dist = (eq[0] * pts[:, 0] + eq[1] * pts[:, 1] + eq[2] * pts[:, 2] + eq[3]) / torch.sqrt(eq[0] ** 2 + eq[1] ** 2 + eq[2] ** 2)
+        self.inliers = torch.where(torch.abs(dist) <= thresh)[0]
+        self.equation = eq
+        return neg_eq, self.inliers

@@ -1,0 +1,49 @@
+"""Samplers and rotation builders of ProposalNetwork/utils/utils.py (the pieces the proposal path uses)."""
+import torch
+
+from ...d2lite import pairwise_iou
+
+
+def normalize_vector(v):
+    v_mag = torch.sqrt(v.pow(2).sum())
+    v_mag = torch.max(v_mag, torch.tensor([1e-8], device=v.device))
+    return v / v_mag
+
+
+def vec_perp_t(vec):
+    """utils.py:112-118."""
+    a, b, c = vec
+    if a == 0:
+        return torch.stack([torch.zeros_like(c), c, -b])
+    return normalize_vector(torch.stack([b, -a, torch.zeros_like(a)]))
+
+
+def rotate_vector_t(v, k, theta):
+    """Rodrigues, utils.py:134-146."""
+    cos_theta, sin_theta = torch.cos(theta), torch.sin(theta)
+    v2 = v.view(-1, 1)
+    term1 = v2 * cos_theta
+    term2 = torch.linalg.cross(k, v).view(-1, 1) * sin_theta
+    term3 = (k * (k @ v)).view(-1, 1) * (1 - cos_theta)
+    return term1 + term2 + term3
+
+
+def orthobasis_from_normal_t(normal, yaw_angles):
+    """utils.py:120-132: (n_yaw,3,3), columns (x_theta, normal, normal x x_theta)."""
+    n = len(yaw_angles)
+    x = rotate_vector_t(vec_perp_t(normal), normal, yaw_angles)
+    y = torch.linalg.cross(normal.view(-1, 1).expand_as(x), x, dim=0)
+    return torch.cat([x.t(), normal.unsqueeze(0).repeat(n, 1), y.t()], dim=1).reshape(n, 3, 3).transpose(2, 1)
+
+
+def vectorized_linspace(start_tensor, end_tensor, number_of_steps):
+    """utils.py:170-177."""
+    spacing = (end_tensor - start_tensor) / (number_of_steps - 1)
+    lin = torch.arange(start=0, end=number_of_steps, dtype=start_tensor.dtype, device=start_tensor.device)
+    lin = lin.repeat(start_tensor.size(0), 1)
+    return lin * spacing[:, None] + start_tensor[:, None]
+
+
+def iou_2d(gt_box, proposal_boxes):
+    """utils.py:186-192."""
+    return pairwise_iou(gt_box, proposal_boxes).flatten()

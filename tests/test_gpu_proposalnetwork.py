@@ -1,0 +1,82 @@
+"""GPU: the ProposalNetwork host mirror (Cubes / cubes_to_box / propose / score_all / Plane) over the kernels."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as og
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+spaces = importlib.import_module("3dod_amd.ProposalNetwork.utils.spaces")
+conv = importlib.import_module("3dod_amd.ProposalNetwork.utils.conversions")
+props = importlib.import_module("3dod_amd.ProposalNetwork.proposals.proposals")
+sf = importlib.import_module("3dod_amd.ProposalNetwork.scoring.scorefunction")
+plane = importlib.import_module("3dod_amd.ProposalNetwork.utils.plane")
+pu = importlib.import_module("3dod_amd.ProposalNetwork.utils.utils")
+d2 = importlib.import_module("3dod_amd.d2lite")
+
+
+def test_cubes_api_against_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "geometry_g2_project_score.npz"), allow_pickle=False)
+    cubes = spaces.Cubes(torch.tensor(g["cubes"]).to(DEV))
+    K = torch.tensor(g["K"]).to(DEV)
+    im = tuple(int(v) for v in g["im_wh"])
+    np.testing.assert_allclose(cubes.get_all_corners().cpu().numpy(), g["corners3d"], rtol=1e-4, atol=2e-5)
+    c2 = cubes.get_bube_corners(K, im).cpu().numpy()
+    assert np.mean(np.abs(c2 - g["corners2d"]) <= 1e-4 * np.abs(g["corners2d"]) + 1e-3) > 0.999
+    boxes = conv.cubes_to_box(cubes, K, im)
+    assert len(boxes) == 4 and isinstance(boxes[0], d2.Boxes)
+    assert (np.stack([b.tensor.cpu().numpy() for b in boxes]) == og.corners_to_boxes(c2)).all()
+    assert cubes[1].tensor.shape == (1, 1000, 15) and cubes[1, 5].tensor.shape == (1, 1, 15)
+    out = sf.score_all(cubes, K, im, d2.Boxes(torch.tensor(g["ref_boxes"]).to(DEV)), torch.tensor(g["prior_mu"]).to(DEV),
+                       torch.tensor(g["prior_sigma"]).to(DEV), torch.tensor(g["rect_pts"]).to(DEV))
+    assert (out["argmax"].cpu().numpy() == g["argmax"]).all()
+    with pytest.raises(UnboundLocalError):
+        cubes.get_bube_corners(K)
+
+
+def test_propose_distribution_and_ranges():
+    g = torch.Generator(device=DEV).manual_seed(0)
+    N, P = 5, 1000
+    boxes = d2.Boxes(torch.tensor([[100., 120, 260, 300], [30, 40, 200, 180], [300, 300, 480, 470], [10, 10, 500, 500],
+                                   [200, 100, 300, 420]], device=DEV))
+    depth = torch.rand(512, 512, device=DEV, generator=g) * 3 + 1
+    mu = torch.rand(N, 3, device=DEV, generator=g) * 0.8 + 0.3
+    sg = 0.3 * mu
+    K = torch.tensor([[600., 0, 256], [0, 600., 256], [0, 0, 1]], device=DEV)
+    normal = torch.tensor([0.0, 1.0, 0.0], device=DEV)
+    cubes, _, _ = props.propose(boxes, depth, (mu, sg), (512, 512), K, P, ground_normal=normal, generator=g)
+    t = cubes.tensor
+    assert t.shape == (N, P, 15) and torch.isfinite(t).all()
+    w, h, l = t[..., 3], t[..., 4], t[..., 5]
+    assert (w >= 0.05).all() and (w <= (mu[:, 0] + 2 * sg[:, 0])[:, None] + 1e-6).all()
+    assert (h >= 0.05).all() and (h <= (mu[:, 1] + 2.2 * sg[:, 1])[:, None] + 1e-6).all()
+    assert (l >= 0.05).all() and (l <= (mu[:, 2] + 2 * sg[:, 2])[:, None] + 1e-6).all()
+    R = t[..., 6:].view(N, P, 3, 3)
+    eye = torch.eye(3, device=DEV)
+    assert ((R @ R.transpose(-1, -2) - eye).abs() < 1e-4).all()                 # yaw table is orthonormal
+    assert (R[..., :, 1] - normal).abs().max() < 1e-6                            # middle column = ground normal
+    tab = pu.orthobasis_from_normal_t(normal, torch.linspace(0, np.pi, 36, device=DEV))
+    d = (R.view(-1, 1, 9) - tab.reshape(1, 36, 9)).abs().amax(-1).amin(-1)
+    assert d.max() < 1e-5                                                        # each rotation is a table entry
+    np.testing.assert_allclose(tab.cpu().numpy(), og.yaw_table(normal.cpu().numpy()), atol=2e-6)
+
+
+def test_plane_fit_parallel():
+    g = torch.Generator(device=DEV).manual_seed(1)
+    Q = 5000
+    xy = (torch.rand(Q, 2, device=DEV, generator=g) - 0.5) * 6
+    pts = torch.stack([xy[:, 0], 1.4 + 0.01 * torch.randn(Q, device=DEV, generator=g), xy[:, 1] + 4], 1)
+    pts[:1000] = torch.rand(1000, 3, device=DEV, generator=g) * 4
+    tri = plane.Plane.sample_triples(Q, 1000, DEV, g)
+    assert ((tri[:, 0] != tri[:, 1]) & (tri[:, 0] != tri[:, 2]) & (tri[:, 1] != tri[:, 2])).all()
+    assert int(tri.min()) >= 0 and int(tri.max()) < Q
+    neg_eq, inl = plane.Plane().fit_parallel(pts, thresh=0.05, maxIteration=1000, id_samples=tri)
+    n = (-neg_eq[:3]).cpu().numpy()
+    assert abs(abs(n[1]) - 1.0) < 2e-2 and len(inl) > 3500                      # the y = 1.4 plane
+    o_eq, o_cnt, _, _ = og.ransac_plane(pts.cpu().numpy(), tri.cpu().numpy(), 0.05)
+    np.testing.assert_allclose(neg_eq.cpu().numpy(), o_eq, atol=1e-6)
+    assert len(inl) == o_cnt
