@@ -132,6 +132,39 @@ class RCNN3D(nn.Module):
         return processed_results
 
 
+@META_ARCH_REGISTRY.register()
+class BoxNet(RCNN3D):
+    """the proposal-and-scoring meta-architecture, rcnn3d.py:594-759 of the reference: 2D detections (or GT boxes) ->
+    ROIHeads_Boxer.  batched_inputs additionally carry "depth_map" (H,W) and optionally "ground_map" (H,W) and
+    "masks" (N,H,W) per image (the reference reads depth/ground .npz files and runs SAM-HQ for the masks)."""
+
+    def forward(self, batched_inputs, experiment_type=None, proposal_function='propose'):
+        assert not self.training, "BoxNet training (pseudo-GT generation) is driven by tools/eval_boxes.py: out of scope"
+        experiment_type = experiment_type or {'use_pred_boxes': True}
+        return self.inference(batched_inputs, experiment_type=experiment_type)
+
+    def inference(self, batched_inputs, experiment_type=None, do_postprocess=True, generator=None):
+        use_pred = (experiment_type or {}).get('use_pred_boxes', True)
+        images, x = self.preprocess_image(batched_inputs)
+        im_scales_ratio = [info['height'] / im_size[0] for (info, im_size) in zip(batched_inputs, images.image_sizes)]
+        Ks = [torch.FloatTensor(info['K']) for info in batched_inputs]
+        depth = torch.stack([b["depth_map"].to(self.device).float() for b in batched_inputs])
+        ground = torch.stack([b["ground_map"].to(self.device) for b in batched_inputs]) \
+            if all(b.get("ground_map") is not None for b in batched_inputs) else None
+        masks = [b.get("masks") for b in batched_inputs] if any("masks" in b for b in batched_inputs) else None
+        if use_pred:
+            features = self.backbone(x)
+            proposals, _ = self.proposal_generator(images, features, None)
+        else:
+            features = None
+            proposals = [b["instances"].to(self.device) for b in batched_inputs]
+        results, _ = self.roi_heads(images, features, proposals, depth, ground, Ks, im_scales_ratio, masks=masks,
+                                    use_pred_boxes=use_pred, generator=generator)
+        if do_postprocess:
+            return RCNN3D._postprocess(results, batched_inputs, images.image_sizes)
+        return results
+
+
 def build_model(cfg, priors=None):
     """rcnn3d.py:894-903."""
     meta_arch = cfg.MODEL.META_ARCHITECTURE
