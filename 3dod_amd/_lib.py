@@ -26,6 +26,7 @@ SIGNATURES = {
     "cr_conv2d_bwd_weight": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "cr_cast_f32_to_bf16": [P, P, P, c_int64],
     "cr_weight_transpose": [P, P, P, c_int, c_int, c_int],
+    "cr_colsum_accum": [P, P, c_int, c_int64, c_int, P, P],
     "cr_bn_fwd": [P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, P],
     "cr_bn_bwd": [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int],
     "cr_pool2x_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int],

@@ -484,7 +484,13 @@ static int launch_wgrad_ks(cr_ctx* ctx, WgP& p) {
     return CR_OK;
 }
 
-// dW[k][r][s][c] (+)= sum dY * X ; dw is f32 [Cout][ks*ks*Cin]; `accumulate`=0 zeroes it first.
+__global__ void k_fill_zero_f32(float* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+// dW[k][r][s][c] (+)= sum dY * X ; dw is f32 [Cout][ks*ks*Cin]; `accumulate`=0 zeroes it first (with a kernel, not
+// hipMemsetAsync: memset nodes inside captured HIP graphs were observed to leave garbage on ROCm 7.2).
 extern "C" int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W,
                                     int Cin, int Cout, int ks, int stride, int pad, int accumulate) {
     CR_CHECK_ARG(ctx && dy && x && dw, "cr_conv2d_bwd_weight: NULL pointer");
@@ -497,7 +503,11 @@ extern "C" int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, 
     p.Wout = (W + 2 * pad - ks) / stride + 1;
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = N * p.Hout * p.Wout;
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cin);
-    if (!accumulate) CR_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * p.Kdim, ctx->stream));
+    if (!accumulate) {
+        const int64_t nz = (int64_t)Cout * p.Kdim;
+        hipLaunchKernelGGL(k_fill_zero_f32, dim3((unsigned)cr_cdiv(nz, 256)), dim3(256), 0, ctx->stream, dw, nz);
+        CR_LAUNCH_CHECK();
+    }
     if (ks == 1) return launch_wgrad_ks<1>(ctx, p);
     if (ks == 3) return launch_wgrad_ks<3>(ctx, p);
     return launch_wgrad_ks<7>(ctx, p);
@@ -764,6 +774,56 @@ extern "C" int cr_bn_bwd(cr_ctx* ctx, const void* dy, const void* out, const voi
     const unsigned grid = (unsigned)(cr_cdiv(total, 256) < 4096 ? cr_cdiv(total, 256) : 4096);
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(256), 0, ctx->stream, (const u16*)dy, (const u16*)out,
                        (const u16*)x, mean_invstd, gamma, reduced, (u16*)dx, (u16*)dres, M, C, relu);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// bias gradient: out[c] += sum_m x[m][c], x bf16 or f32 [M][C]; two fixed-order stages (no atomics, no memset)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_colsum_partial(const T* __restrict__ x, int64_t M, int C, int rows_per_block,
+                                                        float* __restrict__ partial) {
+    // thread -> column c = tid % C' ... simple mapping: each thread owns columns c = tid, tid+256, ...
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) {
+            if (sizeof(T) == 2) s += bf2f(((const u16*)x)[r * C + c]);
+            else s += ((const float*)x)[r * C + c];
+        }
+        partial[(size_t)blockIdx.x * C + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ partial, int nparts, int C,
+                                                      float* __restrict__ out) {
+    __shared__ double ss[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s = 0.0;
+    for (int r = t; r < nparts; r += 256) s += (double)partial[(size_t)r * C + c];
+    ss[t] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) ss[t] += ss[t + off];
+        __syncthreads();
+    }
+    if (t == 0) out[c] += (float)ss[0];
+}
+
+// ws: f32 workspace of 1024*C floats.  out is ACCUMULATED.
+extern "C" int cr_colsum_accum(cr_ctx* ctx, const void* x, int is_f32, int64_t M, int C, float* ws, float* out) {
+    CR_CHECK_ARG(ctx && x && ws && out && M > 0 && C > 0, "cr_colsum_accum: bad args");
+    int64_t rows = cr_cdiv(M, 1024);
+    if (rows < 8) rows = 8;
+    const int nb = (int)cr_cdiv(M, rows);
+    if (is_f32)
+        hipLaunchKernelGGL((k_colsum_partial<float>), dim3(nb), dim3(256), 0, ctx->stream, (const float*)x, M, C, (int)rows, ws);
+    else
+        hipLaunchKernelGGL((k_colsum_partial<u16>), dim3(nb), dim3(256), 0, ctx->stream, (const u16*)x, M, C, (int)rows, ws);
+    CR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_colsum_final, dim3(C), dim3(256), 0, ctx->stream, ws, nb, C, out);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -18,7 +18,7 @@ BatchNorm = nn.BatchNorm2d
 def _conv_bn(x, conv, bn, relu, residual=None):
     w = conv.weight
     if w.shape[1] < 8:      # RGB stem: activations carry 8 channels (3 real + 5 zero)
-        w = F.pad(w, (0, 0, 0, 0, 0, 8 - w.shape[1])).contiguous(memory_format=torch.channels_last)
+        w = ops.pad_input_channels(w, 8)
     return ops.conv_bn_act(x, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, stride=conv.stride[0],
                            pad=conv.padding[0], relu=relu, residual=residual, eps=bn.eps, momentum=bn.momentum,
                            training=bn.training)

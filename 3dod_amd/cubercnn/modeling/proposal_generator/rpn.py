@@ -33,9 +33,8 @@ class StandardRPNHead(nn.Module):
         A, D = self.num_anchors, self.box_dim
         n_out = A + A * D
         pad = (-n_out) % 16
-        w = torch.cat([self.objectness_logits.weight, self.anchor_deltas.weight,
-                       self.conv.weight.new_zeros((pad,) + tuple(self.anchor_deltas.weight.shape[1:]))], 0)
-        b = torch.cat([self.objectness_logits.bias, self.anchor_deltas.bias, self.conv.bias.new_zeros(pad)])
+        w = ops.cat_rows((self.objectness_logits.weight, self.anchor_deltas.weight), n_out + pad)
+        b = ops.cat_rows((self.objectness_logits.bias, self.anchor_deltas.bias), n_out + pad)
         pred_objectness_logits, pred_anchor_deltas = [], []
         for x in features:
             t = ops.conv_bias_act(x, self.conv.weight, self.conv.bias, 1, 1, relu=True)

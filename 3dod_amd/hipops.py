@@ -210,6 +210,7 @@ class _ConvBias(torch.autograd.Function):
         y = conv_fwd_raw(x, wb, Cout, k, stride, pad, bias=None if bias is None else bias.detach(), relu=relu,
                          out_f32=out_f32)
         ctx.cfg = (k, stride, pad, relu, bias is not None)
+        ctx.bias_ref = bias
         ctx.save_for_backward(x, weight, y if relu else None)
         return y
 
@@ -220,7 +221,17 @@ class _ConvBias(torch.autograd.Function):
         g = dy
         if relu:
             g = torch.where(y > 0, g, torch.zeros((), dtype=g.dtype, device=g.device))
-        db = g.to(f32).sum(dim=(0, 1, 2)) if (has_bias and ctx.needs_input_grad[2]) else None
+        g = g.contiguous()
+        db = None
+        if has_bias and ctx.needs_input_grad[2]:
+            C = g.shape[3]
+            bsink = grad_sink(ctx.bias_ref)
+            acc = bsink if bsink is not None else torch.zeros((C,), dtype=f32, device=g.device)
+            ws = torch.empty((1024, C), dtype=f32, device=g.device)
+            lib = _lib.load()
+            _chk(lib.cr_colsum_accum(_ctx(g), _p(g), int(g.dtype == f32), g.numel() // C, C, _p(ws), _p(acc)),
+                 "cr_colsum_accum")
+            db = None if bsink is not None else acc
         g = g.to(bf16).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
@@ -228,6 +239,60 @@ class _ConvBias(torch.autograd.Function):
             dx = conv_bwd_data_raw(g, wt, x.shape, k, stride, pad)
         dw = conv_bwd_weight_raw(g, x, k, stride, pad, grad_sink(weight)) if ctx.needs_input_grad[1] else None
         return dx, dw, db, None, None, None, None
+
+
+class _PadInputChannels(torch.autograd.Function):
+    """(Cout,Cin,k,k) weight -> zero-padded to Cin8 input channels (the RGB stem: 3 -> 8).  Backward adds the slice of
+    the padded gradient straight into the parameter's gradient sink when there is one."""
+    @staticmethod
+    def forward(ctx, w, cin_to):
+        ctx.w_ref = w
+        out = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_to - w.shape[1]))
+        return out.contiguous(memory_format=torch.channels_last)
+
+    @staticmethod
+    def backward(ctx, g):
+        w = ctx.w_ref
+        gs = g[:, :w.shape[1]]
+        sink = grad_sink(w)
+        if sink is not None:
+            sink.add_(gs)
+            return None, None
+        return gs, None
+
+
+def pad_input_channels(w, cin_to=8):
+    return _PadInputChannels.apply(w, cin_to)
+
+
+class _CatRows(torch.autograd.Function):
+    """concatenate parameters along dim 0 (+ zero rows up to `rows`); backward routes each slice into its sink."""
+    @staticmethod
+    def forward(ctx, rows, *params):
+        ctx.refs = params
+        n = sum(p.shape[0] for p in params)
+        parts = list(params)
+        if rows > n:
+            parts.append(params[0].new_zeros((rows - n,) + tuple(params[0].shape[1:])))
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for p in ctx.refs:
+            gs = g[off:off + p.shape[0]]
+            off += p.shape[0]
+            sink = grad_sink(p)
+            if sink is not None:
+                sink.add_(gs)
+                outs.append(None)
+            else:
+                outs.append(gs)
+        return (None,) + tuple(outs)
+
+
+def cat_rows(params, rows):
+    return _CatRows.apply(rows, *params)
 
 
 def conv_bias_act(x, weight, bias, stride=1, pad=0, relu=False, out_f32=False):

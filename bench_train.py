@@ -62,7 +62,8 @@ def bench_train(args, rank, world, dev):
         "config": {"workload": "Cube R-CNN DLA34+FPN train step (fwd+loss+bwd+allreduce+SGD), 4 img/GPU 512x512, "
                                "Base_Omni3D.yaml semantics (BASELINE configs[3] per-GPU shard)",
                    "global_batch": IMS_PER_GPU * world, "parallelism": f"dp{world}",
-                   "final_loss": rep.get("total_loss"), "skipped_steps": rep.get("iterations_explode")},
+                   "final_loss": rep.get("total_loss"), "skipped_steps": rep.get("iterations_explode"),
+                   "valid": bool(rep.get("iterations_explode") == 0 and rep.get("total_loss") == rep.get("total_loss"))},
         "roofline": dict(kern, whole_step={"achieved": achieved_tf, "unit": "TFLOP/s",
                                            "frac": achieved_tf / MFMA_PEAK_TFLOPS,
                                            "algorithmic_gflop_per_step": TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU}),

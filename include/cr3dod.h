@@ -121,6 +121,8 @@ int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, in
 int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
                          int Cout, int ks, int stride, int pad, int accumulate);
 int cr_cast_f32_to_bf16(cr_ctx* ctx, const float* src, void* dst, int64_t n);
+/* bias gradient: out[c] += sum_m x[m][c]; x (M,C) bf16 or f32; ws = 1024*C floats; deterministic. */
+int cr_colsum_accum(cr_ctx* ctx, const void* x, int is_f32, int64_t M, int C, float* ws, float* out);
 /* wt[c][tap][k] (bf16) = w[k][tap][c] (f32) */
 int cr_weight_transpose(cr_ctx* ctx, const float* w, void* wt, int Cout, int ks, int Cin);
 

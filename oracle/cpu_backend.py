@@ -43,6 +43,18 @@ def grad_sink(t):
     return None
 
 
+def pad_input_channels(w, cin_to=8):
+    return F.pad(w, (0, 0, 0, 0, 0, cin_to - w.shape[1]))
+
+
+def cat_rows(params, rows):
+    n = sum(p.shape[0] for p in params)
+    parts = list(params)
+    if rows > n:
+        parts.append(params[0].new_zeros((rows - n,) + tuple(params[0].shape[1:])))
+    return torch.cat(parts, 0)
+
+
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride=1, pad=0, relu=True, residual=None,
                 eps=1e-5, momentum=0.1, training=True):
     if weight.shape[1] != x.shape[3]:
