@@ -1,0 +1,340 @@
+"""Static-shape ("dense") training path of RCNN3D: the same labelling / sampling / loss rules as the reference
+(cubercnn/modeling/proposal_generator/rpn.py:41-328, roi_heads/roi_heads.py:2737-2840, fast_rcnn.py:145-260 and
+the detectron2 Matcher / subsample rules they build on) written over PADDED, fixed-shape tensors with validity
+masks instead of data-dependent shapes.
+
+Why: every boolean index / nonzero() / .tolist() of the reference formulation is a host<->device sync; a Cube R-CNN
+step has ~60 of them, which leaves the GPU idle while Python catches up (profiles/: 23 ms of kernels in a 41 ms
+step).  With fixed shapes nothing syncs, the host runs ahead of the device, and the step becomes capturable.
+
+Sampling rule equivalences (no semantic change):
+  * torch.multinomial(w, k) without replacement == the k largest keys w / E, E ~ Exp(1) (that is literally ATen's
+    implementation), so "min(#candidates, k) IoU-weighted samples" == top-k keys with non-candidates keyed 0 and
+    flagged invalid;
+  * "fill the rest with negatives" == the first (num_samples - #positives taken) of the top negatives.
+Losses are masked sums divided by the same (device-side) counts the reference divides by.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ...d2lite import Boxes, get_event_storage
+from ... import hipops as ops
+from ..util import math_util as util
+
+NEG = -1.0
+
+
+class GTBatch:
+    """ground truth of a batch padded to G objects per image."""
+
+    def __init__(self, gt_instances, device):
+        B = len(gt_instances)
+        G = max(1, max(len(g) for g in gt_instances))
+        self.boxes = torch.zeros((B, G, 4), device=device)
+        self.classes = torch.full((B, G), -2, dtype=torch.int64, device=device)     # -2 = padding, -1 = ignore
+        self.boxes3D = torch.zeros((B, G, 9), device=device)
+        self.poses = torch.eye(3, device=device).expand(B, G, 3, 3).clone()
+        for i, g in enumerate(gt_instances):
+            n = len(g)
+            if n:
+                self.boxes[i, :n] = g.gt_boxes.tensor
+                self.classes[i, :n] = g.gt_classes
+                if g.has("gt_boxes3D"):
+                    self.boxes3D[i, :n] = g.gt_boxes3D
+                    self.poses[i, :n] = g.gt_poses
+        self.valid = self.classes >= 0
+        self.ignore = self.classes == -1
+
+
+def _area(b):
+    return (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+
+
+def pairwise_inter(gt, boxes):
+    """gt (B,G,4), boxes (B,R,4) or (R,4) -> (B,G,R) intersection areas."""
+    if boxes.dim() == 2:
+        boxes = boxes.unsqueeze(0)
+    lt = torch.max(gt[:, :, None, :2], boxes[:, None, :, :2])
+    rb = torch.min(gt[:, :, None, 2:], boxes[:, None, :, 2:])
+    wh = (rb - lt).clamp_(min=0)
+    return wh[..., 0] * wh[..., 1]
+
+
+def pairwise_iou_b(gt, boxes):
+    inter = pairwise_inter(gt, boxes)
+    b = boxes.unsqueeze(0) if boxes.dim() == 2 else boxes
+    union = _area(gt)[:, :, None] + _area(b)[:, None, :] - inter
+    return torch.where(inter > 0, inter / union, torch.zeros((), device=gt.device))
+
+
+def pairwise_ioa_b(gt, boxes):
+    inter = pairwise_inter(gt, boxes)
+    b = boxes.unsqueeze(0) if boxes.dim() == 2 else boxes
+    return torch.where(inter > 0, inter / _area(b)[:, None, :], torch.zeros((), device=gt.device))
+
+
+def _keys(weights, cand, eps=1e-4):
+    """multinomial-without-replacement keys: (w + eps) / Exp(1) for candidates, 0 otherwise."""
+    e = torch.empty_like(weights).exponential_(1.0)
+    return torch.where(cand, (weights + eps) / e, torch.zeros((), device=weights.device))
+
+
+def _take(keys, k, limit=None):
+    """top-k keys -> (idx (B,k), valid (B,k)); valid = real candidate and (if given) within the first `limit` picks."""
+    k = min(k, keys.shape[1])
+    v, idx = keys.topk(k, dim=1)
+    valid = v > 0
+    if limit is not None:
+        valid = valid & (torch.arange(k, device=keys.device)[None, :] < limit[:, None])
+    return idx, valid
+
+
+# ------------------------------------------------------------------------------------------- RPN
+def rpn_label_and_sample(rpn, anchors, gt: GTBatch):
+    """RPNWithIgnore.label_and_sample_anchors (rpn.py:41-110) for the whole batch.  anchors (A,4).
+    Returns labels (B,A) int8 in {-1,0,1}, matched_gt_boxes (B,A,4), matched_ious (B,A)."""
+    B, A = gt.boxes.shape[0], anchors.shape[0]
+    dev = anchors.device
+    iou = pairwise_iou_b(gt.boxes, anchors)                                           # (B,G,A)
+    iou = torch.where(gt.valid[:, :, None], iou, torch.full((), NEG, device=dev))
+    vals, midx = iou.max(dim=1)                                                        # (B,A)
+    lo, hi = rpn.anchor_matcher.thresholds[1], rpn.anchor_matcher.thresholds[2]
+    l0, l1, l2 = rpn.anchor_matcher.labels
+    labels = torch.full((B, A), l2, dtype=torch.int8, device=dev)
+    labels = torch.where(vals < hi, torch.full((), l1, dtype=torch.int8, device=dev), labels)
+    labels = torch.where(vals < lo, torch.full((), l0, dtype=torch.int8, device=dev), labels)
+    # allow_low_quality_matches: every anchor that attains a valid GT's best IoU is foreground
+    best_per_gt, best_idx = iou.max(dim=2)                                             # (B,G)
+    lowq = ((iou == best_per_gt[:, :, None]) & gt.valid[:, :, None]).any(dim=1)
+    labels = torch.where(lowq, torch.ones((), dtype=torch.int8, device=dev), labels)
+    matched_ious = vals.clamp(min=0)
+    # rpn.py:75 -- the argmax anchor of each GT, if it is labelled foreground, is always kept
+    forced = torch.zeros((B, A), dtype=torch.bool, device=dev)
+    forced.scatter_(1, best_idx, (labels.gather(1, best_idx) == 1) & gt.valid)
+    # IoU-weighted subsample (rpn.py:275-328), bg_label 0
+    pos, neg = labels == 1, labels == 0
+    n_s = rpn.batch_size_per_image
+    k_pos = int(n_s * rpn.positive_fraction)
+    pidx, pvalid = _take(_keys(matched_ious, pos), k_pos)
+    n_pos = pvalid.sum(1)
+    nidx, nvalid = _take(_keys(matched_ious, neg), n_s, limit=n_s - n_pos)
+    out = torch.full((B, A), -1, dtype=torch.int32, device=dev)
+    one, zero, m1 = [torch.full((), v, dtype=torch.int32, device=dev) for v in (1, 0, -1)]
+    out.scatter_reduce_(1, pidx, torch.where(pvalid, one, m1), reduce="amax")
+    out.scatter_reduce_(1, nidx, torch.where(nvalid, zero, m1), reduce="amax")
+    out = torch.where(forced, one, out)
+    # ignore regions (rpn.py:93-104): sampled background inside an ignore box -> -1 (only if > 1 background)
+    ioa = pairwise_ioa_b(gt.boxes, anchors)
+    ioa = torch.where(gt.ignore[:, :, None], ioa, torch.zeros((), device=dev)).max(dim=1)[0]
+    bg = out == 0
+    many = bg.sum(1, keepdim=True) > 1
+    out = torch.where(bg & many & (ioa >= rpn.ignore_thresh), m1, out)
+    has_gt = gt.valid.any(1)
+    matched = torch.gather(gt.boxes, 1, midx[:, :, None].expand(-1, -1, 4)) * has_gt[:, None, None]
+    return out, matched, matched_ious
+
+
+def rpn_losses(rpn, anchors, logits, deltas, labels, matched_gt_boxes):
+    """RPNWithIgnore.losses + _dense_box_regression_loss_with_uncertainty (rpn.py:129-273), "IoUness" objectness.
+    logits (B,A), deltas (B,A,4)."""
+    assert rpn.objectness_uncertainty.lower() != "none" and rpn.box_reg_loss_type == "smooth_l1" and rpn.smooth_l1_beta < 1e-5
+    B, A = labels.shape
+    pos = labels == 1
+    a = anchors.unsqueeze(0).expand(B, A, 4)
+    g = torch.where(pos[..., None], matched_gt_boxes, a)                               # sanitised where unused
+    lt = torch.max(a[..., :2], g[..., :2])
+    rb = torch.min(a[..., 2:], g[..., 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    iou_t = (inter / (_area(a) + _area(g) - inter)).detach()
+    iou_t = torch.where(pos, iou_t, torch.zeros((), device=a.device))
+    bce = F.binary_cross_entropy_with_logits(logits, iou_t, reduction="none")
+    loss_conf = (bce * iou_t).sum()
+    tgt = rpn.box2box_transform.get_deltas(a.reshape(-1, 4), g.reshape(-1, 4)).view(B, A, 4)
+    l1 = torch.where(pos[..., None], (deltas - tgt).abs(), torch.zeros((), device=a.device))
+    loss_loc = (l1.sum(-1) * iou_t).sum()
+    storage = get_event_storage()
+    with torch.no_grad():
+        sig = torch.sigmoid(logits)
+        npos = pos.sum().clamp(min=1)
+        storage.put_scalar("rpn/num_pos_anchors", pos.sum() / B)
+        storage.put_scalar("rpn/num_neg_anchors", (labels == 0).sum() / B)
+        storage.put_scalar("rpn/conf_pos_anchors", (sig * pos).sum() / npos)
+        storage.put_scalar("rpn/conf_neg_anchors", (sig * ~pos).sum() / (~pos).sum().clamp(min=1))
+    normalizer = rpn.batch_size_per_image * B
+    losses = {"rpn/cls": loss_conf / normalizer, "rpn/loc": loss_loc / normalizer}
+    return {k: v * rpn.loss_weight.get(k, 1.0) for k, v in losses.items()}
+
+
+def rpn_proposals_padded(rpn, anchors_per_level, logits_per_level, deltas_per_level, image_sizes):
+    """predict_proposals / find_top_rpn_proposals with a padded result: boxes (B,K,4), scores (B,K) (-inf = empty slot)."""
+    from .proposal_generator.rpn import find_top_rpn_proposals
+    with torch.no_grad():
+        props = rpn._decode_proposals(anchors_per_level, deltas_per_level)
+        return find_top_rpn_proposals(props, [t.detach() for t in logits_per_level], image_sizes, rpn.nms_thresh,
+                                      rpn.pre_nms_topk[True], rpn.post_nms_topk[True], rpn.min_box_size, True,
+                                      padded=True)
+
+
+# ------------------------------------------------------------------------------------------- ROI heads
+@torch.no_grad()
+def roi_label_and_sample(rh, prop_boxes, prop_scores, gt: GTBatch):
+    """ROIHeads3D.label_and_sample_proposals (roi_heads.py:2773-2840): append GT, match, ignore, IoU-weighted
+    sampling of <= 25 % foreground + background up to 512.  Output slots: [0,k_fg) foreground picks, then background.
+    Returns dict(boxes (B,S,4), valid (B,S), classes (B,S) with num_classes = background, gt_idx (B,S), k_fg)."""
+    dev = prop_boxes.device
+    B = prop_boxes.shape[0]
+    K = rh.num_classes
+    prop_valid = torch.isfinite(prop_scores)
+    if rh.proposal_append_gt:
+        boxes = torch.cat([prop_boxes, gt.boxes], 1)
+        valid = torch.cat([prop_valid, gt.valid], 1)
+    else:
+        boxes, valid = prop_boxes, prop_valid
+    iou = pairwise_iou_b(gt.boxes, boxes)                                              # (B,G,R)
+    iou = torch.where(gt.valid[:, :, None], iou, torch.full((), NEG, device=dev))
+    vals, midx = iou.max(dim=1)
+    thr = rh.proposal_matcher.thresholds[1]
+    fg_match = vals >= thr
+    ioa = pairwise_ioa_b(gt.boxes, boxes)
+    ioa = torch.where(gt.ignore[:, :, None], ioa, torch.zeros((), device=dev)).max(dim=1)[0]
+    bg_match = ~fg_match
+    ign = bg_match & (bg_match & valid).sum(1, keepdim=True).gt(1) & (ioa >= rh.ignore_thresh)
+    cls = torch.gather(gt.classes.clamp(min=0), 1, midx)
+    cls = torch.where(fg_match, cls, torch.full((), K, dtype=torch.int64, device=dev))
+    cls = torch.where(ign | ~valid, torch.full((), -1, dtype=torch.int64, device=dev), cls)
+    matched_ious = vals.clamp(min=0)
+    n_s = rh.batch_size_per_image
+    k_fg = int(n_s * rh.positive_fraction)
+    fidx, fvalid = _take(_keys(matched_ious, (cls >= 0) & (cls < K)), k_fg)
+    n_fg = fvalid.sum(1)
+    bidx, bvalid = _take(_keys(matched_ious, cls == K), n_s, limit=n_s - n_fg)
+    idx = torch.cat([fidx, bidx], 1)
+    svalid = torch.cat([fvalid, bvalid], 1)
+    s_cls = torch.where(svalid, torch.gather(cls, 1, idx), torch.full((), -1, dtype=torch.int64, device=dev))
+    storage = get_event_storage()
+    storage.put_scalar("roi_head/num_fg_samples", n_fg.float().mean())
+    storage.put_scalar("roi_head/num_bg_samples", bvalid.sum(1).float().mean())
+    return {"boxes": torch.gather(boxes, 1, idx[:, :, None].expand(-1, -1, 4)), "valid": svalid, "classes": s_cls,
+            "gt_idx": torch.gather(midx, 1, idx), "k_fg": fidx.shape[1]}
+
+
+def box_head_losses(rh, features, samp, gt: GTBatch):
+    """_forward_box in training (roi_heads.py:2160-2204) + FastRCNNOutputs.losses (fast_rcnn.py:145-194) on the padded
+    sample.  Returns (losses, pred_boxes (B,S,4) for the sampled classes)."""
+    B, S = samp["valid"].shape
+    K = rh.num_classes
+    feats = [features[f] for f in rh.box_in_features]
+    box_features = rh.box_head(rh.box_pooler(feats, [Boxes(b) for b in samp["boxes"]]))
+    scores, deltas = rh.box_predictor(box_features)                                    # (B*S,K+1), (B*S,K*4)
+    valid = samp["valid"].reshape(-1)
+    cls = samp["classes"].reshape(-1)
+    n_valid = valid.sum().clamp(min=1)
+    ce = F.cross_entropy(scores, cls.clamp(min=0), reduction="none")
+    loss_cls = (ce * valid).sum() / n_valid
+    fg = valid & (cls >= 0) & (cls < K)
+    pb = samp["boxes"].reshape(-1, 4)
+    gb = torch.gather(gt.boxes, 1, samp["gt_idx"][:, :, None].expand(-1, -1, 4)).reshape(-1, 4)
+    gb = torch.where(fg[:, None], gb, pb)                                              # sanitise unused targets
+    tgt = rh.box_predictor.box2box_transform.get_deltas(pb, gb)
+    ar = torch.arange(B * S, device=pb.device)
+    sel = deltas.view(B * S, K, 4)[ar, cls.clamp(0, K - 1)]
+    assert rh.box_predictor.smooth_l1_beta < 1e-5
+    l1 = torch.where(fg[:, None], (sel - tgt).abs(), torch.zeros((), device=pb.device))
+    loss_box = l1.sum() / n_valid
+    lw = rh.box_predictor.loss_weight
+    losses = {"BoxHead/loss_cls": loss_cls * lw.get("BoxHead/loss_cls", 1.0),
+              "BoxHead/loss_box_reg": loss_box * lw.get("BoxHead/loss_box_reg", 1.0)}
+    with torch.no_grad():
+        pred = rh.box_predictor.box2box_transform.apply_deltas(sel, pb).view(B, S, 4)
+    return losses, pred
+
+
+def cube_head_losses(rh, features, samp, pred_boxes, gt: GTBatch, Ks, im_scales_ratio, im_dims):
+    """_forward_cube in training (roi_heads.py:2237-2679) on the k_fg foreground slots of every image; invalid slots
+    are masked out of the reductions (their per-RoI losses are set to +inf, which safely_reduce_losses ignores)."""
+    B, kf = samp["valid"].shape[0], samp["k_fg"]
+    dev = samp["boxes"].device
+    K = rh.num_classes
+    boxes = samp["boxes"][:, :kf]
+    valid = (samp["valid"][:, :kf] & (samp["classes"][:, :kf] >= 0) & (samp["classes"][:, :kf] < K)).reshape(-1)
+    cls = samp["classes"][:, :kf].clamp(0, K - 1).reshape(-1)
+    gi = samp["gt_idx"][:, :kf]
+    n = B * kf
+    g3 = torch.gather(gt.boxes3D, 1, gi[:, :, None].expand(-1, -1, 9)).reshape(n, 9)
+    gp = torch.gather(gt.poses, 1, gi[:, :, None, None].expand(-1, -1, 3, 3)).reshape(n, 3, 3)
+    # sanitise unused slots so that no NaN / Inf enters the kernel: a unit cube 5 m in front of the camera
+    safe = torch.tensor([256., 256, 5, 1, 1, 1, 0, 0, 5], device=dev)
+    g3 = torch.where(valid[:, None], g3, safe)
+    scaled = rh.scale_proposals([Boxes(b) for b in boxes])
+    feats = [features[f] for f in rh.in_features]
+    cube_features = rh.cube_pooler(feats, scaled).flatten(1)
+    # per-image camera constants: ONE small pinned, non-blocking host->device copy (no sync)
+    rows = []
+    for k, r, d in zip(Ks, im_scales_ratio, im_dims):
+        k = torch.as_tensor(k, dtype=torch.float32)
+        v2r_i = util.compute_virtual_scale_from_focal_spaces(float(k[1, 1]), float(d[0]) * float(r), rh.virtual_focal,
+                                                             float(d[0])) if rh.virtual_depth else 1.0
+        rows.append([float(k[0, 0]) / r, float(k[1, 1]) / r, float(k[0, 2]) / r, float(k[1, 2]) / r, float(v2r_i)])
+    meta = torch.tensor(rows, dtype=torch.float32)
+    meta = (meta.pin_memory() if dev.type == "cuda" else meta).to(dev, non_blocking=True)
+    K4 = meta[:, None, :4].expand(B, kf, 4).reshape(n, 4)
+    v2r = meta[:, None, 4].expand(B, kf).reshape(n)
+    d2, z, dims, pose, unc = rh.cube_head(cube_features)
+    ar = torch.arange(n, device=dev)
+    d2, z, dims, pose, unc = d2[ar, cls], z[ar, cls, 0], dims[ar, cls], pose[ar, cls], unc[ar, cls]
+    pm = rh.priors_dims_per_cat.detach()[0][cls][:, 0, :] if rh.dims_priors_enabled else torch.ones(n, 3, device=dev)
+    assert rh.use_confidence > 0 and rh.dims_priors_func == "exp"
+    L, dec = ops.cube_decode_loss(d2, z, dims, pose, unc, boxes.reshape(n, 4), K4, v2r, pm, g3[:, :2], g3[:, 2], g3[:, 3:6],
+                                  gp, allocentric=rh.allocentric_pose, chamfer_pose=rh.chamfer_pose, use_conf=True,
+                                  joint=rh.loss_w_joint > 0)
+    inf = torch.full((), float("inf"), device=dev)
+    L = torch.where(valid[:, None], L, inf)
+    unc_m = torch.where(valid, unc, inf)
+    p = "Cube/"
+    red = rh.safely_reduce_losses
+    w3 = rh.loss_w_3d
+    if rh.inverse_z_weight:
+        L = L * (1 / torch.log(g3[:, 2].clip(2.71828183)))[:, None]
+    losses = {p + "uncert": rh.use_confidence * red(unc_m, absent_if_none=True),
+              p + "loss_xy": red(L[:, 1], absent_if_none=True) * rh.loss_w_xy * w3,
+              p + "loss_z": red(L[:, 2], absent_if_none=True) * rh.loss_w_z * w3,
+              p + "loss_pose": red(L[:, 3], absent_if_none=True) * rh.loss_w_pose * w3}
+    if rh.loss_w_dims > 0:
+        losses[p + "loss_dims"] = red(L[:, 0], absent_if_none=True) * rh.loss_w_dims * w3
+    if rh.loss_w_joint > 0:
+        losses[p + "loss_joint"] = red(L[:, 4], absent_if_none=True) * rh.loss_w_joint * w3
+    storage = get_event_storage()
+    with torch.no_grad():
+        nv = valid.sum().clamp(min=1)
+        zerr = (dec[:, 2] - g3[:, 2]).abs() * valid
+        storage.put_scalar(p + "z_error", zerr.sum() / nv, smoothing_hint=False)
+        storage.put_scalar(p + "dims_error", ((dec[:, 3:6] - g3[:, 3:6]).abs() * valid[:, None]).sum() / (3 * nv), smoothing_hint=False)
+        storage.put_scalar(p + "xy_error", ((dec[:, 0:2] - g3[:, :2]).abs() * valid[:, None]).sum() / (2 * nv), smoothing_hint=False)
+        storage.put_scalar(p + "conf", (torch.exp(-unc) * valid).sum() / nv, smoothing_hint=False)
+    return losses
+
+
+def forward_train(model, images, features, head_outputs, gt_instances, Ks, im_scales_ratio):
+    """RCNN3D.forward in training mode (rcnn3d.py:50-89) on the static-shape path."""
+    rpn, rh = model.proposal_generator, model.roi_heads
+    dev = features[rpn.in_features[0]].device
+    gt = GTBatch(gt_instances, dev)
+    feats = [features[f] for f in rpn.in_features]
+    grid_sizes = [(f.shape[1], f.shape[2]) for f in feats]
+    anchors_lv = rpn.anchor_generator(grid_sizes, dev)
+    anchors = torch.cat([a.tensor for a in anchors_lv])
+    logits_lv, deltas_lv = head_outputs if head_outputs is not None else rpn.rpn_head(feats)
+    logits, deltas = torch.cat(logits_lv, 1), torch.cat(deltas_lv, 1)
+    with torch.no_grad():
+        labels, matched, _ = rpn_label_and_sample(rpn, anchors, gt)
+    losses = rpn_losses(rpn, anchors, logits, deltas, labels, matched)
+    pboxes, pscores = rpn_proposals_padded(rpn, anchors_lv, logits_lv, deltas_lv, images.image_sizes)
+    samp = roi_label_and_sample(rh, pboxes, pscores, gt)
+    lb, pred_boxes = box_head_losses(rh, features, samp, gt)
+    losses.update(lb)
+    if rh.loss_w_3d > 0:
+        im_dims = [tuple(s) for s in images.image_sizes]
+        losses.update(cube_head_losses(rh, features, samp, pred_boxes, gt, Ks, im_scales_ratio, im_dims))
+    return losses

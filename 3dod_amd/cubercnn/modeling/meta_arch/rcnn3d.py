@@ -41,6 +41,8 @@ class RCNN3D(nn.Module):
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
         self._graphed = None
+        # static-shape training path (modeling/dense_train.py): same rules, no host<->device syncs
+        self.dense_train = True
 
     def enable_graphs(self, sample_batched_inputs):
         """capture the static dense region (trunk + FPN + RPN head, forward and backward) as HIP graphs for the
@@ -99,6 +101,9 @@ class RCNN3D(nn.Module):
             gt_instances = [b["instances"].to(self.device) for b in batched_inputs]
         else:
             gt_instances = None
+        if self.dense_train and gt_instances is not None:
+            from ..dense_train import forward_train
+            return forward_train(self, images, features, head_outputs, gt_instances, Ks, im_scales_ratio)
         proposals, proposal_losses = self.proposal_generator(images, features, gt_instances, head_outputs=head_outputs)
         instances, detector_losses = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, gt_instances)
         losses = {}

@@ -46,7 +46,7 @@ class StandardRPNHead(nn.Module):
 
 
 def find_top_rpn_proposals(proposals, pred_objectness_logits, image_sizes, nms_thresh, pre_nms_topk, post_nms_topk,
-                           min_box_size, training):
+                           min_box_size, training, padded=False):
     """detectron2 find_top_rpn_proposals [third-party, restated]: per level top-k, clip, drop empty boxes,
     per-level NMS, then the post_nms_topk best per image."""
     num_images = len(image_sizes)
@@ -75,7 +75,9 @@ def find_top_rpn_proposals(proposals, pred_objectness_logits, image_sizes, nms_t
     flat_boxes = boxes_pad.view(num_images, -1, 4)
     k_post = min(post_nms_topk, flat_scores.shape[1])
     top_scores, top_idx = flat_scores.topk(k_post, dim=1)
-    n_keep = keep.view(num_images, -1).sum(1).clamp(max=k_post).tolist()                 # one host sync per step
+    if padded:       # fixed-shape result for the sync-free training path: empty slots carry score -inf
+        return torch.gather(flat_boxes, 1, top_idx[:, :, None].expand(-1, -1, 4)), top_scores
+    n_keep = keep.view(num_images, -1).sum(1).clamp(max=k_post).tolist()                 # one host sync
     results = []
     for i in range(num_images):
         res = Instances(image_sizes[i])

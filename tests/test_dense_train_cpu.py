@@ -1,0 +1,105 @@
+"""CPU: the static-shape labelling / sampling / loss code (modeling/dense_train.py) against the reference-shaped
+per-image code paths (rpn.py / roi_heads.py restatements) on the same inputs.  Deterministic parts must agree
+exactly; sampled parts must obey the same counting rules."""
+import importlib
+
+import pytest
+import torch
+
+d2 = importlib.import_module("3dod_amd.d2lite")
+syn = importlib.import_module("3dod_amd.synthetic")
+modeling = importlib.import_module("3dod_amd.cubercnn.modeling")
+dt = importlib.import_module("3dod_amd.cubercnn.modeling.dense_train")
+
+
+@pytest.fixture(scope="module")
+def parts():
+    cfg = syn.make_cfg(overrides=["MODEL.DEVICE", "cpu", "VIS_PERIOD", 0, "log", False])
+    shapes = {f"p{l}": d2.ShapeSpec(channels=256, stride=2 ** l) for l in range(2, 7)}
+    rpn = modeling.proposal_generator.build_proposal_generator(cfg, shapes).train()
+    rh = modeling.build_roi_heads(cfg, shapes).train()
+    batch = syn.make_batch(3, 3)
+    batch[1]["instances"].gt_classes[2] = -1            # an ignore region
+    gts = [b["instances"] for b in batch]
+    grid = [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)]
+    anchors_lv = rpn.anchor_generator(grid, torch.device("cpu"))
+    return cfg, rpn, rh, gts, anchors_lv
+
+
+def test_rpn_labels_rules(parts):
+    cfg, rpn, rh, gts, anchors_lv = parts
+    anchors = torch.cat([a.tensor for a in anchors_lv])
+    gt = dt.GTBatch(gts, torch.device("cpu"))
+    torch.manual_seed(0)
+    labels, matched, mious = dt.rpn_label_and_sample(rpn, anchors, gt)
+    A = anchors.shape[0]
+    for i, g in enumerate(gts):
+        valid = g.gt_boxes[g.gt_classes >= 0]
+        q = d2.pairwise_iou(valid, d2.Boxes(anchors))
+        midx, mlab = rpn.anchor_matcher(q)
+        vals = q.max(0)[0]
+        assert torch.allclose(mious[i], vals)                                   # matched IoU per anchor
+        assert torch.equal(matched[i], valid.tensor[midx])                      # matched GT box per anchor
+        lab = labels[i]
+        n_pos, n_neg = int((lab == 1).sum()), int((lab == 0).sum())
+        cand_pos = int((mlab == 1).sum())
+        best = q.max(1)[1]
+        forced = best[mlab[best] == 1].unique()
+        assert (lab[forced] == 1).all()                                         # rpn.py:75-86
+        assert min(cand_pos, 256) <= n_pos <= min(cand_pos, 256) + len(forced)
+        assert n_pos + n_neg <= 256 + len(forced) and ((lab == 1) <= (mlab == 1)).all()
+        assert ((lab == 0) <= (mlab == 0)).all()
+        ign = g.gt_boxes[g.gt_classes < 0]
+        if len(ign):
+            ioa = d2.pairwise_ioa(ign, d2.Boxes(anchors)).max(0)[0]
+            assert not ((lab == 0) & (ioa >= 0.5)).any()
+
+
+def test_rpn_losses_match_reference_shaped_code(parts):
+    cfg, rpn, rh, gts, anchors_lv = parts
+    anchors = torch.cat([a.tensor for a in anchors_lv])
+    gt = dt.GTBatch(gts, torch.device("cpu"))
+    torch.manual_seed(1)
+    labels, matched, _ = dt.rpn_label_and_sample(rpn, anchors, gt)
+    B, A = labels.shape
+    g = torch.Generator().manual_seed(2)
+    logits = torch.randn(B, A, generator=g)
+    deltas = torch.randn(B, A, 4, generator=g) * 0.1
+    with d2.EventStorage(0):
+        new = dt.rpn_losses(rpn, anchors, logits, deltas, labels, matched)
+        sizes = [a.tensor.shape[0] for a in anchors_lv]
+        old = rpn.losses(anchors_lv, list(logits.split(sizes, 1)), [l.to(torch.int8) for l in labels],
+                         list(deltas.split(sizes, 1)), [m for m in matched])
+    for k in old:
+        assert abs(float(new[k]) - float(old[k])) <= 1e-5 * max(1.0, abs(float(old[k]))), (k, float(new[k]), float(old[k]))
+
+
+def test_roi_sampling_rules(parts):
+    cfg, rpn, rh, gts, anchors_lv = parts
+    gt = dt.GTBatch(gts, torch.device("cpu"))
+    g = torch.Generator().manual_seed(3)
+    B, Pn = 3, 300
+    jit = torch.randn(B, Pn, 4, generator=g) * 20
+    base = torch.stack([gi.gt_boxes.tensor[torch.randint(0, len(gi), (Pn,), generator=g)] for gi in gts])
+    pboxes = (base + jit).clamp(0, 511)
+    pscores = torch.randn(B, Pn, generator=g)
+    pscores[:, 250:] = float("-inf")                       # empty proposal slots
+    torch.manual_seed(4)
+    with d2.EventStorage(0):
+        s = dt.roi_label_and_sample(rh, pboxes, pscores, gt)
+    K = rh.num_classes
+    R = Pn + gt.boxes.shape[1]
+    assert s["boxes"].shape == (B, 128 + min(512, R), 4) and s["k_fg"] == 128
+    for i in range(B):
+        v, c = s["valid"][i], s["classes"][i]
+        fg = v & (c < K) & (c >= 0)
+        assert int(v.sum()) <= 512 and int(fg.sum()) <= 128
+        assert not fg[128:].any() and (c[:128][v[:128]] < K).all()            # slot layout: fg first, then bg
+        assert (c[128:][v[128:]] == K).all()
+        # a sampled foreground box really overlaps its matched GT by >= 0.5 and carries its class
+        bi = s["boxes"][i][fg]
+        gi = s["gt_idx"][i][fg]
+        iou = d2.pairwise_iou(d2.Boxes(gt.boxes[i][gi]), d2.Boxes(bi)).diagonal()
+        assert (iou >= 0.5 - 1e-6).all()
+        assert torch.equal(c[fg], gt.classes[i][gi])
+        assert (gt.classes[i][gi] >= 0).all()
