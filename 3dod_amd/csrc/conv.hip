@@ -51,12 +51,16 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 32 + ((chunk ^ ((-(row >> 2)) & 3)) << 3);
 }
 
-template <int BN, int KS, int MODE, typename OutT>
+template <int BM, int BN, int KS, int MODE, typename OutT>
 __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
-    constexpr int BM = 128;
-    constexpr int TP = (BN == 128) ? 4 : 2;          // pixel tiles (16) per wave
-    constexpr int TC = (BN == 128) ? 4 : BN / 16;    // channel tiles per wave
+    // 4 waves tile the BM x BN block: 2x2 for the square-ish tiles, 4x1 (pixels) for narrow channel tiles
+    constexpr int WAVES_M = (BN == 128 || BM == 64) ? 2 : 4;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int TP = BM / WAVES_M / 16;            // pixel tiles (16) per wave
+    constexpr int TC = BN / WAVES_N / 16;            // channel tiles per wave
+    constexpr int NA = BM * 4 / CONV_T;              // pixel-row chunks per thread (2 or 1)
     constexpr int NB = (BN * 4 + CONV_T - 1) / CONV_T;   // weight chunks per thread
+    static_assert(TP >= 1 && TC >= 1 && NA >= 1, "tile too small for 4 waves");
     __shared__ __attribute__((aligned(16))) u16 sX[BM * 32];
     __shared__ __attribute__((aligned(16))) u16 sW[BN * 32];
     __shared__ float sStat[4 * 2 * BN];      // [wave][2][BN]: no atomics -> bitwise reproducible statistics
@@ -68,10 +72,10 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
 
     // ---- per-thread gather bookkeeping (2 pixel rows, one 16-B k-chunk each)
     const int cA = tid & 3;
-    int nimg[2], hb[2], wb[2];
-    bool rv[2];
+    int nimg[NA], hb[NA], wb[NA];
+    bool rv[NA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
         const int m = m0 + (tid >> 2) + 64 * i;
         rv[i] = m < p.M;
         const int mm = rv[i] ? m : 0;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
         if (MODE == 0) { hb[i] = ho * p.stride - p.pad; wb[i] = wo * p.stride - p.pad; }
         else           { hb[i] = ho + p.pad;            wb[i] = wo + p.pad; }
     }
-    uint4 ra[2], rb[NB];
+    uint4 ra[NA], rb[NB];
 
     auto load_tiles = [&](int kt) {
         const int k0 = kt * 32 + cA * 8;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
             s = tap - r * KS;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NA; ++i) {
             int hi, wi;
             bool ok = rv[i] && (k0 < p.Kdim);
             if (MODE == 0) { hi = hb[i] + r; wi = wb[i] + s; }
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NA; ++i)
             *reinterpret_cast<uint4*>(&sX[lds_off((tid >> 2) + 64 * i, cA)]) = ra[i];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -129,8 +133,8 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
         }
     };
 
-    const int poff = (BN == 128) ? (wave >> 1) * 64 : wave * 32;    // pixel offset of this wave in the tile
-    const int coff = (BN == 128) ? (wave & 1) * 64 : 0;             // channel offset
+    const int poff = (wave / WAVES_N) * (BM / WAVES_M);            // pixel offset of this wave in the tile
+    const int coff = (wave % WAVES_N) * (BN / WAVES_N);            // channel offset
 
     f32x4 acc[TC][TP];
 #pragma unroll
@@ -233,7 +237,15 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
     }
     if (do_stats) {
         __syncthreads();
-        float* dst = p.stats + (size_t)mt * 2 * p.Cout;           // this M-tile's partial, fixed wave order
+        // statistics rows are per 64 pixels so that their number does not depend on the tile choice:
+        // a 128-pixel tile writes its sums to row 2*mt and zeros to row 2*mt+1
+        const int srow = (BM == 128) ? 2 * mt : mt;
+        float* dst = p.stats + (size_t)srow * 2 * p.Cout;
+        if (BM == 128 && (size_t)(srow + 1) * 64 < (size_t)p.M + 64) {
+            float* dz = dst + 2 * p.Cout;
+            if ((int64_t)(srow + 1) * 64 < (int64_t)p.M)
+                for (int i = tid; i < BN; i += CONV_T) { dz[n0 + i] = 0.f; dz[p.Cout + n0 + i] = 0.f; }
+        }
         for (int i = tid; i < BN; i += CONV_T) {
             const float a = ((sStat[(0 * 2 + 0) * BN + i] + sStat[(1 * 2 + 0) * BN + i]) + sStat[(2 * 2 + 0) * BN + i]) + sStat[(3 * 2 + 0) * BN + i];
             const float b = ((sStat[(0 * 2 + 1) * BN + i] + sStat[(1 * 2 + 1) * BN + i]) + sStat[(2 * 2 + 1) * BN + i]) + sStat[(3 * 2 + 1) * BN + i];
@@ -243,23 +255,27 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
     }
 }
 
-template <int BN, int KS, int MODE>
+template <int BM, int BN, int KS, int MODE>
 static int launch_igemm_t(cr_ctx* ctx, const ConvP& p, int out_f32) {
-    const int grid = (int)(cr_cdiv(p.M, 128) * (p.Cout / BN));
+    const int grid = (int)(cr_cdiv(p.M, BM) * (p.Cout / BN));
     if (out_f32)
-        hipLaunchKernelGGL((k_conv_igemm<BN, KS, MODE, float>), dim3(grid), dim3(CONV_T), 0, ctx->stream, p);
+        hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, MODE, float>), dim3(grid), dim3(CONV_T), 0, ctx->stream, p);
     else
-        hipLaunchKernelGGL((k_conv_igemm<BN, KS, MODE, u16>), dim3(grid), dim3(CONV_T), 0, ctx->stream, p);
+        hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, MODE, u16>), dim3(grid), dim3(CONV_T), 0, ctx->stream, p);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
 
 template <int KS, int MODE>
 static int launch_igemm_ks(cr_ctx* ctx, const ConvP& p, int out_f32) {
-    if (p.Cout % 128 == 0) return launch_igemm_t<128, KS, MODE>(ctx, p, out_f32);
-    if (p.Cout % 64 == 0) return launch_igemm_t<64, KS, MODE>(ctx, p, out_f32);
-    if (p.Cout % 32 == 0) return launch_igemm_t<32, KS, MODE>(ctx, p, out_f32);
-    return launch_igemm_t<16, KS, MODE>(ctx, p, out_f32);
+    // the 32x32 ... 8x8 levels at 4 images/GPU give only 8-64 tiles of 128x128: use 64x64 tiles there so that the
+    // launch covers the 256 CUs (MI355X: "a launch needs >> 256 workgroups")
+    const int64_t big_tiles = cr_cdiv(p.M, 128) * (p.Cout >= 128 ? p.Cout / 128 : 1);
+    if (p.Cout % 64 == 0 && big_tiles < 512) return launch_igemm_t<64, 64, KS, MODE>(ctx, p, out_f32);
+    if (p.Cout % 128 == 0) return launch_igemm_t<128, 128, KS, MODE>(ctx, p, out_f32);
+    if (p.Cout % 64 == 0) return launch_igemm_t<128, 64, KS, MODE>(ctx, p, out_f32);
+    if (p.Cout % 32 == 0) return launch_igemm_t<128, 32, KS, MODE>(ctx, p, out_f32);
+    return launch_igemm_t<128, 16, KS, MODE>(ctx, p, out_f32);
 }
 
 static int ilog2_exact(int v) {

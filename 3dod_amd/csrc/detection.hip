@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(Pyramid py, const float* 
     const int gh = (int)ceilf(rh / (float)PH), gw = (int)ceilf(rw / (float)PW);
     const float cnt = fmaxf((float)(gh * gw), 1.f);
     const float g = bf2f(dout[i]) / cnt;
+    if (g == 0.f) return;        // masked-out (padding) RoIs and dead channels add nothing: skip their 16 atomics
     float* gq = py.grad[lv] + (size_t)n * H * W * C + c;
     for (int iy = 0; iy < gh; ++iy) {
         const float y = y1 + ph * bh + (iy + 0.5f) * bh / (float)gh;
@@ -263,6 +264,11 @@ __global__ __launch_bounds__(64) void k_nms_scan(const int* __restrict__ counts,
     for (int i = n + t; i < maxn; i += 64) gk[i] = 0;
 }
 
+__global__ void k_fill_zero_u64(unsigned long long* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0ULL;
+}
+
 // mask_ws: workspace of G*maxn*ceil(maxn/64) u64.
 extern "C" int cr_nms_grouped(cr_ctx* ctx, const float* boxes, const int* counts, int G, int maxn, float thresh,
                               void* mask_ws, unsigned char* keep) {
@@ -271,7 +277,12 @@ extern "C" int cr_nms_grouped(cr_ctx* ctx, const float* boxes, const int* counts
     CR_CHECK_ARG(boxes && counts && mask_ws && keep && G > 0 && maxn > 0 && maxn <= 65536, "cr_nms_grouped: bad args");
     const int words = (maxn + 63) / 64;
     // rows below the diagonal block are skipped by the kernel -> clear the matrix first
-    CR_HIP(hipMemsetAsync(mask_ws, 0, (size_t)G * maxn * words * 8, ctx->stream));
+    {   // a kernel, not hipMemsetAsync: memset nodes misbehave inside captured HIP graphs (ROCm 7.2)
+        const int64_t nz = (int64_t)G * maxn * words;
+        hipLaunchKernelGGL(k_fill_zero_u64, dim3((unsigned)cr_cdiv(nz, 256)), dim3(256), 0, ctx->stream,
+                           (unsigned long long*)mask_ws, nz);
+        CR_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_nms_mask, dim3(words, words, G), dim3(64), 0, ctx->stream, boxes, counts, maxn, thresh,
                        (unsigned long long*)mask_ws);
     CR_LAUNCH_CHECK();

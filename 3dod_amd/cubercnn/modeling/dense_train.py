@@ -28,9 +28,11 @@ NEG = -1.0
 class GTBatch:
     """ground truth of a batch padded to G objects per image."""
 
-    def __init__(self, gt_instances, device):
+    def __init__(self, gt_instances, device, G=None):
         B = len(gt_instances)
-        G = max(1, max(len(g) for g in gt_instances))
+        need = max(1, max(len(g) for g in gt_instances))
+        G = need if G is None else G
+        assert need <= G, f"{need} objects in an image but the static GT buffer holds {G}"
         self.boxes = torch.zeros((B, G, 4), device=device)
         self.classes = torch.full((B, G), -2, dtype=torch.int64, device=device)     # -2 = padding, -1 = ignore
         self.boxes3D = torch.zeros((B, G, 9), device=device)
@@ -43,8 +45,34 @@ class GTBatch:
                 if g.has("gt_boxes3D"):
                     self.boxes3D[i, :n] = g.gt_boxes3D
                     self.poses[i, :n] = g.gt_poses
-        self.valid = self.classes >= 0
-        self.ignore = self.classes == -1
+
+    @property
+    def valid(self):
+        return self.classes >= 0
+
+    @property
+    def ignore(self):
+        return self.classes == -1
+
+    def copy_from(self, other):
+        """in-place refresh of a static (graph-captured) buffer set."""
+        self.boxes.copy_(other.boxes)
+        self.classes.copy_(other.classes)
+        self.boxes3D.copy_(other.boxes3D)
+        self.poses.copy_(other.poses)
+
+
+def camera_meta(rh, Ks, im_scales_ratio, im_dims, device):
+    """per-image camera constants (B,5) = [fx,fy,cx,cy of K/ratio, virtual_to_real] (roi_heads.py:2285-2315) made on
+    the host and shipped with ONE pinned, non-blocking copy (no sync)."""
+    rows = []
+    for k, r, d in zip(Ks, im_scales_ratio, im_dims):
+        k = torch.as_tensor(k, dtype=torch.float32)
+        v2r_i = util.compute_virtual_scale_from_focal_spaces(float(k[1, 1]), float(d[0]) * float(r), rh.virtual_focal,
+                                                             float(d[0])) if rh.virtual_depth else 1.0
+        rows.append([float(k[0, 0]) / r, float(k[1, 1]) / r, float(k[0, 2]) / r, float(k[1, 2]) / r, float(v2r_i)])
+    meta = torch.tensor(rows, dtype=torch.float32)
+    return (meta.pin_memory() if device.type == "cuda" else meta).to(device, non_blocking=True)
 
 
 def _area(b):
@@ -210,8 +238,13 @@ def roi_label_and_sample(rh, prop_boxes, prop_scores, gt: GTBatch):
     fidx, fvalid = _take(_keys(matched_ious, (cls >= 0) & (cls < K)), k_fg)
     n_fg = fvalid.sum(1)
     bidx, bvalid = _take(_keys(matched_ious, cls == K), n_s, limit=n_s - n_fg)
+    # compact to n_s slots: at most n_s picks are valid, a stable sort by validity moves them to the front while
+    # keeping "foreground first" (the k_fg leading slots still hold every valid foreground pick)
     idx = torch.cat([fidx, bidx], 1)
     svalid = torch.cat([fvalid, bvalid], 1)
+    if idx.shape[1] > n_s:
+        order = torch.sort((~svalid).to(torch.int8), dim=1, stable=True)[1][:, :n_s]
+        idx, svalid = torch.gather(idx, 1, order), torch.gather(svalid, 1, order)
     s_cls = torch.where(svalid, torch.gather(cls, 1, idx), torch.full((), -1, dtype=torch.int64, device=dev))
     storage = get_event_storage()
     storage.put_scalar("roi_head/num_fg_samples", n_fg.float().mean())
@@ -251,7 +284,10 @@ def box_head_losses(rh, features, samp, gt: GTBatch):
     return losses, pred
 
 
-def cube_head_losses(rh, features, samp, pred_boxes, gt: GTBatch, Ks, im_scales_ratio, im_dims):
+_SAFE = {}
+
+
+def cube_head_losses(rh, features, samp, pred_boxes, gt: GTBatch, meta):
     """_forward_cube in training (roi_heads.py:2237-2679) on the k_fg foreground slots of every image; invalid slots
     are masked out of the reductions (their per-RoI losses are set to +inf, which safely_reduce_losses ignores)."""
     B, kf = samp["valid"].shape[0], samp["k_fg"]
@@ -265,20 +301,13 @@ def cube_head_losses(rh, features, samp, pred_boxes, gt: GTBatch, Ks, im_scales_
     g3 = torch.gather(gt.boxes3D, 1, gi[:, :, None].expand(-1, -1, 9)).reshape(n, 9)
     gp = torch.gather(gt.poses, 1, gi[:, :, None, None].expand(-1, -1, 3, 3)).reshape(n, 3, 3)
     # sanitise unused slots so that no NaN / Inf enters the kernel: a unit cube 5 m in front of the camera
-    safe = torch.tensor([256., 256, 5, 1, 1, 1, 0, 0, 5], device=dev)
+    safe = _SAFE.get(str(dev))
+    if safe is None:
+        safe = _SAFE[str(dev)] = torch.tensor([256., 256, 5, 1, 1, 1, 0, 0, 5], device=dev)
     g3 = torch.where(valid[:, None], g3, safe)
     scaled = rh.scale_proposals([Boxes(b) for b in boxes])
     feats = [features[f] for f in rh.in_features]
     cube_features = rh.cube_pooler(feats, scaled).flatten(1)
-    # per-image camera constants: ONE small pinned, non-blocking host->device copy (no sync)
-    rows = []
-    for k, r, d in zip(Ks, im_scales_ratio, im_dims):
-        k = torch.as_tensor(k, dtype=torch.float32)
-        v2r_i = util.compute_virtual_scale_from_focal_spaces(float(k[1, 1]), float(d[0]) * float(r), rh.virtual_focal,
-                                                             float(d[0])) if rh.virtual_depth else 1.0
-        rows.append([float(k[0, 0]) / r, float(k[1, 1]) / r, float(k[0, 2]) / r, float(k[1, 2]) / r, float(v2r_i)])
-    meta = torch.tensor(rows, dtype=torch.float32)
-    meta = (meta.pin_memory() if dev.type == "cuda" else meta).to(dev, non_blocking=True)
     K4 = meta[:, None, :4].expand(B, kf, 4).reshape(n, 4)
     v2r = meta[:, None, 4].expand(B, kf).reshape(n)
     d2, z, dims, pose, unc = rh.cube_head(cube_features)
@@ -316,11 +345,10 @@ def cube_head_losses(rh, features, samp, pred_boxes, gt: GTBatch, Ks, im_scales_
     return losses
 
 
-def forward_train(model, images, features, head_outputs, gt_instances, Ks, im_scales_ratio):
-    """RCNN3D.forward in training mode (rcnn3d.py:50-89) on the static-shape path."""
+def forward_train(model, image_sizes, features, head_outputs, gt: GTBatch, meta):
+    """RCNN3D.forward in training mode (rcnn3d.py:50-89) on the static-shape path.  gt: GTBatch; meta: camera_meta()."""
     rpn, rh = model.proposal_generator, model.roi_heads
     dev = features[rpn.in_features[0]].device
-    gt = GTBatch(gt_instances, dev)
     feats = [features[f] for f in rpn.in_features]
     grid_sizes = [(f.shape[1], f.shape[2]) for f in feats]
     anchors_lv = rpn.anchor_generator(grid_sizes, dev)
@@ -330,11 +358,10 @@ def forward_train(model, images, features, head_outputs, gt_instances, Ks, im_sc
     with torch.no_grad():
         labels, matched, _ = rpn_label_and_sample(rpn, anchors, gt)
     losses = rpn_losses(rpn, anchors, logits, deltas, labels, matched)
-    pboxes, pscores = rpn_proposals_padded(rpn, anchors_lv, logits_lv, deltas_lv, images.image_sizes)
+    pboxes, pscores = rpn_proposals_padded(rpn, anchors_lv, logits_lv, deltas_lv, image_sizes)
     samp = roi_label_and_sample(rh, pboxes, pscores, gt)
     lb, pred_boxes = box_head_losses(rh, features, samp, gt)
     losses.update(lb)
     if rh.loss_w_3d > 0:
-        im_dims = [tuple(s) for s in images.image_sizes]
-        losses.update(cube_head_losses(rh, features, samp, pred_boxes, gt, Ks, im_scales_ratio, im_dims))
+        losses.update(cube_head_losses(rh, features, samp, pred_boxes, gt, meta))
     return losses

@@ -52,6 +52,16 @@ class RCNN3D(nn.Module):
         self._graphed = GraphedDense(self, batch)
         return self._graphed
 
+    def forward_static(self, images_u8, image_sizes, gt, meta):
+        """training forward from device-resident, fixed-shape inputs only (no host data, no syncs): the body of the
+        whole-step HIP graph (solver.GraphedTrainStep).  images_u8 (B,3,H,W) uint8; gt: dense_train.GTBatch; meta (B,5)."""
+        from ..dense_train import forward_train
+        x = ops.preprocess(images_u8, self.pixel_mean_list, self.pixel_std_list)
+        features = self.backbone(x)
+        pg = self.proposal_generator
+        head = pg.rpn_head([features[f] for f in pg.in_features])
+        return forward_train(self, image_sizes, features, head, gt, meta)
+
     def _stack_images(self, batched_inputs):
         images = [x["image"].to(self.device) for x in batched_inputs]
         il = ImageList.from_tensors(images, self.backbone.size_divisibility,
@@ -102,8 +112,11 @@ class RCNN3D(nn.Module):
         else:
             gt_instances = None
         if self.dense_train and gt_instances is not None:
-            from ..dense_train import forward_train
-            return forward_train(self, images, features, head_outputs, gt_instances, Ks, im_scales_ratio)
+            from ..dense_train import forward_train, GTBatch, camera_meta
+            dev = self.device
+            im_dims = [tuple(s) for s in images.image_sizes]
+            return forward_train(self, im_dims, features, head_outputs, GTBatch(gt_instances, dev),
+                                 camera_meta(self.roi_heads, Ks, im_scales_ratio, im_dims, dev))
         proposals, proposal_losses = self.proposal_generator(images, features, gt_instances, head_outputs=head_outputs)
         instances, detector_losses = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, gt_instances)
         losses = {}

@@ -45,6 +45,9 @@ class StandardRPNHead(nn.Module):
         return pred_objectness_logits, pred_anchor_deltas
 
 
+_CONST = {}
+
+
 def find_top_rpn_proposals(proposals, pred_objectness_logits, image_sizes, nms_thresh, pre_nms_topk, post_nms_topk,
                            min_box_size, training, padded=False):
     """detectron2 find_top_rpn_proposals [third-party, restated]: per level top-k, clip, drop empty boxes,
@@ -60,7 +63,13 @@ def find_top_rpn_proposals(proposals, pred_objectness_logits, image_sizes, nms_t
         topk_scores, topk_idx = logits.topk(k, dim=1)
         boxes_pad[:, l, :k] = torch.gather(props, 1, topk_idx[:, :, None].expand(-1, -1, 4))
         scores_pad[:, l, :k] = topk_scores
-    hw = torch.tensor([[s[1], s[0], s[1], s[0]] for s in image_sizes], dtype=boxes_pad.dtype, device=device)
+    ckey = (tuple(tuple(s) for s in image_sizes), tuple(ks), str(device))
+    cached = _CONST.get(ckey)
+    if cached is None:       # constant per (image sizes, level sizes): made once, never inside a captured region
+        cached = (torch.tensor([[s[1], s[0], s[1], s[0]] for s in image_sizes], dtype=torch.float32, device=device),
+                  torch.tensor(ks, dtype=torch.int32, device=device).repeat(num_images))
+        _CONST[ckey] = cached
+    hw, counts = cached
     finite = torch.isfinite(boxes_pad).all(dim=3) & torch.isfinite(scores_pad)
     boxes_pad = torch.where(finite[..., None], boxes_pad, torch.zeros((), device=device))
     boxes_pad = torch.minimum(boxes_pad.clamp(min=0), hw[:, None, None, :])              # Boxes.clip
@@ -68,7 +77,6 @@ def find_top_rpn_proposals(proposals, pred_objectness_logits, image_sizes, nms_t
         ((boxes_pad[..., 3] - boxes_pad[..., 1]) > min_box_size)
     # invalid boxes become zero-area: they neither suppress nor survive
     nms_boxes = torch.where(valid[..., None], boxes_pad, torch.zeros((), device=device))
-    counts = torch.tensor(ks, dtype=torch.int32, device=device).repeat(num_images)
     keep = ops.nms_grouped(nms_boxes.view(num_images * L, maxn, 4), counts, nms_thresh).view(num_images, L, maxn)
     keep = keep & valid
     flat_scores = torch.where(keep, scores_pad, torch.full((), float("-inf"), device=device)).view(num_images, -1)

@@ -138,7 +138,7 @@ class _ConvBN(torch.autograd.Function):
         if training:
             N_, H_, W_, _ = x.shape
             M = N_ * ((H_ + 2 * pad - k) // stride + 1) * ((W_ + 2 * pad - k) // stride + 1)
-            nparts = (M + 127) // 128
+            nparts = (M + 63) // 64            # statistics rows are per 64 pixels (independent of the tile choice)
             stats = torch.empty((nparts, 2, Cout), dtype=f32, device=dev)
             y_raw = conv_fwd_raw(x, wb, Cout, k, stride, pad, stats=stats)
             out = torch.empty_like(y_raw)

@@ -109,7 +109,7 @@ int cr_ransac_plane(cr_ctx* ctx, const float* pts, int64_t Q, const int32_t* tri
 
 /* y = relu?(conv(x,w) + bias? + residual?)   ks in {1,3,7}, stride in {1,2}.
  * x (N,H,W,Cin) bf16; w (Cout, ks*ks*Cin) bf16; y (N,Ho,Wo,Cout) bf16 or f32 (out_f32).
- * stats: optional f32 [ceil(M/128)][2][Cout] receiving, per 128-pixel tile, the per-channel sum / sum-of-squares
+ * stats: optional f32 [ceil(M/64)][2][Cout] receiving, per 64 output pixels, the per-channel sum / sum-of-squares
  * of the (pre-residual, pre-ReLU) conv output for BatchNorm (every entry is written; no atomics -> reproducible). */
 int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout,
                   int ks, int stride, int pad, const float* bias, const void* residual, int relu,

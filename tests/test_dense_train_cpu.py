@@ -89,13 +89,14 @@ def test_roi_sampling_rules(parts):
         s = dt.roi_label_and_sample(rh, pboxes, pscores, gt)
     K = rh.num_classes
     R = Pn + gt.boxes.shape[1]
-    assert s["boxes"].shape == (B, 128 + min(512, R), 4) and s["k_fg"] == 128
+    assert s["boxes"].shape == (B, min(512, 128 + min(512, R)), 4) and s["k_fg"] == 128
     for i in range(B):
         v, c = s["valid"][i], s["classes"][i]
         fg = v & (c < K) & (c >= 0)
         assert int(v.sum()) <= 512 and int(fg.sum()) <= 128
         assert not fg[128:].any() and (c[:128][v[:128]] < K).all()            # slot layout: fg first, then bg
         assert (c[128:][v[128:]] == K).all()
+        assert (v[:-1].int() >= v[1:].int()).all()                            # valid slots are compacted to the front
         # a sampled foreground box really overlaps its matched GT by >= 0.5 and carries its class
         bi = s["boxes"][i][fg]
         gi = s["gt_idx"][i][fg]
