@@ -11,12 +11,15 @@ IMS_PER_GPU = 4
 TRAIN_GFLOP_PER_IMAGE = 309.0  # BASELINE.md section 2 (fwd 51.5 GMAC x 2 x 3)
 
 
-def build(dev, seed=0):
+def build(dev, seed=0, lr=None, world=1):
+    # linear LR scaling rule of the reference (README.md:230-245): configs/Base.yaml's 0.02 is for 32 images/batch
+    if lr is None:
+        lr = 0.02 * IMS_PER_GPU * world / 32.0
     syn = importlib.import_module("3dod_amd.synthetic")
     modeling = importlib.import_module("3dod_amd.cubercnn.modeling")
     solver = importlib.import_module("3dod_amd.cubercnn.solver")
     cfg = syn.make_cfg(overrides=["MODEL.DEVICE", str(dev), "VIS_PERIOD", 0, "log", False,
-                                  "SOLVER.IMS_PER_BATCH", 32, "SOLVER.BASE_LR", 0.02])
+                                  "SOLVER.IMS_PER_BATCH", 32, "SOLVER.BASE_LR", lr])
     torch.manual_seed(seed)
     model = modeling.build_model(cfg)
     model.train()
@@ -26,7 +29,7 @@ def build(dev, seed=0):
 
 def bench_train(args, rank, world, dev):
     import bench as B
-    cfg, model, opt, syn, solver = build(dev)
+    cfg, model, opt, syn, solver = build(dev, world=world)
     if world > 1:
         import torch.distributed as dist
         dist.broadcast(opt.flat_p, 0)                 # DDP wrap-time parameter broadcast
@@ -61,7 +64,7 @@ def bench_train(args, rank, world, dev):
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "Cube R-CNN DLA34+FPN train step (fwd+loss+bwd+allreduce+SGD), 4 img/GPU 512x512, "
                                "Base_Omni3D.yaml semantics (BASELINE configs[3] per-GPU shard)",
-                   "global_batch": IMS_PER_GPU * world, "parallelism": f"dp{world}",
+                   "global_batch": IMS_PER_GPU * world, "parallelism": f"dp{world}", "base_lr": cfg.SOLVER.BASE_LR,
                    "final_loss": rep.get("total_loss"), "skipped_steps": rep.get("iterations_explode"),
                    "valid": bool(rep.get("iterations_explode") == 0 and rep.get("total_loss") == rep.get("total_loss"))},
         "roofline": dict(kern, whole_step={"achieved": achieved_tf, "unit": "TFLOP/s",
