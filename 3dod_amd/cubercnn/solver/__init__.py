@@ -1,1 +1,1 @@
-from .build import build_optimizer, freeze_bn, FlatSGD, TrainStep
+from .build import build_optimizer, freeze_bn, FlatSGD, TrainStep, GraphedTrainStep

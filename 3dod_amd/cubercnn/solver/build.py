@@ -207,3 +207,142 @@ class TrainStep:
         d["iterations_explode"] = float(self.iterations_explode)
         d["iterations_success"] = float(self.iterations_success)
         return d
+
+
+class GraphedTrainStep:
+    """The whole training step as two HIP graphs around the (eager) RCCL all-reduces:
+
+        graph A   preprocess, trunk, FPN, RPN, static-shape labelling/sampling, RoI heads, losses, backward
+                  (gradients land in the flat gradient through the kernels' sinks / one multi-tensor add)
+        eager     all-reduce of the loss vector and of the gradient buckets (world_size > 1 only)
+        graph B   divergence guard, non-finite scan, fused SGD-momentum update, counters
+
+    Possible because the dense training path has fixed shapes and no host<->device sync.  The reference clips the
+    loss to [0,1] before backward when it diverges (train_net.py:212) but then discards that step's gradients
+    (:259-261), so running backward on the unclipped local loss and skipping the update gives the same parameters.
+    Per step the host only refreshes the static input buffers (image batch, padded ground truth, camera constants).
+    """
+    G_PAD = 32
+    TOLERANCE, GAMMA = TrainStep.TOLERANCE, TrainStep.GAMMA
+
+    def __init__(self, cfg, model, optimizer, sample_data, world_size=1, bucket_mb=32, warmup=2):
+        from ..modeling.dense_train import GTBatch, camera_meta
+        from ..modeling.graphed import _fresh_leaves
+        assert model.training and model.dense_train
+        self.model, self.opt, self.world = model, optimizer, world_size
+        self.stabilize = cfg.MODEL.STABILIZE > 0
+        self._GTBatch, self._camera_meta = GTBatch, camera_meta
+        dev = optimizer.flat_p.device
+        self.dev = dev
+        images, batch = model._stack_images(sample_data)
+        self.image_sizes = [tuple(s) for s in images.image_sizes]
+        assert all(s == tuple(batch.shape[-2:]) for s in self.image_sizes), "whole-step graph: one image size per batch"
+        self.static_img = batch.clone()
+        self.gt = GTBatch([d["instances"].to(dev) for d in sample_data], dev, G=self.G_PAD)
+        self.meta = self._meta_of(sample_data).clone()
+        self.recent_loss = torch.full((), float("nan"), device=dev)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.iterations_success = torch.zeros((), device=dev)
+        self.iterations_explode = torch.zeros((), device=dev)
+        self.total = torch.zeros((), device=dev)
+        self.vals = None
+        self.keys = None
+        n = optimizer.flat_g.numel()
+        be = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets = [(i, min(i + be, n)) for i in range(0, n, be)][::-1]
+        self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        model._graphed = None
+
+        def fwd_bwd():
+            loss_dict = model.forward_static(self.static_img, self.image_sizes, self.gt, self.meta)
+            keys = sorted(loss_dict.keys())
+            vals = torch.stack([loss_dict[k].float() for k in keys])
+            if self.vals is None:
+                self.keys, self.vals = keys, torch.zeros_like(vals.detach())
+                self.red = torch.zeros_like(self.vals)
+            self.vals.copy_(vals.detach())
+            optimizer.flat_g.zero_()
+            leaves = [p for p in model.parameters() if p.requires_grad]
+            grads = torch.autograd.grad(vals.sum(), leaves, allow_unused=True)
+            views = [p._cr_grad for p, g in zip(leaves, grads) if g is not None]
+            if views:
+                torch._foreach_add_(views, [g for g in grads if g is not None])
+
+        def update():
+            red = self.vals / world_size
+            lr_ = red.sum()
+            first = torch.isnan(self.recent_loss)
+            recent = torch.where(first, lr_ * 2.0, self.recent_loss)
+            diverging = (lr_ > recent * self.TOLERANCE) | ~torch.isfinite(lr_)
+            if not self.stabilize:
+                diverging = torch.zeros_like(diverging)
+            self.recent_loss.copy_(torch.where(diverging, recent, recent * (1 - self.GAMMA) + lr_ * self.GAMMA))
+            self.flag.copy_(diverging.to(torch.int32).view(1))
+            if self.stabilize:
+                ops.nonfinite_flag(optimizer.flat_g, self.flag)
+            optimizer.step(skip_flag=self.flag, grad_scale=1.0 / world_size)
+            bad = (self.flag[0] != 0).float()
+            self.iterations_explode.add_(bad)
+            self.iterations_success.add_(1 - bad)
+            self.total.copy_(lr_)
+            self.red.copy_(red)
+
+        # warm-up (eager, side stream), then restore every piece of state the warm-up touched
+        snap = [t.clone() for t in (optimizer.flat_p, optimizer.flat_m)]
+        bn = [(m, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone())
+              for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s), _fresh_leaves([model]):
+            for _ in range(warmup):
+                fwd_bwd()
+                update()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+
+        def restore():
+            optimizer.flat_p.copy_(snap[0]); optimizer.flat_m.copy_(snap[1])
+            for m, a, b, c in bn:
+                m.running_mean.copy_(a); m.running_var.copy_(b); m.num_batches_tracked.copy_(c)
+            self.recent_loss.fill_(float("nan")); self.flag.zero_()
+            self.iterations_success.zero_(); self.iterations_explode.zero_()
+        restore()
+        ops.bump_weight_epoch()
+        with _fresh_leaves([model]):
+            self.graph_a = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a):
+                fwd_bwd()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            update()
+        torch.cuda.synchronize(dev)
+        restore()
+        ops.bump_weight_epoch()
+        self.last = {"keys": self.keys, "values": self.red, "total": self.total, "skipped": self.flag}
+
+    def _meta_of(self, data):
+        Ks = [torch.as_tensor(d["K"], dtype=torch.float32) for d in data]
+        ratios = [d["height"] / s[0] for d, s in zip(data, self.image_sizes)]
+        return self._camera_meta(self.model.roi_heads, Ks, ratios, self.image_sizes, self.dev)
+
+    def load(self, data):
+        """refresh the static inputs (device-side copies only; the one host->device transfer is pinned + async)."""
+        _, batch = self.model._stack_images(data)
+        self.static_img.copy_(batch)
+        self.gt.copy_from(self._GTBatch([d["instances"].to(self.dev) for d in data], self.dev, G=self.G_PAD))
+        self.meta.copy_(self._meta_of(data), non_blocking=True)
+
+    def __call__(self, data):
+        self.load(data)
+        self.graph_a.replay()
+        if self.world > 1:
+            dist.all_reduce(self.vals)
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                for a, b in self.buckets:
+                    dist.all_reduce(self.opt.flat_g[a:b])
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.graph_b.replay()
+        return self.last
+
+    report = TrainStep.report

@@ -33,16 +33,27 @@ def bench_train(args, rank, world, dev):
     if world > 1:
         import torch.distributed as dist
         dist.broadcast(opt.flat_p, 0)                 # DDP wrap-time parameter broadcast
-    step = solver.TrainStep(cfg, model, opt, world_size=world)
     d2 = importlib.import_module("3dod_amd.d2lite")
     batches = [syn.make_batch(IMS_PER_GPU, 1234 + rank * 1000 + i) for i in range(4)]
     for b in batches:                                   # inputs resident in HBM before the timed region
         for d in b:
             d["image"] = d["image"].to(dev)
             d["instances"] = d["instances"].to(dev)
-    if os.environ.get("CR_NO_GRAPHS", "0") != "1":
-        model.enable_graphs(batches[0])
-        opt.zero_grad()
+    mode = os.environ.get("CR_GRAPHS", "step")          # step | dense | none
+    step = None
+    if mode == "step":
+        try:
+            with d2.EventStorage(0):
+                step = solver.GraphedTrainStep(cfg, model, opt, batches[0], world_size=world)
+        except Exception as e:                          # never lose the number to a capture problem
+            import sys
+            print(f"[bench] whole-step graph capture failed ({type(e).__name__}: {e}); falling back", file=sys.stderr, flush=True)
+            mode = "dense"
+    if step is None:
+        step = solver.TrainStep(cfg, model, opt, world_size=world)
+        if mode == "dense":
+            model.enable_graphs(batches[0])
+            opt.zero_grad()
     with d2.EventStorage(0):
         for i in range(args.warmup):
             step(batches[i % len(batches)])
@@ -65,6 +76,7 @@ def bench_train(args, rank, world, dev):
         "config": {"workload": "Cube R-CNN DLA34+FPN train step (fwd+loss+bwd+allreduce+SGD), 4 img/GPU 512x512, "
                                "Base_Omni3D.yaml semantics (BASELINE configs[3] per-GPU shard)",
                    "global_batch": IMS_PER_GPU * world, "parallelism": f"dp{world}", "base_lr": cfg.SOLVER.BASE_LR,
+                   "launch_mode": {"step": "whole-step HIP graphs", "dense": "dense-region HIP graphs", "none": "eager"}[mode],
                    "final_loss": rep.get("total_loss"), "skipped_steps": rep.get("iterations_explode"),
                    "valid": bool(rep.get("iterations_explode") == 0 and rep.get("total_loss") == rep.get("total_loss"))},
         "roofline": dict(kern, whole_step={"achieved": achieved_tf, "unit": "TFLOP/s",
