@@ -35,7 +35,8 @@ __device__ __forceinline__ int roi_level(const float* b, const Pyramid& py) {
 struct Samp { int yl, yh, xl, xh; float w1, w2, w3, w4; bool ok; };
 __device__ __forceinline__ Samp bilinear(float y, float x, int H, int W) {
     Samp s;
-    s.ok = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+    s.ok = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) && (y == y) && (x == x);   // NaN boxes sample nothing
+    if (!s.ok) { s.yl = s.yh = s.xl = s.xh = 0; s.w1 = s.w2 = s.w3 = s.w4 = 0.f; return s; }
     if (y <= 0.f) y = 0.f;
     if (x <= 0.f) x = 0.f;
     s.yl = (int)y; s.xl = (int)x;

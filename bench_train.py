@@ -39,7 +39,7 @@ def bench_train(args, rank, world, dev):
         for d in b:
             d["image"] = d["image"].to(dev)
             d["instances"] = d["instances"].to(dev)
-    mode = os.environ.get("CR_GRAPHS", "step")          # step | dense | none
+    mode = os.environ.get("CR_GRAPHS", "dense")         # dense (default) | step (whole-step graphs, opt-in) | none
     step = None
     if mode == "step":
         try:
