@@ -231,6 +231,8 @@ class GraphedTrainStep:
         assert model.training and model.dense_train
         self.model, self.opt, self.world = model, optimizer, world_size
         self.stabilize = cfg.MODEL.STABILIZE > 0
+        import os
+        self.sync_each_step = os.environ.get("CR_STEP_SYNC", "1") == "1"
         self._GTBatch, self._camera_meta = GTBatch, camera_meta
         dev = optimizer.flat_p.device
         self.dev = dev
@@ -343,6 +345,8 @@ class GraphedTrainStep:
                     dist.all_reduce(self.opt.flat_g[a:b])
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.graph_b.replay()
+        if self.sync_each_step:
+            torch.cuda.current_stream(self.dev).synchronize()
         return self.last
 
     report = TrainStep.report

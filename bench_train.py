@@ -54,19 +54,30 @@ def bench_train(args, rank, world, dev):
         if mode == "dense":
             model.enable_graphs(batches[0])
             opt.zero_grad()
+    trace = os.environ.get("CR_TRACE") == "1"
+    def note(msg):
+        if trace:
+            import sys
+            print(f"[bench-trace] {msg}", file=sys.stderr, flush=True)
+    note(f"built mode={mode}")
     with d2.EventStorage(0):
         for i in range(args.warmup):
             step(batches[i % len(batches)])
+            note(f"warmup {i} enqueued")
         B.barrier(world)
+        note("warmup done")
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(batches[i % len(batches)])
+            note(f"step {i} enqueued")
         B.barrier(world)
+        note("timed loop done")
         dt = B.max_over_ranks(time.perf_counter() - t0, world, dev)
         rep = step.report()
     ims = IMS_PER_GPU * world * args.steps / dt
     achieved_tf = TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU / (dt / args.steps) / 1e3
     kern = dominant_kernel_roofline(dev)
+    note("roofline done")
     import sys
     print(f"[bench] rank {rank}: {ims:.1f} images/s, {dt / args.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
     res = {
