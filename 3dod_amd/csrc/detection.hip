@@ -9,6 +9,7 @@
 //   nms / batched_nms                              cubercnn/modeling/roi_heads/fast_rcnn.py:105; detectron2 RPN
 #include "cr_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 typedef unsigned short u16;
 __device__ __forceinline__ float bf2f(u16 b) { return __uint_as_float(((unsigned)b) << 16); }
@@ -159,6 +160,110 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(Pyramid py, const float* 
     }
 }
 
+// Separable backward.  A sample's bilinear weight factors into a row part and a column part, so the gradient of one
+// RoI w.r.t. its footprint of feature pixels is  Ay . G . Ax^T  per channel, with
+//   Ay[y][ph] = sum over the gh samples of bin-row ph of their weight on feature row y, / gh      (Ax likewise),
+//   G[ph][pw] = d(out)[r][ph][pw][c].
+// One block per RoI builds Ay/Ax in LDS once; a thread owns one channel, keeps G in registers and issues ONE atomic per
+// footprint pixel instead of 4 per sample (3-4x fewer atomics for the 2x2..4x4 sampling grids of FPN RoIs), still
+// 64 consecutive floats per wave-instruction.
+struct Lin1 { int lo, hi; float wlo, whi; bool ok; };
+__device__ __forceinline__ Lin1 lin1(float y, int H) {
+    Lin1 s;
+    s.ok = (y >= -1.0f) && (y <= (float)H);             // false for NaN
+    if (y <= 0.f) y = 0.f;
+    s.lo = s.ok ? (int)y : 0;
+    if (s.lo >= H - 1) { s.hi = s.lo = H - 1; y = (float)s.lo; } else s.hi = s.lo + 1;
+    const float l = y - (float)s.lo;
+    s.wlo = 1.f - l; s.whi = l;
+    return s;
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_roi_align_bwd_sep(Pyramid py, const float* __restrict__ rois, int R,
+                                                           const u16* __restrict__ dout, int maxH) {
+    extern __shared__ float sm[];                        // Ay [maxH][P] | Ax [maxW][P]
+    __shared__ int s_lo[2], s_hi[2];
+    float* Ay = sm;
+    float* Ax = sm + (size_t)maxH * P;
+    const int r = blockIdx.x, t = threadIdx.x, C = py.C;
+    const float* rb = rois + (size_t)r * 5;
+    const int n = (int)rb[0];
+    const int lv = roi_level(rb + 1, py);
+    const int H = py.H[lv], W = py.W[lv];
+    const float sc = py.scale[lv];
+    const float x1 = rb[1] * sc - 0.5f, y1 = rb[2] * sc - 0.5f;
+    const float rw = (rb[3] - rb[1]) * sc, rh = (rb[4] - rb[2]) * sc;
+    const float bw = rw / (float)P, bh = rh / (float)P;
+    const int gh = min((int)ceilf(rh / (float)P), 4096), gw = min((int)ceilf(rw / (float)P), 4096);
+    if (t < 2) { s_lo[t] = 0x7fffffff; s_hi[t] = -1; }
+    __syncthreads();
+    // pass 1: footprint extent per axis (threads 0..P-1 rows, P..2P-1 columns)
+    const bool builder = t < 2 * P;
+    const int ax = t / P, p = t % P;                     // ax 0 = y, 1 = x
+    const int gN = ax ? gw : gh, L = ax ? W : H;
+    const float o1 = ax ? x1 : y1, bsz = ax ? bw : bh;
+    if (builder) {
+        int lo = 0x7fffffff, hi = -1;
+        for (int i = 0; i < gN; ++i) {
+            const Lin1 s = lin1(o1 + p * bsz + (i + 0.5f) * bsz / (float)gN, L);
+            if (s.ok) { lo = min(lo, s.lo); hi = max(hi, s.hi); }
+        }
+        if (hi >= 0) { atomicMin(&s_lo[ax], lo); atomicMax(&s_hi[ax], hi); }
+    }
+    __syncthreads();
+    const int y0 = s_lo[0], Py = s_hi[0] - y0 + 1, x0 = s_lo[1], Px = s_hi[1] - x0 + 1;
+    if (s_hi[0] < 0 || s_hi[1] < 0 || n < 0) return;     // no valid sample at all (block-uniform)
+    for (int i = t; i < Py * P; i += 256) Ay[i] = 0.f;
+    for (int i = t; i < Px * P; i += 256) Ax[i] = 0.f;
+    __syncthreads();
+    if (builder) {                                       // pass 2: column p of Ay / Ax is owned by one thread
+        float* A = ax ? Ax : Ay;
+        const int base = ax ? x0 : y0;
+        const float inv = 1.f / (float)gN;
+        for (int i = 0; i < gN; ++i) {
+            const Lin1 s = lin1(o1 + p * bsz + (i + 0.5f) * bsz / (float)gN, L);
+            if (!s.ok) continue;
+            A[(s.lo - base) * P + p] += s.wlo * inv;
+            A[(s.hi - base) * P + p] += s.whi * inv;
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        float G[P][P];
+        bool any = false;
+#pragma unroll
+        for (int ph = 0; ph < P; ++ph)
+#pragma unroll
+            for (int pw = 0; pw < P; ++pw) {
+                G[ph][pw] = bf2f(dout[(((size_t)r * P + ph) * P + pw) * C + c]);
+                any |= G[ph][pw] != 0.f;
+            }
+        if (!any) continue;                              // masked (padding) RoIs carry zero gradient
+        float* gq = py.grad[lv] + (((size_t)n * H + y0) * W + x0) * C + c;
+        for (int yy = 0; yy < Py; ++yy) {
+            float tr[P];
+#pragma unroll
+            for (int pw = 0; pw < P; ++pw) tr[pw] = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < P; ++ph) {
+                const float a = Ay[yy * P + ph];         // LDS broadcast: uniform
+                if (a != 0.f) {
+#pragma unroll
+                    for (int pw = 0; pw < P; ++pw) tr[pw] += a * G[ph][pw];
+                }
+            }
+            float* grow = gq + (size_t)yy * W * C;
+            for (int xx = 0; xx < Px; ++xx) {
+                float v = 0.f;
+#pragma unroll
+                for (int pw = 0; pw < P; ++pw) v += Ax[xx * P + pw] * tr[pw];
+                if (v != 0.f) atomicAdd(grow + (size_t)xx * C, v);
+            }
+        }
+    }
+}
+
 static int fill_pyramid(Pyramid& py, const void* const* feats, float* const* grads, const int* Hs, const int* Ws,
                         const float* scales, int nlev, int C) {
     CR_CHECK_ARG(nlev >= 1 && nlev <= MAX_LEVELS, "roi_align: 1..%d levels", MAX_LEVELS);
@@ -199,6 +304,17 @@ extern "C" int cr_roi_align_bwd(cr_ctx* ctx, float* const* grads, const int* Hs,
     Pyramid py;
     int rc = fill_pyramid(py, nullptr, grads, Hs, Ws, scales, nlev, C);
     if (rc) return rc;
+    if (PH == 7 && PW == 7 && !getenv("CR_ROI_BWD_PLAIN")) {
+        int maxH = 0, maxW = 0;
+        for (int l = 0; l < nlev; ++l) { maxH = Hs[l] > maxH ? Hs[l] : maxH; maxW = Ws[l] > maxW ? Ws[l] : maxW; }
+        const size_t lds = (size_t)(maxH + maxW) * 7 * sizeof(float);
+        if (lds <= 60 * 1024) {
+            hipLaunchKernelGGL((k_roi_align_bwd_sep<7>), dim3((unsigned)R), dim3(256), lds, ctx->stream, py, rois, (int)R,
+                               (const u16*)dout, maxH);
+            CR_LAUNCH_CHECK();
+            return CR_OK;
+        }
+    }
     const int64_t total = R * PH * PW * (int64_t)C;
     CR_CHECK_ARG(cr_cdiv(total, 256) < 0x7fffffff, "cr_roi_align_bwd: too many RoIs");
     hipLaunchKernelGGL(k_roi_align_bwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py, rois, (int)R,
@@ -265,6 +381,68 @@ __global__ __launch_bounds__(64) void k_nms_scan(const int* __restrict__ counts,
     for (int i = n + t; i < maxn; i += 64) gk[i] = 0;
 }
 
+// Fast walk for maxn <= 2048 (words <= 32): 256 threads = 8 row-slots x 32 words.  Per 64-box chunk the rows are
+// prefetched into registers while wave 0 resolves the diagonal block with register-only readlane steps, so no
+// global-memory latency sits on the serial chain (the plain kernel above pays one load per box).
+__global__ __launch_bounds__(256) void k_nms_scan32(const int* __restrict__ counts, int maxn,
+                                                    const unsigned long long* __restrict__ mask,
+                                                    unsigned char* __restrict__ keep) {
+    __shared__ unsigned long long removed[32];
+    __shared__ unsigned long long diag[64];
+    __shared__ unsigned long long s_alive;
+    const int g = blockIdx.x, n = counts[g], t = threadIdx.x;
+    const int words = (maxn + 63) / 64, nch = (n + 63) / 64;
+    const int w = t & 31, bs = t >> 5;
+    if (t < 32) removed[t] = 0;
+    const unsigned long long* gm = mask + (size_t)g * maxn * words;
+    unsigned char* gk = keep + (size_t)g * maxn;
+    unsigned long long cur[8], nxt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int row = bs + 8 * k;
+        cur[k] = (w < words && row < n) ? gm[(size_t)row * words + w] : 0ULL;
+    }
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        if (w == c) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) diag[bs + 8 * k] = cur[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                       // prefetch the next chunk's rows (words right of it only)
+            const int row = (c + 1) * 64 + bs + 8 * k;
+            nxt[k] = (c + 1 < nch && w > c && w < words && row < n) ? gm[(size_t)row * words + w] : 0ULL;
+        }
+        __syncthreads();
+        if (t < 64) {
+            const unsigned long long d = diag[t];
+            const int dlo = (int)(unsigned)d, dhi = (int)(unsigned)(d >> 32);
+            unsigned long long rem = removed[c];
+#pragma unroll
+            for (int b = 0; b < 64; ++b) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane(dlo, b), hi = (unsigned)__builtin_amdgcn_readlane(dhi, b);
+                const unsigned long long row = ((unsigned long long)hi << 32) | lo;
+                if (!((rem >> b) & 1ULL)) rem |= row;
+            }
+            const int left = n - c * 64;
+            const unsigned long long valid = left >= 64 ? ~0ULL : ((1ULL << left) - 1ULL);
+            const unsigned long long alive = ~rem & valid;
+            if (c * 64 + t < maxn) gk[c * 64 + t] = (unsigned char)((alive >> t) & 1ULL);
+            if (t == 0) s_alive = alive;
+        }
+        __syncthreads();
+        const unsigned long long alive = s_alive;
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if ((alive >> (bs + 8 * k)) & 1ULL) acc |= cur[k];
+        if (w > c && acc) atomicOr(&removed[w], acc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+        __syncthreads();
+    }
+    for (int i = nch * 64 + t; i < maxn; i += 256) gk[i] = 0;
+}
+
 __global__ void k_fill_zero_u64(unsigned long long* __restrict__ p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0ULL;
@@ -287,8 +465,12 @@ extern "C" int cr_nms_grouped(cr_ctx* ctx, const float* boxes, const int* counts
     hipLaunchKernelGGL(k_nms_mask, dim3(words, words, G), dim3(64), 0, ctx->stream, boxes, counts, maxn, thresh,
                        (unsigned long long*)mask_ws);
     CR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_scan, dim3(G), dim3(64), words * 8, ctx->stream, counts, maxn,
-                       (const unsigned long long*)mask_ws, keep);
+    if (words <= 32)
+        hipLaunchKernelGGL(k_nms_scan32, dim3(G), dim3(256), 0, ctx->stream, counts, maxn,
+                           (const unsigned long long*)mask_ws, keep);
+    else
+        hipLaunchKernelGGL(k_nms_scan, dim3(G), dim3(64), words * 8, ctx->stream, counts, maxn,
+                           (const unsigned long long*)mask_ws, keep);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -194,10 +194,13 @@ def test_roi_align_fwd_bwd():
             assert relerr(nchw(a.grad), b.grad) < 2e-2
 
 
-def test_nms_grouped():
+@pytest.mark.parametrize("maxn,counts", [(300, [300, 257, 64, 1, 0]), (2000, [2000, 1999, 1025, 640, 63]),
+                                         (2048, [2048, 2047, 1, 0, 130]), (2300, [2300, 2049, 64, 1, 0])])
+def test_nms_grouped(maxn, counts):
+    """maxn <= 2048 takes the register-pipelined walk (k_nms_scan32), larger groups the generic one."""
     g = torch.Generator().manual_seed(6)
-    G, maxn = 5, 300
-    counts = torch.tensor([300, 257, 64, 1, 0], dtype=torch.int32)
+    G = len(counts)
+    counts = torch.tensor(counts, dtype=torch.int32)
     ctr = torch.rand(G, maxn, 2, generator=g) * 200; wh = torch.rand(G, maxn, 2, generator=g) * 60 + 5
     boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 2)
     boxes[0, 10] = boxes[0, 3]          # exact duplicate -> suppressed
