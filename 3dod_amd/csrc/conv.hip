@@ -18,6 +18,7 @@
 // We feed WEIGHTS as A (rows = output channels) and PIXELS as B (cols = pixels), so a lane
 // ends up with 4 consecutive output channels of one pixel = one 8-byte NHWC store.
 #include "cr_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -43,16 +44,28 @@ struct ConvP {
     float* stats;        // optional [ceil(M/128)][2][Cout]: per-M-tile sum and sum of squares of the conv output
     int N, Hin, Win, Cin, Hout, Wout, Cout;
     int stride, pad, Kdim, M, cshift, relu;
+    unsigned x_bytes, w_bytes;   // extents for the buffer-load descriptors (out-of-range voffset reads 0)
 };
 
 // LDS image of a [rows][32] bf16 tile (64-B rows, four 16-B chunks): chunk' = chunk ^ ((-(row>>2)) & 3)
 // makes the 16x16x32 fragment read (lane -> row l&15, chunk l>>4) conflict-free per ds_read_b128 lane group.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 32 + ((chunk ^ ((-(row >> 2)) & 3)) << 3);
 }
 
-template <int BM, int BN, int KS, int MODE, typename OutT>
-__global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
+// KU = 32-wide k sub-steps per pipeline stage: small tiles on small grids are bound by the latency of one
+// global->LDS round trip per stage, so they take 4 sub-steps (BK = 128) per round trip.
+// KG = wave groups per block (intra-block split-K): layers whose grid is <= ~1 block per CU run 4 groups of 4 waves on
+// interleaved k sub-steps of the same output tile (4 waves per SIMD to overlap the per-sub-step instruction/latency
+// chain that a single wave per SIMD exposes) and reduce the accumulators through LDS before the shared epilogue.
+template <int BM, int BN, int KS, int MODE, typename OutT, int KU, int KG>
+__global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
     // 4 waves tile the BM x BN block: 2x2 for the square-ish tiles, 4x1 (pixels) for narrow channel tiles
     constexpr int WAVES_M = (BN == 128 || BM == 64) ? 2 : 4;
     constexpr int WAVES_N = 4 / WAVES_M;
@@ -61,11 +74,18 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
     constexpr int NA = BM * 4 / CONV_T;              // pixel-row chunks per thread (2 or 1)
     constexpr int NB = (BN * 4 + CONV_T - 1) / CONV_T;   // weight chunks per thread
     static_assert(TP >= 1 && TC >= 1 && NA >= 1, "tile too small for 4 waves");
-    __shared__ __attribute__((aligned(16))) u16 sX[BM * 32];
-    __shared__ __attribute__((aligned(16))) u16 sW[BN * 32];
-    __shared__ float sStat[4 * 2 * BN];      // [wave][2][BN]: no atomics -> bitwise reproducible statistics
+    constexpr int XE = KU * BM * 32, WE = KU * BN * 32;          // LDS elements per group
+    __shared__ __attribute__((aligned(16))) u16 smem[KG * (XE + WE)];
+    u16* sXall = smem;
+    u16* sWall = smem + KG * XE;
+    static_assert(4 * 2 * BN * sizeof(float) <= XE * sizeof(u16), "sStat must fit in sX");
+    static_assert(KG == 1 || (KG - 1) * BM * BN * sizeof(float) <= KG * (XE + WE) * sizeof(u16), "reduction buffer");
+    float* sStat = reinterpret_cast<float*>(smem);    // [wave][2][BN], epilogue only (the k loop ends with a barrier)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);       // k group of this wave
+    const int tid = threadIdx.x & (CONV_T - 1), lane = tid & 63, wave = tid >> 6;
+    u16* sX = sXall + grp * XE;
+    u16* sW = sWall + grp * WE;
     const int n_tiles = p.Cout / BN;
     const int nt = blockIdx.x % n_tiles, mt = blockIdx.x / n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -87,50 +107,88 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
         if (MODE == 0) { hb[i] = ho * p.stride - p.pad; wb[i] = wo * p.stride - p.pad; }
         else           { hb[i] = ho + p.pad;            wb[i] = wo + p.pad; }
     }
-    uint4 ra[NA], rb[NB];
+    uint4 ra[KU][NA], rb[KU][NB];
 
-    auto load_tiles = [&](int kt) {
-        const int k0 = kt * 32 + cA * 8;
-        int r = 0, s = 0, c0 = k0;
-        if (KS > 1) {
-            const int tap = k0 >> p.cshift;
-            c0 = k0 & (p.Cin - 1);
-            r = tap / KS;
-            s = tap - r * KS;
-        }
+    // All global reads are raw buffer loads: masked-out elements (padding taps, k tail, rows past M) get a voffset
+    // past the descriptor's extent and read as zero, so the gather is branch-free.  (With flat loads under exec-mask
+    // branches the compiler put `s_waitcnt vmcnt(0)` in front of every load of the loop, serialising them.)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    // Fast gather path (KS > 1, Cin % 32 == 0): a 32-wide k sub-step never straddles a filter tap, so the tap
+    // decomposition, the bounds test and the pixel offset are recomputed only when the tap changes.
+    const bool fast = (KS > 1) && ((p.Cin & 31) == 0);
+    int cur_tap = -1;
+    unsigned tb[NA];                                // byte offset of (pixel, current tap, chunk cA) or OOB
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            int hi, wi;
-            bool ok = rv[i] && (k0 < p.Kdim);
-            if (MODE == 0) { hi = hb[i] + r; wi = wb[i] + s; }
-            else {
-                const int th = hb[i] - r, tw = wb[i] - s;
-                if (p.stride == 2) { ok = ok && (((th | tw) & 1) == 0); hi = th >> 1; wi = tw >> 1; }
-                else { hi = th; wi = tw; }
+    for (int i = 0; i < NA; ++i) tb[i] = OOB;
+    auto pix_off = [&](int i, int r, int s2, bool kin) -> unsigned {
+        int hi, wi;
+        bool ok = rv[i] && kin;
+        if (MODE == 0) { hi = hb[i] + r; wi = wb[i] + s2; }
+        else {
+            const int th = hb[i] - r, tw = wb[i] - s2;
+            if (p.stride == 2) { ok = ok && (((th | tw) & 1) == 0); hi = th >> 1; wi = tw >> 1; }
+            else { hi = th; wi = tw; }
+        }
+        ok = ok && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
+        const unsigned off = (unsigned)(((nimg[i] * p.Hin + hi) * p.Win + wi) * p.Cin) * 2u;
+        return ok ? off : OOB;
+    };
+
+    auto load_tiles = [&](int stage) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int kt = (stage * KG + grp) * KU + u;     // groups take interleaved stages
+        if (fast) {
+            const int tap = (kt * 32) >> p.cshift, cc = (kt * 32) & (p.Cin - 1);
+            if (tap != cur_tap) {
+                const int r = tap / KS, s2 = tap - r * KS;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const unsigned o = pix_off(i, r, s2, tap < KS * KS);
+                    tb[i] = o == OOB ? OOB : o + cA * 16;
+                }
+                cur_tap = tap;
             }
-            ok = ok && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(nimg[i] * p.Hin + hi) * p.Win + wi) * p.Cin + c0);
-            ra[i] = v;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[u][i] = buf_load16(rx, tb[i] + (unsigned)cc * 2u);
+        } else {
+            const int k0 = kt * 32 + cA * 8;
+            int r = 0, s2 = 0, c0 = k0;
+            if (KS > 1) {
+                const int tap = k0 >> p.cshift;
+                c0 = k0 & (p.Cin - 1);
+                r = tap / KS;
+                s2 = tap - r * KS;
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const unsigned o = pix_off(i, r, s2, k0 < p.Kdim);
+                ra[u][i] = buf_load16(rx, o == OOB ? OOB : o + (unsigned)c0 * 2u);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + CONV_T * i;
             const int row = idx >> 2, kb = kt * 32 + (idx & 3) * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < BN * 4 && kb < p.Kdim) v = *reinterpret_cast<const uint4*>(p.w + (size_t)(n0 + row) * p.Kdim + kb);
-            rb[i] = v;
+            const bool ok = idx < BN * 4 && kb < p.Kdim;
+            rb[u][i] = buf_load16(rw, ok ? (unsigned)((n0 + row) * p.Kdim + kb) * 2u : OOB);
         }
+      }
     };
     auto store_tiles = [&]() {
 #pragma unroll
+      for (int u = 0; u < KU; ++u) {
+#pragma unroll
         for (int i = 0; i < NA; ++i)
-            *reinterpret_cast<uint4*>(&sX[lds_off((tid >> 2) + 64 * i, cA)]) = ra[i];
+            *reinterpret_cast<uint4*>(&sX[u * BM * 32 + lds_off((tid >> 2) + 64 * i, cA)]) = ra[u][i];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + CONV_T * i;
-            if (idx < BN * 4) *reinterpret_cast<uint4*>(&sW[lds_off(idx >> 2, idx & 3)]) = rb[i];
+            if (idx < BN * 4) *reinterpret_cast<uint4*>(&sW[u * BN * 32 + lds_off(idx >> 2, idx & 3)]) = rb[u][i];
         }
+      }
     };
 
     const int poff = (wave / WAVES_N) * (BM / WAVES_M);            // pixel offset of this wave in the tile
@@ -143,35 +201,68 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
         for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.Kdim + 31) >> 5;
+    const int nstage = (nk + KU * KG - 1) / (KU * KG);
     load_tiles(0);
     store_tiles();
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tiles(kt + 1);        // global loads in flight under the MFMAs
-        bf16x8 xf[TP], wf[TC];
+    for (int st = 0; st < nstage; ++st) {
+        load_tiles(st + 1);        // next stage in flight under the MFMAs (past the end: every offset is OOB -> zeros, no traffic)
         const int fr = lane & 15, fc = lane >> 4;
 #pragma unroll
-        for (int j = 0; j < TP; ++j)
-            xf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sX[lds_off(poff + j * 16 + fr, fc)]));
-#pragma unroll
-        for (int i = 0; i < TC; ++i)
-            wf[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sW[lds_off(coff + i * 16 + fr, fc)]));
-#pragma unroll
-        for (int i = 0; i < TC; ++i)
+        for (int u = 0; u < KU; ++u) {
+            if (KG == 1 && KU > 1 && st * KU + u >= nk) break;  // block-uniform k tail (KG > 1: the tail multiplies zeros)
+            bf16x8 xf[TP], wf[TC];
 #pragma unroll
             for (int j = 0; j < TP; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        __syncthreads();
-        if (kt + 1 < nk) {
-            store_tiles();
-            __syncthreads();
+                xf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sX[u * BM * 32 + lds_off(poff + j * 16 + fr, fc)]));
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+                wf[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sW[u * BN * 32 + lds_off(coff + i * 16 + fr, fc)]));
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
     }
 
+    if (KG > 1) {
+        // groups 1.. park their accumulators in LDS ([group-1][wave][reg][lane]: lane-contiguous, conflict-free),
+        // group 0 adds them in a fixed order (bitwise reproducible) and runs the epilogue alone
+        float* red = reinterpret_cast<float*>(smem);
+        constexpr int PER_WAVE = TC * TP * 4 * 64;
+        if (grp > 0) {
+            float* dst = red + ((grp - 1) * 4 + wave) * PER_WAVE + lane;
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[((i * TP + j) * 4 + e) * 64] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+        for (int g2 = 1; g2 < KG; ++g2) {
+            const float* src = red + ((g2 - 1) * 4 + wave) * PER_WAVE + lane;
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][e] += src[((i * TP + j) * 4 + e) * 64];
+        }
+        }
+        __syncthreads();                 // `red` is dead from here on (sStat aliases it)
+    }
+    const bool lead = grp == 0;          // groups 1.. only keep the epilogue's barriers company
     // ---- epilogue: bias, BN statistics, residual, ReLU, store (4 consecutive channels per lane)
     const bool do_stats = p.stats != nullptr;
     if (do_stats) {
-        for (int i = tid; i < 4 * 2 * BN; i += CONV_T) sStat[i] = 0.f;
+        if (lead) for (int i = tid; i < 4 * 2 * BN; i += CONV_T) sStat[i] = 0.f;
         __syncthreads();
     }
     const int g = lane >> 4, pl = lane & 15;
@@ -188,7 +279,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int m = m0 + poff + j * 16 + pl;
-            if (m < p.M) {
+            if (m < p.M && lead) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[e];
@@ -226,7 +317,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
                     ssq[e] += __shfl_xor(ssq[e], off, 64);
                 }
             }
-            if (pl == 0) {          // exactly one lane per (wave, channel): plain stores
+            if (pl == 0 && lead) {  // exactly one lane per (wave, channel): plain stores
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     sStat[(wave * 2 + 0) * BN + chl + e] = ssum[e];
@@ -237,6 +328,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
     }
     if (do_stats) {
         __syncthreads();
+        if (!lead) return;
         // statistics rows are per 64 pixels so that their number does not depend on the tile choice:
         // a 128-pixel tile writes its sums to row 2*mt and zeros to row 2*mt+1
         const int srow = (BM == 128) ? 2 * mt : mt;
@@ -255,15 +347,20 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm(ConvP p) {
     }
 }
 
-template <int BM, int BN, int KS, int MODE>
+template <int BM, int BN, int KS, int MODE, int KU = 1, int KG = 1>
 static int launch_igemm_t(cr_ctx* ctx, const ConvP& p, int out_f32) {
     const int grid = (int)(cr_cdiv(p.M, BM) * (p.Cout / BN));
     if (out_f32)
-        hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, MODE, float>), dim3(grid), dim3(CONV_T), 0, ctx->stream, p);
+        hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, MODE, float, KU, KG>), dim3(grid), dim3(CONV_T * KG), 0, ctx->stream, p);
     else
-        hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, MODE, u16>), dim3(grid), dim3(CONV_T), 0, ctx->stream, p);
+        hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, MODE, u16, KU, KG>), dim3(grid), dim3(CONV_T * KG), 0, ctx->stream, p);
     CR_LAUNCH_CHECK();
     return CR_OK;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 template <int KS, int MODE>
@@ -271,8 +368,20 @@ static int launch_igemm_ks(cr_ctx* ctx, const ConvP& p, int out_f32) {
     // the 32x32 ... 8x8 levels at 4 images/GPU give only 8-64 tiles of 128x128: use 64x64 tiles there so that the
     // launch covers the 256 CUs (MI355X: "a launch needs >> 256 workgroups")
     const int64_t big_tiles = cr_cdiv(p.M, 128) * (p.Cout >= 128 ? p.Cout / 128 : 1);
-    if (p.Cout % 64 == 0 && big_tiles < 512) return launch_igemm_t<64, 64, KS, MODE>(ctx, p, out_f32);
-    if (p.Cout % 128 == 0) return launch_igemm_t<128, 128, KS, MODE>(ctx, p, out_f32);
+    static const int ku_small = env_int("CR_IGEMM_KU_SMALL", 4), ku_big = env_int("CR_IGEMM_KU_BIG", 1);
+    static const int ku_tiny_blocks = env_int("CR_IGEMM_KU8_BLOCKS", 320);
+    if (p.Cout % 64 == 0 && big_tiles < 512) {
+        // <= ~1 block per CU: 16 waves per block on interleaved k (intra-block split-K)
+        if (cr_cdiv(p.M, 64) * (p.Cout / 64) <= ku_tiny_blocks && p.Kdim >= 512 && (KS == 1 || (p.Cin & 31) == 0))
+            return launch_igemm_t<64, 64, KS, MODE, 2, 4>(ctx, p, out_f32);
+        if (ku_small == 4) return launch_igemm_t<64, 64, KS, MODE, 4>(ctx, p, out_f32);
+        if (ku_small == 2) return launch_igemm_t<64, 64, KS, MODE, 2>(ctx, p, out_f32);
+        return launch_igemm_t<64, 64, KS, MODE>(ctx, p, out_f32);
+    }
+    if (p.Cout % 128 == 0) {
+        if (ku_big == 2) return launch_igemm_t<128, 128, KS, MODE, 2>(ctx, p, out_f32);
+        return launch_igemm_t<128, 128, KS, MODE>(ctx, p, out_f32);
+    }
     if (p.Cout % 64 == 0) return launch_igemm_t<128, 64, KS, MODE>(ctx, p, out_f32);
     if (p.Cout % 32 == 0) return launch_igemm_t<128, 32, KS, MODE>(ctx, p, out_f32);
     return launch_igemm_t<128, 16, KS, MODE>(ctx, p, out_f32);
@@ -292,8 +401,9 @@ static int conv_common_checks(const char* who, int N, int H, int W, int Cin, int
     CR_CHECK_ARG(stride == 1 || stride == 2, "%s: stride %d not supported (1,2)", who, stride);
     CR_CHECK_ARG(ks == 1 || ilog2_exact(Cin) >= 0, "%s: Cin=%d must be a power of two for %dx%d kernels", who, Cin, ks, ks);
     CR_CHECK_ARG(pad >= 0 && pad <= ks / 2, "%s: pad %d", who, pad);
-    CR_CHECK_ARG((int64_t)N * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < (int64_t)0x7fffffff,
-                 "%s: tensor too large for 32-bit pixel indexing", who);
+    CR_CHECK_ARG((int64_t)N * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < (int64_t)0x3fffffff &&
+                 (int64_t)Cout * ks * ks * Cin < (int64_t)0x3fffffff,
+                 "%s: tensor too large for 31-bit byte offsets (buffer loads)", who);
     return CR_OK;
 }
 
@@ -310,6 +420,7 @@ extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y,
     p.Wout = (W + 2 * pad - ks) / stride + 1;
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = N * p.Hout * p.Wout;
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cin); p.relu = relu;
+    p.x_bytes = (unsigned)((size_t)N * H * W * Cin * 2); p.w_bytes = (unsigned)((size_t)Cout * p.Kdim * 2);
     if (ks == 1) return launch_igemm_ks<1, 0>(ctx, p, out_f32);
     if (ks == 3) return launch_igemm_ks<3, 0>(ctx, p, out_f32);
     return launch_igemm_ks<7, 0>(ctx, p, out_f32);
@@ -330,6 +441,7 @@ extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, v
     p.Hout = H; p.Wout = W; p.Cout = Cin;               // GEMM output = dX
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cout; p.M = N * H * W;
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cout); p.relu = 0;
+    p.x_bytes = (unsigned)((size_t)N * Ho * Wo * Cout * 2); p.w_bytes = (unsigned)((size_t)Cin * p.Kdim * 2);
     if (ks == 1) return launch_igemm_ks<1, 1>(ctx, p, 0);
     if (ks == 3) return launch_igemm_ks<3, 1>(ctx, p, 0);
     return launch_igemm_ks<7, 1>(ctx, p, 0);
@@ -352,16 +464,17 @@ __device__ __forceinline__ s16x4 lds_tr16(const u16* ptr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ptr));
 }
 
-template <int TM, int KS>
+template <int TM, int KS, int KU>
 __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
     constexpr int TN = 128;
     constexpr int WM = (TM == 128) ? 2 : 1, WN = 4 / WM;
     constexpr int WTM = TM / WM, WTN = TN / WN;          // wave tile
     constexpr int TI = WTM / 16, TJ = WTN / 16;
     constexpr int PP = TM + 8, PQ = TN + 8;              // padded row pitches (elements)
-    constexpr int NP = (32 * TM / 8 + CONV_T - 1) / CONV_T;   // dy chunks per thread
-    __shared__ __attribute__((aligned(16))) u16 sP[32 * PP];
-    __shared__ __attribute__((aligned(16))) u16 sQ[32 * PQ];
+    constexpr int CPR = TM / 8;                          // dy chunks per pixel row
+    constexpr int NP = (32 * CPR + CONV_T - 1) / CONV_T; // dy chunks per thread per 32-pixel sub-step
+    __shared__ __attribute__((aligned(16))) u16 sP[KU * 32 * PP];
+    __shared__ __attribute__((aligned(16))) u16 sQ[KU * 32 * PQ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = blockIdx.x * TM;        // output-channel tile
@@ -371,7 +484,9 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
     const int step1 = min(step0 + p.steps_per_split, nsteps_total);
     if (step0 >= step1) return;
 
-    // Q-gather bookkeeping: 32 pixels x 16 chunks = 512 chunks, 2 per thread; the k-chunk is fixed per thread
+    // Q-gather bookkeeping: 32 pixels x 16 chunks = 512 chunks per sub-step, 2 per thread; the k-chunk (filter tap and
+    // channel) is fixed per thread for the whole kernel, the two pixel rows walk forward by 32 pixels per sub-step and
+    // are tracked incrementally as (n, ho, wo) -- no division in the loop.
     const int qc = tid & 15;                   // chunk within the 128-wide k tile
     const int qk = q0 + qc * 8;
     int qr = 0, qs = 0, qch = qk;
@@ -382,48 +497,63 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
         qr = tap / KS;
         qs = tap - qr * KS;
     }
-    const int hw = p.Hout * p.Wout;
-    uint4 rq[2], rp[NP];
-
-    auto load_step = [&](int st) {
+    int pn[2], pho[2], pwo[2];
+    {
+        const int hw = p.Hout * p.Wout;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int prow = (tid >> 4) + 16 * i;
-            const int m = st * 32 + prow;
+            const int m = step0 * 32 + (tid >> 4) + 16 * i;
+            pn[i] = m / hw;
+            const int rem = m - pn[i] * hw;
+            pho[i] = rem / p.Wout;
+            pwo[i] = rem - pho[i] * p.Wout;
+        }
+    }
+    const u16* pdy = p.dy + (size_t)step0 * 32 * p.Cout + c0;      // dy rows of the current sub-step
+    int mrow = step0 * 32;                                         // first pixel of the next sub-step to load
+    const int mend = min(p.M, step1 * 32);                         // rows of later splits / past M contribute zeros
+    uint4 rq[KU][2], rp[KU][NP];
+
+    auto load_stage = [&]() {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (qvalid && m < p.M) {
-                const int n = m / hw;
-                const int rem = m - n * hw;
-                const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
-                const int hi = ho * p.stride - p.pad + qr, wi = wo * p.stride - p.pad + qs;
-                if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
-                    v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(n * p.Hin + hi) * p.Win + wi) * p.Cin + qch);
-            }
-            rq[i] = v;
+            const int hi = pho[i] * p.stride - p.pad + qr, wi = pwo[i] * p.stride - p.pad + qs;
+            if (qvalid && pn[i] < p.N && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
+                v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(pn[i] * p.Hin + hi) * p.Win + wi) * p.Cin + qch);
+            rq[u][i] = v;
+            pwo[i] += 32;
+            while (pwo[i] >= p.Wout) { pwo[i] -= p.Wout; ++pho[i]; }
+            while (pho[i] >= p.Hout) { pho[i] -= p.Hout; ++pn[i]; }
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int idx = tid + CONV_T * i;
-            constexpr int CPR = TM / 8;           // chunks per pixel row
             const int prow = idx / CPR, pc = idx - prow * CPR;
-            const int m = st * 32 + prow;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < 32 * CPR && m < p.M && c0 + pc * 8 < p.Cout)
-                v = *reinterpret_cast<const uint4*>(p.dy + (size_t)m * p.Cout + c0 + pc * 8);
-            rp[i] = v;
+            if (idx < 32 * CPR && mrow + prow < mend && c0 + pc * 8 < p.Cout)
+                v = *reinterpret_cast<const uint4*>(pdy + (size_t)prow * p.Cout + pc * 8);
+            rp[u][i] = v;
         }
+        pdy += (size_t)32 * p.Cout;
+        mrow += 32;
+      }
     };
-    auto store_step = [&]() {
+    auto store_stage = [&]() {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<uint4*>(&sQ[((tid >> 4) + 16 * i) * PQ + qc * 8]) = rq[i];
+            *reinterpret_cast<uint4*>(&sQ[u * 32 * PQ + ((tid >> 4) + 16 * i) * PQ + qc * 8]) = rq[u][i];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int idx = tid + CONV_T * i;
-            constexpr int CPR = TM / 8;
             const int prow = idx / CPR, pc = idx - prow * CPR;
-            if (idx < 32 * CPR) *reinterpret_cast<uint4*>(&sP[prow * PP + pc * 8]) = rp[i];
+            if (idx < 32 * CPR) *reinterpret_cast<uint4*>(&sP[u * 32 * PP + prow * PP + pc * 8]) = rp[u][i];
         }
+      }
     };
 
     const int wm = (WM == 2) ? (wave >> 1) : 0, wn = (WM == 2) ? (wave & 1) : wave;
@@ -436,32 +566,38 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
 
     // transposed-read addressing: 16-lane group g covers pixel rows 8g..8g+7; lane 4q+pp supplies row q, cols 4pp..
     const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-    load_step(step0);
-    store_step();
+    // dy rows at or past `mend` load zeros (and the x gather never reads past the batch), so the last stage may run
+    // all its KU sub-steps
+    const int nstage = (step1 - step0 + KU - 1) / KU;
+    load_stage();
+    store_stage();
     __syncthreads();
-    for (int st = step0; st < step1; ++st) {
-        if (st + 1 < step1) load_step(st + 1);
-        bf16x8 af[TI], bfr[TJ];
+    for (int st = 0; st < nstage; ++st) {
+        if (st + 1 < nstage) load_stage();
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const u16* b0 = &sP[(8 * g + tq) * PP + moff + i * 16 + 4 * tp];
-            const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b0 + 4 * PP);
-            af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        for (int u = 0; u < KU; ++u) {
+            bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const u16* b0 = &sP[u * 32 * PP + (8 * g + tq) * PP + moff + i * 16 + 4 * tp];
+                const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b0 + 4 * PP);
+                af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const u16* b0 = &sQ[u * 32 * PQ + (8 * g + tq) * PQ + noff + j * 16 + 4 * tp];
+                const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b0 + 4 * PQ);
+                bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const u16* b0 = &sQ[(8 * g + tq) * PQ + noff + j * 16 + 4 * tp];
-            const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b0 + 4 * PQ);
-            bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         __syncthreads();
-        if (st + 1 < step1) {
-            store_step();
+        if (st + 1 < nstage) {
+            store_stage();
             __syncthreads();
         }
     }
@@ -485,17 +621,39 @@ static int launch_wgrad_ks(cr_ctx* ctx, WgP& p) {
     const int tn = (int)cr_cdiv(p.Kdim, 128);
     int TM = p.Cout >= 128 ? 128 : (p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16));
     const int tm = (int)cr_cdiv(p.Cout, TM);
-    // split the pixel range so that the grid is ~ 4 blocks per CU
-    int splits = (1024 + tm * tn - 1) / (tm * tn);
+    // Split the pixel range over blockIdx.z.  Every split adds one full set of f32 atomics over dW (1.3 TB/s on
+    // MI355X), so the split count is bounded by ~16 pixel steps (512 pixels) of MFMA work per block and by the number
+    // of blocks the chip holds at once (measured per layer shape with scripts/conv_shapes_bench.py, CR_WG_SPLITS sweep).
+    const int tiles = tm * tn;
+    const int block_cap = TM >= 64 ? 576 : 2048;
+    int splits = nsteps / 16;
+    if (splits > block_cap / tiles) splits = block_cap / tiles;
+    if (splits < 1) splits = 1;
+    if (tiles * splits < 256) {     // far fewer blocks than CUs: trade steps per block (down to ~8) for more blocks
+        int lo = nsteps < 4 ? nsteps : 4;
+        int s2 = nsteps / 8 > lo ? nsteps / 8 : lo;
+        if (s2 > 256 / tiles) s2 = 256 / tiles;
+        if (s2 > splits) splits = s2;
+    }
+    static const int force_splits = env_int("CR_WG_SPLITS", 0);
+    if (force_splits > 0) splits = force_splits;
     if (splits > nsteps) splits = nsteps;
     if (splits < 1) splits = 1;
     p.steps_per_split = (nsteps + splits - 1) / splits;
     splits = (nsteps + p.steps_per_split - 1) / p.steps_per_split;
     dim3 grid(tm, tn, splits);
-    if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad<128, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
-    else if (TM == 64) hipLaunchKernelGGL((k_conv_wgrad<64, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
-    else if (TM == 32) hipLaunchKernelGGL((k_conv_wgrad<32, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((k_conv_wgrad<16, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    static const int ku = env_int("CR_WG_KU", 2);
+    if (ku == 2) {
+        if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad<128, KS, 2>), grid, dim3(CONV_T), 0, ctx->stream, p);
+        else if (TM == 64) hipLaunchKernelGGL((k_conv_wgrad<64, KS, 2>), grid, dim3(CONV_T), 0, ctx->stream, p);
+        else if (TM == 32) hipLaunchKernelGGL((k_conv_wgrad<32, KS, 2>), grid, dim3(CONV_T), 0, ctx->stream, p);
+        else hipLaunchKernelGGL((k_conv_wgrad<16, KS, 2>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    } else {
+        if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad<128, KS, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
+        else if (TM == 64) hipLaunchKernelGGL((k_conv_wgrad<64, KS, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
+        else if (TM == 32) hipLaunchKernelGGL((k_conv_wgrad<32, KS, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
+        else hipLaunchKernelGGL((k_conv_wgrad<16, KS, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    }
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
