@@ -39,6 +39,11 @@ SIGNATURES = {
     "cr_nms_grouped": [P, P, P, c_int, c_int, c_float, P, P],
     "cr_cube_loss_fwd": [P, P, c_int64, c_int, c_int, c_int, c_int, P, P],
     "cr_cube_loss_bwd": [P, P, c_int64, c_int, c_int, c_int, c_int, P, P, P, P, P, P],
+    "cr_rpn_decode_select": [P, P, P, P, P, c_int, c_int, c_int, P, c_float, P, c_float, P, P, P],
+    "cr_box_match": [P, P, c_int, P, P, c_int, c_int, c_int, P, P, P, P],
+    "cr_rpn_label": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, c_float, P, P, P, P],
+    "cr_rpn_scatter": [P, P, P, c_int, P, P, c_int, c_int, P, c_float, c_int, c_int, P],
+    "cr_rpn_loss": [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P],
     "cr_nonfinite_flag": [P, P, c_int64, P],
     "cr_sgd_step": [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P],
 }

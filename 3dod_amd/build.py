@@ -20,7 +20,8 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
           "-I", os.path.join(HERE, "..", "include")]
 # per-file extra flags.  geometry.hip: the float32 op order is part of the parity
 # contract with oracle/geometry.py -> no fused multiply-add contraction.
-EXTRA = {"geometry.hip": ["-ffp-contract=off"]}
+# dense_train.hip: two kernels must reproduce the same IoU bits (equality test of allow_low_quality_matches).
+EXTRA = {"geometry.hip": ["-ffp-contract=off"], "dense_train.hip": ["-ffp-contract=off"]}
 
 
 def _newer(a, b):

@@ -121,88 +121,86 @@ def _take(keys, k, limit=None):
 # ------------------------------------------------------------------------------------------- RPN
 def rpn_label_and_sample(rpn, anchors, gt: GTBatch):
     """RPNWithIgnore.label_and_sample_anchors (rpn.py:41-110) for the whole batch.  anchors (A,4).
-    Returns labels (B,A) int8 in {-1,0,1}, matched_gt_boxes (B,A,4), matched_ious (B,A)."""
+    Returns labels (B,A) int32 in {-1,0,1}, matched gt index (B,A) int32, matched_ious (B,A).
+    Five launches + two top-k: match, label + keys, scatter (ops.box_match / rpn_label / rpn_scatter)."""
     B, A = gt.boxes.shape[0], anchors.shape[0]
-    dev = anchors.device
-    iou = pairwise_iou_b(gt.boxes, anchors)                                           # (B,G,A)
-    iou = torch.where(gt.valid[:, :, None], iou, torch.full((), NEG, device=dev))
-    vals, midx = iou.max(dim=1)                                                        # (B,A)
+    max_iou, midx, ioa, best = ops.box_match(anchors, gt.boxes, gt.classes, want_best=True)
     lo, hi = rpn.anchor_matcher.thresholds[1], rpn.anchor_matcher.thresholds[2]
-    l0, l1, l2 = rpn.anchor_matcher.labels
-    labels = torch.full((B, A), l2, dtype=torch.int8, device=dev)
-    labels = torch.where(vals < hi, torch.full((), l1, dtype=torch.int8, device=dev), labels)
-    labels = torch.where(vals < lo, torch.full((), l0, dtype=torch.int8, device=dev), labels)
-    # allow_low_quality_matches: every anchor that attains a valid GT's best IoU is foreground
-    best_per_gt, best_idx = iou.max(dim=2)                                             # (B,G)
-    lowq = ((iou == best_per_gt[:, :, None]) & gt.valid[:, :, None]).any(dim=1)
-    labels = torch.where(lowq, torch.ones((), dtype=torch.int8, device=dev), labels)
-    matched_ious = vals.clamp(min=0)
-    # rpn.py:75 -- the argmax anchor of each GT, if it is labelled foreground, is always kept
-    forced = torch.zeros((B, A), dtype=torch.bool, device=dev)
-    forced.scatter_(1, best_idx, (labels.gather(1, best_idx) == 1) & gt.valid)
-    # IoU-weighted subsample (rpn.py:275-328), bg_label 0
-    pos, neg = labels == 1, labels == 0
+    expo = torch.empty((2, B, A), device=anchors.device).exponential_(1.0)
+    # keys = (IoU + eps) / Exp(1) on the positive / negative candidates: their top-k is the IoU-weighted multinomial
+    # sampling without replacement of rpn.py:275-328
+    _, out, matched_ious, keys = ops.rpn_label(anchors, gt.boxes, gt.classes, max_iou, best, expo, lo, hi,
+                                               rpn.anchor_matcher.labels, 1e-4)
     n_s = rpn.batch_size_per_image
     k_pos = int(n_s * rpn.positive_fraction)
-    pidx, pvalid = _take(_keys(matched_ious, pos), k_pos)
-    n_pos = pvalid.sum(1)
-    nidx, nvalid = _take(_keys(matched_ious, neg), n_s, limit=n_s - n_pos)
-    out = torch.full((B, A), -1, dtype=torch.int32, device=dev)
-    one, zero, m1 = [torch.full((), v, dtype=torch.int32, device=dev) for v in (1, 0, -1)]
-    out.scatter_reduce_(1, pidx, torch.where(pvalid, one, m1), reduce="amax")
-    out.scatter_reduce_(1, nidx, torch.where(nvalid, zero, m1), reduce="amax")
-    out = torch.where(forced, one, out)
-    # ignore regions (rpn.py:93-104): sampled background inside an ignore box -> -1 (only if > 1 background)
-    ioa = pairwise_ioa_b(gt.boxes, anchors)
-    ioa = torch.where(gt.ignore[:, :, None], ioa, torch.zeros((), device=dev)).max(dim=1)[0]
-    bg = out == 0
-    many = bg.sum(1, keepdim=True) > 1
-    out = torch.where(bg & many & (ioa >= rpn.ignore_thresh), m1, out)
+    pkey, pidx = keys[0].topk(min(k_pos, A), dim=1)
+    nkey, nidx = keys[1].topk(min(n_s, A), dim=1)
+    # rpn.py:75 (forced arg-max anchors) is already in `out`; rpn.py:93-104 (ignore regions) inside the scatter
+    ops.rpn_scatter(out, pidx, pkey, nidx, nkey, n_s, ioa, rpn.ignore_thresh)
+    return out, midx, matched_ious
+
+
+def matched_boxes(gt: GTBatch, midx):
+    """(B,A,4) matched gt box per anchor (zeros for images without objects), as the reference's per-image lists."""
     has_gt = gt.valid.any(1)
-    matched = torch.gather(gt.boxes, 1, midx[:, :, None].expand(-1, -1, 4)) * has_gt[:, None, None]
-    return out, matched, matched_ious
+    return torch.gather(gt.boxes, 1, midx.long()[:, :, None].expand(-1, -1, 4)) * has_gt[:, None, None]
 
 
-def rpn_losses(rpn, anchors, logits, deltas, labels, matched_gt_boxes):
+def rpn_losses(rpn, anchors, logits, deltas, labels, midx, gt: GTBatch):
     """RPNWithIgnore.losses + _dense_box_regression_loss_with_uncertainty (rpn.py:129-273), "IoUness" objectness.
-    logits (B,A), deltas (B,A,4)."""
+    logits (B,A), deltas (B,A,4); one fused kernel computes both sums, the logging counters and the gradients."""
     assert rpn.objectness_uncertainty.lower() != "none" and rpn.box_reg_loss_type == "smooth_l1" and rpn.smooth_l1_beta < 1e-5
     B, A = labels.shape
-    pos = labels == 1
-    a = anchors.unsqueeze(0).expand(B, A, 4)
-    g = torch.where(pos[..., None], matched_gt_boxes, a)                               # sanitised where unused
-    lt = torch.max(a[..., :2], g[..., :2])
-    rb = torch.min(a[..., 2:], g[..., 2:])
-    wh = (rb - lt).clamp(min=0)
-    inter = wh[..., 0] * wh[..., 1]
-    iou_t = (inter / (_area(a) + _area(g) - inter)).detach()
-    iou_t = torch.where(pos, iou_t, torch.zeros((), device=a.device))
-    bce = F.binary_cross_entropy_with_logits(logits, iou_t, reduction="none")
-    loss_conf = (bce * iou_t).sum()
-    tgt = rpn.box2box_transform.get_deltas(a.reshape(-1, 4), g.reshape(-1, 4)).view(B, A, 4)
-    l1 = torch.where(pos[..., None], (deltas - tgt).abs(), torch.zeros((), device=a.device))
-    loss_loc = (l1.sum(-1) * iou_t).sum()
+    loss_conf, loss_loc, sums = ops.rpn_loss(logits, deltas, anchors, labels, midx, gt.boxes, rpn.box2box_transform.weights)
     storage = get_event_storage()
     with torch.no_grad():
-        sig = torch.sigmoid(logits)
-        npos = pos.sum().clamp(min=1)
-        storage.put_scalar("rpn/num_pos_anchors", pos.sum() / B)
-        storage.put_scalar("rpn/num_neg_anchors", (labels == 0).sum() / B)
-        storage.put_scalar("rpn/conf_pos_anchors", (sig * pos).sum() / npos)
-        storage.put_scalar("rpn/conf_neg_anchors", (sig * ~pos).sum() / (~pos).sum().clamp(min=1))
+        npos = sums[2]
+        storage.put_scalar("rpn/num_pos_anchors", npos / B)
+        storage.put_scalar("rpn/num_neg_anchors", sums[3] / B)
+        storage.put_scalar("rpn/conf_pos_anchors", sums[4] / npos.clamp(min=1))
+        storage.put_scalar("rpn/conf_neg_anchors", sums[5] / (B * A - npos).clamp(min=1))
     normalizer = rpn.batch_size_per_image * B
     losses = {"rpn/cls": loss_conf / normalizer, "rpn/loc": loss_loc / normalizer}
     return {k: v * rpn.loss_weight.get(k, 1.0) for k, v in losses.items()}
 
 
-def rpn_proposals_padded(rpn, anchors_per_level, logits_per_level, deltas_per_level, image_sizes):
-    """predict_proposals / find_top_rpn_proposals with a padded result: boxes (B,K,4), scores (B,K) (-inf = empty slot)."""
-    from .proposal_generator.rpn import find_top_rpn_proposals
+_PCONST = {}
+
+
+def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes):
+    """RPN.predict_proposals / find_top_rpn_proposals (detectron2 [third-party], restated in proposal_generator/rpn.py)
+    with a padded result: boxes (B,K,4), scores (B,K) (-inf = empty slot).  anchors (A,4) and deltas (B,A,4) are the
+    level-concatenated tensors.  Only the per-level top-k candidates are decoded (one fused launch: decode, clip,
+    validity), instead of decoding every anchor of every level first."""
     with torch.no_grad():
-        props = rpn._decode_proposals(anchors_per_level, deltas_per_level)
-        return find_top_rpn_proposals(props, [t.detach() for t in logits_per_level], image_sizes, rpn.nms_thresh,
-                                      rpn.pre_nms_topk[True], rpn.post_nms_topk[True], rpn.min_box_size, True,
-                                      padded=True)
+        B = deltas.shape[0]
+        dev = deltas.device
+        sizes = [int(t.shape[1]) for t in logits_per_level]
+        ks = [min(n, rpn.pre_nms_topk[True]) for n in sizes]
+        maxn, L = max(ks), len(ks)
+        ckey = (tuple(tuple(s) for s in image_sizes), tuple(sizes), tuple(ks), str(dev))
+        cached = _PCONST.get(ckey)
+        if cached is None:       # constants of the configuration: made once, never inside a captured region
+            cached = (torch.tensor([[float(s[0]), float(s[1])] for s in image_sizes], dtype=torch.float32, device=dev),
+                      torch.tensor(ks, dtype=torch.int32, device=dev).repeat(B))
+            _PCONST[ckey] = cached
+        img_hw, counts = cached
+        idx = torch.full((B, L, maxn), -1, dtype=torch.int64, device=dev)
+        scores = torch.full((B, L, maxn), float("-inf"), dtype=torch.float32, device=dev)
+        off = 0
+        for l, (lg, k) in enumerate(zip(logits_per_level, ks)):
+            v, i = lg.detach().float().topk(k, dim=1)
+            idx[:, l, :k] = i + off
+            scores[:, l, :k] = v
+            off += sizes[l]
+        t = rpn.box2box_transform
+        boxes, nms_boxes, valid = ops.rpn_decode_select(anchors, deltas.detach(), idx.view(B, -1), scores.view(B, -1),
+                                                        t.weights, t.scale_clamp, img_hw, rpn.min_box_size)
+        keep = ops.nms_grouped(nms_boxes.view(B * L, maxn, 4), counts, rpn.nms_thresh).view(B, -1) & valid
+        flat_scores = torch.where(keep, scores.view(B, -1), torch.full((), float("-inf"), device=dev))
+        k_post = min(rpn.post_nms_topk[True], flat_scores.shape[1])
+        top_scores, top_idx = flat_scores.topk(k_post, dim=1)
+        return torch.gather(boxes, 1, top_idx[:, :, None].expand(-1, -1, 4)), top_scores
 
 
 # ------------------------------------------------------------------------------------------- ROI heads
@@ -356,9 +354,9 @@ def forward_train(model, image_sizes, features, head_outputs, gt: GTBatch, meta)
     logits_lv, deltas_lv = head_outputs if head_outputs is not None else rpn.rpn_head(feats)
     logits, deltas = torch.cat(logits_lv, 1), torch.cat(deltas_lv, 1)
     with torch.no_grad():
-        labels, matched, _ = rpn_label_and_sample(rpn, anchors, gt)
-    losses = rpn_losses(rpn, anchors, logits, deltas, labels, matched)
-    pboxes, pscores = rpn_proposals_padded(rpn, anchors_lv, logits_lv, deltas_lv, image_sizes)
+        labels, midx, _ = rpn_label_and_sample(rpn, anchors, gt)
+    losses = rpn_losses(rpn, anchors, logits, deltas, labels, midx, gt)
+    pboxes, pscores = rpn_proposals_padded(rpn, anchors, logits_lv, deltas, image_sizes)
     samp = roi_label_and_sample(rh, pboxes, pscores, gt)
     lb, pred_boxes = box_head_losses(rh, features, samp, gt)
     losses.update(lb)

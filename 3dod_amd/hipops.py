@@ -486,6 +486,108 @@ def nms_grouped(boxes, counts, thresh):
 
 
 # --------------------------------------------------------------------------
+# static-shape RPN training glue (csrc/dense_train.hip)
+# --------------------------------------------------------------------------
+import ctypes as _ct
+
+
+def _f4(vals):
+    return (_ct.c_float * 4)(*[float(v) for v in vals])
+
+
+def rpn_decode_select(anchors, deltas, idx, scores, weights, scale_clamp, img_hw, min_size):
+    """anchors (A,4), deltas (B,A,4), idx (B,S) int64 (-1 = empty), scores (B,S), img_hw (B,2) ->
+    boxes (B,S,4) clipped, nms_boxes (B,S,4) (zero where invalid), valid (B,S) bool."""
+    _need_cuda(deltas, "deltas")
+    B, A = deltas.shape[0], anchors.shape[0]
+    S = idx.shape[1]
+    dev = deltas.device
+    boxes = torch.empty((B, S, 4), dtype=f32, device=dev)
+    nmsb = torch.empty((B, S, 4), dtype=f32, device=dev)
+    valid = torch.empty((B, S), dtype=torch.uint8, device=dev)
+    lib = _lib.load()
+    _chk(lib.cr_rpn_decode_select(_ctx(deltas), _p(anchors.contiguous()), _p(deltas.contiguous()), _p(idx.contiguous()),
+                                  _p(scores.contiguous()), B, A, S, _f4(weights), float(scale_clamp), _p(img_hw.contiguous()),
+                                  float(min_size), _p(boxes), _p(nmsb), _p(valid)), "cr_rpn_decode_select")
+    return boxes, nmsb, valid.bool()
+
+
+def box_match(boxes, gt_boxes, gt_classes, want_best=False):
+    """boxes (R,4) or (B,R,4); gt_boxes (B,G,4); gt_classes (B,G) int64 -> max_iou (B,R), argmax (B,R) int32,
+    max_ioa (B,R), best (B,G) int64 (packed, see include/cr3dod.h) or None."""
+    _need_cuda(gt_boxes, "gt_boxes")
+    B, G = gt_classes.shape
+    per_image = boxes.dim() == 3
+    R = boxes.shape[-2]
+    dev = gt_boxes.device
+    mi = torch.empty((B, R), dtype=f32, device=dev)
+    am = torch.empty((B, R), dtype=torch.int32, device=dev)
+    ma = torch.empty((B, R), dtype=f32, device=dev)
+    best = torch.empty((B, G), dtype=torch.int64, device=dev) if want_best else None
+    lib = _lib.load()
+    _chk(lib.cr_box_match(_ctx(gt_boxes), _p(boxes.contiguous()), int(per_image), _p(gt_boxes.contiguous()),
+                          _p(gt_classes.contiguous()), B, R, G, _p(mi), _p(am), _p(ma), _p(best)), "cr_box_match")
+    return mi, am, ma, best
+
+
+def rpn_label(anchors, gt_boxes, gt_classes, max_iou, best, expo, lo, hi, labels3, eps):
+    B, A = max_iou.shape
+    G = gt_classes.shape[1]
+    dev = max_iou.device
+    labels_pre = torch.empty((B, A), dtype=torch.int8, device=dev)
+    out = torch.empty((B, A), dtype=torch.int32, device=dev)
+    miou = torch.empty((B, A), dtype=f32, device=dev)
+    keys = torch.empty((2, B, A), dtype=f32, device=dev)
+    lib = _lib.load()
+    _chk(lib.cr_rpn_label(_ctx(max_iou), _p(anchors.contiguous()), _p(gt_boxes.contiguous()), _p(gt_classes.contiguous()),
+                          _p(max_iou), _p(best), _p(expo.contiguous()), B, A, G, float(lo), float(hi),
+                          (_ct.c_int * 3)(*[int(v) for v in labels3]), float(eps), _p(labels_pre), _p(out), _p(miou),
+                          _p(keys)), "cr_rpn_label")
+    return labels_pre, out, miou, keys
+
+
+def rpn_scatter(out, pos_idx, pos_key, neg_idx, neg_key, n_s, ioa, ignore_thresh):
+    """in place on out (B,A) int32."""
+    B, A = out.shape
+    lib = _lib.load()
+    _chk(lib.cr_rpn_scatter(_ctx(out), _p(pos_idx.contiguous()), _p(pos_key.contiguous()), pos_idx.shape[1],
+                            _p(neg_idx.contiguous()), _p(neg_key.contiguous()), neg_idx.shape[1], int(n_s),
+                            _p(ioa.contiguous()), float(ignore_thresh), B, A, _p(out)), "cr_rpn_scatter")
+    return out
+
+
+class _RPNLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, deltas, anchors, labels, midx, gt_boxes, weights):
+        B, A = logits.shape
+        G = gt_boxes.shape[1]
+        dev = logits.device
+        nb = (A + 255) // 256
+        ws = torch.empty((B * nb * 6,), dtype=f32, device=dev)
+        sums = torch.empty((6,), dtype=f32, device=dev)
+        dl = torch.empty((B, A), dtype=f32, device=dev)
+        dd = torch.empty((B, A, 4), dtype=f32, device=dev)
+        lib = _lib.load()
+        _chk(lib.cr_rpn_loss(_ctx(logits), _p(logits.detach().float().contiguous()), _p(deltas.detach().float().contiguous()),
+                             _p(anchors.contiguous()), _p(labels.contiguous()), _p(midx.contiguous()),
+                             _p(gt_boxes.contiguous()), B, A, G, _f4(weights), _p(ws), _p(sums), _p(dl), _p(dd)),
+             "cr_rpn_loss")
+        ctx.save_for_backward(dl, dd)
+        ctx.mark_non_differentiable(sums)
+        return sums[0], sums[1], sums
+
+    @staticmethod
+    def backward(ctx, g_cls, g_loc, _gs):
+        dl, dd = ctx.saved_tensors
+        return dl * g_cls, dd * g_loc, None, None, None, None, None
+
+
+def rpn_loss(logits, deltas, anchors, labels, midx, gt_boxes, weights):
+    """-> (loss_cls_sum, loss_loc_sum, sums6) unnormalised; labels (B,A) int32, midx (B,A) int32."""
+    return _RPNLoss.apply(logits, deltas, anchors, labels, midx, gt_boxes, tuple(weights))
+
+
+# --------------------------------------------------------------------------
 # optimizer
 # --------------------------------------------------------------------------
 def nonfinite_flag(flat_grad, flag):

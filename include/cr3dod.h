@@ -178,6 +178,37 @@ int cr_cube_loss_bwd(cr_ctx* ctx, const float* const* inputs, int64_t n, int all
                      int use_conf, int joint, const float* gl, float* g_dxy, float* g_zr, float* g_dr, float* g_Ra,
                      float* g_u);
 
+/* ---- static-shape training glue of the RPN (3dod_amd/csrc/dense_train.hip) -----------------------------------
+ * Batched, sync-free forms of cubercnn/modeling/proposal_generator/rpn.py:41-110 (label_and_sample_anchors with
+ * ignore regions), :129-273 (losses) and :275-328 (subsample_labels), and of detectron2's Matcher /
+ * Box2BoxTransform / find_top_rpn_proposals [third-party] that the reference calls there.  All pointers are device
+ * pointers unless marked HOST.  gt classes: >= 0 object, -1 ignore region, -2 padding (G <= 64 per image). */
+
+/* decode + clip + validity of the per-level top-k candidates.  idx (B,S) int64 = anchor index (or -1 = empty slot),
+ * scores (B,S); weights4 HOST [wx,wy,ww,wh]; img_hw (B,2) = (h,w).  boxes/nms_boxes (B,S,4), valid (B,S) u8. */
+int cr_rpn_decode_select(cr_ctx* ctx, const float* anchors, const float* deltas, const int64_t* idx,
+                         const float* scores, int B, int A, int S, const float* weights4, float scale_clamp,
+                         const float* img_hw, float min_size, float* boxes, float* nms_boxes, unsigned char* valid);
+/* IoU matching of boxes (R,4) [boxes_per_image = 0] or (B,R,4) [= 1] against gt (B,G,4): max_iou (-1 when the image
+ * has no object), argmax (first), max_ioa over ignore regions; best (B,G) u64 or NULL: (iou bits << 32) | ~argmax box. */
+int cr_box_match(cr_ctx* ctx, const float* boxes, int boxes_per_image, const float* gt_boxes, const int64_t* gt_classes,
+                 int B, int R, int G, float* max_iou, int* argmax, float* max_ioa, unsigned long long* best);
+/* Matcher labels + allow_low_quality_matches + sampling keys.  expo (2,B,A) ~ Exp(1); labels3 HOST = Matcher labels.
+ * labels_pre (B,A) i8, out (B,A) i32 (-1, or 1 for each gt's arg-max anchor), matched_iou (B,A), keys (2,B,A). */
+int cr_rpn_label(cr_ctx* ctx, const float* anchors, const float* gt_boxes, const int64_t* gt_classes,
+                 const float* max_iou, const unsigned long long* best, const float* expo, int B, int A, int G, float lo,
+                 float hi, const int* labels3, float eps, signed char* labels_pre, int* out, float* matched_iou,
+                 float* keys);
+/* writes the sampled picks (top-k of the keys; key > 0 = real) into out: positives 1, negatives 0 (rank < n_s - n_pos),
+ * negatives inside an ignore region -1 when the image has more than one sampled negative. */
+int cr_rpn_scatter(cr_ctx* ctx, const int64_t* pos_idx, const float* pos_key, int KP, const int64_t* neg_idx,
+                   const float* neg_key, int KN, int n_s, const float* ioa, float ignore_thresh, int B, int A, int* out);
+/* losses + gradients.  sums6 = [cls, loc, n_pos, n_neg, sum sigmoid | pos, sum sigmoid | not pos] (unnormalised);
+ * partial_ws: B*ceil(A/256)*6 floats; dlogits (B,A), ddeltas (B,A,4) = d(cls)/d(logits), d(loc)/d(deltas). */
+int cr_rpn_loss(cr_ctx* ctx, const float* logits, const float* deltas, const float* anchors, const int* labels,
+                const int* matched_idx, const float* gt_boxes, int B, int A, int G, const float* weights4,
+                float* partial_ws, float* sums6, float* dlogits, float* ddeltas);
+
 /* ---- optimizer (tools/train_net.py:233-266, cubercnn/solver/build.py:50-56) ------------- */
 int cr_nonfinite_flag(cr_ctx* ctx, const float* g, int64_t n, int* flag);
 /* SGD momentum on flat f32 buffers; skipped on device when *skip_flag != 0 (may be NULL). */

@@ -214,6 +214,134 @@ def cube_decode_loss(dxy, zr, dr, Ra, u, src_boxes, K4, v2r, prior_mean, gt2d, g
     return L, dec.detach()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# static-shape RPN training glue: the tensor-op formulation the fused kernels of csrc/dense_train.hip replaced
+# (rpn.py:41-110,129-273,275-328 of the reference; detectron2 Matcher / Box2BoxTransform restated in d2lite)
+# ---------------------------------------------------------------------------------------------------------------
+NEG = -1.0
+
+
+def _area(b):
+    return (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+
+
+def _pairwise_inter(gt, boxes):
+    if boxes.dim() == 2:
+        boxes = boxes.unsqueeze(0)
+    lt = torch.max(gt[:, :, None, :2], boxes[:, None, :, :2])
+    rb = torch.min(gt[:, :, None, 2:], boxes[:, None, :, 2:])
+    wh = (rb - lt).clamp_(min=0)
+    return wh[..., 0] * wh[..., 1]
+
+
+def rpn_decode_select(anchors, deltas, idx, scores, weights, scale_clamp, img_hw, min_size):
+    B, A = deltas.shape[0], anchors.shape[0]
+    ok = (idx >= 0) & (idx < A)
+    j = idx.clamp(0, A - 1)
+    a = anchors[j]                                                      # (B,S,4)
+    d = torch.gather(deltas.float(), 1, j[:, :, None].expand(-1, -1, 4))
+    w, h = a[..., 2] - a[..., 0], a[..., 3] - a[..., 1]
+    cx, cy = a[..., 0] + 0.5 * w, a[..., 1] + 0.5 * h
+    wx, wy, ww, wh = weights
+    dx, dy = d[..., 0] / wx, d[..., 1] / wy
+    dw, dh = (d[..., 2] / ww).clamp(max=scale_clamp), (d[..., 3] / wh).clamp(max=scale_clamp)
+    pcx, pcy, pw, ph = dx * w + cx, dy * h + cy, torch.exp(dw) * w, torch.exp(dh) * h
+    b = torch.stack([pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph], -1)
+    fin = ok & torch.isfinite(b).all(-1) & torch.isfinite(scores)
+    b = torch.where(fin[..., None], b, torch.zeros(()))
+    hw = img_hw[:, [1, 0, 1, 0]][:, None, :]
+    b = torch.minimum(b.clamp(min=0), hw)
+    valid = fin & ((b[..., 2] - b[..., 0]) > min_size) & ((b[..., 3] - b[..., 1]) > min_size)
+    return b, torch.where(valid[..., None], b, torch.zeros(())), valid
+
+
+def box_match(boxes, gt_boxes, gt_classes, want_best=False):
+    bb = boxes.unsqueeze(0) if boxes.dim() == 2 else boxes
+    inter = _pairwise_inter(gt_boxes, bb)
+    union = _area(gt_boxes)[:, :, None] + _area(bb)[:, None, :] - inter
+    iou = torch.where(inter > 0, inter / union, torch.zeros(()))
+    valid, ign = gt_classes >= 0, gt_classes == -1
+    ioum = torch.where(valid[:, :, None], iou, torch.full((), NEG))
+    mi, am = ioum.max(dim=1)
+    ioa = torch.where(inter > 0, inter / _area(bb)[:, None, :], torch.zeros(()))
+    ma = torch.where(ign[:, :, None], ioa, torch.zeros(())).max(dim=1)[0]
+    best = None
+    if want_best:                                   # packed like the kernel: (iou bits << 32) | ~lowest arg-max index
+        bv, _ = ioum.max(dim=2)
+        R = iou.shape[2]
+        first = torch.where(ioum == bv[:, :, None], torch.arange(R)[None, None, :], torch.full((), R)).min(dim=2)[0]
+        bits = bv.clamp(min=0).contiguous().view(torch.int32).to(torch.int64) & 0xffffffff
+        best = torch.where(valid, (bits << 32) | ((~first) & 0xffffffff), torch.zeros((), dtype=torch.int64))
+    return mi, am.to(torch.int32), ma, best
+
+
+def rpn_label(anchors, gt_boxes, gt_classes, max_iou, best, expo, lo, hi, labels3, eps):
+    B, A = max_iou.shape
+    valid = gt_classes >= 0
+    best_v = ((best >> 32) & 0xffffffff).to(torch.int32).view(torch.float32)      # IoU <= 1: the bits fit in int32
+    best_i = (~best) & 0xffffffff
+    inter = _pairwise_inter(gt_boxes, anchors.unsqueeze(0))
+    union = _area(gt_boxes)[:, :, None] + _area(anchors)[None, None, :] - inter
+    iou = torch.where(inter > 0, inter / union, torch.zeros(()))
+    l0, l1, l2 = labels3
+    lab = torch.full((B, A), l2, dtype=torch.int8)
+    lab = torch.where(max_iou < hi, torch.full((), l1, dtype=torch.int8), lab)
+    lab = torch.where(max_iou < lo, torch.full((), l0, dtype=torch.int8), lab)
+    lowq = ((iou == best_v[:, :, None]) & valid[:, :, None]).any(dim=1)
+    lab = torch.where(lowq, torch.ones((), dtype=torch.int8), lab)
+    miou = max_iou.clamp(min=0)
+    forced = torch.zeros((B, A), dtype=torch.bool)
+    bi = best_i.clamp(0, A - 1)
+    forced.scatter_(1, bi, (lab.gather(1, bi) == 1) & valid)
+    out = torch.where(forced, torch.ones((), dtype=torch.int32), torch.full((), -1, dtype=torch.int32))
+    keys = torch.stack([torch.where(lab == 1, (miou + eps) / expo[0], torch.zeros(())),
+                        torch.where(lab == 0, (miou + eps) / expo[1], torch.zeros(()))])
+    return lab, out, miou, keys
+
+
+def rpn_scatter(out, pos_idx, pos_key, neg_idx, neg_key, n_s, ioa, ignore_thresh):
+    B, A = out.shape
+    pvalid = pos_key > 0
+    limit = n_s - pvalid.sum(1)
+    nvalid = (neg_key > 0) & (torch.arange(neg_key.shape[1])[None, :] < limit[:, None])
+    many = nvalid.sum(1, keepdim=True) > 1
+    for b in range(B):
+        o = out[b]
+        o[pos_idx[b][pvalid[b]]] = 1
+        ni = neg_idx[b][nvalid[b]]
+        ni = ni[o[ni] != 1]
+        o[ni] = torch.where(many[b] & (ioa[b][ni] >= ignore_thresh), torch.full((), -1, dtype=torch.int32),
+                            torch.zeros((), dtype=torch.int32))
+    return out
+
+
+def rpn_loss(logits, deltas, anchors, labels, midx, gt_boxes, weights):
+    B, A = labels.shape
+    pos = labels == 1
+    a = anchors.unsqueeze(0).expand(B, A, 4)
+    g = torch.gather(gt_boxes, 1, midx.long()[:, :, None].expand(-1, -1, 4))
+    g = torch.where(pos[..., None], g, a)
+    lt, rb = torch.max(a[..., :2], g[..., :2]), torch.min(a[..., 2:], g[..., 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    t = torch.where(pos, inter / (_area(a) + _area(g) - inter), torch.zeros(())).detach()
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), t, reduction="none")
+    loss_cls = (bce * t).sum()
+    sw, sh = a[..., 2] - a[..., 0], a[..., 3] - a[..., 1]
+    sx, sy = a[..., 0] + 0.5 * sw, a[..., 1] + 0.5 * sh
+    tw, th = g[..., 2] - g[..., 0], g[..., 3] - g[..., 1]
+    tx, ty = g[..., 0] + 0.5 * tw, g[..., 1] + 0.5 * th
+    wx, wy, ww, wh_ = weights
+    tgt = torch.stack([wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * torch.log(tw / sw), wh_ * torch.log(th / sh)], -1)
+    l1 = torch.where(pos[..., None], (deltas.float() - tgt).abs(), torch.zeros(()))
+    loss_loc = (l1.sum(-1) * t).sum()
+    with torch.no_grad():
+        sig = torch.sigmoid(logits.float())
+        sums = torch.stack([loss_cls.detach(), loss_loc.detach(), pos.sum().float(), (labels == 0).sum().float(),
+                            (sig * pos).sum(), (sig * ~pos).sum()])
+    return loss_cls, loss_loc, sums
+
+
 PATCHED = ("3dod_amd.cubercnn.modeling.dense_train", "3dod_amd.cubercnn.modeling.backbone.dla", "3dod_amd.cubercnn.modeling.backbone.fpn",
            "3dod_amd.cubercnn.modeling.proposal_generator.rpn", "3dod_amd.cubercnn.modeling.roi_heads.roi_heads",
            "3dod_amd.cubercnn.modeling.roi_heads.fast_rcnn", "3dod_amd.cubercnn.modeling.meta_arch.rcnn3d",

@@ -1,0 +1,110 @@
+"""GPU: the fused static-shape training-glue kernels (csrc/dense_train.hip, through the C-ABI) against the oracle's
+tensor-op restatement (oracle/cpu_backend.py) on the same seeded inputs.  Integer outputs must agree exactly, IoUs to
+float rounding (same operation order, contraction off), losses to 1e-5."""
+import importlib
+
+import pytest
+import torch
+
+from oracle import cpu_backend as O
+
+pytestmark = pytest.mark.gpu
+ops = importlib.import_module("3dod_amd.hipops")
+d2 = importlib.import_module("3dod_amd.d2lite")
+DEV = torch.device("cuda:0")
+
+
+def _anchors():
+    gen = d2.DefaultAnchorGenerator(sizes=[[32], [64], [128], [256], [512]], aspect_ratios=[[0.5, 1.0, 2.0]] * 5,
+                                    strides=[4, 8, 16, 32, 64])
+    lv = gen([(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)], torch.device("cpu"))
+    return torch.cat([a.tensor for a in lv])
+
+
+def _gt(B, G, seed, img=256.0):
+    g = torch.Generator().manual_seed(seed)
+    ctr = torch.rand(B, G, 2, generator=g) * img
+    wh = torch.rand(B, G, 2, generator=g) * 100 + 8
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).clamp(0, img)
+    cls = torch.randint(0, 5, (B, G), generator=g)
+    cls[0, G - 2:] = -2                      # padding
+    cls[1, 1] = -1                           # an ignore region
+    cls[B - 1, :] = -2                       # an image without objects
+    if B > 2:
+        cls[B - 1, 0] = -1                   # ... but with an ignore region
+    return boxes, cls
+
+
+@pytest.mark.parametrize("per_image", [False, True])
+def test_box_match(per_image):
+    anchors = _anchors()
+    B, G = 3, 8
+    gtb, gtc = _gt(B, G, 1)
+    boxes = anchors if not per_image else (anchors[None] + torch.arange(B)[:, None, None] * 3.0)
+    mi, am, ma, best = ops.box_match(boxes.to(DEV), gtb.to(DEV), gtc.to(DEV), want_best=True)
+    rmi, ram, rma, rbest = O.box_match(boxes, gtb, gtc, want_best=True)
+    assert torch.equal(mi.cpu(), rmi) and torch.equal(ma.cpu(), rma)
+    has = (gtc >= 0).any(1)
+    assert torch.equal(am.cpu()[has], ram[has])
+    assert torch.equal(best.cpu(), rbest)
+    mi2, am2, ma2, none = ops.box_match(boxes.to(DEV), gtb.to(DEV), gtc.to(DEV))
+    assert none is None and torch.equal(mi2, mi) and torch.equal(am2, am) and torch.equal(ma2, ma)
+
+
+def test_rpn_decode_select():
+    anchors = _anchors()
+    A, B, S = anchors.shape[0], 2, 700
+    g = torch.Generator().manual_seed(3)
+    deltas = torch.randn(B, A, 4, generator=g) * 0.5
+    deltas[0, 5, 2] = 50.0                       # clamped by scale_clamp
+    deltas[1, 7, 0] = float("nan")               # non-finite box -> invalid, zeros
+    idx = torch.randint(0, A, (B, S), generator=g)
+    idx[0, :3] = torch.tensor([5, 7, 9]); idx[1, :3] = torch.tensor([5, 7, 9])
+    idx[:, -50:] = -1                            # empty slots
+    scores = torch.randn(B, S, generator=g)
+    scores[:, -50:] = float("-inf")
+    hw = torch.tensor([[256.0, 256.0], [200.0, 240.0]])
+    args = ((1.0, 1.0, 2.0, 2.0), 4.135, hw, 2.0)
+    b, nb, v = ops.rpn_decode_select(anchors.to(DEV), deltas.to(DEV), idx.to(DEV), scores.to(DEV), args[0], args[1],
+                                     hw.to(DEV), args[3])
+    rb, rnb, rv = O.rpn_decode_select(anchors, deltas, idx, scores, *args)
+    assert torch.equal(v.cpu(), rv) and 0 < int(rv.sum()) < rv.numel()
+    assert torch.allclose(b.cpu(), rb, rtol=1e-5, atol=1e-4) and torch.allclose(nb.cpu(), rnb, rtol=1e-5, atol=1e-4)
+
+
+def test_rpn_label_scatter_and_loss():
+    anchors = _anchors()
+    A, B, G = anchors.shape[0], 3, 8
+    gtb, gtc = _gt(B, G, 5)
+    g = torch.Generator().manual_seed(6)
+    expo = torch.empty(2, B, A).exponential_(1.0, generator=g)
+    mi, am, ma, best = ops.box_match(anchors.to(DEV), gtb.to(DEV), gtc.to(DEV), want_best=True)
+    lab, out, miou, keys = ops.rpn_label(anchors.to(DEV), gtb.to(DEV), gtc.to(DEV), mi, best, expo.to(DEV), 0.3, 0.7,
+                                         [0, -1, 1], 1e-4)
+    rmi, ram, rma, rbest = O.box_match(anchors, gtb, gtc, want_best=True)
+    rlab, rout, rmiou, rkeys = O.rpn_label(anchors, gtb, gtc, rmi, rbest, expo, 0.3, 0.7, [0, -1, 1], 1e-4)
+    assert torch.equal(lab.cpu(), rlab) and torch.equal(out.cpu(), rout) and torch.equal(miou.cpu(), rmiou)
+    assert torch.allclose(keys.cpu(), rkeys, rtol=1e-6, atol=0)
+    assert int((rlab == 1).sum()) > 0 and int((rout == 1).sum()) > 0
+    # sampling picks from the (identical) keys, scatter on both sides
+    n_s, kp = 64, 32
+    pkey, pidx = rkeys[0].topk(kp, dim=1)
+    nkey, nidx = rkeys[1].topk(n_s, dim=1)
+    o_gpu = ops.rpn_scatter(out.clone(), pidx.to(DEV), pkey.to(DEV), nidx.to(DEV), nkey.to(DEV), n_s, ma, 0.5)
+    o_ref = O.rpn_scatter(rout.clone(), pidx, pkey, nidx, nkey, n_s, rma, 0.5)
+    assert torch.equal(o_gpu.cpu(), o_ref)
+    assert int((o_ref == 0).sum()) > 0 and int((o_ref == 1).sum()) > 0
+    # losses and gradients
+    logits = torch.randn(B, A, generator=g)
+    deltas = torch.randn(B, A, 4, generator=g) * 0.2
+    w = (1.0, 1.0, 1.0, 1.0)
+    lg, dg = logits.to(DEV).requires_grad_(), deltas.to(DEV).requires_grad_()
+    lc, ll, sums = ops.rpn_loss(lg, dg, anchors.to(DEV), o_gpu, am, gtb.to(DEV), w)
+    (lc * 0.7 + ll * 1.3).backward()
+    lr_, dr_ = logits.clone().requires_grad_(), deltas.clone().requires_grad_()
+    rc, rl, rsums = O.rpn_loss(lr_, dr_, anchors, o_ref, ram, gtb, w)
+    (rc * 0.7 + rl * 1.3).backward()
+    assert torch.allclose(sums.cpu(), rsums, rtol=1e-5, atol=1e-5)
+    assert abs(float(lc) - float(rc)) < 1e-5 * max(1, abs(float(rc))) and abs(float(ll) - float(rl)) < 1e-5 * max(1, abs(float(rl)))
+    assert torch.allclose(lg.grad.cpu(), lr_.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(dg.grad.cpu(), dr_.grad, rtol=1e-5, atol=1e-6)
