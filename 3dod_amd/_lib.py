@@ -44,6 +44,9 @@ SIGNATURES = {
     "cr_rpn_label": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, c_float, P, P, P, P],
     "cr_rpn_scatter": [P, P, P, c_int, P, P, c_int, c_int, P, c_float, c_int, c_int, P],
     "cr_rpn_loss": [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P],
+    "cr_roi_label": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, P, P, P],
+    "cr_roi_compact": [P, P, P, c_int, P, P, c_int, c_int, P, P, P, c_int, c_int, P, P, P, P, P],
+    "cr_box_loss": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_float, P, P, P, P, P],
     "cr_nonfinite_flag": [P, P, c_int64, P],
     "cr_sgd_step": [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P],
 }

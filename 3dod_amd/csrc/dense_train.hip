@@ -370,3 +370,208 @@ extern "C" int cr_rpn_loss(cr_ctx* ctx, const float* logits, const float* deltas
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// 6. RoI labels before sampling (roi_heads.py:2773-2840, one block per image).
+//    cls (B,R) int64: matched gt class where IoU >= thr, K = background otherwise; -1 for invalid proposals and for
+//    background inside an ignore region (only when the image has > 1 valid background proposals).
+//    keys (2,B,R): (IoU + eps) / e for foreground / background candidates, 0 otherwise.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_roi_label(const float* __restrict__ max_iou, const int* __restrict__ argmax,
+                                                   const float* __restrict__ max_ioa, const unsigned char* __restrict__ valid,
+                                                   const int64_t* __restrict__ gtc, const float* __restrict__ e, int B, int R,
+                                                   int G, int K, float thr, float ignore_thresh, float eps,
+                                                   int64_t* __restrict__ cls, float* __restrict__ matched_iou,
+                                                   float* __restrict__ keys) {
+    __shared__ int s_bg;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t == 0) s_bg = 0;
+    __syncthreads();
+    int c = 0;
+    for (int r = t; r < R; r += 256) {
+        const size_t i = (size_t)b * R + r;
+        c += (!(max_iou[i] >= thr)) && valid[i];
+    }
+    if (c) atomicAdd(&s_bg, c);
+    __syncthreads();
+    const bool many = s_bg > 1;
+    const size_t BR = (size_t)B * R;
+    for (int r = t; r < R; r += 256) {
+        const size_t i = (size_t)b * R + r;
+        const float v = max_iou[i];
+        const bool fg = v >= thr;
+        const bool ign = !fg && many && max_ioa[i] >= ignore_thresh;
+        int64_t cl = K;
+        if (fg) { const int64_t gc = gtc[(size_t)b * G + argmax[i]]; cl = gc > 0 ? gc : 0; }
+        if (ign || !valid[i]) cl = -1;
+        cls[i] = cl;
+        const float mi = fmaxf(v, 0.f);
+        matched_iou[i] = mi;
+        keys[i] = (cl >= 0 && cl < K) ? (mi + eps) / e[i] : 0.f;
+        keys[BR + i] = cl == K ? (mi + eps) / e[BR + i] : 0.f;
+    }
+}
+
+extern "C" int cr_roi_label(cr_ctx* ctx, const float* max_iou, const int* argmax, const float* max_ioa,
+                            const unsigned char* valid, const int64_t* gt_classes, const float* expo, int B, int R, int G,
+                            int K, float thr, float ignore_thresh, float eps, int64_t* cls, float* matched_iou, float* keys) {
+    CR_CHECK_ARG(ctx && max_iou && argmax && max_ioa && valid && gt_classes && expo && cls && matched_iou && keys,
+                 "cr_roi_label: NULL pointer");
+    if (B == 0 || R == 0) return CR_OK;
+    hipLaunchKernelGGL(k_roi_label, dim3(B), dim3(256), 0, ctx->stream, max_iou, argmax, max_ioa, valid, gt_classes, expo, B,
+                       R, G, K, thr, ignore_thresh, eps, cls, matched_iou, keys);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 7. compaction of the sampled picks to n_s slots per image (one block per image, blockDim >= KF + KB, <= 1024):
+//    entries = [foreground picks (KF) | background picks (KB)], valid = key > 0 (background also rank < n_s - n_fg);
+//    a stable partition moves the valid entries to the front ("foreground first"), the first n_s slots are kept.
+//    Outputs per slot: box, valid, class (-1 when invalid), matched gt index; counts (B,2) = [n_fg, n_bg].
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_roi_compact(const int64_t* __restrict__ fidx, const float* __restrict__ fkey, int KF,
+                                                      const int64_t* __restrict__ bidx, const float* __restrict__ bkey, int KB,
+                                                      int n_s, const float* __restrict__ boxes, const int64_t* __restrict__ cls,
+                                                      const int* __restrict__ argmax, int R, float* __restrict__ o_boxes,
+                                                      unsigned char* __restrict__ o_valid, int64_t* __restrict__ o_cls,
+                                                      int64_t* __restrict__ o_gt, int* __restrict__ counts) {
+    __shared__ int s_nfg, s_wv[16], s_wi[16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    if (t == 0) s_nfg = 0;
+    __syncthreads();
+    const bool isf = t < KF, isb = t >= KF && t < KF + KB;
+    const bool fv = isf && fkey[(size_t)b * KF + t] > 0.f;
+    const unsigned long long fm = __ballot(fv);
+    if (lane == 0 && fm) atomicAdd(&s_nfg, __popcll(fm));
+    __syncthreads();
+    const int nfg = s_nfg, limit = n_s - nfg;
+    const bool bv = isb && bkey[(size_t)b * KB + (t - KF)] > 0.f && (t - KF) < limit;
+    const bool v = fv || bv, inv = (isf || isb) && !v;
+    const unsigned long long vm = __ballot(v), im = __ballot(inv);
+    if (lane == 0) { s_wv[wave] = __popcll(vm); s_wi[wave] = __popcll(im); }
+    __syncthreads();
+    int vbefore = 0, ibefore = 0, vtotal = 0;
+    for (int w = 0; w < nw; ++w) {
+        if (w < wave) { vbefore += s_wv[w]; ibefore += s_wi[w]; }
+        vtotal += s_wv[w];
+    }
+    const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    vbefore += __popcll(vm & below);
+    ibefore += __popcll(im & below);
+    if (t == 0) { counts[b * 2] = nfg; counts[b * 2 + 1] = vtotal - nfg; }
+    if (!(isf || isb)) return;
+    const int pos = v ? vbefore : vtotal + ibefore;
+    if (pos >= n_s) return;
+    const int64_t src = isf ? fidx[(size_t)b * KF + t] : bidx[(size_t)b * KB + (t - KF)];
+    const size_t o = (size_t)b * n_s + pos, si = (size_t)b * R + src;
+    *reinterpret_cast<float4*>(o_boxes + o * 4) = *reinterpret_cast<const float4*>(boxes + si * 4);
+    o_valid[o] = v ? 1 : 0;
+    o_cls[o] = v ? cls[si] : -1;
+    o_gt[o] = argmax[si];
+}
+
+extern "C" int cr_roi_compact(cr_ctx* ctx, const int64_t* fg_idx, const float* fg_key, int KF, const int64_t* bg_idx,
+                              const float* bg_key, int KB, int n_s, const float* boxes, const int64_t* cls, const int* argmax,
+                              int B, int R, float* o_boxes, unsigned char* o_valid, int64_t* o_cls, int64_t* o_gt, int* counts) {
+    CR_CHECK_ARG(ctx && fg_idx && fg_key && bg_idx && bg_key && boxes && cls && argmax && o_boxes && o_valid && o_cls && o_gt &&
+                 counts, "cr_roi_compact: NULL pointer");
+    if (B == 0) return CR_OK;
+    CR_CHECK_ARG(KF >= 0 && KB >= 0 && KF + KB >= n_s && KF + KB <= 1024, "cr_roi_compact: n_s <= KF + KB <= 1024 required");
+    const int threads = (int)cr_cdiv(KF + KB, 64) * 64;
+    hipLaunchKernelGGL(k_roi_compact, dim3(B), dim3(threads), 0, ctx->stream, fg_idx, fg_key, KF, bg_idx, bg_key, KB, n_s,
+                       boxes, cls, argmax, R, o_boxes, o_valid, o_cls, o_gt, counts);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 8. Fast R-CNN losses on the padded sample (fast_rcnn.py:145-194): softmax cross-entropy over K+1 classes on the
+//    valid rows, L1 (smooth_l1, beta 0) box regression on the foreground rows' own class, both as sums (the caller
+//    divides by the number of valid rows), with gradients and the decoded boxes of the sampled class.  One wave / row.
+//    sums3 = [sum ce, sum l1, n_valid];  dscores (N,K+1), ddeltas (N,K*4), pred (N,4).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_box_loss(const float* __restrict__ scores, const float* __restrict__ deltas,
+                                                  const unsigned char* __restrict__ valid, const int64_t* __restrict__ cls,
+                                                  const float* __restrict__ pboxes, const int64_t* __restrict__ gt_idx,
+                                                  const float* __restrict__ gtb, int N, int S, int G, int K, float wx, float wy,
+                                                  float ww, float wh, float scale_clamp, float* __restrict__ partial,
+                                                  float* __restrict__ dscores, float* __restrict__ ddeltas,
+                                                  float* __restrict__ pred) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (row < N) {
+        const int C = K + 1;
+        const bool ok = valid[row] != 0;
+        const int64_t c0 = cls[row];
+        const int tcls = (int)(c0 > 0 ? c0 : 0);
+        const float* sr = scores + (size_t)row * C;
+        float m = -INFINITY;
+        for (int j = lane; j < C; j += 64) m = fmaxf(m, sr[j]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        float se = 0.f;
+        for (int j = lane; j < C; j += 64) se += expf(sr[j] - m);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) se += __shfl_xor(se, off, 64);
+        const float lse = m + logf(se);
+        for (int j = lane; j < C; j += 64) {
+            const float p = expf(sr[j] - lse);
+            dscores[(size_t)row * C + j] = ok ? (p - (j == tcls ? 1.f : 0.f)) : 0.f;
+        }
+        const bool fg = ok && c0 >= 0 && c0 < K;
+        const int kcls = tcls < K ? tcls : K - 1;
+        float* dr = ddeltas + (size_t)row * K * 4;
+        for (int j = lane; j < K * 4; j += 64) dr[j] = 0.f;
+        if (lane == 0) {
+            v[0] = ok ? lse - sr[tcls] : 0.f;
+            v[2] = ok ? 1.f : 0.f;
+            const Box pb = ldbox(pboxes + (size_t)row * 4);
+            const float4 d = *reinterpret_cast<const float4*>(deltas + ((size_t)row * K + kcls) * 4);
+            const float sw = pb.x2 - pb.x1, sh = pb.y2 - pb.y1, sx = pb.x1 + 0.5f * sw, sy = pb.y1 + 0.5f * sh;
+            if (fg) {
+                const int b = row / S;
+                const Box g = ldbox(gtb + ((size_t)b * G + gt_idx[row]) * 4);
+                const float tw = g.x2 - g.x1, th = g.y2 - g.y1, tx = g.x1 + 0.5f * tw, ty = g.y1 + 0.5f * th;
+                const float e0 = d.x - wx * (tx - sx) / sw, e1 = d.y - wy * (ty - sy) / sh;
+                const float e2 = d.z - ww * logf(tw / sw), e3 = d.w - wh * logf(th / sh);
+                v[1] = ((fabsf(e0) + fabsf(e1)) + fabsf(e2)) + fabsf(e3);
+                auto sgn = [](float z) { return z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f); };
+                *reinterpret_cast<float4*>(dr + kcls * 4) = make_float4(sgn(e0), sgn(e1), sgn(e2), sgn(e3));
+            }
+            // Box2BoxTransform.apply_deltas of the row's own class
+            const float dx = d.x / wx, dy = d.y / wy, dw = fminf(d.z / ww, scale_clamp), dh = fminf(d.w / wh, scale_clamp);
+            const float pcx = dx * sw + sx, pcy = dy * sh + sy, pw = expf(dw) * sw, ph = expf(dh) * sh;
+            *reinterpret_cast<float4*>(pred + (size_t)row * 4) =
+                make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+        }
+    }
+    __shared__ float red[4][3];
+    if (lane == 0) { red[wave][0] = v[0]; red[wave][1] = v[1]; red[wave][2] = v[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        partial[(size_t)blockIdx.x * 3 + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    }
+}
+
+extern "C" int cr_box_loss(cr_ctx* ctx, const float* scores, const float* deltas, const unsigned char* valid,
+                           const int64_t* cls, const float* prop_boxes, const int64_t* gt_idx, const float* gt_boxes, int B,
+                           int S, int G, int K, const float* weights4, float scale_clamp, float* partial_ws, float* sums3,
+                           float* dscores, float* ddeltas, float* pred) {
+    CR_CHECK_ARG(ctx && scores && deltas && valid && cls && prop_boxes && gt_idx && gt_boxes && weights4 && partial_ws && sums3 &&
+                 dscores && ddeltas && pred, "cr_box_loss: NULL pointer");
+    const int N = B * S;
+    if (N == 0) return CR_OK;
+    CR_CHECK_ARG(K > 0 && G > 0, "cr_box_loss: bad sizes");
+    const int nb = (int)cr_cdiv(N, 4);
+    hipLaunchKernelGGL(k_box_loss, dim3(nb), dim3(256), 0, ctx->stream, scores, deltas, valid, cls, prop_boxes, gt_idx, gt_boxes,
+                       N, S, G, K, weights4[0], weights4[1], weights4[2], weights4[3], scale_clamp, partial_ws, dscores, ddeltas,
+                       pred);
+    CR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, partial_ws, nb, 3, sums3);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

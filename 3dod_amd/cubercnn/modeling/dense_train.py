@@ -218,68 +218,41 @@ def roi_label_and_sample(rh, prop_boxes, prop_scores, gt: GTBatch):
         valid = torch.cat([prop_valid, gt.valid], 1)
     else:
         boxes, valid = prop_boxes, prop_valid
-    iou = pairwise_iou_b(gt.boxes, boxes)                                              # (B,G,R)
-    iou = torch.where(gt.valid[:, :, None], iou, torch.full((), NEG, device=dev))
-    vals, midx = iou.max(dim=1)
-    thr = rh.proposal_matcher.thresholds[1]
-    fg_match = vals >= thr
-    ioa = pairwise_ioa_b(gt.boxes, boxes)
-    ioa = torch.where(gt.ignore[:, :, None], ioa, torch.zeros((), device=dev)).max(dim=1)[0]
-    bg_match = ~fg_match
-    ign = bg_match & (bg_match & valid).sum(1, keepdim=True).gt(1) & (ioa >= rh.ignore_thresh)
-    cls = torch.gather(gt.classes.clamp(min=0), 1, midx)
-    cls = torch.where(fg_match, cls, torch.full((), K, dtype=torch.int64, device=dev))
-    cls = torch.where(ign | ~valid, torch.full((), -1, dtype=torch.int64, device=dev), cls)
-    matched_ious = vals.clamp(min=0)
+    R = boxes.shape[1]
+    max_iou, midx, ioa, _ = ops.box_match(boxes, gt.boxes, gt.classes)
+    expo = torch.empty((2, B, R), device=dev).exponential_(1.0)
+    cls, _, keys = ops.roi_label(max_iou, midx, ioa, valid, gt.classes, expo, K, rh.proposal_matcher.thresholds[1],
+                                 rh.ignore_thresh, 1e-4)
     n_s = rh.batch_size_per_image
-    k_fg = int(n_s * rh.positive_fraction)
-    fidx, fvalid = _take(_keys(matched_ious, (cls >= 0) & (cls < K)), k_fg)
-    n_fg = fvalid.sum(1)
-    bidx, bvalid = _take(_keys(matched_ious, cls == K), n_s, limit=n_s - n_fg)
-    # compact to n_s slots: at most n_s picks are valid, a stable sort by validity moves them to the front while
-    # keeping "foreground first" (the k_fg leading slots still hold every valid foreground pick)
-    idx = torch.cat([fidx, bidx], 1)
-    svalid = torch.cat([fvalid, bvalid], 1)
-    if idx.shape[1] > n_s:
-        order = torch.sort((~svalid).to(torch.int8), dim=1, stable=True)[1][:, :n_s]
-        idx, svalid = torch.gather(idx, 1, order), torch.gather(svalid, 1, order)
-    s_cls = torch.where(svalid, torch.gather(cls, 1, idx), torch.full((), -1, dtype=torch.int64, device=dev))
+    k_fg = min(int(n_s * rh.positive_fraction), R)
+    fkey, fidx = keys[0].topk(k_fg, dim=1)
+    bkey, bidx = keys[1].topk(min(n_s, R), dim=1)
+    # at most n_s picks are valid; the stable compaction keeps "foreground first" (the k_fg leading slots hold every
+    # valid foreground pick)
+    s_boxes, s_valid, s_cls, s_gt, counts = ops.roi_compact(fidx, fkey, bidx, bkey, n_s, boxes, cls, midx)
     storage = get_event_storage()
-    storage.put_scalar("roi_head/num_fg_samples", n_fg.float().mean())
-    storage.put_scalar("roi_head/num_bg_samples", bvalid.sum(1).float().mean())
-    return {"boxes": torch.gather(boxes, 1, idx[:, :, None].expand(-1, -1, 4)), "valid": svalid, "classes": s_cls,
-            "gt_idx": torch.gather(midx, 1, idx), "k_fg": fidx.shape[1]}
+    cm = counts.float().mean(0)
+    storage.put_scalar("roi_head/num_fg_samples", cm[0])
+    storage.put_scalar("roi_head/num_bg_samples", cm[1])
+    return {"boxes": s_boxes, "valid": s_valid, "classes": s_cls, "gt_idx": s_gt, "k_fg": k_fg}
 
 
 def box_head_losses(rh, features, samp, gt: GTBatch):
     """_forward_box in training (roi_heads.py:2160-2204) + FastRCNNOutputs.losses (fast_rcnn.py:145-194) on the padded
     sample.  Returns (losses, pred_boxes (B,S,4) for the sampled classes)."""
     B, S = samp["valid"].shape
-    K = rh.num_classes
     feats = [features[f] for f in rh.box_in_features]
     box_features = rh.box_head(rh.box_pooler(feats, [Boxes(b) for b in samp["boxes"]]))
     scores, deltas = rh.box_predictor(box_features)                                    # (B*S,K+1), (B*S,K*4)
-    valid = samp["valid"].reshape(-1)
-    cls = samp["classes"].reshape(-1)
-    n_valid = valid.sum().clamp(min=1)
-    ce = F.cross_entropy(scores, cls.clamp(min=0), reduction="none")
-    loss_cls = (ce * valid).sum() / n_valid
-    fg = valid & (cls >= 0) & (cls < K)
-    pb = samp["boxes"].reshape(-1, 4)
-    gb = torch.gather(gt.boxes, 1, samp["gt_idx"][:, :, None].expand(-1, -1, 4)).reshape(-1, 4)
-    gb = torch.where(fg[:, None], gb, pb)                                              # sanitise unused targets
-    tgt = rh.box_predictor.box2box_transform.get_deltas(pb, gb)
-    ar = torch.arange(B * S, device=pb.device)
-    sel = deltas.view(B * S, K, 4)[ar, cls.clamp(0, K - 1)]
     assert rh.box_predictor.smooth_l1_beta < 1e-5
-    l1 = torch.where(fg[:, None], (sel - tgt).abs(), torch.zeros((), device=pb.device))
-    loss_box = l1.sum() / n_valid
+    t = rh.box_predictor.box2box_transform
+    sum_ce, sum_l1, sums, pred = ops.box_loss(scores, deltas, samp["valid"], samp["classes"], samp["boxes"], samp["gt_idx"],
+                                              gt.boxes, t.weights, t.scale_clamp)
+    n_valid = sums[2].clamp(min=1)
     lw = rh.box_predictor.loss_weight
-    losses = {"BoxHead/loss_cls": loss_cls * lw.get("BoxHead/loss_cls", 1.0),
-              "BoxHead/loss_box_reg": loss_box * lw.get("BoxHead/loss_box_reg", 1.0)}
-    with torch.no_grad():
-        pred = rh.box_predictor.box2box_transform.apply_deltas(sel, pb).view(B, S, 4)
-    return losses, pred
+    losses = {"BoxHead/loss_cls": sum_ce / n_valid * lw.get("BoxHead/loss_cls", 1.0),
+              "BoxHead/loss_box_reg": sum_l1 / n_valid * lw.get("BoxHead/loss_box_reg", 1.0)}
+    return losses, pred.view(B, S, 4)
 
 
 _SAFE = {}

@@ -587,6 +587,69 @@ def rpn_loss(logits, deltas, anchors, labels, midx, gt_boxes, weights):
     return _RPNLoss.apply(logits, deltas, anchors, labels, midx, gt_boxes, tuple(weights))
 
 
+def roi_label(max_iou, argmax, max_ioa, valid, gt_classes, expo, K, thr, ignore_thresh, eps):
+    B, R = max_iou.shape
+    dev = max_iou.device
+    cls = torch.empty((B, R), dtype=torch.int64, device=dev)
+    miou = torch.empty((B, R), dtype=f32, device=dev)
+    keys = torch.empty((2, B, R), dtype=f32, device=dev)
+    lib = _lib.load()
+    _chk(lib.cr_roi_label(_ctx(max_iou), _p(max_iou), _p(argmax), _p(max_ioa), _p(valid.to(torch.uint8).contiguous()),
+                          _p(gt_classes.contiguous()), _p(expo.contiguous()), B, R, gt_classes.shape[1], int(K), float(thr),
+                          float(ignore_thresh), float(eps), _p(cls), _p(miou), _p(keys)), "cr_roi_label")
+    return cls, miou, keys
+
+
+def roi_compact(fg_idx, fg_key, bg_idx, bg_key, n_s, boxes, cls, argmax):
+    """-> boxes (B,n_s,4), valid (B,n_s) bool, classes (B,n_s) int64, gt_idx (B,n_s) int64, counts (B,2) int32."""
+    B, R = cls.shape
+    dev = cls.device
+    ob = torch.empty((B, n_s, 4), dtype=f32, device=dev)
+    ov = torch.empty((B, n_s), dtype=torch.uint8, device=dev)
+    oc = torch.empty((B, n_s), dtype=torch.int64, device=dev)
+    og = torch.empty((B, n_s), dtype=torch.int64, device=dev)
+    counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    _chk(lib.cr_roi_compact(_ctx(cls), _p(fg_idx.contiguous()), _p(fg_key.contiguous()), fg_idx.shape[1],
+                            _p(bg_idx.contiguous()), _p(bg_key.contiguous()), bg_idx.shape[1], int(n_s), _p(boxes.contiguous()),
+                            _p(cls), _p(argmax), B, R, _p(ob), _p(ov), _p(oc), _p(og), _p(counts)), "cr_roi_compact")
+    return ob, ov.bool(), oc, og, counts
+
+
+class _BoxLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, deltas, valid, cls, pboxes, gt_idx, gt_boxes, weights, scale_clamp):
+        B, S = valid.shape
+        N, C = scores.shape
+        K = C - 1
+        dev = scores.device
+        nb = (N + 3) // 4
+        ws = torch.empty((nb * 3,), dtype=f32, device=dev)
+        sums = torch.empty((3,), dtype=f32, device=dev)
+        ds = torch.empty((N, C), dtype=f32, device=dev)
+        dd = torch.empty((N, K * 4), dtype=f32, device=dev)
+        pred = torch.empty((N, 4), dtype=f32, device=dev)
+        lib = _lib.load()
+        _chk(lib.cr_box_loss(_ctx(scores), _p(scores.detach().float().contiguous()), _p(deltas.detach().float().contiguous()),
+                             _p(valid.to(torch.uint8).contiguous()), _p(cls.contiguous()), _p(pboxes.contiguous()),
+                             _p(gt_idx.contiguous()), _p(gt_boxes.contiguous()), B, S, gt_boxes.shape[1], K, _f4(weights),
+                             float(scale_clamp), _p(ws), _p(sums), _p(ds), _p(dd), _p(pred)), "cr_box_loss")
+        ctx.save_for_backward(ds, dd)
+        ctx.dt = (scores.dtype, deltas.dtype)
+        ctx.mark_non_differentiable(sums, pred)
+        return sums[0], sums[1], sums, pred
+
+    @staticmethod
+    def backward(ctx, g_ce, g_l1, _gs, _gp):
+        ds, dd = ctx.saved_tensors
+        return (ds * g_ce).to(ctx.dt[0]), (dd * g_l1).to(ctx.dt[1]), None, None, None, None, None, None, None
+
+
+def box_loss(scores, deltas, valid, cls, pboxes, gt_idx, gt_boxes, weights, scale_clamp):
+    """-> (sum CE, sum L1, sums3 = [.., .., n_valid], pred (N,4)); valid/cls/gt_idx (B,S), pboxes (B,S,4)."""
+    return _BoxLoss.apply(scores, deltas, valid, cls, pboxes, gt_idx, gt_boxes, tuple(weights), scale_clamp)
+
+
 # --------------------------------------------------------------------------
 # optimizer
 # --------------------------------------------------------------------------

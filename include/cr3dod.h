@@ -209,6 +209,28 @@ int cr_rpn_loss(cr_ctx* ctx, const float* logits, const float* deltas, const flo
                 const int* matched_idx, const float* gt_boxes, int B, int A, int G, const float* weights4,
                 float* partial_ws, float* sums6, float* dlogits, float* ddeltas);
 
+/* ---- static-shape training glue of the RoI heads (3dod_amd/csrc/dense_train.hip) -------------------------------
+ * cubercnn/modeling/roi_heads/roi_heads.py:2773-2840 (label_and_sample_proposals with ignore regions) and
+ * cubercnn/modeling/roi_heads/fast_rcnn.py:145-194 (FastRCNNOutputs.losses), batched and sync-free. */
+
+/* labels before sampling from cr_box_match's outputs.  valid (B,R) u8 = real proposal; K = number of classes
+ * (= background label).  cls (B,R) int64 in {-1, 0..K}; keys (2,B,R) = fg / bg sampling keys (expo (2,B,R) ~ Exp(1)). */
+int cr_roi_label(cr_ctx* ctx, const float* max_iou, const int* argmax, const float* max_ioa, const unsigned char* valid,
+                 const int64_t* gt_classes, const float* expo, int B, int R, int G, int K, float thr, float ignore_thresh,
+                 float eps, int64_t* cls, float* matched_iou, float* keys);
+/* stable compaction of [fg picks (KF) | bg picks (KB)] (top-k of the keys) to n_s slots per image, valid picks first.
+ * outputs (B,n_s,..): boxes, valid u8, cls (-1 = empty slot), matched gt index; counts (B,2) int32 = [n_fg, n_bg]. */
+int cr_roi_compact(cr_ctx* ctx, const int64_t* fg_idx, const float* fg_key, int KF, const int64_t* bg_idx,
+                   const float* bg_key, int KB, int n_s, const float* boxes, const int64_t* cls, const int* argmax, int B,
+                   int R, float* o_boxes, unsigned char* o_valid, int64_t* o_cls, int64_t* o_gt, int* counts);
+/* scores (B*S,K+1), deltas (B*S,K*4) f32.  sums3 = [sum CE over valid rows, sum L1 over fg rows, n_valid];
+ * dscores/ddeltas = gradients of those sums; pred (B*S,4) = boxes decoded with each row's own class.
+ * partial_ws: ceil(B*S/4)*3 floats. */
+int cr_box_loss(cr_ctx* ctx, const float* scores, const float* deltas, const unsigned char* valid, const int64_t* cls,
+                const float* prop_boxes, const int64_t* gt_idx, const float* gt_boxes, int B, int S, int G, int K,
+                const float* weights4, float scale_clamp, float* partial_ws, float* sums3, float* dscores, float* ddeltas,
+                float* pred);
+
 /* ---- optimizer (tools/train_net.py:233-266, cubercnn/solver/build.py:50-56) ------------- */
 int cr_nonfinite_flag(cr_ctx* ctx, const float* g, int64_t n, int* flag);
 /* SGD momentum on flat f32 buffers; skipped on device when *skip_flag != 0 (may be NULL). */

@@ -108,3 +108,48 @@ def test_rpn_label_scatter_and_loss():
     assert abs(float(lc) - float(rc)) < 1e-5 * max(1, abs(float(rc))) and abs(float(ll) - float(rl)) < 1e-5 * max(1, abs(float(rl)))
     assert torch.allclose(lg.grad.cpu(), lr_.grad, rtol=1e-5, atol=1e-6)
     assert torch.allclose(dg.grad.cpu(), dr_.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_roi_label_compact_and_box_loss():
+    B, G, R, K = 3, 8, 600, 5
+    gtb, gtc = _gt(B, G, 11)
+    g = torch.Generator().manual_seed(12)
+    ctr = torch.rand(B, R, 2, generator=g) * 256
+    wh = torch.rand(B, R, 2, generator=g) * 90 + 6
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).clamp(0, 256)
+    boxes[:, :G] = gtb                                   # some exact hits -> foreground
+    boxes[:, G:3 * G] = gtb.repeat(1, 2, 1) + torch.randn(B, 2 * G, 4, generator=g) * 3
+    valid = torch.rand(B, R, generator=g) > 0.1
+    valid[B - 1] = torch.rand(R, generator=g) > 0.9      # fewer valid proposals than sample slots -> empty slots
+    expo = torch.empty(2, B, R).exponential_(1.0, generator=g)
+    mi, am, ma, _ = ops.box_match(boxes.to(DEV), gtb.to(DEV), gtc.to(DEV))
+    rmi, ram, rma, _ = O.box_match(boxes, gtb, gtc)
+    cls, miou, keys = ops.roi_label(mi, am, ma, valid.to(DEV), gtc.to(DEV), expo.to(DEV), K, 0.5, 0.5, 1e-4)
+    rcls, rmiou, rkeys = O.roi_label(rmi, ram, rma, valid, gtc, expo, K, 0.5, 0.5, 1e-4)
+    assert torch.equal(cls.cpu(), rcls) and torch.equal(miou.cpu(), rmiou)
+    assert torch.allclose(keys.cpu(), rkeys, rtol=1e-6, atol=0)
+    assert int(((rcls >= 0) & (rcls < K)).sum()) > 0 and int((rcls == -1).sum()) > 0 and int((rcls == K).sum()) > 0
+    n_s, kf = 128, 32
+    fkey, fidx = rkeys[0].topk(kf, dim=1)
+    bkey, bidx = rkeys[1].topk(n_s, dim=1)
+    outs = ops.roi_compact(fidx.to(DEV), fkey.to(DEV), bidx.to(DEV), bkey.to(DEV), n_s, boxes.to(DEV), cls, am)
+    refs = O.roi_compact(fidx, fkey, bidx, bkey, n_s, boxes, rcls, ram)
+    for a, b in zip(outs, refs):
+        assert torch.equal(a.cpu(), b), (a.shape, a.dtype)
+    s_boxes, s_valid, s_cls, s_gt, counts = refs
+    assert int(counts[:, 0].sum()) > 0 and int(counts[:, 1].sum()) > 0 and not bool(s_valid.all())
+    # Fast R-CNN losses on that sample
+    N = B * n_s
+    scores = torch.randn(N, K + 1, generator=g)
+    deltas = torch.randn(N, K * 4, generator=g) * 0.3
+    w, clamp = (10.0, 10.0, 5.0, 5.0), 4.135
+    sg, dg = scores.to(DEV).requires_grad_(), deltas.to(DEV).requires_grad_()
+    ce, l1, sums, pred = ops.box_loss(sg, dg, outs[1], outs[2], outs[0], outs[3], gtb.to(DEV), w, clamp)
+    (ce * 0.3 + l1 * 1.7).backward()
+    sr, dr = scores.clone().requires_grad_(), deltas.clone().requires_grad_()
+    rce, rl1, rsums, rpred = O.box_loss(sr, dr, s_valid, s_cls, s_boxes, s_gt, gtb, w, clamp)
+    (rce * 0.3 + rl1 * 1.7).backward()
+    assert torch.allclose(sums.cpu(), rsums, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(pred.cpu(), rpred, rtol=1e-5, atol=1e-3)
+    assert torch.allclose(sg.grad.cpu(), sr.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(dg.grad.cpu(), dr.grad, rtol=1e-5, atol=1e-6)
