@@ -308,3 +308,259 @@ extern "C" int cr_cube_loss_bwd(cr_ctx* ctx, const float* const* inputs, int64_t
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Glue around the fused loss on the static-shape training path (ROIHeads3D._forward_cube, roi_heads.py:2237-2679):
+//   cr_cube_select       per-RoI gather of the RoI's own class from the fused predictor output (n, 13K) =
+//                        [deltas 2K | dims 3K | pose6d 6K | z K | uncert K], 6D -> rotation matrix (Gram-Schmidt,
+//                        pytorch3d rotation_6d_to_matrix [third-party, restated]), uncertainty clip(0.01), the matched
+//                        ground truth (sanitised on empty slots), camera constants and dimension priors
+//   cr_cube_select_bwd   the transpose: dense gradient of the predictor output (zeros off the RoI's class)
+//   cr_cube_reduce(_bwd) safely_reduce_losses (roi_heads.py:2843-2851) of the five losses + the uncertainty over the
+//                        valid RoIs, optional inverse-z weighting (:2607-2611), and the logged error statistics.
+// `buf` (39, n) chunks, each (n,d) contiguous, in CubeIn order without src_boxes:
+//   dxy 2 | zr 1 | dr 3 | Ra 9 | u 1 | K4 4 | v2r 1 | prior_mean 3 | gt2d 2 | gtz 1 | gtdims 3 | gtR 9
+// ---------------------------------------------------------------------------------------------------------------
+struct CubeSel {
+    const float* raw; int ld, o_d2, o_dims, o_pose, o_z, o_unc, K;
+    const int64_t* cls; const unsigned char* valid; const int64_t* gt_idx;   // (B,S) rows, first kf columns used
+    int S, kf, G, n;
+    const float* gt3d; const float* gtpose; const float* priors; const float* meta;
+};
+__device__ __constant__ int CUBE_OFF[12] = {0, 2, 3, 6, 15, 16, 20, 21, 24, 26, 27, 30};   // chunk starts (x n)
+
+__device__ __forceinline__ void rot6d(const float* a, float* R, float* n1, float* nu) {
+    const float l1 = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), 1e-12f);
+    const float b1[3] = {a[0] / l1, a[1] / l1, a[2] / l1};
+    const float d = b1[0] * a[3] + b1[1] * a[4] + b1[2] * a[5];
+    const float u[3] = {a[3] - d * b1[0], a[4] - d * b1[1], a[5] - d * b1[2]};
+    const float lu = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-12f);
+    const float b2[3] = {u[0] / lu, u[1] / lu, u[2] / lu};
+    R[0] = b1[0]; R[1] = b1[1]; R[2] = b1[2];
+    R[3] = b2[0]; R[4] = b2[1]; R[5] = b2[2];
+    R[6] = b1[1] * b2[2] - b1[2] * b2[1]; R[7] = b1[2] * b2[0] - b1[0] * b2[2]; R[8] = b1[0] * b2[1] - b1[1] * b2[0];
+    *n1 = l1; *nu = lu;
+}
+
+__global__ __launch_bounds__(64) void k_cube_select(CubeSel p, float* __restrict__ buf, unsigned char* __restrict__ validf,
+                                                    int* __restrict__ clsc) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= p.n) return;
+    const int b = i / p.kf, j = i - b * p.kf;
+    const size_t bs = (size_t)b * p.S + j;
+    const int64_t c0 = p.cls[bs];
+    const bool v = p.valid[bs] && c0 >= 0 && c0 < p.K;
+    const int c = (int)(c0 < 0 ? 0 : (c0 >= p.K ? p.K - 1 : c0));
+    validf[i] = v ? 1 : 0;
+    clsc[i] = c;
+    const float* r = p.raw + (size_t)i * p.ld;
+    const size_t n = p.n;
+    float* o = buf;
+    o[CUBE_OFF[0] * n + i * 2] = r[p.o_d2 + c * 2]; o[CUBE_OFF[0] * n + i * 2 + 1] = r[p.o_d2 + c * 2 + 1];
+    o[CUBE_OFF[1] * n + i] = r[p.o_z + c];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[CUBE_OFF[2] * n + i * 3 + k] = r[p.o_dims + c * 3 + k];
+    float a[6], R[9], l1, lu;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] = r[p.o_pose + c * 6 + k];
+    rot6d(a, R, &l1, &lu);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[CUBE_OFF[3] * n + i * 9 + k] = R[k];
+    o[CUBE_OFF[4] * n + i] = fmaxf(r[p.o_unc + c], 0.01f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[CUBE_OFF[5] * n + i * 4 + k] = p.meta[b * 5 + k];
+    o[CUBE_OFF[6] * n + i] = p.meta[b * 5 + 4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[CUBE_OFF[7] * n + i * 3 + k] = p.priors ? p.priors[c * 3 + k] : 1.f;
+    const int64_t gi = p.gt_idx[bs];
+    const float* g3 = p.gt3d + ((size_t)b * p.G + gi) * 9;
+    const float safe[6] = {256.f, 256.f, 5.f, 1.f, 1.f, 1.f};      // a unit cube 5 m in front of the camera
+    o[CUBE_OFF[8] * n + i * 2] = v ? g3[0] : safe[0]; o[CUBE_OFF[8] * n + i * 2 + 1] = v ? g3[1] : safe[1];
+    o[CUBE_OFF[9] * n + i] = v ? g3[2] : safe[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[CUBE_OFF[10] * n + i * 3 + k] = v ? g3[3 + k] : safe[3 + k];
+    const float* gp = p.gtpose + ((size_t)b * p.G + gi) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[CUBE_OFF[11] * n + i * 9 + k] = gp[k];
+}
+
+// one wave per RoI: lane 0 back-propagates to the 13 selected predictor outputs, the wave writes the dense row
+__global__ __launch_bounds__(64) void k_cube_select_bwd(CubeSel p, const unsigned char* __restrict__ validf,
+                                                        const int* __restrict__ clsc, const float* __restrict__ g_dxy,
+                                                        const float* __restrict__ g_zr, const float* __restrict__ g_dr,
+                                                        const float* __restrict__ g_Ra, const float* __restrict__ g_u,
+                                                        const float* __restrict__ g_usel, float* __restrict__ g_raw) {
+    __shared__ float s[13];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int c = clsc[i];
+    const bool v = validf[i] != 0;
+    const float* r = p.raw + (size_t)i * p.ld;
+    if (lane == 0) {
+        if (!v) {
+            for (int k = 0; k < 13; ++k) s[k] = 0.f;
+        } else {
+            s[0] = g_dxy[i * 2]; s[1] = g_dxy[i * 2 + 1];
+            s[2] = g_dr[i * 3]; s[3] = g_dr[i * 3 + 1]; s[4] = g_dr[i * 3 + 2];
+            float a[6], R[9], l1, lu;
+            for (int k = 0; k < 6; ++k) a[k] = r[p.o_pose + c * 6 + k];
+            rot6d(a, R, &l1, &lu);
+            const float* gR = g_Ra + (size_t)i * 9;
+            const float* b1 = R; const float* b2 = R + 3;
+            // b3 = b1 x b2
+            float gb1[3] = {gR[0] + (b2[1] * gR[8] - b2[2] * gR[7]), gR[1] + (b2[2] * gR[6] - b2[0] * gR[8]),
+                            gR[2] + (b2[0] * gR[7] - b2[1] * gR[6])};
+            float gb2[3] = {gR[3] + (gR[7] * b1[2] - gR[8] * b1[1]), gR[4] + (gR[8] * b1[0] - gR[6] * b1[2]),
+                            gR[5] + (gR[6] * b1[1] - gR[7] * b1[0])};
+            // b2 = u / |u|
+            const float dot2 = gb2[0] * b2[0] + gb2[1] * b2[1] + gb2[2] * b2[2];
+            float gu[3] = {(gb2[0] - dot2 * b2[0]) / lu, (gb2[1] - dot2 * b2[1]) / lu, (gb2[2] - dot2 * b2[2]) / lu};
+            // u = a2 - d b1, d = b1 . a2
+            const float d = b1[0] * a[3] + b1[1] * a[4] + b1[2] * a[5];
+            const float gd = -(gu[0] * b1[0] + gu[1] * b1[1] + gu[2] * b1[2]);
+            float ga2[3] = {gu[0] + gd * b1[0], gu[1] + gd * b1[1], gu[2] + gd * b1[2]};
+            for (int k = 0; k < 3; ++k) gb1[k] += -d * gu[k] + gd * a[3 + k];
+            // b1 = a1 / |a1|
+            const float dot1 = gb1[0] * b1[0] + gb1[1] * b1[1] + gb1[2] * b1[2];
+            for (int k = 0; k < 3; ++k) { s[5 + k] = (gb1[k] - dot1 * b1[k]) / l1; s[8 + k] = ga2[k]; }
+            s[11] = g_zr[i];
+            s[12] = r[p.o_unc + c] >= 0.01f ? g_u[i] + g_usel[i] : 0.f;      // clip(0.01) passes the gradient where raw >= 0.01
+        }
+    }
+    __syncthreads();
+    float* g = g_raw + (size_t)i * p.ld;
+    for (int col = lane; col < p.ld; col += 64) {
+        float val = 0.f;
+        int e;
+        if ((e = col - (p.o_d2 + c * 2)) >= 0 && e < 2) val = s[e];
+        else if ((e = col - (p.o_dims + c * 3)) >= 0 && e < 3) val = s[2 + e];
+        else if ((e = col - (p.o_pose + c * 6)) >= 0 && e < 6) val = s[5 + e];
+        else if (col == p.o_z + c) val = s[11];
+        else if (col == p.o_unc + c) val = s[12];
+        g[col] = val;
+    }
+}
+
+static int cube_sel_args(CubeSel& p, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
+                         const unsigned char* valid, const int64_t* gt_idx, int B, int S, int kf, int G, const float* gt3d,
+                         const float* gtpose, const float* priors, const float* meta) {
+    CR_CHECK_ARG(raw && layout5 && cls && valid && gt_idx && gt3d && gtpose && meta, "cube_select: NULL pointer");
+    CR_CHECK_ARG(B > 0 && kf > 0 && kf <= S && G > 0 && K > 0 && ld >= 13 * K, "cube_select: bad sizes");
+    p.raw = raw; p.ld = ld; p.o_d2 = layout5[0]; p.o_dims = layout5[1]; p.o_pose = layout5[2]; p.o_z = layout5[3];
+    p.o_unc = layout5[4]; p.K = K; p.cls = cls; p.valid = valid; p.gt_idx = gt_idx; p.S = S; p.kf = kf; p.G = G; p.n = B * kf;
+    p.gt3d = gt3d; p.gtpose = gtpose; p.priors = priors; p.meta = meta;
+    return CR_OK;
+}
+
+extern "C" int cr_cube_select(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
+                              const unsigned char* valid, const int64_t* gt_idx, int B, int S, int kf, int G,
+                              const float* gt3d, const float* gtpose, const float* priors, const float* meta, float* buf39,
+                              unsigned char* validf, int* clsc) {
+    CR_CHECK_ARG(ctx && buf39 && validf && clsc, "cr_cube_select: NULL pointer");
+    CubeSel p;
+    int rc = cube_sel_args(p, raw, ld, layout5, K, cls, valid, gt_idx, B, S, kf, G, gt3d, gtpose, priors, meta);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cube_select, dim3((unsigned)cr_cdiv(p.n, 64)), dim3(64), 0, ctx->stream, p, buf39, validf, clsc);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+extern "C" int cr_cube_select_bwd(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, int B, int kf,
+                                  const unsigned char* validf, const int* clsc, const float* g_dxy, const float* g_zr,
+                                  const float* g_dr, const float* g_Ra, const float* g_u, const float* g_usel, float* g_raw) {
+    CR_CHECK_ARG(ctx && raw && layout5 && validf && clsc && g_dxy && g_zr && g_dr && g_Ra && g_u && g_usel && g_raw,
+                 "cr_cube_select_bwd: NULL pointer");
+    CubeSel p = {};
+    p.raw = raw; p.ld = ld; p.o_d2 = layout5[0]; p.o_dims = layout5[1]; p.o_pose = layout5[2]; p.o_z = layout5[3];
+    p.o_unc = layout5[4]; p.K = K; p.kf = kf; p.n = B * kf;
+    if (p.n == 0) return CR_OK;
+    hipLaunchKernelGGL(k_cube_select_bwd, dim3(p.n), dim3(64), 0, ctx->stream, p, validf, clsc, g_dxy, g_zr, g_dr, g_Ra, g_u,
+                       g_usel, g_raw);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// red (6) = mean over the valid, finite entries of [dims, xy, z, pose, joint] (x inverse-z weight) and of the uncertainty
+// (0 when there is none); cnt (6); stats (4) = mean |z|, |dims|, |xy| errors and mean exp(-u) over the valid RoIs.
+__global__ __launch_bounds__(256) void k_cube_reduce(const float* __restrict__ L, const float* __restrict__ buf,
+                                                     const float* __restrict__ dec, const unsigned char* __restrict__ validf,
+                                                     int n, int inverse_z, float* __restrict__ red, float* __restrict__ cnt,
+                                                     float* __restrict__ stats) {
+    __shared__ float sm[256][17];
+    const int t = threadIdx.x;
+    float acc[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) acc[k] = 0.f;
+    const size_t N = n;
+    for (int i = t; i < n; i += 256) {
+        if (!validf[i]) continue;
+        const float gz = buf[CUBE_OFF[9] * N + i], u = buf[CUBE_OFF[4] * N + i];
+        const float w = inverse_z ? 1.f / logf(fmaxf(gz, 2.71828183f)) : 1.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float x = L[(size_t)i * 5 + k] * w;
+            if (isfinite(x)) { acc[k] += x; acc[6 + k] += 1.f; }
+        }
+        if (isfinite(u)) { acc[5] += u; acc[11] += 1.f; }
+        acc[12] += fabsf(dec[(size_t)i * 17 + 2] - gz);
+        acc[13] += (fabsf(dec[(size_t)i * 17 + 3] - buf[CUBE_OFF[10] * N + i * 3]) +
+                    fabsf(dec[(size_t)i * 17 + 4] - buf[CUBE_OFF[10] * N + i * 3 + 1])) +
+                   fabsf(dec[(size_t)i * 17 + 5] - buf[CUBE_OFF[10] * N + i * 3 + 2]);
+        acc[14] += fabsf(dec[(size_t)i * 17] - buf[CUBE_OFF[8] * N + i * 2]) + fabsf(dec[(size_t)i * 17 + 1] - buf[CUBE_OFF[8] * N + i * 2 + 1]);
+        acc[15] += expf(-u);
+        acc[16] += 1.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 17; ++k) sm[t][k] = acc[k];
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {                 // fixed-order tree: bitwise reproducible
+        if (t < s) {
+#pragma unroll
+            for (int k = 0; k < 17; ++k) sm[t][k] += sm[t + s][k];
+        }
+        __syncthreads();
+    }
+    if (t < 6) {
+        const float c = sm[0][6 + t];
+        red[t] = c > 0.f ? sm[0][t] / c : 0.f;
+        cnt[t] = c;
+    }
+    if (t == 0) {
+        const float nv = fmaxf(sm[0][16], 1.f);
+        stats[0] = sm[0][12] / nv; stats[1] = sm[0][13] / (3.f * nv); stats[2] = sm[0][14] / (2.f * nv); stats[3] = sm[0][15] / nv;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cube_reduce_bwd(const float* __restrict__ L, const float* __restrict__ buf,
+                                                         const unsigned char* __restrict__ validf, int n, int inverse_z,
+                                                         const float* __restrict__ cnt, const float* __restrict__ gred,
+                                                         float* __restrict__ gL, float* __restrict__ gu) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = n;
+    const bool v = validf[i] != 0;
+    const float gz = buf[CUBE_OFF[9] * N + i], u = buf[CUBE_OFF[4] * N + i];
+    const float w = inverse_z ? 1.f / logf(fmaxf(gz, 2.71828183f)) : 1.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float x = L[(size_t)i * 5 + k] * w;
+        gL[(size_t)i * 5 + k] = (v && isfinite(x) && cnt[k] > 0.f) ? gred[k] * w / cnt[k] : 0.f;
+    }
+    gu[i] = (v && isfinite(u) && cnt[5] > 0.f) ? gred[5] / cnt[5] : 0.f;
+}
+
+extern "C" int cr_cube_reduce(cr_ctx* ctx, const float* L, const float* buf39, const float* dec, const unsigned char* validf,
+                              int n, int inverse_z, float* red6, float* cnt6, float* stats4) {
+    CR_CHECK_ARG(ctx && L && buf39 && dec && validf && red6 && cnt6 && stats4 && n > 0, "cr_cube_reduce: bad args");
+    hipLaunchKernelGGL(k_cube_reduce, dim3(1), dim3(256), 0, ctx->stream, L, buf39, dec, validf, n, inverse_z, red6, cnt6, stats4);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+extern "C" int cr_cube_reduce_bwd(cr_ctx* ctx, const float* L, const float* buf39, const unsigned char* validf, int n,
+                                  int inverse_z, const float* cnt6, const float* gred6, float* gL, float* gu) {
+    CR_CHECK_ARG(ctx && L && buf39 && validf && cnt6 && gred6 && gL && gu && n > 0, "cr_cube_reduce_bwd: bad args");
+    hipLaunchKernelGGL(k_cube_reduce_bwd, dim3((unsigned)cr_cdiv(n, 256)), dim3(256), 0, ctx->stream, L, buf39, validf, n,
+                       inverse_z, cnt6, gred6, gL, gu);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

@@ -255,64 +255,40 @@ def box_head_losses(rh, features, samp, gt: GTBatch):
     return losses, pred.view(B, S, 4)
 
 
-_SAFE = {}
-
-
 def cube_head_losses(rh, features, samp, pred_boxes, gt: GTBatch, meta):
-    """_forward_cube in training (roi_heads.py:2237-2679) on the k_fg foreground slots of every image; invalid slots
-    are masked out of the reductions (their per-RoI losses are set to +inf, which safely_reduce_losses ignores)."""
+    """_forward_cube in training (roi_heads.py:2237-2679) on the k_fg foreground slots of every image.  Empty slots
+    are excluded from the reductions (safely_reduce_losses, roi_heads.py:2843-2851) by their validity flag."""
     B, kf = samp["valid"].shape[0], samp["k_fg"]
-    dev = samp["boxes"].device
     K = rh.num_classes
     boxes = samp["boxes"][:, :kf]
-    valid = (samp["valid"][:, :kf] & (samp["classes"][:, :kf] >= 0) & (samp["classes"][:, :kf] < K)).reshape(-1)
-    cls = samp["classes"][:, :kf].clamp(0, K - 1).reshape(-1)
-    gi = samp["gt_idx"][:, :kf]
     n = B * kf
-    g3 = torch.gather(gt.boxes3D, 1, gi[:, :, None].expand(-1, -1, 9)).reshape(n, 9)
-    gp = torch.gather(gt.poses, 1, gi[:, :, None, None].expand(-1, -1, 3, 3)).reshape(n, 3, 3)
-    # sanitise unused slots so that no NaN / Inf enters the kernel: a unit cube 5 m in front of the camera
-    safe = _SAFE.get(str(dev))
-    if safe is None:
-        safe = _SAFE[str(dev)] = torch.tensor([256., 256, 5, 1, 1, 1, 0, 0, 5], device=dev)
-    g3 = torch.where(valid[:, None], g3, safe)
     scaled = rh.scale_proposals([Boxes(b) for b in boxes])
     feats = [features[f] for f in rh.in_features]
     cube_features = rh.cube_pooler(feats, scaled).flatten(1)
-    K4 = meta[:, None, :4].expand(B, kf, 4).reshape(n, 4)
-    v2r = meta[:, None, 4].expand(B, kf).reshape(n)
-    d2, z, dims, pose, unc = rh.cube_head(cube_features)
-    ar = torch.arange(n, device=dev)
-    d2, z, dims, pose, unc = d2[ar, cls], z[ar, cls, 0], dims[ar, cls], pose[ar, cls], unc[ar, cls]
-    pm = rh.priors_dims_per_cat.detach()[0][cls][:, 0, :] if rh.dims_priors_enabled else torch.ones(n, 3, device=dev)
+    raw, layout = rh.cube_head.forward_fused(cube_features)
     assert rh.use_confidence > 0 and rh.dims_priors_func == "exp"
-    L, dec = ops.cube_decode_loss(d2, z, dims, pose, unc, boxes.reshape(n, 4), K4, v2r, pm, g3[:, :2], g3[:, 2], g3[:, 3:6],
-                                  gp, allocentric=rh.allocentric_pose, chamfer_pose=rh.chamfer_pose, use_conf=True,
-                                  joint=rh.loss_w_joint > 0)
-    inf = torch.full((), float("inf"), device=dev)
-    L = torch.where(valid[:, None], L, inf)
-    unc_m = torch.where(valid, unc, inf)
+    priors = rh.priors_dims_per_cat.detach()[0, :, 0, :].contiguous() if rh.dims_priors_enabled else None
+    L, u_sel, dec, buf, validf = ops.cube_head_loss(raw, layout, K, samp["classes"], samp["valid"], samp["gt_idx"], kf,
+                                                    gt.boxes3D, gt.poses, priors, meta, boxes.reshape(n, 4),
+                                                    allocentric=rh.allocentric_pose, chamfer_pose=rh.chamfer_pose,
+                                                    use_conf=True, joint=rh.loss_w_joint > 0)
+    red, stats = ops.cube_reduce(L, u_sel, buf, dec, validf, inverse_z=bool(rh.inverse_z_weight))
     p = "Cube/"
-    red = rh.safely_reduce_losses
     w3 = rh.loss_w_3d
-    if rh.inverse_z_weight:
-        L = L * (1 / torch.log(g3[:, 2].clip(2.71828183)))[:, None]
-    losses = {p + "uncert": rh.use_confidence * red(unc_m, absent_if_none=True),
-              p + "loss_xy": red(L[:, 1], absent_if_none=True) * rh.loss_w_xy * w3,
-              p + "loss_z": red(L[:, 2], absent_if_none=True) * rh.loss_w_z * w3,
-              p + "loss_pose": red(L[:, 3], absent_if_none=True) * rh.loss_w_pose * w3}
+    # red = [dims, xy, z, pose, joint, uncert]
+    losses = {p + "uncert": red[5] * rh.use_confidence,
+              p + "loss_xy": red[1] * (rh.loss_w_xy * w3),
+              p + "loss_z": red[2] * (rh.loss_w_z * w3),
+              p + "loss_pose": red[3] * (rh.loss_w_pose * w3)}
     if rh.loss_w_dims > 0:
-        losses[p + "loss_dims"] = red(L[:, 0], absent_if_none=True) * rh.loss_w_dims * w3
+        losses[p + "loss_dims"] = red[0] * (rh.loss_w_dims * w3)
     if rh.loss_w_joint > 0:
-        losses[p + "loss_joint"] = red(L[:, 4], absent_if_none=True) * rh.loss_w_joint * w3
+        losses[p + "loss_joint"] = red[4] * (rh.loss_w_joint * w3)
     storage = get_event_storage()
-    with torch.no_grad():
-        nv = valid.sum().clamp(min=1)
-        zerr = (dec[:, 2] - g3[:, 2]).abs() * valid
-        storage.put_scalar(p + "z_error", zerr.sum() / nv, smoothing_hint=False)
-        storage.put_scalar(p + "dims_error", ((dec[:, 3:6] - g3[:, 3:6]).abs() * valid[:, None]).sum() / (3 * nv), smoothing_hint=False)
-        storage.put_scalar(p + "xy_error", ((dec[:, 0:2] - g3[:, :2]).abs() * valid[:, None]).sum() / (2 * nv), smoothing_hint=False)
-        storage.put_scalar(p + "conf", (torch.exp(-unc) * valid).sum() / nv, smoothing_hint=False)
+    storage.put_scalar(p + "z_error", stats[0], smoothing_hint=False)
+    storage.put_scalar(p + "dims_error", stats[1], smoothing_hint=False)
+    storage.put_scalar(p + "xy_error", stats[2], smoothing_hint=False)
+    storage.put_scalar(p + "conf", stats[3], smoothing_hint=False)
     return losses
 
 

@@ -89,6 +89,26 @@ class CubeHead(nn.Module):
         return box_2d_deltas, box_z, box_dims, box_pose, box_uncert
 
 
+def _forward_fused(self, x):
+    """training form for the static-shape path: the five predictors as ONE GEMM.  Returns (raw (n, 13K) f32, layout) with
+    layout = column offsets of [deltas 2K, dims 3K, pose6d 6K, z K, uncert K]; the per-class gather, the 6D -> matrix
+    conversion and the uncertainty clip happen in ops.cube_head_loss (only for each RoI's own class)."""
+    fcs = [m for m in self.feature_generator if isinstance(m, nn.Linear)]
+    h = F.relu(fc_nhwc(x, fcs[0], self._in_chw))
+    for fc in fcs[1:]:
+        h = F.relu(F.linear(h, fc.weight.to(h.dtype), fc.bias.to(h.dtype)))
+    assert self.use_conf
+    preds = [self.bbox_3D_center_deltas, self.bbox_3D_dims, self.bbox_3D_pose, self.bbox_3D_center_depth,
+             self.bbox_3D_uncertainty]
+    W = torch.cat([m.weight for m in preds]).to(h.dtype)
+    b = torch.cat([m.bias for m in preds]).to(h.dtype)
+    K = self.num_classes
+    return F.linear(h, W, b).float(), (0, 2 * K, 5 * K, 11 * K, 12 * K)
+
+
+CubeHead.forward_fused = _forward_fused
+
+
 def build_cube_head(cfg, input_shape: ShapeSpec):
     name = cfg.MODEL.ROI_CUBE_HEAD.NAME
     return ROI_CUBE_HEAD_REGISTRY.get(name)(cfg, input_shape)

@@ -651,6 +651,110 @@ def box_loss(scores, deltas, valid, cls, pboxes, gt_idx, gt_boxes, weights, scal
 
 
 # --------------------------------------------------------------------------
+# 3D head on the static-shape path: class gather + fused decode/loss + reductions
+# --------------------------------------------------------------------------
+CUBE_OFF = (0, 2, 3, 6, 15, 16, 20, 21, 24, 26, 27, 30)      # chunk starts of buf39 (x n), see include/cr3dod.h
+CUBE_DIM = (2, 1, 3, 9, 1, 4, 1, 3, 2, 1, 3, 9)
+
+
+def _chunks(buf, n):
+    return [buf[o * n:(o + d) * n] for o, d in zip(CUBE_OFF, CUBE_DIM)]
+
+
+class _CubeHeadLoss(torch.autograd.Function):
+    """raw (n,13K) -> per-RoI losses (n,5), selected uncertainty (n); saves what the two backward kernels need."""
+
+    @staticmethod
+    def forward(ctx, raw, layout, K, cls, valid, gt_idx, kf, gt3d, gtpose, priors, meta, boxes, flags):
+        _need_cuda(raw, "cube head output")
+        B, S = cls.shape
+        n = B * kf
+        dev = raw.device
+        raw32 = raw.detach().float().contiguous()
+        buf = torch.empty((39 * n,), dtype=f32, device=dev)
+        validf = torch.empty((n,), dtype=torch.uint8, device=dev)
+        clsc = torch.empty((n,), dtype=torch.int32, device=dev)
+        lay = (_ct.c_int * 5)(*[int(v) for v in layout])
+        lib = _lib.load()
+        _chk(lib.cr_cube_select(_ctx(raw), _p(raw32), raw32.shape[1], lay, int(K), _p(cls.contiguous()),
+                                _p(valid.to(torch.uint8).contiguous()), _p(gt_idx.contiguous()), B, S, int(kf), gt3d.shape[1],
+                                _p(gt3d.contiguous()), _p(gtpose.contiguous()), _p(priors), _p(meta.contiguous()), _p(buf),
+                                _p(validf), _p(clsc)), "cr_cube_select")
+        ch = _chunks(buf, n)
+        boxes = boxes.contiguous()
+        ins = ch[:5] + [boxes] + ch[5:]
+        arr = (ctypes.c_void_p * 13)(*[t.data_ptr() for t in ins])
+        losses = torch.empty((n, 5), dtype=f32, device=dev)
+        dec = torch.empty((n, 17), dtype=f32, device=dev)
+        _chk(lib.cr_cube_loss_fwd(_ctx(raw), ctypes.cast(arr, ctypes.c_void_p), n, *flags, _p(losses), _p(dec)),
+             "cr_cube_loss_fwd")
+        ctx.keep = (raw32, buf, validf, clsc, boxes, tuple(layout), int(K), B, int(kf), flags, raw.dtype)
+        ctx.mark_non_differentiable(dec, buf, validf)
+        return losses, ch[4].clone(), dec, buf, validf
+
+    @staticmethod
+    def backward(ctx, gl, g_usel, _gd, _gb, _gv):
+        raw32, buf, validf, clsc, boxes, layout, K, B, kf, flags, dt = ctx.keep
+        n = B * kf
+        dev = raw32.device
+        ch = _chunks(buf, n)
+        ins = ch[:5] + [boxes] + ch[5:]
+        arr = (ctypes.c_void_p * 13)(*[t.data_ptr() for t in ins])
+        g = torch.empty((16 * n,), dtype=f32, device=dev)
+        g_dxy, g_zr, g_dr, g_Ra, g_u = g[:2 * n], g[2 * n:3 * n], g[3 * n:6 * n], g[6 * n:15 * n], g[15 * n:]
+        lib = _lib.load()
+        _chk(lib.cr_cube_loss_bwd(_ctx(raw32), ctypes.cast(arr, ctypes.c_void_p), n, *flags, _p(gl.contiguous()),
+                                  _p(g_dxy), _p(g_zr), _p(g_dr), _p(g_Ra), _p(g_u)), "cr_cube_loss_bwd")
+        g_raw = torch.empty_like(raw32)
+        lay = (_ct.c_int * 5)(*layout)
+        _chk(lib.cr_cube_select_bwd(_ctx(raw32), _p(raw32), raw32.shape[1], lay, K, B, kf, _p(validf), _p(clsc), _p(g_dxy),
+                                    _p(g_zr), _p(g_dr), _p(g_Ra), _p(g_u), _p(g_usel.contiguous()), _p(g_raw)),
+             "cr_cube_select_bwd")
+        return (g_raw.to(dt),) + (None,) * 12
+
+
+def cube_head_loss(raw, layout, K, cls, valid, gt_idx, kf, gt3d, gtpose, priors, meta, boxes, allocentric=True,
+                   chamfer_pose=True, use_conf=True, joint=True):
+    """raw (n,13K) fused predictor output; cls/valid/gt_idx (B,S); gt3d (B,G,9); gtpose (B,G,3,3); priors (K,3) or None;
+    meta (B,5); boxes (n,4).  -> losses (n,5), u_sel (n), dec (n,17), buf39, validf (n) uint8."""
+    flags = (int(bool(allocentric)), int(bool(chamfer_pose)), int(bool(use_conf)), int(bool(joint)))
+    return _CubeHeadLoss.apply(raw, tuple(layout), K, cls, valid, gt_idx, kf, gt3d, gtpose.reshape(gtpose.shape[0], -1, 9),
+                               priors, meta, boxes, flags)
+
+
+class _CubeReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, L, u_sel, buf, dec, validf, inverse_z):
+        n = L.shape[0]
+        dev = L.device
+        out = torch.empty((16,), dtype=f32, device=dev)
+        red, cnt, stats = out[:6], out[6:12], out[12:]
+        lib = _lib.load()
+        Lc = L.detach().contiguous()
+        _chk(lib.cr_cube_reduce(_ctx(L), _p(Lc), _p(buf), _p(dec), _p(validf), n, int(inverse_z), _p(red), _p(cnt),
+                                _p(stats)), "cr_cube_reduce")
+        ctx.keep = (Lc, buf, validf, cnt, int(inverse_z))
+        ctx.mark_non_differentiable(stats)
+        return red, stats
+
+    @staticmethod
+    def backward(ctx, gred, _gs):
+        Lc, buf, validf, cnt, inverse_z = ctx.keep
+        n = Lc.shape[0]
+        gL = torch.empty_like(Lc)
+        gu = torch.empty((n,), dtype=f32, device=Lc.device)
+        lib = _lib.load()
+        _chk(lib.cr_cube_reduce_bwd(_ctx(Lc), _p(Lc), _p(buf), _p(validf), n, inverse_z, _p(cnt), _p(gred.contiguous()),
+                                    _p(gL), _p(gu)), "cr_cube_reduce_bwd")
+        return gL, gu, None, None, None, None
+
+
+def cube_reduce(L, u_sel, buf, dec, validf, inverse_z=False):
+    """-> red (6) = means of [dims, xy, z, pose, joint, uncert] over the valid finite entries, stats (4)."""
+    return _CubeReduce.apply(L, u_sel, buf, dec, validf, inverse_z)
+
+
+# --------------------------------------------------------------------------
 # optimizer
 # --------------------------------------------------------------------------
 def nonfinite_flag(flat_grad, flag):

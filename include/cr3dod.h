@@ -231,6 +231,27 @@ int cr_box_loss(cr_ctx* ctx, const float* scores, const float* deltas, const uns
                 const float* weights4, float scale_clamp, float* partial_ws, float* sums3, float* dscores, float* ddeltas,
                 float* pred);
 
+/* ---- glue around the fused 3D-head loss on the static-shape path (roi_heads.py:2237-2679, :2843-2851) ---------
+ * raw (n, ld) f32 = fused predictor output, layout5 HOST = column offsets of [deltas 2K, dims 3K, pose6d 6K, z K,
+ * uncert K]; cls/valid/gt_idx are (B,S) arrays of which the first kf columns (foreground slots) are used, n = B*kf.
+ * buf39 (39*n f32): chunks dxy 2|zr 1|dr 3|Ra 9|u 1|K4 4|v2r 1|prior 3|gt2d 2|gtz 1|gtdims 3|gtR 9, each (n,d):
+ * the 12 pointers cr_cube_loss_fwd takes besides the RoI boxes.  validf (n) u8, clsc (n) i32 (clamped class). */
+int cr_cube_select(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
+                   const unsigned char* valid, const int64_t* gt_idx, int B, int S, int kf, int G, const float* gt3d,
+                   const float* gtpose, const float* priors, const float* meta, float* buf39, unsigned char* validf,
+                   int* clsc);
+/* transpose of the gather: g_raw (n, ld) dense (zeros off each RoI's class), 6D rotation and clip(0.01) back-propagated;
+ * g_usel (n) = extra gradient on the selected uncertainty (from the uncertainty loss term). */
+int cr_cube_select_bwd(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, int B, int kf,
+                       const unsigned char* validf, const int* clsc, const float* g_dxy, const float* g_zr, const float* g_dr,
+                       const float* g_Ra, const float* g_u, const float* g_usel, float* g_raw);
+/* red6 = safely_reduce_losses of [dims, xy, z, pose, joint] (losses (n,5) from cr_cube_loss_fwd) and of the uncertainty
+ * over the valid RoIs; cnt6 = entries averaged; stats4 = mean |z|, |dims|, |xy| errors, mean exp(-u) (dec from the fwd). */
+int cr_cube_reduce(cr_ctx* ctx, const float* L, const float* buf39, const float* dec, const unsigned char* validf, int n,
+                   int inverse_z, float* red6, float* cnt6, float* stats4);
+int cr_cube_reduce_bwd(cr_ctx* ctx, const float* L, const float* buf39, const unsigned char* validf, int n, int inverse_z,
+                       const float* cnt6, const float* gred6, float* gL, float* gu);
+
 /* ---- optimizer (tools/train_net.py:233-266, cubercnn/solver/build.py:50-56) ------------- */
 int cr_nonfinite_flag(cr_ctx* ctx, const float* g, int64_t n, int* flag);
 /* SGD momentum on flat f32 buffers; skipped on device when *skip_flag != 0 (may be NULL). */
