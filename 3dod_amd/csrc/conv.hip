@@ -45,6 +45,7 @@ struct ConvP {
     int N, Hin, Win, Cin, Hout, Wout, Cout;
     int stride, pad, Kdim, M, cshift, relu;
     unsigned x_bytes, w_bytes;   // extents for the buffer-load descriptors (out-of-range voffset reads 0)
+    int xcd;                     // 1 = XCD-aware tile order
 };
 
 // LDS image of a [rows][32] bf16 tile (64-B rows, four 16-B chunks): chunk' = chunk ^ ((-(row>>2)) & 3)
@@ -53,6 +54,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  xcd_swizzle() renumbers them so that XCD x
+// works on one contiguous range of logical tiles: neighbouring tiles (which share input rows / weight tiles / the pixel
+// range of a wgrad split) then hit the same L2 instead of each XCD re-fetching the operand from the Infinity Cache.
+__device__ __forceinline__ int xcd_swizzle(int b, int nblocks) {
+    const int per = nblocks >> 3, body = per << 3;
+    return b < body ? (b & 7) * per + (b >> 3) : b;
 }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -87,7 +96,8 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
     u16* sX = sXall + grp * XE;
     u16* sW = sWall + grp * WE;
     const int n_tiles = p.Cout / BN;
-    const int nt = blockIdx.x % n_tiles, mt = blockIdx.x / n_tiles;
+    const int bid = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int nt = bid % n_tiles, mt = bid / n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- per-thread gather bookkeeping (2 pixel rows, one 16-B k-chunk each)
@@ -362,6 +372,10 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
+static int xcd_enabled() {
+    static const int v = env_int("CR_XCD", 1);
+    return v;
+}
 
 template <int KS, int MODE>
 static int launch_igemm_ks(cr_ctx* ctx, const ConvP& p, int out_f32) {
@@ -419,7 +433,7 @@ extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y,
     p.Hout = (H + 2 * pad - ks) / stride + 1;
     p.Wout = (W + 2 * pad - ks) / stride + 1;
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = N * p.Hout * p.Wout;
-    p.cshift = ks == 1 ? 0 : ilog2_exact(Cin); p.relu = relu;
+    p.cshift = ks == 1 ? 0 : ilog2_exact(Cin); p.relu = relu; p.xcd = xcd_enabled();
     p.x_bytes = (unsigned)((size_t)N * H * W * Cin * 2); p.w_bytes = (unsigned)((size_t)Cout * p.Kdim * 2);
     if (ks == 1) return launch_igemm_ks<1, 0>(ctx, p, out_f32);
     if (ks == 3) return launch_igemm_ks<3, 0>(ctx, p, out_f32);
@@ -440,7 +454,7 @@ extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, v
     p.N = N; p.Hin = Ho; p.Win = Wo; p.Cin = Cout;      // gather source = dY
     p.Hout = H; p.Wout = W; p.Cout = Cin;               // GEMM output = dX
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cout; p.M = N * H * W;
-    p.cshift = ks == 1 ? 0 : ilog2_exact(Cout); p.relu = 0;
+    p.cshift = ks == 1 ? 0 : ilog2_exact(Cout); p.relu = 0; p.xcd = xcd_enabled();
     p.x_bytes = (unsigned)((size_t)N * Ho * Wo * Cout * 2); p.w_bytes = (unsigned)((size_t)Cin * p.Kdim * 2);
     if (ks == 1) return launch_igemm_ks<1, 1>(ctx, p, 0);
     if (ks == 3) return launch_igemm_ks<3, 1>(ctx, p, 0);
@@ -455,7 +469,8 @@ struct WgP {
     const u16* x;    // NHWC
     float* dw;       // [Cout][Kdim] f32, accumulated with atomics
     int N, Hin, Win, Cin, Hout, Wout, Cout, stride, pad, Kdim, M, cshift;
-    int steps_per_split;    // 32-pixel steps handled by one blockIdx.z
+    int steps_per_split;    // 32-pixel steps handled by one split
+    int tm, tn, xcd;        // tile counts (the grid is 1-D: tm * tn * splits blocks)
 };
 
 // transposing LDS read: 16-lane group reads a 4(row) x 16(col) block of 16-bit elements and
@@ -477,9 +492,12 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
     __shared__ __attribute__((aligned(16))) u16 sQ[KU * 32 * PQ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c0 = blockIdx.x * TM;        // output-channel tile
-    const int q0 = blockIdx.y * TN;        // k (r,s,c) tile
-    const int step0 = blockIdx.z * p.steps_per_split;
+    // 1-D grid, channel tile fastest, split slowest: all tiles of one split (same pixel range) are neighbours
+    const int bid = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int bx = bid % p.tm, by = (bid / p.tm) % p.tn, bz = bid / (p.tm * p.tn);
+    const int c0 = bx * TM;                // output-channel tile
+    const int q0 = by * TN;                // k (r,s,c) tile
+    const int step0 = bz * p.steps_per_split;
     const int nsteps_total = (p.M + 31) >> 5;
     const int step1 = min(step0 + p.steps_per_split, nsteps_total);
     if (step0 >= step1) return;
@@ -641,7 +659,8 @@ static int launch_wgrad_ks(cr_ctx* ctx, WgP& p) {
     if (splits < 1) splits = 1;
     p.steps_per_split = (nsteps + splits - 1) / splits;
     splits = (nsteps + p.steps_per_split - 1) / p.steps_per_split;
-    dim3 grid(tm, tn, splits);
+    dim3 grid(tm * tn * splits);
+    p.tm = tm; p.tn = tn; p.xcd = xcd_enabled();
     static const int ku = env_int("CR_WG_KU", 2);
     if (ku == 2) {
         if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad<128, KS, 2>), grid, dim3(CONV_T), 0, ctx->stream, p);
