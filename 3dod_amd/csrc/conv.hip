@@ -755,6 +755,54 @@ extern "C" int cr_weight_transpose(cr_ctx* ctx, const float* w, void* wt, int Co
 }
 
 // ---------------------------------------------------------------------------
+// Multi-tensor weight preparation: ALL conv weights of the model (views into the optimizer's flat f32 parameter
+// buffer) are recast to bf16 and re-laid for bwd-data by ONE launch per step instead of two tiny launches per layer.
+// A block handles a 32 (cout) x 32 (cin) tile of one filter tap of one tensor (host-built tile table), writing the
+// bf16 copy in place order and the transposed copy through an LDS tile (both sides coalesced).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_weights_prepare(const float* __restrict__ src_base, u16* __restrict__ dst_base,
+                                                         u16* __restrict__ dstT_base, const cr_wdesc* __restrict__ descs,
+                                                         const int4* __restrict__ tiles) {
+    __shared__ u16 tile[32][33];
+    const int4 tl = tiles[blockIdx.x];                   // (tensor, tap, cout0, cin0)
+    const cr_wdesc d = descs[tl.x];
+    const int r = tl.y, o0 = tl.z, c0 = tl.w;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const float* src = src_base + d.src_off;
+    u16* dst = dst_base + d.dst_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = o0 + ty + 8 * i, c = c0 + tx;
+        u16 v = 0;
+        if (o < d.Cout && c < d.Cin) {
+            const int64_t e = ((int64_t)o * d.KK + r) * d.Cin + c;
+            v = f2bf(src[e]);
+            dst[e] = v;
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    if (!d.need_T) return;                               // block-uniform
+    __syncthreads();
+    u16* dstT = dstT_base + d.dstT_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, o = o0 + tx;
+        if (o < d.Cout && c < d.Cin) dstT[((int64_t)c * d.KK + r) * d.Cout + o] = tile[tx][ty + 8 * i];
+    }
+}
+
+extern "C" int cr_weights_prepare(cr_ctx* ctx, const float* src_base, void* dst_base, void* dstT_base,
+                                  const cr_wdesc* descs_dev, const int* tiles_dev, int ntiles) {
+    CR_CHECK_ARG(ctx && ntiles >= 0, "cr_weights_prepare: bad args");
+    if (ntiles == 0) return CR_OK;
+    CR_CHECK_ARG(src_base && dst_base && dstT_base && descs_dev && tiles_dev, "cr_weights_prepare: NULL pointer");
+    hipLaunchKernelGGL(k_weights_prepare, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, src_base, (u16*)dst_base,
+                       (u16*)dstT_base, descs_dev, (const int4*)tiles_dev);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // BatchNorm2d (training mode, per-GPU statistics: dla.py:17 BatchNorm = nn.BatchNorm2d)
 // ---------------------------------------------------------------------------
 // finalize: per-tile partials [nparts][2][C] -> mean / invstd (+ running stats update, momentum, unbiased var).

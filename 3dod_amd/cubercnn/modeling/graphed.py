@@ -31,6 +31,8 @@ def _fresh_leaves(modules):
                 sink = ops.grad_sink(p)
                 if sink is not None:
                     q._cr_grad = sink
+                if hasattr(p, "_cr_bank"):
+                    q._cr_bank = p._cr_bank
                 m._parameters[name] = q
                 swapped.append((m, name, p))
     try:

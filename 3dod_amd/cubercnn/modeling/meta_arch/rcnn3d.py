@@ -38,6 +38,8 @@ class RCNN3D(nn.Module):
         self.vis_period = cfg.VIS_PERIOD
         self.pixel_mean_list = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
         self.pixel_std_list = [float(v) for v in cfg.MODEL.PIXEL_STD]
+        # bf16 compute copies of the weights are cached per "weight epoch" (hipops): loading a checkpoint moves it
+        self.register_load_state_dict_post_hook(lambda module, incompatible: ops.bump_weight_epoch())
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
         self._graphed = None

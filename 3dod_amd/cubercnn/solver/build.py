@@ -97,6 +97,16 @@ class FlatSGD:
         self.param_groups = [{"lr": s[2], "weight_decay": s[3], "range": (s[0], s[1])} for s in self.segments]
         self.lr_scale = 1.0
 
+    def enable_weight_bank(self):
+        """one-launch-per-step bf16 recast of every conv weight (hipops.WeightBank); training-step objects call this."""
+        if getattr(self, "weight_bank", None) is None and self.flat_p.is_cuda and hasattr(ops, "WeightBank"):
+            convs = [p for p in self.params if p.dim() == 4 and p.shape[2] == p.shape[3] and
+                     p.is_contiguous(memory_format=torch.channels_last)]
+            if convs:
+                self.weight_bank = ops.WeightBank(convs, self.flat_p)
+                ops.bump_weight_epoch()
+        return getattr(self, "weight_bank", None)
+
     def zero_grad(self):
         self.flat_g.zero_()
         for p in self.params:
@@ -143,6 +153,7 @@ class TrainStep:
 
     def __init__(self, cfg, model, optimizer, world_size=1, bucket_mb=32):
         self.model, self.opt = model, optimizer
+        optimizer.enable_weight_bank()
         self.world = world_size
         self.stabilize = cfg.MODEL.STABILIZE > 0
         dev = optimizer.flat_p.device
@@ -230,6 +241,7 @@ class GraphedTrainStep:
         from ..modeling.graphed import _fresh_leaves
         assert model.training and model.dense_train
         self.model, self.opt, self.world = model, optimizer, world_size
+        optimizer.enable_weight_bank()
         self.stabilize = cfg.MODEL.STABILIZE > 0
         import os
         self.sync_each_step = os.environ.get("CR_STEP_SYNC", "1") == "1"

@@ -55,10 +55,62 @@ def as_krsc(weight):
     return weight
 
 
+class WeightBank:
+    """bf16 compute copies ([Cout][k*k*Cin] and the bwd-data layout [Cin][k*k*Cout]) of ALL registered conv weights,
+    refreshed by ONE launch (cr_weights_prepare) the first time any of them is asked for after the weight epoch
+    moved (= after an optimizer step).  The weights must be views into one flat f32 buffer (FlatSGD.flat_p).
+    Activated by the training step objects; anything that changes weights outside the optimizer must call
+    bump_weight_epoch() (the model's load_state_dict hook does)."""
+
+    def __init__(self, params, flat_p):
+        import numpy as np
+        dev = flat_p.device
+        self.flat_p = flat_p
+        descs, tiles, self.shapes = [], [], []
+        off = 0
+        for i, p in enumerate(params):
+            Cout, Cin, k, _ = p.shape
+            KK, n = k * k, p.numel()
+            src_off = (p.data_ptr() - flat_p.data_ptr()) // 4
+            assert 0 <= src_off and src_off + n <= flat_p.numel(), "conv weight is not a view of the flat buffer"
+            descs.append((src_off, off, off, Cout, KK, Cin, 1))
+            for r in range(KK):
+                for o0 in range(0, Cout, 32):
+                    for c0 in range(0, Cin, 32):
+                        tiles.append((i, r, o0, c0))
+            self.shapes.append((off, n, Cout, KK, Cin))
+            off += (n + 7) // 8 * 8
+        dt = np.dtype([("src", "<i8"), ("dst", "<i8"), ("dstT", "<i8"), ("Cout", "<i4"), ("KK", "<i4"), ("Cin", "<i4"),
+                       ("needT", "<i4")])
+        assert dt.itemsize == 40
+        self.descs = torch.from_numpy(np.array(descs, dtype=dt).view(np.uint8).copy()).to(dev)
+        self.tiles = torch.tensor(tiles, dtype=torch.int32, device=dev)
+        self.ntiles = len(tiles)
+        self.dst = torch.empty((off,), dtype=bf16, device=dev)
+        self.dstT = torch.empty((off,), dtype=bf16, device=dev)
+        self.views = [(self.dst[o:o + n].view(Cout, KK * Cin), self.dstT[o:o + n].view(Cin, KK * Cout))
+                      for (o, n, Cout, KK, Cin) in self.shapes]
+        self.epoch = None
+        for i, p in enumerate(params):
+            p._cr_bank = (self, i)
+
+    def get(self, i):
+        if self.epoch != _WEIGHT_EPOCH[0]:
+            lib = _lib.load()
+            _chk(lib.cr_weights_prepare(_ctx(self.flat_p), _p(self.flat_p), _p(self.dst), _p(self.dstT), _p(self.descs),
+                                        _p(self.tiles), self.ntiles), "cr_weights_prepare")
+            self.epoch = _WEIGHT_EPOCH[0]
+        return self.views[i]
+
+
 def prepared_weights(weight, need_transposed):
     """bf16 [Cout][k*k*Cin] and (optionally) bf16 [Cin][k*k*Cout] copies of a f32 channels_last weight.
-    Cached ON the tensor object (so a new tensor at a recycled address never hits a stale entry), keyed by
+    Weights registered in a WeightBank come from the bank (one launch per step for the whole model); others are
+    cached ON the tensor object (so a new tensor at a recycled address never hits a stale entry), keyed by
     torch's version counter and the global weight epoch."""
+    bk = getattr(weight, "_cr_bank", None)
+    if bk is not None:
+        return bk[0].get(bk[1])
     ent = getattr(weight, "_cr_wcache", None)
     tag = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr())
     lib = _lib.load()

@@ -178,6 +178,16 @@ int cr_cube_loss_bwd(cr_ctx* ctx, const float* const* inputs, int64_t n, int all
                      int use_conf, int joint, const float* gl, float* g_dxy, float* g_zr, float* g_dr, float* g_Ra,
                      float* g_u);
 
+/* multi-tensor form of cr_cast_f32_to_bf16 + cr_weight_transpose: every conv weight of the model in one launch.
+ * descs_dev: device array of cr_wdesc (offsets in ELEMENTS from the three base pointers); tiles_dev: device array of
+ * ntiles int4 = (tensor index, filter tap, first cout, first cin) covering each tensor in 32x32 (cout x cin) tiles. */
+typedef struct cr_wdesc {
+    int64_t src_off, dst_off, dstT_off;
+    int Cout, KK, Cin, need_T;          /* KK = k*k taps; need_T = 0 skips the transposed copy */
+} cr_wdesc;
+int cr_weights_prepare(cr_ctx* ctx, const float* src_base, void* dst_base, void* dstT_base, const cr_wdesc* descs_dev,
+                       const int* tiles_dev, int ntiles);
+
 /* ---- static-shape training glue of the RPN (3dod_amd/csrc/dense_train.hip) -----------------------------------
  * Batched, sync-free forms of cubercnn/modeling/proposal_generator/rpn.py:41-110 (label_and_sample_anchors with
  * ignore regions), :129-273 (losses) and :275-328 (subsample_labels), and of detectron2's Matcher /

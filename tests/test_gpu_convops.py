@@ -231,3 +231,33 @@ def test_sgd_and_nonfinite():
     before = pd.clone()
     ops.sgd_step(pd, gd, md, 0.02, 0.9, 1e-4, 1.0, flag)       # skipped on device
     assert int(flag.item()) == 1 and torch.equal(pd, before)
+
+
+def test_weight_bank_matches_per_tensor_prep():
+    """cr_weights_prepare (one launch for all conv weights) == cr_cast_f32_to_bf16 + cr_weight_transpose per tensor,
+    bit for bit, including ragged 32x32 tiles (Cin/Cout not multiples of 32)."""
+    g = torch.Generator().manual_seed(31)
+    shapes = [(128, 64, 3), (32, 48, 1), (16, 8, 7), (40, 24, 3), (256, 256, 1)]
+    sizes = [co * ci * k * k for co, ci, k in shapes]
+    flat = torch.randn(sum((n + 3) // 4 * 4 for n in sizes) + 8, generator=g).to(DEV)
+    params, off = [], 4
+    for (co, ci, k), n in zip(shapes, sizes):
+        v = flat[off:off + n].view(co, k, k, ci).permute(0, 3, 1, 2)          # logical KCRS over physical KRSC
+        params.append(torch.nn.Parameter(v))
+        params[-1].data = v
+        off += (n + 3) // 4 * 4
+    ref = []
+    for p in params:
+        wb, wt = ops.prepared_weights(p, True)
+        ref.append((wb.clone(), wt.clone()))
+    bank = ops.WeightBank(params, flat)
+    ops.bump_weight_epoch()
+    for i, p in enumerate(params):
+        wb, wt = ops.prepared_weights(p, True)
+        assert wb.data_ptr() == bank.views[i][0].data_ptr()
+        assert torch.equal(wb.view(torch.int16), ref[i][0].view(torch.int16)), i
+        assert torch.equal(wt.view(torch.int16), ref[i][1].view(torch.int16)), i
+    flat.mul_(2.0)                                   # "optimizer step": raw update + epoch bump -> one refresh
+    ops.bump_weight_epoch()
+    wb, _ = ops.prepared_weights(params[0], False)
+    assert torch.equal(wb.float(), (ref[0][0].float() * 2.0))
