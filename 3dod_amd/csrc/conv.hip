@@ -479,8 +479,12 @@ __device__ __forceinline__ s16x4 lds_tr16(const u16* ptr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ptr));
 }
 
-template <int TM, int KS, int KU>
-__global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
+// KG = wave groups per block: the groups walk interleaved 32*KU-pixel stages of the block's pixel range (4 waves per
+// SIMD instead of 1 on the small-map layers, where the grid is only ~1 block per CU), sum their accumulators in an
+// LDS tile and issue the atomics from there (full 256-B rows per wave-instruction).  Each group keeps its own
+// operand buffers; the reduction tile re-uses them after the loop.
+template <int TM, int KS, int KU, int KG>
+__global__ __launch_bounds__(CONV_T * KG) void k_conv_wgrad(WgP p) {
     constexpr int TN = 128;
     constexpr int WM = (TM == 128) ? 2 : 1, WN = 4 / WM;
     constexpr int WTM = TM / WM, WTN = TN / WN;          // wave tile
@@ -488,10 +492,15 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
     constexpr int PP = TM + 8, PQ = TN + 8;              // padded row pitches (elements)
     constexpr int CPR = TM / 8;                          // dy chunks per pixel row
     constexpr int NP = (32 * CPR + CONV_T - 1) / CONV_T; // dy chunks per thread per 32-pixel sub-step
-    __shared__ __attribute__((aligned(16))) u16 sP[KU * 32 * PP];
-    __shared__ __attribute__((aligned(16))) u16 sQ[KU * 32 * PQ];
+    constexpr int PE = KU * 32 * PP, QE = KU * 32 * PQ;  // operand elements per group
+    constexpr int TNP = TN + 4;                          // reduction tile pitch (floats)
+    constexpr int OPB = KG * (PE + QE) * 2, REDB = (KG > 1) ? TM * TNP * 4 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[OPB > REDB ? OPB : REDB];
+    const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
+    u16* sP = reinterpret_cast<u16*>(smem) + grp * (PE + QE);
+    u16* sQ = sP + PE;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & (CONV_T - 1), lane = tid & 63, wave = tid >> 6;
     // 1-D grid, channel tile fastest, split slowest: all tiles of one split (same pixel range) are neighbours
     const int bid = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int bx = bid % p.tm, by = (bid / p.tm) % p.tn, bz = bid / (p.tm * p.tn);
@@ -500,11 +509,11 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
     const int step0 = bz * p.steps_per_split;
     const int nsteps_total = (p.M + 31) >> 5;
     const int step1 = min(step0 + p.steps_per_split, nsteps_total);
-    if (step0 >= step1) return;
+    if (step0 >= step1) return;            // block-uniform
 
     // Q-gather bookkeeping: 32 pixels x 16 chunks = 512 chunks per sub-step, 2 per thread; the k-chunk (filter tap and
-    // channel) is fixed per thread for the whole kernel, the two pixel rows walk forward by 32 pixels per sub-step and
-    // are tracked incrementally as (n, ho, wo) -- no division in the loop.
+    // channel) is fixed per thread for the whole kernel, the two pixel rows walk forward and are tracked incrementally
+    // as (n, ho, wo) -- no division in the loop.
     const int qc = tid & 15;                   // chunk within the 128-wide k tile
     const int qk = q0 + qc * 8;
     int qr = 0, qs = 0, qch = qk;
@@ -515,23 +524,34 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
         qr = tap / KS;
         qs = tap - qr * KS;
     }
+    const int first = step0 + grp * KU;        // first 32-pixel sub-step of this group
     int pn[2], pho[2], pwo[2];
     {
         const int hw = p.Hout * p.Wout;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int m = step0 * 32 + (tid >> 4) + 16 * i;
+            const int m = first * 32 + (tid >> 4) + 16 * i;
             pn[i] = m / hw;
             const int rem = m - pn[i] * hw;
             pho[i] = rem / p.Wout;
             pwo[i] = rem - pho[i] * p.Wout;
         }
     }
-    const u16* pdy = p.dy + (size_t)step0 * 32 * p.Cout + c0;      // dy rows of the current sub-step
-    int mrow = step0 * 32;                                         // first pixel of the next sub-step to load
+    const u16* pdy = p.dy + (size_t)first * 32 * p.Cout + c0;      // dy rows of the next sub-step to load
+    int mrow = first * 32;
     const int mend = min(p.M, step1 * 32);                         // rows of later splits / past M contribute zeros
     uint4 rq[KU][2], rp[KU][NP];
 
+    auto advance = [&](int pixels) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            pwo[i] += pixels;
+            while (pwo[i] >= p.Wout) { pwo[i] -= p.Wout; ++pho[i]; }
+            while (pho[i] >= p.Hout) { pho[i] -= p.Hout; ++pn[i]; }
+        }
+        pdy += (size_t)pixels * p.Cout;
+        mrow += pixels;
+    };
     auto load_stage = [&]() {
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
@@ -542,9 +562,6 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
             if (qvalid && pn[i] < p.N && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
                 v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(pn[i] * p.Hin + hi) * p.Win + wi) * p.Cin + qch);
             rq[u][i] = v;
-            pwo[i] += 32;
-            while (pwo[i] >= p.Wout) { pwo[i] -= p.Wout; ++pho[i]; }
-            while (pho[i] >= p.Hout) { pho[i] -= p.Hout; ++pn[i]; }
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -555,9 +572,9 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
                 v = *reinterpret_cast<const uint4*>(pdy + (size_t)prow * p.Cout + pc * 8);
             rp[u][i] = v;
         }
-        pdy += (size_t)32 * p.Cout;
-        mrow += 32;
+        advance(32);
       }
+      if (KG > 1) advance(32 * KU * (KG - 1));           // the other groups' stages
     };
     auto store_stage = [&]() {
 #pragma unroll
@@ -584,9 +601,9 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
 
     // transposed-read addressing: 16-lane group g covers pixel rows 8g..8g+7; lane 4q+pp supplies row q, cols 4pp..
     const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-    // dy rows at or past `mend` load zeros (and the x gather never reads past the batch), so the last stage may run
-    // all its KU sub-steps
-    const int nstage = (step1 - step0 + KU - 1) / KU;
+    // dy rows at or past `mend` load zeros (and the x gather never reads past the batch), so stages past the end of the
+    // range (k tail, idle groups) multiply zeros; every group runs the same number of stages (shared barriers)
+    const int nstage = (step1 - step0 + KU * KG - 1) / (KU * KG);
     load_stage();
     store_stage();
     __syncthreads();
@@ -620,17 +637,41 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad(WgP p) {
         }
     }
     // D: col (lane&15) = k index, row 4(lane>>4)+reg = channel
+    if (KG == 1) {
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int kk = q0 + noff + j * 16 + li;
+            for (int j = 0; j < TJ; ++j) {
+                const int kk = q0 + noff + j * 16 + li;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ch = c0 + moff + i * 16 + 4 * g + e;
-                if (kk < p.Kdim && ch < p.Cout) atomicAdd(&p.dw[(size_t)ch * p.Kdim + kk], acc[i][j][e]);
+                for (int e = 0; e < 4; ++e) {
+                    const int ch = c0 + moff + i * 16 + 4 * g + e;
+                    if (kk < p.Kdim && ch < p.Cout) atomicAdd(&p.dw[(size_t)ch * p.Kdim + kk], acc[i][j][e]);
+                }
             }
+    } else {
+        float* tile = reinterpret_cast<float*>(smem);     // operands are dead: the loop ended with a barrier
+#pragma unroll
+        for (int gg = 0; gg < KG; ++gg) {
+            if (grp == gg) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float* d = &tile[(moff + i * 16 + 4 * g + e) * TNP + noff + j * 16 + li];
+                            if (gg == 0) *d = acc[i][j][e]; else *d += acc[i][j][e];
+                        }
+            }
+            __syncthreads();
         }
+        for (int idx = threadIdx.x; idx < TM * TN; idx += CONV_T * KG) {
+            const int chl = idx / TN, kl = idx - chl * TN;
+            const int ch = c0 + chl, kk = q0 + kl;
+            if (kk < p.Kdim && ch < p.Cout) atomicAdd(&p.dw[(size_t)ch * p.Kdim + kk], tile[chl * TNP + kl]);
+        }
+    }
 }
 
 template <int KS>
@@ -638,13 +679,24 @@ static int launch_wgrad_ks(cr_ctx* ctx, WgP& p) {
     const int nsteps = (p.M + 31) >> 5;
     const int tn = (int)cr_cdiv(p.Kdim, 128);
     int TM = p.Cout >= 128 ? 128 : (p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16));
+    // wave groups per block (intra-block split over pixels): 0 = decide below
+    static const int force_kg = env_int("CR_WG_KG", 0);
+    int kg = force_kg;
+    if (kg <= 0) {      // measured per layer shape (scripts/conv_shapes_bench.py, CR_WG_KG sweep)
+        const int64_t dw_elems = (int64_t)p.Cout * p.Kdim;
+        if (p.M >= 1024 && p.Cout >= 64 && dw_elems <= 160 * 1024) kg = 4;
+        else if (p.M >= 1024 && p.M <= 4096 && p.Cout >= 128) kg = 2;
+        else kg = 1;
+    }
+    if (kg == 4 && TM == 128) TM = 64;              // 16 waves per block: 128 registers per lane
+    if (kg == 2 && TM != 128) kg = 1;
     const int tm = (int)cr_cdiv(p.Cout, TM);
     // Split the pixel range over blockIdx.z.  Every split adds one full set of f32 atomics over dW (1.3 TB/s on
     // MI355X), so the split count is bounded by ~16 pixel steps (512 pixels) of MFMA work per block and by the number
     // of blocks the chip holds at once (measured per layer shape with scripts/conv_shapes_bench.py, CR_WG_SPLITS sweep).
     const int tiles = tm * tn;
     const int block_cap = TM >= 64 ? 576 : 2048;
-    int splits = nsteps / 16;
+    int splits = nsteps / (16 * kg);
     if (splits > block_cap / tiles) splits = block_cap / tiles;
     if (splits < 1) splits = 1;
     if (tiles * splits < 256) {     // far fewer blocks than CUs: trade steps per block (down to ~8) for more blocks
@@ -661,17 +713,17 @@ static int launch_wgrad_ks(cr_ctx* ctx, WgP& p) {
     splits = (nsteps + p.steps_per_split - 1) / p.steps_per_split;
     dim3 grid(tm * tn * splits);
     p.tm = tm; p.tn = tn; p.xcd = xcd_enabled();
-    static const int ku = env_int("CR_WG_KU", 2);
-    if (ku == 2) {
-        if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad<128, KS, 2>), grid, dim3(CONV_T), 0, ctx->stream, p);
-        else if (TM == 64) hipLaunchKernelGGL((k_conv_wgrad<64, KS, 2>), grid, dim3(CONV_T), 0, ctx->stream, p);
-        else if (TM == 32) hipLaunchKernelGGL((k_conv_wgrad<32, KS, 2>), grid, dim3(CONV_T), 0, ctx->stream, p);
-        else hipLaunchKernelGGL((k_conv_wgrad<16, KS, 2>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    if (kg == 4) {
+        if (TM == 64) hipLaunchKernelGGL((k_conv_wgrad<64, KS, 2, 4>), grid, dim3(CONV_T * 4), 0, ctx->stream, p);
+        else if (TM == 32) hipLaunchKernelGGL((k_conv_wgrad<32, KS, 2, 4>), grid, dim3(CONV_T * 4), 0, ctx->stream, p);
+        else hipLaunchKernelGGL((k_conv_wgrad<16, KS, 2, 4>), grid, dim3(CONV_T * 4), 0, ctx->stream, p);
+    } else if (kg == 2) {
+        hipLaunchKernelGGL((k_conv_wgrad<128, KS, 2, 2>), grid, dim3(CONV_T * 2), 0, ctx->stream, p);
     } else {
-        if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad<128, KS, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
-        else if (TM == 64) hipLaunchKernelGGL((k_conv_wgrad<64, KS, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
-        else if (TM == 32) hipLaunchKernelGGL((k_conv_wgrad<32, KS, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
-        else hipLaunchKernelGGL((k_conv_wgrad<16, KS, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
+        if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad<128, KS, 2, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
+        else if (TM == 64) hipLaunchKernelGGL((k_conv_wgrad<64, KS, 2, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
+        else if (TM == 32) hipLaunchKernelGGL((k_conv_wgrad<32, KS, 2, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
+        else hipLaunchKernelGGL((k_conv_wgrad<16, KS, 2, 1>), grid, dim3(CONV_T), 0, ctx->stream, p);
     }
     CR_LAUNCH_CHECK();
     return CR_OK;

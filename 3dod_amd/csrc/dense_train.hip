@@ -348,12 +348,19 @@ __global__ __launch_bounds__(256) void k_rpn_loss(const float* __restrict__ logi
 }
 
 __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ partial, int n, int nv, float* __restrict__ sums) {
-    // one block; thread k < nv walks its column in index order (f64 accumulate, fixed order)
-    const int k = threadIdx.x;
-    if (k >= nv) return;
+    // one block, nv <= 8 columns: 32 threads per column take strided rows (f64), then a fixed-order LDS tree
+    __shared__ double sm[8][32];
+    const int k = threadIdx.x >> 5, j = threadIdx.x & 31;
     double s = 0.0;
-    for (int i = 0; i < n; ++i) s += (double)partial[(size_t)i * nv + k];
-    sums[k] = (float)s;
+    if (k < nv)
+        for (int i = j; i < n; i += 32) s += (double)partial[(size_t)i * nv + k];
+    sm[k][j] = s;
+    __syncthreads();
+    for (int w = 16; w >= 1; w >>= 1) {
+        if (j < w) sm[k][j] += sm[k][j + w];
+        __syncthreads();
+    }
+    if (j == 0 && k < nv) sums[k] = (float)sm[k][0];
 }
 
 extern "C" int cr_rpn_loss(cr_ctx* ctx, const float* logits, const float* deltas, const float* anchors, const int* labels,
@@ -366,7 +373,7 @@ extern "C" int cr_rpn_loss(cr_ctx* ctx, const float* logits, const float* deltas
     hipLaunchKernelGGL(k_rpn_loss, dim3(nb, B), dim3(256), 0, ctx->stream, logits, deltas, anchors, labels, matched_idx,
                        gt_boxes, B, A, G, weights4[0], weights4[1], weights4[2], weights4[3], partial_ws, dlogits, ddeltas);
     CR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, partial_ws, nb * B, LOSS_NV, sums6);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, partial_ws, nb * B, LOSS_NV, sums6);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -571,7 +578,7 @@ extern "C" int cr_box_loss(cr_ctx* ctx, const float* scores, const float* deltas
                        N, S, G, K, weights4[0], weights4[1], weights4[2], weights4[3], scale_clamp, partial_ws, dscores, ddeltas,
                        pred);
     CR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, partial_ws, nb, 3, sums3);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, partial_ws, nb, 3, sums3);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
