@@ -1,6 +1,7 @@
 """Cube R-CNN DLA34-FPN train step benchmark (BASELINE.json metric): 4 synthetic 512x512 images per GPU,
 forward + losses + backward + gradient all-reduce + SGD-momentum update, every step."""
 import importlib
+import json
 import os
 import time
 
@@ -135,7 +136,8 @@ def dominant_kernel_roofline(dev, reps=20):
     wb, wt = ops.prepared_weights(w, need_transposed=True)
     flop = 2.0 * N * H * W * C * 9 * C
     out = {}
-    for name, fn in (("k_conv_wgrad<128,3>", lambda: ops.conv_bwd_weight_raw(dy, x, 3, 1, 1)),
+    sink = torch.zeros(C * C * 9, device=dev)           # accumulate target (the flat gradient in the train step)
+    for name, fn in (("k_conv_wgrad<128,3>", lambda: ops.conv_bwd_weight_raw(dy, x, 3, 1, 1, sink=sink)),
                      ("k_conv_igemm<128,3,0,bf16> (fwd)", lambda: ops.conv_fwd_raw(x, wb, C, 3, 1, 1)),
                      ("k_conv_igemm<128,3,1,bf16> (bwd-data)", lambda: ops.conv_bwd_data_raw(dy, wt, x.shape, 3, 1, 1))):
         for _ in range(3):
@@ -149,7 +151,17 @@ def dominant_kernel_roofline(dev, reps=20):
         ms = e0.elapsed_time(e1) / reps
         out[name] = {"ms": ms, "tflops": flop / ms / 1e9}
     worst = min(out, key=lambda k: out[k]["tflops"])
+    # memory-side traffic per launch from the committed PMC passes of the same kernel and shape (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction applied: profiles/r01_pmc_conv_traffic.json)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_conv_traffic.json")))
+        key = {"k_conv_wgrad<128,3>": "k_conv_wgrad<128, 3", "k_conv_igemm<128,3,0,bf16> (fwd)": "k_conv_igemm<128, 128, 3, 0",
+               "k_conv_igemm<128,3,1,bf16> (bwd-data)": "k_conv_igemm<128, 128, 3, 1"}[worst]
+        traffic = [v["traffic_bytes"] for k, v in pmc["kernels"].items() if k.startswith(key)][0]
+    except Exception:
+        pass
     return {"bound": "mfma", "kernel": worst, "shape": "3x3 conv 256->256 on 4x128x128 (FPN p2 output), bf16 in / f32 acc",
             "achieved": out[worst]["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": out[worst]["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None,
+            "frac": out[worst]["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
             "algorithmic_flop_per_launch": flop, "kernel_ms": out[worst]["ms"], "all_directions": out}
