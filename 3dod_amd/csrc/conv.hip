@@ -1233,6 +1233,96 @@ extern "C" int cr_pool2x_bwd(cr_ctx* ctx, const void* x, const void* dy, void* d
     return CR_OK;
 }
 
+// nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the torchvision ResNet stem (resnet.py:33,49 of the reference
+// takes it from torchvision.models.resnet34 [third-party]).  NaN propagates, ties go to the first element in scan
+// order (PyTorch).  Backward is a gather: an input pixel belongs to at most 4 windows; it receives a window's
+// gradient when it is that window's (first) arg-max -- no atomics.
+__device__ __forceinline__ void pool3_window(const u16* __restrict__ x, int n, int ho, int wo, int H, int W, int C, int c8,
+                                             float* m, int* am) {
+    const int h0 = max(2 * ho - 1, 0), w0 = max(2 * wo - 1, 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; am[e] = h0 * W + w0; }
+    for (int r = 0; r < 3; ++r) {
+        const int h = 2 * ho - 1 + r;
+        if ((unsigned)h >= (unsigned)H) continue;
+        for (int q = 0; q < 3; ++q) {
+            const int w = 2 * wo - 1 + q;
+            if ((unsigned)w >= (unsigned)W) continue;
+            float t[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + (((size_t)(n * H + h) * W + w) * C) + c8), t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (t[e] > m[e] || t[e] != t[e]) { m[e] = t[e]; am[e] = h * W + w; }     // ATen's update rule
+        }
+    }
+}
+
+__global__ void k_pool3s2_fwd(const u16* __restrict__ x, u16* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+    const int cg = C >> 3;
+    const int64_t total = (int64_t)N * Ho * Wo * cg;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cg);
+    const int wo = (int)((i / cg) % Wo);
+    const int ho = (int)((i / ((int64_t)cg * Wo)) % Ho);
+    const int n = (int)(i / ((int64_t)cg * Wo * Ho));
+    float m[8];
+    int am[8];
+    pool3_window(x, n, ho, wo, H, W, C, c * 8, m, am);
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8(m);
+}
+
+__global__ void k_pool3s2_bwd(const u16* __restrict__ x, const u16* __restrict__ dy, u16* __restrict__ dx, int N, int H,
+                              int W, int C, int Ho, int Wo) {
+    const int cg = C >> 3;
+    const int64_t total = (int64_t)N * H * W * cg;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cg);
+    const int w = (int)((i / cg) % W);
+    const int h = (int)((i / ((int64_t)cg * W)) % H);
+    const int n = (int)(i / ((int64_t)cg * W * H));
+    float g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int me = h * W + w;
+    // windows (ho, wo) with 2*ho-1 <= h <= 2*ho+1
+    for (int ho = (h >> 1); ho <= ((h + 1) >> 1); ++ho) {
+        if (ho >= Ho) continue;
+        for (int wo = (w >> 1); wo <= ((w + 1) >> 1); ++wo) {
+            if (wo >= Wo) continue;
+            float m[8], d[8];
+            int am[8];
+            pool3_window(x, n, ho, wo, H, W, C, c * 8, m, am);
+            unpack8(*reinterpret_cast<const uint4*>(dy + (((size_t)(n * Ho + ho) * Wo + wo) * C) + c * 8), d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (am[e] == me) g[e] += d[e];
+        }
+    }
+    *reinterpret_cast<uint4*>(dx + i * 8) = pack8(g);
+}
+
+extern "C" int cr_maxpool3x3s2_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C) {
+    CR_CHECK_ARG(ctx && x && y, "cr_maxpool3x3s2_fwd: NULL pointer");
+    CR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 8 == 0, "cr_maxpool3x3s2_fwd: bad dims");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(k_pool3s2_fwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)x, (u16*)y, N,
+                       H, W, C, Ho, Wo);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+extern "C" int cr_maxpool3x3s2_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C) {
+    CR_CHECK_ARG(ctx && x && dy && dx, "cr_maxpool3x3s2_bwd: NULL pointer");
+    CR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 8 == 0, "cr_maxpool3x3s2_bwd: bad dims");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)N * H * W * (C / 8);
+    hipLaunchKernelGGL(k_pool3s2_bwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)x,
+                       (const u16*)dy, (u16*)dx, N, H, W, C, Ho, Wo);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
 // FPN top-down: y[n,h,w,:] = lat[n,h,w,:] + top[n,h/2,w/2,:]   (nearest 2x upsample + sum)
 __global__ void k_upsample_add(const u16* __restrict__ lat, const u16* __restrict__ top, u16* __restrict__ y, int N,
                                int H, int W, int C) {

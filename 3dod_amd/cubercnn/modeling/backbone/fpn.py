@@ -39,12 +39,24 @@ class Backbone(nn.Module):
         return {}
 
 
+class LastLevelMaxPool(nn.Module):
+    """detectron2 LastLevelMaxPool [third-party]: one extra level = max_pool2d(kernel 1, stride 2) of "p5"."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_levels = 1
+        self.in_feature = "p5"
+
+    def forward(self, x):
+        return [ops.subsample2x(x)]
+
+
 class FPN(Backbone):
-    """lateral 1x1 + top-down nearest-2x sum + output 3x3, no norm, no top block."""
+    """lateral 1x1 + top-down nearest-2x sum + output 3x3, no norm; optional top block (LastLevelMaxPool)."""
 
     def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
         super().__init__()
-        assert norm == "" and top_block is None, "only the configuration used by the reference is built"
+        assert norm == "", "only the configuration used by the reference is built"
         assert fuse_type in ("sum", "avg")
         input_shapes = bottom_up.output_shape()
         strides = [input_shapes[f].stride for f in in_features]
@@ -64,7 +76,12 @@ class FPN(Backbone):
         self.output_convs = output_convs[::-1]
         self.in_features = tuple(in_features)
         self.bottom_up = bottom_up
+        self.top_block = top_block
         self._out_feature_strides = {"p{}".format(int(math.log2(s))): s for s in strides}
+        if top_block is not None:                    # detectron2 FPN: extra levels named after the last stage
+            stage = int(math.log2(strides[-1]))
+            for s_ in range(stage, stage + top_block.num_levels):
+                self._out_feature_strides["p{}".format(s_ + 1)] = 2 ** (s_ + 1)
         self._out_features = list(self._out_feature_strides.keys())
         self._out_feature_channels = {k: out_channels for k in self._out_features}
         self._size_divisibility = strides[-1]
@@ -94,5 +111,9 @@ class FPN(Backbone):
                 if self._fuse_type == "avg":
                     prev = prev / 2
                 results.insert(0, ops.conv_bias_act(prev, output_conv.weight, output_conv.bias, 1, 1))
+        if self.top_block is not None:
+            src = bottom_up_features[self.top_block.in_feature] if self.top_block.in_feature in bottom_up_features \
+                else results[self._out_features.index(self.top_block.in_feature)]
+            results.extend(self.top_block(src))
         assert len(self._out_features) == len(results)
         return {f: res for f, res in zip(self._out_features, results)}

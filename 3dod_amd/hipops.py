@@ -376,6 +376,32 @@ class _Pool2x(torch.autograd.Function):
         return dx, None
 
 
+class _Pool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x, "pool input")
+        N, H, W, C = x.shape
+        y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=bf16, device=x.device)
+        lib = _lib.load()
+        _chk(lib.cr_maxpool3x3s2_fwd(_ctx(x), _p(x), _p(y), N, H, W, C), "cr_maxpool3x3s2_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        lib = _lib.load()
+        _chk(lib.cr_maxpool3x3s2_bwd(_ctx(x), _p(x), _p(dy.contiguous()), _p(dx), N, H, W, C), "cr_maxpool3x3s2_bwd")
+        return dx
+
+
+def maxpool3x3s2(x):
+    """nn.MaxPool2d(3, stride=2, padding=1) -- the torchvision ResNet stem (resnet.py:33,49)."""
+    return _Pool3s2.apply(x)
+
+
 def maxpool2x2(x):
     """nn.MaxPool2d(2, stride=2) -- dla.py:208."""
     return _Pool2x.apply(x, 2)

@@ -19,7 +19,12 @@ def build(dev, seed=0, lr=None, world=1):
     syn = importlib.import_module("3dod_amd.synthetic")
     modeling = importlib.import_module("3dod_amd.cubercnn.modeling")
     solver = importlib.import_module("3dod_amd.cubercnn.solver")
-    cfg = syn.make_cfg(overrides=["MODEL.DEVICE", str(dev), "VIS_PERIOD", 0, "log", False,
+    # CR_CONFIG selects another model config of configs/ (e.g. cubercnn_ResNet34_FPN.yaml); the default is the
+    # BASELINE one (Base_Omni3D.yaml = DLA34-FPN)
+    cfg_file = os.environ.get("CR_CONFIG")
+    if cfg_file and not os.path.isabs(cfg_file):
+        cfg_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", cfg_file)
+    cfg = syn.make_cfg(cfg_file, overrides=["MODEL.DEVICE", str(dev), "VIS_PERIOD", 0, "log", False,
                                   "SOLVER.IMS_PER_BATCH", 32, "SOLVER.BASE_LR", lr])
     torch.manual_seed(seed)
     model = modeling.build_model(cfg)

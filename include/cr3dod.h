@@ -178,6 +178,11 @@ int cr_cube_loss_bwd(cr_ctx* ctx, const float* const* inputs, int64_t n, int all
                      int use_conf, int joint, const float* gl, float* g_dxy, float* g_zr, float* g_dr, float* g_Ra,
                      float* g_u);
 
+/* nn.MaxPool2d(3, stride=2, padding=1) of the torchvision ResNet stem (cubercnn/modeling/backbone/resnet.py:33,49),
+ * NHWC bf16, output ((H-1)/2+1, (W-1)/2+1); PyTorch's NaN and first-max tie rules. */
+int cr_maxpool3x3s2_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C);
+int cr_maxpool3x3s2_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C);
+
 /* multi-tensor form of cr_cast_f32_to_bf16 + cr_weight_transpose: every conv weight of the model in one launch.
  * descs_dev: device array of cr_wdesc (offsets in ELEMENTS from the three base pointers); tiles_dev: device array of
  * ntiles int4 = (tensor index, filter tap, first cout, first cin) covering each tensor in 32x32 (cout x cin) tiles. */

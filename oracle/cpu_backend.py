@@ -83,6 +83,10 @@ def conv_bias_act(x, weight, bias, stride=1, pad=0, relu=False, out_f32=False):
     return y if out_f32 else _q(y)
 
 
+def maxpool3x3s2(x):
+    return _nhwc(_q(torch.nn.functional.max_pool2d(_nchw(x), 3, 2, 1)))
+
+
 def maxpool2x2(x):
     return _nhwc(F.max_pool2d(_nchw(x), 2, 2))
 
@@ -453,7 +457,7 @@ def cube_reduce(L, u_sel, buf, dec, validf, inverse_z=False):
     return red, stats
 
 
-PATCHED = ("3dod_amd.cubercnn.modeling.dense_train", "3dod_amd.cubercnn.modeling.backbone.dla", "3dod_amd.cubercnn.modeling.backbone.fpn",
+PATCHED = ("3dod_amd.cubercnn.modeling.dense_train", "3dod_amd.cubercnn.modeling.backbone.dla", "3dod_amd.cubercnn.modeling.backbone.fpn", "3dod_amd.cubercnn.modeling.backbone.resnet",
            "3dod_amd.cubercnn.modeling.proposal_generator.rpn", "3dod_amd.cubercnn.modeling.roi_heads.roi_heads",
            "3dod_amd.cubercnn.modeling.roi_heads.fast_rcnn", "3dod_amd.cubercnn.modeling.meta_arch.rcnn3d",
            "3dod_amd.cubercnn.solver.build")

@@ -261,3 +261,19 @@ def test_weight_bank_matches_per_tensor_prep():
     ops.bump_weight_epoch()
     wb, _ = ops.prepared_weights(params[0], False)
     assert torch.equal(wb.float(), (ref[0][0].float() * 2.0))
+
+
+@pytest.mark.parametrize("hw", [(12, 20), (13, 21), (2, 2)])
+def test_maxpool3x3s2(hw):
+    """ResNet stem pool: forward values, backward routing (overlapping windows accumulate, first-max ties) == ATen;
+    the bf16 sum of up to 4 window gradients is compared after the same rounding."""
+    g = torch.Generator().manual_seed(13)
+    x = q(torch.randn(2, 16, *hw, generator=g)).clamp(min=0)          # post-ReLU like: many exact ties at 0
+    xo = x.clone().requires_grad_(True)
+    yo = torch.nn.functional.max_pool2d(xo, 3, 2, 1)
+    dy = q(torch.randn_like(yo)); yo.backward(dy)
+    xd = nhwc(x).to(DEV).to(bf16).requires_grad_(True)
+    yd = ops.maxpool3x3s2(xd); yd.backward(nhwc(dy).to(DEV).to(bf16))
+    assert torch.equal(nchw(yd).float().cpu(), yo.detach())
+    assert torch.allclose(nchw(xd.grad).float().cpu(), xo.grad, rtol=1e-2, atol=1e-2)
+    assert torch.equal(nchw(xd.grad).float().cpu() != 0, xo.grad != 0)       # same routing
