@@ -267,6 +267,12 @@ int cr_cube_reduce(cr_ctx* ctx, const float* L, const float* buf39, const float*
 int cr_cube_reduce_bwd(cr_ctx* ctx, const float* L, const float* buf39, const unsigned char* validf, int n, int inverse_z,
                        const float* cnt6, const float* gred6, float* gL, float* gu);
 
+/* ---- exact IoU of oriented 3D boxes -----------------------------------------------------------
+ * replaces pytorch3d box3d_overlap / _C.iou_box3d [third-party] at ProposalNetwork/utils/utils.py:194-210,
+ * cubercnn/evaluation/omni3d_evaluation.py:155, cubercnn/modeling/roi_heads/roi_heads.py:518,526,1563.
+ * boxes1 (N,8,3), boxes2 (M,8,3) f32 corners in pytorch3d's order -> vol (N,M), iou (N,M). */
+int cr_box3d_overlap(cr_ctx* ctx, const float* boxes1, const float* boxes2, int N, int M, float* vol, float* iou);
+
 /* ---- optimizer (tools/train_net.py:233-266, cubercnn/solver/build.py:50-56) ------------- */
 int cr_nonfinite_flag(cr_ctx* ctx, const float* g, int64_t n, int* flag);
 /* SGD momentum on flat f32 buffers; skipped on device when *skip_flag != 0 (may be NULL). */
