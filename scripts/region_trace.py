@@ -110,7 +110,7 @@ def parse(path):
     print(f"total {tot/1e3:.3f} ms over {sum(v[0] for v in acc.values())} kernels")
     for k, (c, t) in acc.items():
         print(f"\n== {REGIONS[k]:32s} {c:5d} kernels {t/1e3:8.3f} ms")
-        for nm, (cc, tt) in sorted(names[k].items(), key=lambda kv: -kv[1][1])[:12]:
+        for nm, (cc, tt) in sorted(names[k].items(), key=lambda kv: -kv[1][1])[:22]:
             print(f"      {tt/1e3:7.3f} ms {cc:4d}x  {nm}")
 
 

@@ -51,3 +51,28 @@ def test_on_cuboid_corners_kernel():
     assert torch.allclose(torch.diagonal(vol).cpu(), box6[:, 3:].prod(1), rtol=1e-4)
     rvol, riou = O.box3d_overlap(verts.cpu().numpy(), verts.cpu().numpy())
     assert np.abs(iou.cpu().numpy() - riou).max() < 2e-4
+
+
+def test_ap3d_same_through_kernel_and_oracle():
+    """SURVEY 8(d) "AP3D parity": the same detections scored with the HIP IoU3D kernel and with the float64 oracle give
+    the same AP3D (1e-3)."""
+    ev = importlib.import_module("3dod_amd.cubercnn.evaluation")
+    rng = np.random.default_rng(11)
+    gts, dts = [], []
+    for img in range(6):
+        for k in range(5):
+            ctr = rng.normal(size=3) * [3, 1, 4] + [0, 0, 18]
+            dims = rng.uniform(0.5, 3, 3)
+            R = rot([0, 1, 0], rng.uniform(0, 3))
+            cat = int(rng.integers(0, 3))
+            c = box(ctr, dims, R)
+            gts.append({"image_id": img, "category_id": cat, "id": len(gts) + 1, "bbox": [0, 0, 10, 10], "area": 100.0,
+                        "bbox3D": c.tolist(), "depth": float(ctr[2]), "ignore2D": 0, "ignore3D": int(rng.random() < 0.1)})
+            for j in range(2):                       # a good and a sloppy detection per object
+                c2 = box(ctr + rng.normal(size=3) * (0.1 + 0.5 * j), dims * rng.uniform(0.8, 1.2, 3), R @ rot([0, 1, 0], rng.normal() * 0.2))
+                dts.append({"image_id": img, "category_id": cat, "bbox": [0, 0, 10, 10], "area": 100.0, "bbox3D": c2.tolist(),
+                            "depth": float(ctr[2]), "score": float(rng.random())})
+    a = ev.Omni3Deval(gts, dts, "3D").evaluate().accumulate().summarize()              # cr_box3d_overlap
+    b = ev.Omni3Deval(gts, dts, "3D", iou3d_fn=lambda d, g: O.box3d_overlap(np.asarray(d), np.asarray(g))[1]).evaluate().accumulate().summarize()
+    assert 0.05 < b[0] < 0.95
+    assert np.abs(a - b).max() < 1e-3, (a, b)
