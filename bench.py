@@ -11,6 +11,7 @@ Workloads
   geometry  BASELINE.json configs[2]: ProposalNetwork 1000-cube/object project + IoU/size/corner
             scoring + argmax, 64 images x 16 objects x 1000 cubes per GPU, ONE launch per step.
   train     BASELINE.json metric: Cube R-CNN DLA34-FPN train step (see bench_train.py).
+  inference BASELINE.json configs[1] (secondary): the same model in eval mode, 8 images per GPU.
 """
 import argparse
 import importlib
@@ -140,12 +141,42 @@ def cpu_baseline_geometry(inp, P):
             "sample": f"{n} objects x {P} cubes, numpy float32 oracle, per-object loop, {dt:.2f} s"}
 
 
+def bench_inference(args, rank, world, dev):
+    """BASELINE.json configs[1] (secondary metric): Cube R-CNN DLA34-FPN inference, 8 synthetic 512x512 images per GPU,
+    random-init weights, full post-processing (NMS, top-100, cube decoding) -> images/s."""
+    bt = importlib.import_module("bench_train")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    cfg, model, opt, syn, solver = bt.build(dev, world=world)
+    model.eval()
+    B = 8
+    batches = [syn.make_batch(B, 4321 + rank * 100 + i, with_gt=False) for i in range(2)]
+    for b in batches:
+        for d in b:
+            d["image"] = d["image"].to(dev)
+    n_det = 0
+    with torch.no_grad(), d2.EventStorage(0):
+        for i in range(args.warmup):
+            model(batches[i % 2])
+        barrier(world)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = model(batches[i % 2])
+            n_det += sum(len(o["instances"]) for o in out)
+        barrier(world)
+        dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    return {"metric": "images/sec Cube R-CNN DLA34-FPN inference (BASELINE configs[1])", "value": B * world * args.steps / dt,
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Cube R-CNN DLA34+FPN inference, 8 img/GPU 512x512, random-init weights, full post-processing",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "detections_per_step": n_det / max(args.steps, 1)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="train", choices=["train", "geometry"])
+    ap.add_argument("--workload", default="train", choices=["train", "geometry", "inference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
@@ -156,6 +187,8 @@ def main():
     dev = torch.device("cuda", local)
     if args.workload == "geometry":
         res = bench_geometry(args, rank, world, dev)
+    elif args.workload == "inference":
+        res = bench_inference(args, rank, world, dev)
     else:
         bt = importlib.import_module("bench_train")
         res = bt.bench_train(args, rank, world, dev)
