@@ -80,6 +80,9 @@ def load():
             raise CrError(
                 f"{LIB_PATH} not found: build it with `python 3dod_amd/build.py` "
                 "(or __graft_entry__.build()). There is no fallback path.")
+        # torch ships its own libamdhip64; it has to be in the process BEFORE this library pulls in a HIP runtime, or
+        # two runtimes coexist and the second one sees no device ("no ROCm-capable device is detected")
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         lib.cr_last_error.restype = ctypes.c_char_p
         lib.cr_last_error.argtypes = []
