@@ -24,6 +24,7 @@ SIGNATURES = {
     "cr_conv2d_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int],
     "cr_conv2d_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "cr_conv2d_bwd_weight": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "cr_conv2d_bwd_weight_bias": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "cr_cast_f32_to_bf16": [P, P, P, c_int64],
     "cr_weight_transpose": [P, P, P, c_int, c_int, c_int],
     "cr_colsum_accum": [P, P, c_int, c_int64, c_int, P, P],

@@ -471,6 +471,7 @@ struct WgP {
     int N, Hin, Win, Cin, Hout, Wout, Cout, stride, pad, Kdim, M, cshift;
     int steps_per_split;    // 32-pixel steps handled by one split
     int tm, tn, xcd;        // tile counts (the grid is 1-D: tm * tn * splits blocks)
+    float* dbias;           // optional [Cout]: += column sums of dy (bias gradient), accumulated by the first k-tile's blocks
 };
 
 // transposing LDS read: 16-lane group reads a 4(row) x 16(col) block of 16-bit elements and
@@ -607,8 +608,15 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_wgrad(WgP p) {
     load_stage();
     store_stage();
     __syncthreads();
+    // bias gradient = column sums of dy: the blocks of the first k-tile add them up from the dy tile they stage anyway
+    const bool do_bias = p.dbias != nullptr && by == 0 && tid < TM;
+    float bsum = 0.f;
     for (int st = 0; st < nstage; ++st) {
         if (st + 1 < nstage) load_stage();
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = 0; r < KU * 32; ++r) bsum += bf2f(sP[r * PP + tid]);
+        }
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             bf16x8 af[TI], bfr[TJ];
@@ -636,6 +644,7 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_wgrad(WgP p) {
             __syncthreads();
         }
     }
+    if (do_bias && c0 + tid < p.Cout) atomicAdd(&p.dbias[c0 + tid], bsum);
     // D: col (lane&15) = k index, row 4(lane>>4)+reg = channel
     if (KG == 1) {
 #pragma unroll
@@ -736,13 +745,13 @@ __global__ void k_fill_zero_f32(float* __restrict__ p, int64_t n) {
 
 // dW[k][r][s][c] (+)= sum dY * X ; dw is f32 [Cout][ks*ks*Cin]; `accumulate`=0 zeroes it first (with a kernel, not
 // hipMemsetAsync: memset nodes inside captured HIP graphs were observed to leave garbage on ROCm 7.2).
-extern "C" int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W,
-                                    int Cin, int Cout, int ks, int stride, int pad, int accumulate) {
+static int conv2d_bwd_weight_impl(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
+                                  int Cin, int Cout, int ks, int stride, int pad, int accumulate) {
     CR_CHECK_ARG(ctx && dy && x && dw, "cr_conv2d_bwd_weight: NULL pointer");
     int rc = conv_common_checks("cr_conv2d_bwd_weight", N, H, W, Cin, Cout, ks, stride, pad);
     if (rc) return rc;
     WgP p;
-    p.dy = (const u16*)dy; p.x = (const u16*)x; p.dw = dw;
+    p.dy = (const u16*)dy; p.x = (const u16*)x; p.dw = dw; p.dbias = dbias;
     p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Cout = Cout;
     p.Hout = (H + 2 * pad - ks) / stride + 1;
     p.Wout = (W + 2 * pad - ks) / stride + 1;
@@ -756,6 +765,18 @@ extern "C" int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, 
     if (ks == 1) return launch_wgrad_ks<1>(ctx, p);
     if (ks == 3) return launch_wgrad_ks<3>(ctx, p);
     return launch_wgrad_ks<7>(ctx, p);
+}
+
+extern "C" int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W,
+                                    int Cin, int Cout, int ks, int stride, int pad, int accumulate) {
+    return conv2d_bwd_weight_impl(ctx, dy, x, dw, nullptr, N, H, W, Cin, Cout, ks, stride, pad, accumulate);
+}
+
+// same, and dbias[Cout] += sum over pixels of dy (the bias gradient of a conv with bias: detectron2 FPN / RPN head convs)
+extern "C" int cr_conv2d_bwd_weight_bias(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int N, int H,
+                                         int W, int Cin, int Cout, int ks, int stride, int pad, int accumulate) {
+    CR_CHECK_ARG(dbias, "cr_conv2d_bwd_weight_bias: NULL dbias");
+    return conv2d_bwd_weight_impl(ctx, dy, x, dw, dbias, N, H, W, Cin, Cout, ks, stride, pad, accumulate);
 }
 
 // ---------------------------------------------------------------------------

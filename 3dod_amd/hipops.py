@@ -161,10 +161,17 @@ def grad_sink(t):
     return getattr(t, "_cr_grad", None)
 
 
-def conv_bwd_weight_raw(dy, x, k, stride, pad, sink=None):
+def conv_bwd_weight_raw(dy, x, k, stride, pad, sink=None, bias_acc=None):
+    """dW (into `sink` when given).  bias_acc: f32 [Cout] buffer that additionally receives += sum_pixels dy (fused)."""
     N, H, W, Cin = x.shape
     Cout = dy.shape[3]
     lib = _lib.load()
+    if bias_acc is not None:
+        dw = sink if sink is not None else torch.empty((Cout, Cin, k, k), dtype=f32, device=x.device).contiguous(
+            memory_format=torch.channels_last)
+        _chk(lib.cr_conv2d_bwd_weight_bias(_ctx(x), _p(dy), _p(x), _p(dw), _p(bias_acc), N, H, W, Cin, Cout, k, stride, pad,
+                                           int(sink is not None)), "cr_conv2d_bwd_weight_bias")
+        return None if sink is not None else dw
     if sink is not None:
         _chk(lib.cr_conv2d_bwd_weight(_ctx(x), _p(dy), _p(x), _p(sink), N, H, W, Cin, Cout, k, stride, pad, 1),
              "cr_conv2d_bwd_weight")
@@ -274,22 +281,27 @@ class _ConvBias(torch.autograd.Function):
         if relu:
             g = torch.where(y > 0, g, torch.zeros((), dtype=g.dtype, device=g.device))
         g = g.contiguous()
-        db = None
-        if has_bias and ctx.needs_input_grad[2]:
+        db, acc = None, None
+        want_db = has_bias and ctx.needs_input_grad[2]
+        if want_db:
             C = g.shape[3]
             bsink = grad_sink(ctx.bias_ref)
             acc = bsink if bsink is not None else torch.zeros((C,), dtype=f32, device=g.device)
-            ws = torch.empty((1024, C), dtype=f32, device=g.device)
-            lib = _lib.load()
-            _chk(lib.cr_colsum_accum(_ctx(g), _p(g), int(g.dtype == f32), g.numel() // C, C, _p(ws), _p(acc)),
-                 "cr_colsum_accum")
             db = None if bsink is not None else acc
+            if not (ctx.needs_input_grad[1] and g.dtype == bf16):
+                # no weight-gradient launch to ride on (or an f32 upstream gradient): separate column sum
+                ws = torch.empty((1024, C), dtype=f32, device=g.device)
+                lib = _lib.load()
+                _chk(lib.cr_colsum_accum(_ctx(g), _p(g), int(g.dtype == f32), g.numel() // C, C, _p(ws), _p(acc)),
+                     "cr_colsum_accum")
+                acc = None
         g = g.to(bf16).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
             _, wt = prepared_weights(weight, need_transposed=True)
             dx = conv_bwd_data_raw(g, wt, x.shape, k, stride, pad)
-        dw = conv_bwd_weight_raw(g, x, k, stride, pad, grad_sink(weight)) if ctx.needs_input_grad[1] else None
+        # the bias gradient (column sums of dy) is accumulated inside the weight-gradient kernel
+        dw = conv_bwd_weight_raw(g, x, k, stride, pad, grad_sink(weight), bias_acc=acc) if ctx.needs_input_grad[1] else None
         return dx, dw, db, None, None, None, None
 
 

@@ -120,6 +120,10 @@ int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, in
 /* dw f32 (Cout, ks*ks*Cin); accumulate=0 zeroes it first (shared RPN-head weights accumulate over levels). */
 int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
                          int Cout, int ks, int stride, int pad, int accumulate);
+/* same, plus dbias[Cout] += sum over output pixels of dy (bias gradient of the FPN / RPN-head convs), accumulated inside
+ * the same kernel from the dy tiles it stages anyway (dbias must be zeroed or hold the running gradient). */
+int cr_conv2d_bwd_weight_bias(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
+                              int Cin, int Cout, int ks, int stride, int pad, int accumulate);
 int cr_cast_f32_to_bf16(cr_ctx* ctx, const float* src, void* dst, int64_t n);
 /* bias gradient: out[c] += sum_m x[m][c]; x (M,C) bf16 or f32; ws = 1024*C floats; deterministic. */
 int cr_colsum_accum(cr_ctx* ctx, const void* x, int is_f32, int64_t M, int C, float* ws, float* out);
