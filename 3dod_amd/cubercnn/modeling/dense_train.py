@@ -181,18 +181,19 @@ def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes):
         ckey = (tuple(tuple(s) for s in image_sizes), tuple(sizes), tuple(ks), str(dev))
         cached = _PCONST.get(ckey)
         if cached is None:       # constants of the configuration: made once, never inside a captured region
-            cached = (torch.tensor([[float(s[0]), float(s[1])] for s in image_sizes], dtype=torch.float32, device=dev),
-                      torch.tensor(ks, dtype=torch.int32, device=dev).repeat(B))
+            cached = [torch.tensor([[float(s[0]), float(s[1])] for s in image_sizes], dtype=torch.float32, device=dev),
+                      torch.tensor(ks, dtype=torch.int32, device=dev).repeat(B),
+                      torch.tensor([sum(sizes[:l]) for l in range(len(sizes))], dtype=torch.int64, device=dev).view(1, -1, 1)]
             _PCONST[ckey] = cached
-        img_hw, counts = cached
-        idx = torch.full((B, L, maxn), -1, dtype=torch.int64, device=dev)
-        scores = torch.full((B, L, maxn), float("-inf"), dtype=torch.float32, device=dev)
-        off = 0
-        for l, (lg, k) in enumerate(zip(logits_per_level, ks)):
-            v, i = lg.detach().float().topk(k, dim=1)
-            idx[:, l, :k] = i + off
-            scores[:, l, :k] = v
-            off += sizes[l]
+        img_hw, counts = cached[0], cached[1]
+        # ONE top-k for all levels: logits padded to the largest level with -inf (a per-level call costs as much as
+        # this single batched one: the select is one workgroup per row either way)
+        amax = max(sizes)
+        padded = torch.full((B, L, amax), float("-inf"), dtype=torch.float32, device=dev)
+        for l, lg in enumerate(logits_per_level):
+            padded[:, l, :sizes[l]] = lg.detach()
+        scores, idx = padded.topk(min(maxn, amax), dim=2)                     # (B, L, maxn), sorted descending
+        idx = torch.where(torch.isfinite(scores), idx + cached[2], torch.full((), -1, dtype=torch.int64, device=dev))
         t = rpn.box2box_transform
         boxes, nms_boxes, valid = ops.rpn_decode_select(anchors, deltas.detach(), idx.view(B, -1), scores.view(B, -1),
                                                         t.weights, t.scale_clamp, img_hw, rpn.min_box_size)
