@@ -53,6 +53,8 @@ SIGNATURES = {
     "cr_cube_reduce": [P, P, P, P, P, c_int, c_int, P, P, P],
     "cr_cube_reduce_bwd": [P, P, P, P, c_int, c_int, P, P, P, P],
     "cr_weights_prepare": [P, P, P, P, P, P, c_int],
+    "cr_fc_weight_prepare": [P, P, P, c_int, c_int, c_int],
+    "cr_fc_grad_accum": [P, P, P, c_int, c_int, c_int],
     "cr_maxpool3x3s2_fwd": [P, P, P, c_int, c_int, c_int, c_int],
     "cr_maxpool3x3s2_bwd": [P, P, P, P, c_int, c_int, c_int, c_int],
     "cr_box3d_overlap": [P, P, P, c_int, c_int, P, P],

@@ -876,6 +876,79 @@ extern "C" int cr_weights_prepare(cr_ctx* ctx, const float* src_base, void* dst_
 }
 
 // ---------------------------------------------------------------------------
+// FC weights of the RoI heads.  The first FC consumes RoI features flattened in (h,w,c) order (NHWC) while the
+// checkpoint keeps its columns in (c,h,w) order (roi_heads.py:2160-2204, cube_head.py:152-202 flatten NCHW):
+//   cr_fc_weight_prepare   f32 (O, C, HW) -> bf16 (O, HW, C)   (HW = 1: plain cast), once per optimizer step
+//   cr_fc_grad_accum       f32 (O, C, HW) += bf16 (O, HW, C)    the weight gradient lands in the flat gradient
+// A block handles one output row and a tile of 64 input channels: both sides move whole contiguous runs.
+// ---------------------------------------------------------------------------
+#define FC_CT 64
+__global__ __launch_bounds__(256) void k_fc_weight_prepare(const float* __restrict__ src, u16* __restrict__ dst, int C, int HW) {
+    extern __shared__ float s_fc[];                       // [FC_CT][HW + 1]
+    const int o = blockIdx.y, c0 = blockIdx.x * FC_CT;
+    const int nc = min(FC_CT, C - c0), P1 = HW + 1;
+    const float* in = src + ((size_t)o * C + c0) * HW;    // nc * HW contiguous floats
+    for (int i = threadIdx.x; i < nc * HW; i += 256) s_fc[(i / HW) * P1 + (i % HW)] = in[i];
+    __syncthreads();
+    u16* out = dst + (size_t)o * HW * C + c0;
+    for (int i = threadIdx.x; i < nc * HW; i += 256) {
+        const int hw = i / nc, c = i - hw * nc;
+        out[(size_t)hw * C + c] = f2bf(s_fc[c * P1 + hw]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fc_grad_accum(const u16* __restrict__ g, float* __restrict__ acc, int C, int HW) {
+    extern __shared__ float s_fc[];
+    const int o = blockIdx.y, c0 = blockIdx.x * FC_CT;
+    const int nc = min(FC_CT, C - c0), P1 = HW + 1;
+    const u16* in = g + (size_t)o * HW * C + c0;
+    for (int i = threadIdx.x; i < nc * HW; i += 256) {
+        const int hw = i / nc, c = i - hw * nc;
+        s_fc[c * P1 + hw] = bf2f(in[(size_t)hw * C + c]);
+    }
+    __syncthreads();
+    float* out = acc + ((size_t)o * C + c0) * HW;
+    for (int i = threadIdx.x; i < nc * HW; i += 256) out[i] += s_fc[(i / HW) * P1 + (i % HW)];
+}
+
+__global__ void k_axpy_bf16_f32(const u16* __restrict__ g, float* __restrict__ acc, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const uint2 v = *reinterpret_cast<const uint2*>(g + i);
+        float4 a = *reinterpret_cast<float4*>(acc + i);
+        a.x += bf2f((u16)(v.x & 0xffff)); a.y += bf2f((u16)(v.x >> 16));
+        a.z += bf2f((u16)(v.y & 0xffff)); a.w += bf2f((u16)(v.y >> 16));
+        *reinterpret_cast<float4*>(acc + i) = a;
+    } else {
+        for (int64_t j = i; j < n; ++j) acc[j] += bf2f(g[j]);
+    }
+}
+
+extern "C" int cr_fc_weight_prepare(cr_ctx* ctx, const float* w, void* wb, int O, int C, int HW) {
+    CR_CHECK_ARG(ctx && w && wb && O > 0 && C > 0 && HW > 0 && HW <= 1024, "cr_fc_weight_prepare: bad args");
+    if (HW == 1) return cr_cast_f32_to_bf16(ctx, w, wb, (int64_t)O * C);
+    hipLaunchKernelGGL(k_fc_weight_prepare, dim3((unsigned)cr_cdiv(C, FC_CT), O), dim3(256), FC_CT * (HW + 1) * sizeof(float),
+                       ctx->stream, w, (u16*)wb, C, HW);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+extern "C" int cr_fc_grad_accum(cr_ctx* ctx, const void* g, float* acc, int O, int C, int HW) {
+    CR_CHECK_ARG(ctx && g && acc && O > 0 && C > 0 && HW > 0 && HW <= 1024, "cr_fc_grad_accum: bad args");
+    if (HW == 1) {
+        const int64_t n = (int64_t)O * C;
+        CR_CHECK_ARG((((uintptr_t)g) & 7) == 0 && (((uintptr_t)acc) & 15) == 0, "cr_fc_grad_accum: misaligned");
+        hipLaunchKernelGGL(k_axpy_bf16_f32, dim3((unsigned)cr_cdiv(cr_cdiv(n, 4), 256)), dim3(256), 0, ctx->stream, (const u16*)g,
+                           acc, n);
+    } else {
+        hipLaunchKernelGGL(k_fc_grad_accum, dim3((unsigned)cr_cdiv(C, FC_CT), O), dim3(256), FC_CT * (HW + 1) * sizeof(float),
+                           ctx->stream, (const u16*)g, acc, C, HW);
+    }
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // BatchNorm2d (training mode, per-GPU statistics: dla.py:17 BatchNorm = nn.BatchNorm2d)
 // ---------------------------------------------------------------------------
 // finalize: per-tile partials [nparts][2][C] -> mean / invstd (+ running stats update, momentum, unbiased var).

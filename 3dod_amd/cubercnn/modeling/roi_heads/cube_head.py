@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ....d2lite import Registry, ShapeSpec
+from .... import hipops as ops
 from ...util.math_util import rotation_6d_to_matrix
 from ..backbone.fpn import c2_xavier_fill
 
@@ -19,9 +20,7 @@ bf16 = torch.bfloat16
 
 def fc_nhwc(x_nhwc_flat, fc, chw):
     """Linear whose weight columns are in (c,h,w) order applied to an (h,w,c)-flattened bf16 input."""
-    C, H, W = chw
-    w = fc.weight.view(fc.out_features, C, H, W).permute(0, 2, 3, 1).reshape(fc.out_features, -1)
-    return F.linear(x_nhwc_flat, w.to(x_nhwc_flat.dtype), fc.bias.to(x_nhwc_flat.dtype))
+    return ops.linear(x_nhwc_flat, fc.weight, fc.bias, chw=tuple(chw))
 
 
 @ROI_CUBE_HEAD_REGISTRY.register()
@@ -74,7 +73,7 @@ class CubeHead(nn.Module):
         fcs = [m for m in self.feature_generator if isinstance(m, nn.Linear)]
         h = F.relu(fc_nhwc(x, fcs[0], self._in_chw))
         for fc in fcs[1:]:
-            h = F.relu(F.linear(h, fc.weight.to(h.dtype), fc.bias.to(h.dtype)))
+            h = F.relu(ops.linear(h, fc.weight, fc.bias))
         lin = lambda m: F.linear(h, m.weight.to(h.dtype), m.bias.to(h.dtype)).float()
         box_2d_deltas = lin(self.bbox_3D_center_deltas)
         box_dims = lin(self.bbox_3D_dims)
@@ -96,7 +95,7 @@ def _forward_fused(self, x):
     fcs = [m for m in self.feature_generator if isinstance(m, nn.Linear)]
     h = F.relu(fc_nhwc(x, fcs[0], self._in_chw))
     for fc in fcs[1:]:
-        h = F.relu(F.linear(h, fc.weight.to(h.dtype), fc.bias.to(h.dtype)))
+        h = F.relu(ops.linear(h, fc.weight, fc.bias))
     assert self.use_conf
     preds = [self.bbox_3D_center_deltas, self.bbox_3D_dims, self.bbox_3D_pose, self.bbox_3D_center_depth,
              self.bbox_3D_uncertainty]

@@ -98,8 +98,8 @@ class FastRCNNOutputLayers(nn.Module):
     def forward(self, x):
         if x.dim() > 2:
             x = torch.flatten(x, start_dim=1)
-        scores = F.linear(x, self.cls_score.weight.to(x.dtype), self.cls_score.bias.to(x.dtype)).float()
-        proposal_deltas = F.linear(x, self.bbox_pred.weight.to(x.dtype), self.bbox_pred.bias.to(x.dtype)).float()
+        scores = ops.linear(x, self.cls_score.weight, self.cls_score.bias).float()
+        proposal_deltas = ops.linear(x, self.bbox_pred.weight, self.bbox_pred.bias).float()
         return scores, proposal_deltas
 
     def predict_boxes_for_gt_classes(self, predictions, proposals):

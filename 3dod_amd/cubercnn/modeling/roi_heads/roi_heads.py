@@ -69,7 +69,7 @@ class FastRCNNConvFCHead(nn.Sequential):
         """x (R, H, W, C) bf16."""
         h = F.relu(fc_nhwc(x.flatten(1), self.fcs[0], self._in_chw))
         for fc in self.fcs[1:]:
-            h = F.relu(F.linear(h, fc.weight.to(h.dtype), fc.bias.to(h.dtype)))
+            h = F.relu(ops.linear(h, fc.weight, fc.bias))
         return h
 
     @property

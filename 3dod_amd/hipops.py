@@ -558,6 +558,73 @@ def cube_decode_loss(dxy, zr, dr, Ra, u, src_boxes, K4, v2r, prior_mean, gt2d, g
 
 
 # --------------------------------------------------------------------------
+# FC layers of the RoI heads: library GEMMs (hipBLASLt through torch.mm) around own weight-prep / gradient kernels
+# --------------------------------------------------------------------------
+def prepared_fc_weight(weight, chw=None):
+    """bf16 copy of an nn.Linear weight (O, K) f32, cached per weight epoch on the tensor.  chw = (C,H,W): the columns are
+    re-ordered from the checkpoint's (c,h,w) flattening to (h,w,c) for NHWC-flattened RoI features."""
+    ent = getattr(weight, "_cr_fccache", None)
+    tag = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr(), chw)
+    if ent is None or ent[0] != tag:
+        O, K = weight.shape
+        C, HW = (chw[0], chw[1] * chw[2]) if chw is not None else (K, 1)
+        assert C * HW == K
+        wb = torch.empty((O, K), dtype=bf16, device=weight.device)
+        lib = _lib.load()
+        _chk(lib.cr_fc_weight_prepare(_ctx(weight), _p(weight.detach().contiguous()), _p(wb), O, C, HW), "cr_fc_weight_prepare")
+        ent = (tag, wb)
+        try:
+            weight._cr_fccache = ent
+        except Exception:
+            pass
+    return ent[1]
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, chw):
+        _need_cuda(x, "linear input")
+        wb = prepared_fc_weight(weight, chw)
+        xb = x.to(bf16)
+        y = torch.addmm(bias.detach().to(bf16), xb, wb.t()) if bias is not None else torch.mm(xb, wb.t())
+        ctx.save_for_backward(xb, wb)
+        ctx.refs = (weight, bias, chw, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        weight, bias, chw, xdt = ctx.refs
+        dy = dy.to(bf16).contiguous()
+        dx = torch.mm(dy, wb).to(xdt) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        lib = _lib.load()
+        O, K = weight.shape
+        C, HW = (chw[0], chw[1] * chw[2]) if chw is not None else (K, 1)
+        if ctx.needs_input_grad[1]:
+            g = torch.mm(dy.t(), xb)                                   # (O, K) bf16 in the compute (h,w,c) order
+            acc = grad_sink(weight)
+            if acc is None:
+                acc = torch.zeros((O, K), dtype=f32, device=dy.device)
+                dw = acc
+            _chk(lib.cr_fc_grad_accum(_ctx(dy), _p(g), _p(acc), O, C, HW), "cr_fc_grad_accum")
+        if bias is not None and ctx.needs_input_grad[2]:
+            acc = grad_sink(bias)
+            if acc is None:
+                acc = torch.zeros((O,), dtype=f32, device=dy.device)
+                db = acc
+            ws = torch.empty((1024, O), dtype=f32, device=dy.device)
+            _chk(lib.cr_colsum_accum(_ctx(dy), _p(dy), 0, dy.shape[0], O, _p(ws), _p(acc)), "cr_colsum_accum")
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, chw=None):
+    """F.linear in bf16 with the weight copy cached per optimizer step and the gradients accumulated straight into the
+    optimizer's flat gradient (when the parameters carry sinks).  chw: see prepared_fc_weight."""
+    return _Linear.apply(x, weight, bias, chw)
+
+
+# --------------------------------------------------------------------------
 # NMS
 # --------------------------------------------------------------------------
 def nms_grouped(boxes, counts, thresh):

@@ -187,6 +187,12 @@ int cr_cube_loss_bwd(cr_ctx* ctx, const float* const* inputs, int64_t n, int all
 int cr_maxpool3x3s2_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C);
 int cr_maxpool3x3s2_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C);
 
+/* FC weights of the RoI heads (roi_heads.py:2160-2204, cube_head.py:152-202).  w f32 (O, C, HW) in the checkpoint's
+ * (c,h,w) column order -> wb bf16 (O, HW, C) for NHWC-flattened inputs (HW = 1: plain cast); and the transpose for the
+ * gradient: acc f32 (O, C, HW) += g bf16 (O, HW, C). */
+int cr_fc_weight_prepare(cr_ctx* ctx, const float* w, void* wb, int O, int C, int HW);
+int cr_fc_grad_accum(cr_ctx* ctx, const void* g, float* acc, int O, int C, int HW);
+
 /* multi-tensor form of cr_cast_f32_to_bf16 + cr_weight_transpose: every conv weight of the model in one launch.
  * descs_dev: device array of cr_wdesc (offsets in ELEMENTS from the three base pointers); tiles_dev: device array of
  * ntiles int4 = (tensor index, filter tap, first cout, first cin) covering each tensor in 32x32 (cout x cin) tiles. */

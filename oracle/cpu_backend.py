@@ -159,6 +159,15 @@ def roi_align_pyramid(feats, rois, scales, out_size):
     return _q(out)
 
 
+def linear(x, weight, bias=None, chw=None):
+    """F.linear; chw = (C,H,W): x is flattened in (h,w,c) order while the weight columns are in (c,h,w) order."""
+    w = weight
+    if chw is not None:
+        C, H, W = chw
+        w = weight.view(weight.shape[0], C, H, W).permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
+    return _q(F.linear(_q(x.float()), _q(w), None if bias is None else _q(bias)))
+
+
 def nms_grouped(boxes, counts, thresh):
     G, maxn, _ = boxes.shape
     keep = torch.zeros((G, maxn), dtype=torch.bool)
@@ -459,7 +468,7 @@ def cube_reduce(L, u_sel, buf, dec, validf, inverse_z=False):
 
 PATCHED = ("3dod_amd.cubercnn.modeling.dense_train", "3dod_amd.cubercnn.modeling.backbone.dla", "3dod_amd.cubercnn.modeling.backbone.fpn", "3dod_amd.cubercnn.modeling.backbone.resnet",
            "3dod_amd.cubercnn.modeling.proposal_generator.rpn", "3dod_amd.cubercnn.modeling.roi_heads.roi_heads",
-           "3dod_amd.cubercnn.modeling.roi_heads.fast_rcnn", "3dod_amd.cubercnn.modeling.meta_arch.rcnn3d",
+           "3dod_amd.cubercnn.modeling.roi_heads.fast_rcnn", "3dod_amd.cubercnn.modeling.roi_heads.cube_head", "3dod_amd.cubercnn.modeling.meta_arch.rcnn3d",
            "3dod_amd.cubercnn.solver.build")
 
 

@@ -277,3 +277,36 @@ def test_maxpool3x3s2(hw):
     assert torch.equal(nchw(yd).float().cpu(), yo.detach())
     assert torch.allclose(nchw(xd.grad).float().cpu(), xo.grad, rtol=1e-2, atol=1e-2)
     assert torch.equal(nchw(xd.grad).float().cpu() != 0, xo.grad != 0)       # same routing
+
+
+@pytest.mark.parametrize("chw", [None, (24, 7, 7), (70, 3, 5)])
+def test_linear_fc(chw):
+    """ops.linear: cached bf16 weight copy (with the (c,h,w)->(h,w,c) column re-ordering of the first RoI-head FC), library
+    GEMMs, gradients through cr_fc_grad_accum / cr_colsum_accum -- against F.linear on the re-ordered weight."""
+    from oracle import cpu_backend as O
+    g = torch.Generator().manual_seed(17)
+    K = 96 if chw is None else chw[0] * chw[1] * chw[2]
+    n, Odim = 50, 40
+    x, w, b = q(torch.randn(n, K, generator=g)), q(torch.randn(Odim, K, generator=g) * 0.1), q(torch.randn(Odim, generator=g))
+    dy = q(torch.randn(n, Odim, generator=g))
+    xo, wo, bo = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yo = O.linear(xo, wo, bo, chw=chw)
+    yo.backward(dy)
+    xd, wd, bd = x.to(DEV).to(bf16).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    yd = ops.linear(xd, wd, bd, chw=chw)
+    yd.backward(dy.to(DEV).to(bf16))
+    assert relerr(yd.float().cpu(), yo.detach()) < 1e-2
+    assert relerr(xd.grad.float().cpu(), xo.grad) < 1e-2
+    assert relerr(wd.grad.cpu(), wo.grad) < 1e-2 and relerr(bd.grad.cpu(), bo.grad) < 1e-2
+    # with gradient sinks (the optimizer's flat gradient): accumulated in place, autograd returns None
+    wd2, bd2 = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    wd2._cr_grad, bd2._cr_grad = torch.ones_like(wd2), torch.ones_like(bd2)
+    ops.linear(xd.detach(), wd2, bd2, chw=chw).backward(dy.to(DEV).to(bf16))
+    assert wd2.grad is None and bd2.grad is None
+    assert relerr((wd2._cr_grad - 1).cpu(), wo.grad) < 1e-2 and relerr((bd2._cr_grad - 1).cpu(), bo.grad) < 1e-2
+    # the cached copy follows the weight epoch
+    with torch.no_grad():
+        wd2.mul_(2.0)
+    ops.bump_weight_epoch()
+    y2 = ops.linear(xd.detach(), wd2, None, chw=chw)
+    assert relerr(y2.float().cpu(), (yo.detach() - b) * 2) < 2e-2
