@@ -238,12 +238,49 @@ def roi_label_and_sample(rh, prop_boxes, prop_scores, gt: GTBatch):
     return {"boxes": s_boxes, "valid": s_valid, "classes": s_cls, "gt_idx": s_gt, "k_fg": k_fg}
 
 
-def box_head_losses(rh, features, samp, gt: GTBatch):
+_BIDX = {}
+
+
+def _rois(boxes):
+    """(B,n,4) -> (B*n,5) [image index, x1,y1,x2,y2] (the index column is a cached constant)."""
+    B, n = boxes.shape[:2]
+    key = (B, n, str(boxes.device))
+    col = _BIDX.get(key)
+    if col is None:
+        col = _BIDX[key] = torch.arange(B, device=boxes.device, dtype=boxes.dtype).repeat_interleave(n)[:, None]
+    return torch.cat([col, boxes.reshape(B * n, 4)], 1)
+
+
+def pool_roi_features(rh, features, samp):
+    """ROIAlign for the box head (all S slots) and the cube head (the k_fg foreground slots, optionally rescaled boxes,
+    roi_heads.py:2217-2235) in ONE launch when both poolers share their configuration: one forward kernel, and one
+    backward accumulation pyramid instead of two (zero-fill, atomics, cast and the autograd add of the two results)."""
+    B, S = samp["valid"].shape
+    kf = samp["k_fg"]
+    cb = samp["boxes"][:, :kf]
+    if rh.scale_roi_boxes > 0:           # (the reference uses the width for the height as well)
+        ctr = (cb[..., :2] + cb[..., 2:]) * 0.5
+        half = (cb[..., 2:3] - cb[..., 0:1]) * (0.5 * rh.scale_roi_boxes)
+        cb = torch.cat([ctr - half, ctr + half], -1)
+    bp, cp = rh.box_pooler, rh.cube_pooler
+    if rh.loss_w_3d > 0 and tuple(rh.box_in_features) == tuple(rh.in_features) and bp.scales == cp.scales and \
+            bp.output_size == cp.output_size:
+        feats = [features[f] for f in rh.in_features]
+        out = ops.roi_align_pyramid(feats, torch.cat([_rois(samp["boxes"]), _rois(cb)], 0), bp.scales, bp.output_size)
+        return out[:B * S], out[B * S:]
+    box = ops.roi_align_pyramid([features[f] for f in rh.box_in_features], _rois(samp["boxes"]), bp.scales, bp.output_size)
+    cube = ops.roi_align_pyramid([features[f] for f in rh.in_features], _rois(cb), cp.scales, cp.output_size) \
+        if rh.loss_w_3d > 0 else None
+    return box, cube
+
+
+def box_head_losses(rh, features, samp, gt: GTBatch, pooled=None):
     """_forward_box in training (roi_heads.py:2160-2204) + FastRCNNOutputs.losses (fast_rcnn.py:145-194) on the padded
     sample.  Returns (losses, pred_boxes (B,S,4) for the sampled classes)."""
     B, S = samp["valid"].shape
-    feats = [features[f] for f in rh.box_in_features]
-    box_features = rh.box_head(rh.box_pooler(feats, [Boxes(b) for b in samp["boxes"]]))
+    if pooled is None:
+        pooled = pool_roi_features(rh, features, samp)[0]
+    box_features = rh.box_head(pooled)
     scores, deltas = rh.box_predictor(box_features)                                    # (B*S,K+1), (B*S,K*4)
     assert rh.box_predictor.smooth_l1_beta < 1e-5
     t = rh.box_predictor.box2box_transform
@@ -256,16 +293,16 @@ def box_head_losses(rh, features, samp, gt: GTBatch):
     return losses, pred.view(B, S, 4)
 
 
-def cube_head_losses(rh, features, samp, pred_boxes, gt: GTBatch, meta):
+def cube_head_losses(rh, features, samp, pred_boxes, gt: GTBatch, meta, pooled=None):
     """_forward_cube in training (roi_heads.py:2237-2679) on the k_fg foreground slots of every image.  Empty slots
     are excluded from the reductions (safely_reduce_losses, roi_heads.py:2843-2851) by their validity flag."""
     B, kf = samp["valid"].shape[0], samp["k_fg"]
     K = rh.num_classes
     boxes = samp["boxes"][:, :kf]
     n = B * kf
-    scaled = rh.scale_proposals([Boxes(b) for b in boxes])
-    feats = [features[f] for f in rh.in_features]
-    cube_features = rh.cube_pooler(feats, scaled).flatten(1)
+    if pooled is None:
+        pooled = pool_roi_features(rh, features, samp)[1]
+    cube_features = pooled.flatten(1)
     raw, layout = rh.cube_head.forward_fused(cube_features)
     assert rh.use_confidence > 0 and rh.dims_priors_func == "exp"
     priors = rh.priors_dims_per_cat.detach()[0, :, 0, :].contiguous() if rh.dims_priors_enabled else None
@@ -308,8 +345,9 @@ def forward_train(model, image_sizes, features, head_outputs, gt: GTBatch, meta)
     losses = rpn_losses(rpn, anchors, logits, deltas, labels, midx, gt)
     pboxes, pscores = rpn_proposals_padded(rpn, anchors, logits_lv, deltas, image_sizes)
     samp = roi_label_and_sample(rh, pboxes, pscores, gt)
-    lb, pred_boxes = box_head_losses(rh, features, samp, gt)
+    box_pooled, cube_pooled = pool_roi_features(rh, features, samp)
+    lb, pred_boxes = box_head_losses(rh, features, samp, gt, pooled=box_pooled)
     losses.update(lb)
     if rh.loss_w_3d > 0:
-        losses.update(cube_head_losses(rh, features, samp, pred_boxes, gt, meta))
+        losses.update(cube_head_losses(rh, features, samp, pred_boxes, gt, meta, pooled=cube_pooled))
     return losses
