@@ -52,6 +52,8 @@ class _Replay(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         r = ctx.runner
+        if r.pre_bwd is not None:          # every gradient of the RoI heads is final here (they feed this node's inputs)
+            r.pre_bwd()
         for sg, g in zip(r.static_grads, grads):
             if g is None:
                 sg.zero_()
@@ -68,6 +70,7 @@ class GraphedDense:
         self.shape = tuple(images_u8.shape)
         dev = images_u8.device
         self.static_img = images_u8.clone()
+        self.pre_bwd = None                 # optional callback run right before the backward graph is replayed
         self.trigger = torch.zeros((), device=dev, requires_grad=True)
         pg = model.proposal_generator
         self.feat_names = None

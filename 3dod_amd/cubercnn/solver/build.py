@@ -146,12 +146,47 @@ def build_optimizer(cfg, model):
     return FlatSGD(_param_groups(cfg, model), cfg.SOLVER.MOMENTUM, cfg.SOLVER.NESTEROV)
 
 
+def early_allreduce_ranges(model, optimizer):
+    """[start, end) ranges of the flat gradient holding the FC weights of the RoI heads that carry gradient sinks."""
+    rh = getattr(model, "roi_heads", None)
+    if rh is None:
+        return []
+    base = optimizer.flat_g.data_ptr()
+    out = []
+    for m in list(getattr(getattr(rh, "box_head", None), "fcs", [])) + \
+            [l for l in getattr(getattr(rh, "cube_head", None), "feature_generator", []) if isinstance(l, torch.nn.Linear)]:
+        sink = ops.grad_sink(m.weight) if hasattr(ops, "grad_sink") else None
+        if sink is not None and sink.is_contiguous():
+            a = (sink.data_ptr() - base) // 4
+            out.append((a, a + sink.numel()))
+    out.sort()
+    merged = []
+    for a, b in out:
+        if merged and a <= merged[-1][1]:
+            merged[-1] = (merged[-1][0], max(b, merged[-1][1]))
+        else:
+            merged.append((a, b))
+    return merged
+
+
+def complement_ranges(ranges, n, bucket):
+    """[0,n) minus `ranges`, chopped into buckets of at most `bucket` elements, last parameters first."""
+    out, pos = [], 0
+    for a, b in list(ranges) + [(n, n)]:
+        while pos < a:
+            e = min(a, pos + bucket)
+            out.append((pos, e))
+            pos = e
+        pos = max(pos, b)
+    return out[::-1]
+
+
 class TrainStep:
     """One iteration of do_train (tools/train_net.py:184-304) without host round trips."""
     TOLERANCE = 4.0
     GAMMA = 0.02
 
-    def __init__(self, cfg, model, optimizer, world_size=1, bucket_mb=32):
+    def __init__(self, cfg, model, optimizer, world_size=1, bucket_mb=32, force_comm=False):
         self.model, self.opt = model, optimizer
         optimizer.enable_weight_bank()
         self.world = world_size
@@ -164,8 +199,24 @@ class TrainStep:
         n = optimizer.flat_g.numel()
         be = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets = [(i, min(i + be, n)) for i in range(0, n, be)][::-1]     # last-used params first
-        self.comm_stream = torch.cuda.Stream(device=dev) if (world_size > 1 and dev.type == 'cuda') else None
+        self.force_comm = force_comm         # tests: run the multi-rank protocol on a 1-rank process group
+        self.comm_stream = torch.cuda.Stream(device=dev) if ((world_size > 1 or force_comm) and dev.type == 'cuda') else None
+        # ranges of the flat gradient that are final as soon as the RoI heads' backward is done (the big FC weights of
+        # both heads: their kernels write straight into the flat gradient): all-reduced on the side stream WHILE the
+        # captured trunk/FPN/RPN backward graph runs; the rest goes after backward.
+        self.early_ranges = early_allreduce_ranges(model, optimizer)
+        self.late_ranges = complement_ranges(self.early_ranges, n, be)
+        self._early_done = False
         self.last = {}
+
+    def _early_allreduce(self):
+        if self.comm_stream is None or not self.early_ranges:
+            return
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            for a, b in self.early_ranges:
+                dist.all_reduce(self.opt.flat_g[a:b])
+        self._early_done = True
 
     def __call__(self, data):
         opt, world = self.opt, self.world
@@ -188,13 +239,18 @@ class TrainStep:
         losses = torch.where(diverging, losses.clip(0, 1), losses)
         self.recent_loss = torch.where(diverging, recent, recent * (1 - self.GAMMA) + losses_reduced * self.GAMMA)
         opt.zero_grad()
+        g = getattr(self.model, "_graphed", None)
+        if g is not None and self.comm_stream is not None and g.pre_bwd is None:
+            g.pre_bwd = self._early_allreduce
+        self._early_done = False
         losses.backward()
         opt.collect_grads()
-        # ---- gradient all-reduce (DDP, train_net.py:477-480), bucketed, overlapped on a side stream
-        if world > 1 and self.comm_stream is not None:
+        # ---- gradient all-reduce (DDP, train_net.py:477-480), bucketed, on a side stream; the RoI heads' part was
+        # started before the trunk's backward graph (see _early_allreduce) when the dense-region graphs are active
+        if self.comm_stream is not None and (world > 1 or self.force_comm):
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                for a, b in self.buckets:
+                for a, b in (self.late_ranges if self._early_done else self.buckets):
                     dist.all_reduce(opt.flat_g[a:b])
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         elif world > 1:                      # gloo / CPU rehearsal of the same protocol

@@ -87,3 +87,19 @@ def test_two_rank_train_step_protocol():
         assert skipped_kept, "the poisoned step was not skipped on every rank"
         assert explode == 1.0
     assert res[0][4] == res[1][4], "the fused loss all-reduce must give every rank the same total"
+
+
+def test_allreduce_range_bookkeeping():
+    """early (RoI-head FC weights) + late ranges of the flat gradient tile [0, n) exactly once."""
+    import importlib
+    b = importlib.import_module("3dod_amd.cubercnn.solver.build")
+    n, bucket = 1000, 64
+    for early in ([], [(0, 10)], [(990, 1000)], [(100, 300), (300, 420), (700, 701)], [(0, 1000)]):
+        late = b.complement_ranges(early, n, bucket)
+        cover = sorted(list(early) + late)
+        assert all(e - a <= bucket for a, e in late)
+        pos = 0
+        for a, e in cover:
+            assert a == pos and e > a, (early, cover)
+            pos = e
+        assert pos == n

@@ -321,3 +321,36 @@ def test_whole_step_graph_trains_like_eager():
     assert abs(tg[0]["total_loss"] - te[0]["total_loss"]) < 0.05 * te[0]["total_loss"]
     assert all(t["total_loss"] == t["total_loss"] and t["total_loss"] < 50 for t in tg)
     assert tg[-1]["total_loss"] < tg[0]["total_loss"]
+
+
+def test_train_step_comm_protocol_single_rank_group(built):
+    """the multi-rank protocol (side stream, RoI-head FC gradients all-reduced while the captured trunk backward runs,
+    the rest after backward) exercised on a 1-rank RCCL group: same code path as N > 1, all-reduce = identity."""
+    import torch.distributed as dist
+    cfg, model, opt, syn, solver = built
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    model.train()
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29731", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        step = solver.TrainStep(cfg, model, opt, world_size=1, force_comm=True)
+        n = opt.flat_g.numel()
+        assert step.early_ranges and sum(b - a for a, b in step.early_ranges) > 20_000_000      # the four big FC weights
+        cover = sorted(step.early_ranges + step.late_ranges)
+        assert cover[0][0] == 0 and cover[-1][1] == n and all(x[1] == y[0] for x, y in zip(cover, cover[1:]))
+        batch = syn.make_batch(4, 9)
+        if model._graphed is None or not model._graphed.matches(model._stack_images(batch)[1]):
+            model.enable_graphs(batch)
+        opt.zero_grad()
+        p0 = opt.flat_p.clone()
+        with d2.EventStorage(0):
+            for _ in range(3):
+                step(batch)
+                assert step._early_done                      # the hook fired before the backward graph
+        rep = step.report()
+        assert rep["total_loss"] == rep["total_loss"] and rep["iterations_explode"] == 0, rep
+        assert not torch.equal(p0, opt.flat_p)
+    finally:
+        model._graphed = None
+        dist.destroy_process_group()
