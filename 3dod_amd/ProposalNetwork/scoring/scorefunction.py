@@ -30,3 +30,19 @@ def score_dimensions(category, dimensions, gt_boxes, pred_boxes):
     pred_ratios = (pred_boxes.tensor[:, 2] - pred_boxes.tensor[:, 0]) / (pred_boxes.tensor[:, 3] - pred_boxes.tensor[:, 1])
     differences = torch.abs(gt_ratio - pred_ratios)
     return (1 - differences / torch.max(differences)) * scores
+
+
+def score_point_cloud(point_cloud, cubes, K=None, segmentation_mask=None):
+    """scorefunction.py:9-43 (MABO diagnostics only, roi_heads.py:535): number of cloud points inside a box derived from
+    the cubes' corners.  Mirrors the reference expression exactly -- it reads the bounds off `verts[:, i].min(1)` /
+    `.max(1)` for i = 0,1,2, i.e. the smallest / largest coordinate of corners 0, 1 and 2 of each cube, not the per-axis
+    extent over the eight corners -- so that MABO numbers stay comparable.  point_cloud (Q,3), cubes: Cubes with one
+    object (1,P,15) -> (P,) int64."""
+    verts = cubes.get_all_corners().squeeze(0)                                # (P,8,3)
+    lo = [verts[:, i].min(1)[0] for i in range(3)]
+    hi = [verts[:, i].max(1)[0] for i in range(3)]
+    pc = point_cloud
+    inside = (pc[:, 0].view(-1, 1) > lo[0]) & (pc[:, 0].view(-1, 1) < hi[0]) & \
+             (pc[:, 1].view(-1, 1) > lo[1]) & (pc[:, 1].view(-1, 1) < hi[1]) & \
+             (pc[:, 2].view(-1, 1) > lo[2]) & (pc[:, 2].view(-1, 1) < hi[2])
+    return inside.sum(0)

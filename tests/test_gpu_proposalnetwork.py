@@ -111,3 +111,35 @@ def test_boxnet_gt_boxes_path_runs_batched():
         assert len(inst) == n and inst.pred_bbox3D.shape == (n, 8, 3) and inst.pred_pose.shape == (n, 3, 3)
         assert torch.isfinite(inst.pred_bbox3D).all() and (inst.pred_dimensions >= 0.05).all()
         assert ((inst.scores >= 0) | torch.isnan(inst.scores)).all()
+
+
+def test_iou_3d_and_score_point_cloud():
+    """utils.iou_3d (exact IoU3D of a GT cube vs an object's proposals) and scorefunction.score_point_cloud (MABO)."""
+    import importlib
+    import numpy as np
+    from oracle import iou3d as OI
+    spaces = importlib.import_module("3dod_amd.ProposalNetwork.utils.spaces")
+    utils = importlib.import_module("3dod_amd.ProposalNetwork.utils.utils")
+    sf = importlib.import_module("3dod_amd.ProposalNetwork.scoring.scorefunction")
+    mu = importlib.import_module("3dod_amd.cubercnn.util.math_util")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    P = 40
+    ctr = torch.randn(P, 3, generator=g) * 0.4 + torch.tensor([0.0, 0.0, 6.0])
+    dims = torch.rand(P, 3, generator=g) + 0.6
+    R = mu.rotation_6d_to_matrix(torch.randn(P, 6, generator=g))
+    t = torch.cat([ctr, dims, R.reshape(P, 9)], 1)
+    props = spaces.Cubes(t[None].to(dev))
+    gt = spaces.Cubes(t[None, :1].clone().to(dev))
+    iou = utils.iou_3d(gt, props)
+    assert iou.shape == (P,) and abs(float(iou[0]) - 1.0) < 1e-4
+    ref = OI.box3d_overlap(gt.get_all_corners()[0].cpu().numpy(), props.get_all_corners()[0].cpu().numpy())[1][0]
+    assert np.abs(iou.cpu().numpy() - ref).max() < 2e-4
+    pc = (torch.randn(5000, 3, generator=g) * 1.5 + torch.tensor([0.0, 0.0, 6.0])).to(dev)
+    s = sf.score_point_cloud(pc, props)
+    v = props.get_all_corners()[0].cpu()
+    lo = [v[:, i].min(1)[0] for i in range(3)]; hi = [v[:, i].max(1)[0] for i in range(3)]
+    p = pc.cpu()
+    want = torch.stack([((p[:, 0] > lo[0][k]) & (p[:, 0] < hi[0][k]) & (p[:, 1] > lo[1][k]) & (p[:, 1] < hi[1][k]) &
+                         (p[:, 2] > lo[2][k]) & (p[:, 2] < hi[2][k])).sum() for k in range(P)])
+    assert torch.equal(s.cpu(), want) and s.dtype == torch.int64
