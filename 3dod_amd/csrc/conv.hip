@@ -490,7 +490,13 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_wgrad(WgP p) {
     constexpr int WM = (TM == 128) ? 2 : 1, WN = 4 / WM;
     constexpr int WTM = TM / WM, WTN = TN / WN;          // wave tile
     constexpr int TI = WTM / 16, TJ = WTN / 16;
-    constexpr int PP = TM + 8, PQ = TN + 8;              // padded row pitches (elements)
+    // LDS images of the 128-wide tiles: 144-element row pitch (row stride = 8 banks) and a 64-column rotation of the
+    // rows with bit 3 set, so that the eight rows one 32-lane half of ds_read_b64_tr_b16 touches ({0-3, 8-11} / {4-7,
+    // 12-15} of a 16-row slab) land on eight disjoint 8-bank windows (the 136-pitch image measured 33 % of its LDS
+    // cycles as bank conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
+    constexpr int PP = TM == 128 ? 144 : TM + 8, PQ = TN + 16;
+    auto rotQ = [](int row, int col) { return (col + (((row >> 3) & 1) << 6)) & 127; };
+    auto rotP = [&](int row, int col) { return TM == 128 ? rotQ(row, col) : col; };
     constexpr int CPR = TM / 8;                          // dy chunks per pixel row
     constexpr int NP = (32 * CPR + CONV_T - 1) / CONV_T; // dy chunks per thread per 32-pixel sub-step
     constexpr int PE = KU * 32 * PP, QE = KU * 32 * PQ;  // operand elements per group
@@ -582,12 +588,12 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_wgrad(WgP p) {
       for (int u = 0; u < KU; ++u) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<uint4*>(&sQ[u * 32 * PQ + ((tid >> 4) + 16 * i) * PQ + qc * 8]) = rq[u][i];
+            *reinterpret_cast<uint4*>(&sQ[u * 32 * PQ + ((tid >> 4) + 16 * i) * PQ + rotQ((tid >> 4) + 16 * i, qc * 8)]) = rq[u][i];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int idx = tid + CONV_T * i;
             const int prow = idx / CPR, pc = idx - prow * CPR;
-            if (idx < 32 * CPR) *reinterpret_cast<uint4*>(&sP[u * 32 * PP + prow * PP + pc * 8]) = rp[u][i];
+            if (idx < 32 * CPR) *reinterpret_cast<uint4*>(&sP[u * 32 * PP + prow * PP + rotP(prow, pc * 8)]) = rp[u][i];
         }
       }
     };
@@ -615,20 +621,20 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_wgrad(WgP p) {
         if (st + 1 < nstage) load_stage();
         if (do_bias) {
 #pragma unroll 8
-            for (int r = 0; r < KU * 32; ++r) bsum += bf2f(sP[r * PP + tid]);
+            for (int r = 0; r < KU * 32; ++r) bsum += bf2f(sP[r * PP + rotP(r & 31, tid)]);
         }
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             bf16x8 af[TI], bfr[TJ];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                const u16* b0 = &sP[u * 32 * PP + (8 * g + tq) * PP + moff + i * 16 + 4 * tp];
+                const u16* b0 = &sP[u * 32 * PP + (8 * g + tq) * PP + rotP(8 * g + tq, moff + i * 16 + 4 * tp)];
                 const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b0 + 4 * PP);
                 af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                const u16* b0 = &sQ[u * 32 * PQ + (8 * g + tq) * PQ + noff + j * 16 + 4 * tp];
+                const u16* b0 = &sQ[u * 32 * PQ + (8 * g + tq) * PQ + rotQ(8 * g + tq, noff + j * 16 + 4 * tp)];
                 const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b0 + 4 * PQ);
                 bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
