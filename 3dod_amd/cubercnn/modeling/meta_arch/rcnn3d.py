@@ -144,12 +144,29 @@ class RCNN3D(nn.Module):
 
     @staticmethod
     def _postprocess(instances, batched_inputs, image_sizes):
-        processed_results = []
-        for results_per_image, input_per_image, image_size in zip(instances, batched_inputs, image_sizes):
-            height = input_per_image.get("height", image_size[0])
-            width = input_per_image.get("width", image_size[1])
-            processed_results.append({"instances": detector_postprocess(results_per_image, height, width)})
-        return processed_results
+        """detectron2 GeneralizedRCNN._postprocess [third-party]: rescale the 2D boxes to the requested output size, clip,
+        drop empty boxes.  Done for the whole batch with one host sync; the per-image path (detector_postprocess) is
+        taken only when some box actually becomes empty."""
+        sizes = [(inp.get("height", isz[0]), inp.get("width", isz[1])) for inp, isz in zip(batched_inputs, image_sizes)]
+        if len(instances) > 1 and all(r.has("pred_boxes") for r in instances):
+            counts = [len(r) for r in instances]
+            dev = instances[0].pred_boxes.tensor.device
+            per_img = torch.tensor([[w / r.image_size[1], h / r.image_size[0], float(w), float(h)]
+                                    for r, (h, w) in zip(instances, sizes)], dtype=torch.float32, device=dev)
+            row = per_img.repeat_interleave(torch.tensor(counts, device=dev), dim=0)               # (n,4) sx, sy, W, H
+            b = torch.cat([r.pred_boxes.tensor for r in instances])
+            scale = row[:, [0, 1, 0, 1]]
+            limit = row[:, [2, 3, 2, 3]]
+            b = torch.minimum((b * scale).clamp(min=0), limit)
+            nonempty = ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
+            if bool(nonempty.all()):                                                              # the one host sync
+                out = []
+                for r, (h, w), bb in zip(instances, sizes, b.split(counts)):
+                    o = Instances((h, w), **r.get_fields())
+                    o.pred_boxes = Boxes(bb)
+                    out.append({"instances": o})
+                return out
+        return [{"instances": detector_postprocess(r, h, w)} for r, (h, w) in zip(instances, sizes)]
 
 
 @META_ARCH_REGISTRY.register()

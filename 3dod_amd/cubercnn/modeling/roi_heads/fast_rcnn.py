@@ -65,9 +65,54 @@ def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, n
 
 
 def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image):
-    result_per_image = [fast_rcnn_inference_single_image(b, s, shp, score_thresh, nms_thresh, topk_per_image)
-                        for s, b, shp in zip(scores, boxes, image_shapes)]
-    return [x[0] for x in result_per_image], [x[1] for x in result_per_image]
+    """fast_rcnn.py:57-116 for the whole batch at once: the reference filters / NMSes / truncates image by image; here
+    the candidates of all images go through ONE grouped NMS (group = image x class) and one per-image top-k, with two
+    host syncs per batch instead of several per image.  Same result as fast_rcnn_inference_single_image per image."""
+    if len(boxes) <= 1:
+        res = [fast_rcnn_inference_single_image(b, s, shp, score_thresh, nms_thresh, topk_per_image)
+               for s, b, shp in zip(scores, boxes, image_shapes)]
+        return [x[0] for x in res], [x[1] for x in res]
+    dev = boxes[0].device
+    sizes = [int(b.shape[0]) for b in boxes]
+    B, S = torch.cat(boxes), torch.cat(scores)
+    n_img, K = len(boxes), S.shape[1] - 1
+    img = torch.repeat_interleave(torch.arange(n_img, device=dev), torch.tensor(sizes, device=dev))
+    start = torch.tensor([sum(sizes[:i]) for i in range(n_img)], device=dev)
+    valid = torch.isfinite(B).all(dim=1) & torch.isfinite(S).all(dim=1)
+    S = S[:, :-1]
+    nreg = B.shape[1] // 4
+    hw = torch.tensor([[s[1], s[0], s[1], s[0]] for s in image_shapes], dtype=B.dtype, device=dev)[img]      # (R,4)
+    Bc = torch.minimum(B.view(-1, nreg, 4).clamp(min=0), hw[:, None, :])                                         # Boxes.clip
+    mask = (S > score_thresh) & valid[:, None]
+    inds = mask.nonzero()                                                   # (n, 2) = (proposal row, class); host sync 1
+    bsel = Bc[inds[:, 0], 0] if nreg == 1 else Bc[mask]
+    ssel, sfull = S[mask], S[inds[:, 0]]
+    grp = img[inds[:, 0]] * K + inds[:, 1]
+    keep = batched_nms(bsel, ssel, grp, nms_thresh)                        # descending score over the whole batch
+    kimg = img[inds[keep, 0]]
+    order = torch.argsort(kimg, stable=True)                               # image-major, score-descending inside
+    keep, kimg = keep[order], kimg[order]
+    counts = torch.bincount(kimg, minlength=n_img)
+    if topk_per_image >= 0:
+        first = torch.cumsum(counts, 0) - counts
+        rank = torch.arange(keep.numel(), device=dev) - first[kimg]
+        sel = rank < topk_per_image
+        keep, kimg = keep[sel], kimg[sel]
+        counts = counts.clamp(max=topk_per_image)
+    splits = counts.tolist()                                                # host sync 2
+    results, kept_rows = [], []
+    rows = inds[keep, 0] - start[kimg]
+    for i, (kb, ks, kf, kc, kr) in enumerate(zip(bsel[keep].split(splits), ssel[keep].split(splits),
+                                                 sfull[keep].split(splits), inds[keep, 1].split(splits),
+                                                 rows.split(splits))):
+        r = Instances(image_shapes[i])
+        r.pred_boxes = Boxes(kb)
+        r.scores = ks
+        r.scores_full = kf
+        r.pred_classes = kc
+        results.append(r)
+        kept_rows.append(kr)
+    return results, kept_rows
 
 
 class FastRCNNOutputLayers(nn.Module):

@@ -354,3 +354,29 @@ def test_train_step_comm_protocol_single_rank_group(built):
     finally:
         model._graphed = None
         dist.destroy_process_group()
+
+
+def test_batched_fast_rcnn_inference_equals_per_image():
+    """the batched post-processing (one grouped NMS over image x class groups) returns exactly what the reference-shaped
+    per-image function returns (fast_rcnn.py:57-116)."""
+    fr = importlib.import_module("3dod_amd.cubercnn.modeling.roi_heads.fast_rcnn")
+    g = torch.Generator().manual_seed(4)
+    K, shapes, sizes = 6, [(200, 240), (256, 256), (180, 300)], [300, 257, 120]
+    boxes, scores = [], []
+    for n, (h, w) in zip(sizes, shapes):
+        ctr = torch.rand(n, K, 2, generator=g) * torch.tensor([w, h])
+        wh = torch.rand(n, K, 2, generator=g) * 80 + 4
+        b = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).reshape(n, K * 4)
+        s = torch.softmax(torch.randn(n, K + 1, generator=g) * 2, 1)
+        b[3, 0] = float("nan")                                   # a non-finite row is dropped
+        boxes.append(b.to(DEV)); scores.append(s.to(DEV))
+    got, got_rows = fr.fast_rcnn_inference(boxes, scores, shapes, 0.05, 0.5, 40)
+    for i in range(3):
+        ref, ref_rows = fr.fast_rcnn_inference_single_image(boxes[i], scores[i], shapes[i], 0.05, 0.5, 40)
+        # the per-image function compacts non-finite rows first: map its row indices back
+        valid = torch.isfinite(boxes[i]).all(1) & torch.isfinite(scores[i]).all(1)
+        ref_rows = valid.nonzero()[:, 0][ref_rows]
+        assert len(ref) == len(got[i]) and 0 < len(ref) <= 40
+        assert torch.equal(got[i].pred_boxes.tensor, ref.pred_boxes.tensor) and torch.equal(got[i].scores, ref.scores)
+        assert torch.equal(got[i].pred_classes, ref.pred_classes) and torch.equal(got[i].scores_full, ref.scores_full)
+        assert torch.equal(got_rows[i], ref_rows)
