@@ -57,6 +57,7 @@ SIGNATURES = {
     "cr_fc_grad_accum": [P, P, P, c_int, c_int, c_int],
     "cr_maxpool3x3s2_fwd": [P, P, P, c_int, c_int, c_int, c_int],
     "cr_maxpool3x3s2_bwd": [P, P, P, P, c_int, c_int, c_int, c_int],
+    "cr_cube_decode_infer": [P, P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, P],
     "cr_box3d_overlap": [P, P, P, c_int, c_int, P, P],
     "cr_nonfinite_flag": [P, P, c_int64, P],
     "cr_sgd_step": [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P],

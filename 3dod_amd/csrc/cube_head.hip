@@ -564,3 +564,66 @@ extern "C" int cr_cube_reduce_bwd(cr_ctx* ctx, const float* L, const float* buf3
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Inference: decode of the 3D head for the detections kept by the box head (roi_heads.py:2353-2436, 2682-2735), one
+// lane per detection, straight from the fused predictor output: class gather, 6D -> R, allocentric -> egocentric,
+// virtual depth, exp dims priors, back-projection of the centre, confidence, and the 8 corners (corners(): the
+// get_cuboid_verts_faces order of math_util.py:198-207).
+//   meta (B,6) = [fx, fy, cx, cy of K / ratio, virtual_to_real, ratio]; img (n) int32 image of each detection
+//   out (n,42) = [x3d, y3d, z | w, h, l | cx2d*ratio, cy2d*ratio | conf | R (9) | corners (8x3)]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cube_decode_infer(const float* __restrict__ raw, int ld, int o_d2, int o_dims, int o_pose,
+                                                          int o_z, int o_unc, int K, const int64_t* __restrict__ cls,
+                                                          const int* __restrict__ img, const float* __restrict__ boxes,
+                                                          const float* __restrict__ meta, const float* __restrict__ priors,
+                                                          int n, int allocentric, float* __restrict__ out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t c0 = cls[i];
+    const int c = (int)(c0 < 0 ? 0 : (c0 >= K ? K - 1 : c0));
+    const float* r = raw + (size_t)i * ld;
+    const float* m = meta + (size_t)img[i] * 6;
+    const float K4[4] = {m[0], m[1], m[2], m[3]};
+    const float* sb = boxes + (size_t)i * 4;
+    const float sw = sb[2] - sb[0], sh = sb[3] - sb[1];
+    const float cux = (sb[0] + 0.5f * sw) + sw * r[o_d2 + c * 2], cuy = (sb[1] + 0.5f * sh) + sh * r[o_d2 + c * 2 + 1];
+    float dims[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dims[k] = expf(fminf(r[o_dims + c * 3 + k], 5.0f)) * (priors ? priors[c * 3 + k] : 1.f);
+    float a[6], Ra[9], R[9], M[9], l1, lu;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] = r[o_pose + c * 6 + k];
+    rot6d(a, Ra, &l1, &lu);
+    const bool rot = allocentric ? ray_rotation(cux, cuy, K4, M) : false;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            R[p * 3 + q] = rot ? (M[p * 3] * Ra[q] + M[p * 3 + 1] * Ra[3 + q]) + M[p * 3 + 2] * Ra[6 + q] : Ra[p * 3 + q];
+    const float z = r[o_z + c] * m[4];
+    const float ctr[3] = {z * (cux - K4[2]) / K4[0], z * (cuy - K4[3]) / K4[1], z};
+    float* o = out + (size_t)i * 42;
+    o[0] = ctr[0]; o[1] = ctr[1]; o[2] = ctr[2];
+    o[3] = dims[0]; o[4] = dims[1]; o[5] = dims[2];
+    o[6] = cux * m[5]; o[7] = cuy * m[5];
+    o[8] = expf(-fmaxf(r[o_unc + c], 0.01f));
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[9 + k] = R[k];
+    float P[8][3];
+    corners(ctr, dims, R, P);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) { o[18 + v * 3] = P[v][0]; o[19 + v * 3] = P[v][1]; o[20 + v * 3] = P[v][2]; }
+}
+
+extern "C" int cr_cube_decode_infer(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
+                                    const int* img, const float* boxes, const float* meta6, const float* priors, int n,
+                                    int allocentric, float* out42) {
+    CR_CHECK_ARG(ctx && n >= 0, "cr_cube_decode_infer: bad args");
+    if (n == 0) return CR_OK;
+    CR_CHECK_ARG(raw && layout5 && cls && img && boxes && meta6 && out42 && K > 0 && ld >= 13 * K, "cr_cube_decode_infer: bad args");
+    hipLaunchKernelGGL(k_cube_decode_infer, dim3((unsigned)cr_cdiv(n, 64)), dim3(64), 0, ctx->stream, raw, ld, layout5[0],
+                       layout5[1], layout5[2], layout5[3], layout5[4], K, cls, img, boxes, meta6, priors, n, allocentric, out42);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

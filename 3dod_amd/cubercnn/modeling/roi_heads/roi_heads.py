@@ -287,6 +287,10 @@ class ROIHeads3D(StandardROIHeads):
         n = sum(len(b) for b in proposal_boxes_scaled)
         if n == 0:
             return instances if not self.training else (instances, {})
+        if (not self.training) and feats[0].is_cuda and hasattr(ops, "cube_decode_infer") and self.use_confidence > 0 \
+                and (self.dims_priors_func == 'exp' or not self.dims_priors_enabled):
+            return self._infer_cube_fused(feats, instances, proposal_boxes_scaled, proposal_boxes, box_classes, Ks,
+                                          im_current_dims, im_scales_ratio)
         cube_features = self.cube_pooler(feats, proposal_boxes_scaled).flatten(1)
         device = cube_features.device
         num_boxes_per_image = [len(i) for i in proposals]
@@ -488,6 +492,39 @@ class ROIHeads3D(StandardROIHeads):
         if self.training:
             return pred_instances, losses
         return pred_instances
+
+    def _infer_cube_fused(self, feats, instances, boxes_scaled, boxes, box_classes, Ks, im_current_dims, im_scales_ratio):
+        """inference decode + packing (roi_heads.py:2353-2436, 2682-2735) on the fused path: one ROIAlign, the shared
+        FCs + one predictor GEMM, one decode kernel (cr_cube_decode_infer); the torch expressions of _forward_cube stay
+        the CPU / oracle statement of the same arithmetic (tests/test_gpu_model.py compares the two)."""
+        dev = feats[0].device
+        counts = [len(b) for b in boxes]
+        n = sum(counts)
+        idx = torch.repeat_interleave(torch.arange(len(counts), device=dev), torch.tensor(counts, device=dev))
+        rois = torch.cat([idx[:, None].float(), torch.cat([b.tensor for b in boxes_scaled])], 1)
+        cube_features = ops.roi_align_pyramid(feats, rois, self.cube_pooler.scales, self.cube_pooler.output_size).flatten(1)
+        raw, layout = self.cube_head.forward_fused(cube_features)
+        rows = []
+        for k, r, d in zip(Ks, im_scales_ratio, im_current_dims):
+            k = torch.as_tensor(k, dtype=torch.float32)
+            v2r = util.compute_virtual_scale_from_focal_spaces(float(k[1, 1]), float(d[0]) * float(r), self.virtual_focal,
+                                                               float(d[0])) if self.virtual_depth else 1.0
+            rows.append([float(k[0, 0]) / r, float(k[1, 1]) / r, float(k[0, 2]) / r, float(k[1, 2]) / r, float(v2r), float(r)])
+        meta6 = torch.tensor(rows, dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
+        priors = self.priors_dims_per_cat.detach()[0, :, 0, :].contiguous() if self.dims_priors_enabled else None
+        out = ops.cube_decode_infer(raw, layout, self.num_classes, box_classes, idx, torch.cat([b.tensor for b in boxes]),
+                                    meta6, priors, allocentric=self.allocentric_pose)
+        for inst, o, cls_i in zip(instances, out.split(counts), box_classes.split(counts)):
+            m = o.shape[0]
+            inst.scores = (inst.scores * o[:, 8]) ** (1 / 2) if inst.has('scores') else o[:, 8]
+            if not inst.has('pred_classes'):
+                inst.pred_classes = cls_i
+            inst.pred_bbox3D = o[:, 18:42].reshape(m, 8, 3)
+            inst.pred_center_cam = o[:, 0:3]
+            inst.pred_center_2D = o[:, 6:8]
+            inst.pred_dimensions = o[:, 3:6]
+            inst.pred_pose = o[:, 9:18].reshape(m, 3, 3)
+        return instances
 
     def _finish_fused_cube(self, fused, cube_uncert, gt_boxes3D, num_boxes_per_image, im_ratios_per_box,
                            im_current_dims, box_classes, pred_boxes, n):

@@ -879,6 +879,20 @@ def cube_head_loss(raw, layout, K, cls, valid, gt_idx, kf, gt3d, gtpose, priors,
                                priors, meta, boxes, flags)
 
 
+def cube_decode_infer(raw, layout, K, cls, img, boxes, meta6, priors, allocentric=True):
+    """inference decode of the 3D head (no autograd) -> (n,42), see cr_cube_decode_infer."""
+    _need_cuda(raw, "cube head output")
+    n = raw.shape[0]
+    out = torch.empty((n, 42), dtype=f32, device=raw.device)
+    raw32 = raw.detach().float().contiguous()
+    lay = (_ct.c_int * 5)(*[int(v) for v in layout])
+    lib = _lib.load()
+    _chk(lib.cr_cube_decode_infer(_ctx(raw), _p(raw32), raw32.shape[1], lay, int(K), _p(cls.contiguous()),
+                                  _p(img.to(torch.int32).contiguous()), _p(boxes.float().contiguous()), _p(meta6.contiguous()),
+                                  _p(priors), n, int(bool(allocentric)), _p(out)), "cr_cube_decode_infer")
+    return out
+
+
 class _CubeReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, L, u_sel, buf, dec, validf, inverse_z):

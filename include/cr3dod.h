@@ -277,6 +277,14 @@ int cr_cube_reduce(cr_ctx* ctx, const float* L, const float* buf39, const float*
 int cr_cube_reduce_bwd(cr_ctx* ctx, const float* L, const float* buf39, const unsigned char* validf, int n, int inverse_z,
                        const float* cnt6, const float* gred6, float* gL, float* gu);
 
+/* inference decode of the 3D head for n kept detections (roi_heads.py:2353-2436,2682-2735) from the fused predictor
+ * output raw (n, ld) (layout as in cr_cube_select).  cls (n) int64, img (n) int32, boxes (n,4); meta6 (B,6) =
+ * [fx,fy,cx,cy of K/ratio, virtual_to_real, ratio]; priors (K,3) or NULL.
+ * out42 (n,42) = [x3d,y3d,z | w,h,l | 2D centre x ratio | exp(-uncert) | R (9) | corners (8,3)]. */
+int cr_cube_decode_infer(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
+                         const int* img, const float* boxes, const float* meta6, const float* priors, int n,
+                         int allocentric, float* out42);
+
 /* ---- exact IoU of oriented 3D boxes -----------------------------------------------------------
  * replaces pytorch3d box3d_overlap / _C.iou_box3d [third-party] at ProposalNetwork/utils/utils.py:194-210,
  * cubercnn/evaluation/omni3d_evaluation.py:155, cubercnn/modeling/roi_heads/roi_heads.py:518,526,1563.

@@ -21,3 +21,7 @@ with torch.no_grad(), d2.EventStorage(0):
     print("rpn", T(lambda: model.proposal_generator(images, feats, None)))
     print("roi_heads", T(lambda: model.roi_heads(images, feats, props, Ks, r, None)))
     print("total", T(lambda: model(b)))
+    rh = model.roi_heads
+    print("  _forward_box", T(lambda: rh._forward_box(feats, props)))
+    inst = rh._forward_box(feats, props)
+    print("  _forward_cube", T(lambda: rh._forward_cube(feats, inst, Ks, [im.shape[-2:] for im in [d["image"] for d in b]], r)))

@@ -380,3 +380,47 @@ def test_batched_fast_rcnn_inference_equals_per_image():
         assert torch.equal(got[i].pred_boxes.tensor, ref.pred_boxes.tensor) and torch.equal(got[i].scores, ref.scores)
         assert torch.equal(got[i].pred_classes, ref.pred_classes) and torch.equal(got[i].scores_full, ref.scores_full)
         assert torch.equal(got_rows[i], ref_rows)
+
+
+def test_fused_cube_inference_equals_torch_path(built):
+    """the fused inference decode (cr_cube_decode_infer) against the reference-shaped torch expressions of _forward_cube
+    on the same detections (the torch path is what tests/test_cubehead_golden.py pins to the reference)."""
+    cfg, model, opt, syn, solver = built
+    ops = importlib.import_module("3dod_amd.hipops")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    rh = model.roi_heads
+    model.eval()
+    try:
+        batch = syn.make_batch(3, 17, with_gt=False)
+        with torch.no_grad():
+            images, x = model.preprocess_image(batch)
+            feats = model.backbone(x)
+            g = torch.Generator().manual_seed(2)
+            dets = []
+            for i, n in enumerate((7, 1, 12)):
+                ctr = torch.rand(n, 2, generator=g) * 300 + 100
+                wh = torch.rand(n, 2, generator=g) * 150 + 20
+                inst = d2.Instances(images.image_sizes[i])
+                inst.pred_boxes = d2.Boxes(torch.cat([ctr - wh / 2, ctr + wh / 2], 1).to(DEV))
+                inst.pred_classes = torch.randint(0, rh.num_classes, (n,), generator=g).to(DEV)
+                inst.scores = torch.rand(n, generator=g).to(DEV)
+                dets.append(inst)
+            Ks = [torch.FloatTensor(b["K"]) for b in batch]
+            ratios = [1.0, 1.0, 1.0]
+            dims = [tuple(s) for s in images.image_sizes]
+            clone = lambda L: [d2.Instances(i.image_size, **{k: (v.clone() if torch.is_tensor(v) else d2.Boxes(v.tensor.clone()))
+                                                             for k, v in i.get_fields().items()}) for i in L]
+            fused = rh._forward_cube(feats, clone(dets), Ks, dims, ratios)
+            f = ops.cube_decode_infer
+            try:
+                del ops.cube_decode_infer                     # force the torch expressions
+                ref = rh._forward_cube(feats, clone(dets), Ks, dims, ratios)
+            finally:
+                ops.cube_decode_infer = f
+        for a, b in zip(fused, ref):
+            for k in ("scores", "pred_bbox3D", "pred_center_cam", "pred_center_2D", "pred_dimensions", "pred_pose"):
+                x1, x2 = a.get(k).float(), b.get(k).float()
+                assert x1.shape == x2.shape, k
+                assert float((x1 - x2).abs().max()) <= 2e-2 * float(x2.abs().max()) + 1e-3, (k, float((x1 - x2).abs().max()))
+    finally:
+        model.train()
