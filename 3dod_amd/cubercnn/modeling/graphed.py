@@ -134,3 +134,46 @@ class GraphedDense:
         nf, nl = len(self.feat_names), self.n_levels
         feats = dict(zip(self.feat_names, outs[:nf]))
         return feats, list(outs[nf:nf + nl]), list(outs[nf + nl:nf + 2 * nl])
+
+
+class GraphedDenseEval:
+    """Forward-only HIP graph of the static dense region in eval mode (preprocess, trunk with BatchNorm on running
+    statistics, FPN, RPN head) for one image-batch shape: inference is launch-bound at 8 images per step."""
+
+    def __init__(self, model, images_u8, warmup=2):
+        assert not model.training, "capture the eval-mode dense region"
+        self.shape = tuple(images_u8.shape)
+        dev = images_u8.device
+        self.static_img = images_u8.clone()
+        pg = model.proposal_generator
+
+        def dense():
+            x = ops.preprocess(self.static_img, model.pixel_mean_list, model.pixel_std_list)
+            feats = model.backbone(x)
+            logits, deltas = pg.rpn_head([feats[f] for f in pg.in_features])
+            self.feat_names = list(feats.keys())
+            self.n_levels = len(logits)
+            return tuple(feats.values()) + tuple(logits) + tuple(deltas)
+
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(warmup):
+                dense()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        ops.bump_weight_epoch()          # the bf16 weight copies are made inside the graph (cheap; weights may change)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.static_outs = dense()
+        torch.cuda.synchronize(dev)
+
+    def matches(self, images_u8):
+        return tuple(images_u8.shape) == self.shape and images_u8.device == self.static_img.device
+
+    def __call__(self, images_u8):
+        self.static_img.copy_(images_u8)
+        self.graph.replay()
+        outs = self.static_outs
+        nf, nl = len(self.feat_names), self.n_levels
+        return dict(zip(self.feat_names, outs[:nf])), list(outs[nf:nf + nl]), list(outs[nf + nl:nf + 2 * nl])

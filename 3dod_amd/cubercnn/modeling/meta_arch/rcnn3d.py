@@ -43,6 +43,7 @@ class RCNN3D(nn.Module):
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
         self._graphed = None
+        self._graphed_eval = None
         # static-shape training path (modeling/dense_train.py): same rules, no host<->device syncs
         self.dense_train = True
 
@@ -53,6 +54,13 @@ class RCNN3D(nn.Module):
         il, batch = self._stack_images(sample_batched_inputs)
         self._graphed = GraphedDense(self, batch)
         return self._graphed
+
+    def enable_graphs_eval(self, sample_batched_inputs):
+        """eval-mode counterpart of enable_graphs: forward-only graph of preprocess + trunk + FPN + RPN head."""
+        from ..graphed import GraphedDenseEval
+        il, batch = self._stack_images(sample_batched_inputs)
+        self._graphed_eval = GraphedDenseEval(self, batch)
+        return self._graphed_eval
 
     def forward_static(self, images_u8, image_sizes, gt, meta):
         """training forward from device-resident, fixed-shape inputs only (no host data, no syncs): the body of the
@@ -128,15 +136,25 @@ class RCNN3D(nn.Module):
 
     def inference(self, batched_inputs, detected_instances=None, do_postprocess: bool = True):
         assert not self.training
-        images, x = self.preprocess_image(batched_inputs)
+        head_outputs = None
+        ge = self._graphed_eval
+        if ge is not None:
+            images, batch = self._stack_images(batched_inputs)
+            if all(tuple(sz) == tuple(batch.shape[-2:]) for sz in images.image_sizes) and ge.matches(batch):
+                features, logits, deltas = ge(batch)
+                head_outputs = (logits, deltas)
+            else:
+                ge = None
+        if ge is None:
+            images, x = self.preprocess_image(batched_inputs)
+            features = self.backbone(x)
         im_scales_ratio = [info['height'] / im_size[0] for (info, im_size) in zip(batched_inputs, images.image_sizes)]
         Ks = [torch.FloatTensor(info['K']) for info in batched_inputs]
-        features = self.backbone(x)
         if type(batched_inputs == list) and np.any(['oracle2D' in b for b in batched_inputs]):
             oracles = [b['oracle2D'] for b in batched_inputs]
             results, _ = self.roi_heads(images, features, oracles, Ks, im_scales_ratio, None)
         else:
-            proposals, _ = self.proposal_generator(images, features, None)
+            proposals, _ = self.proposal_generator(images, features, None, head_outputs=head_outputs)
             results, _ = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, None)
         if do_postprocess:
             return RCNN3D._postprocess(results, batched_inputs, images.image_sizes)

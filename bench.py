@@ -153,6 +153,9 @@ def bench_inference(args, rank, world, dev):
     for b in batches:
         for d in b:
             d["image"] = d["image"].to(dev)
+    if os.environ.get("CR_GRAPHS", "dense") != "none":
+        with torch.no_grad(), d2.EventStorage(0):
+            model.enable_graphs_eval(batches[0])         # forward-only HIP graph of preprocess + trunk + FPN + RPN head
     n_det = 0
     with torch.no_grad(), d2.EventStorage(0):
         for i in range(args.warmup):

@@ -424,3 +424,29 @@ def test_fused_cube_inference_equals_torch_path(built):
                 assert float((x1 - x2).abs().max()) <= 2e-2 * float(x2.abs().max()) + 1e-3, (k, float((x1 - x2).abs().max()))
     finally:
         model.train()
+
+
+def test_eval_graph_matches_eager_inference(built):
+    """inference through the forward-only HIP graph (trunk + FPN + RPN head) == eager inference on the same weights."""
+    cfg, model, opt, syn, solver = built
+    model.eval()
+    thr = model.roi_heads.box_predictor.test_score_thresh
+    model.roi_heads.box_predictor.test_score_thresh = -1.0
+    try:
+        batch = syn.make_batch(2, 23, with_gt=False)
+        with torch.no_grad():
+            eager = model(batch)
+            model.enable_graphs_eval(batch)
+            graphed = model(batch)
+            graphed2 = model(syn.make_batch(2, 24, with_gt=False))       # new pixels through the same graph
+        for a, b in zip(eager, graphed):
+            ia, ib = a["instances"], b["instances"]
+            assert len(ia) == len(ib) > 0
+            assert torch.allclose(ia.pred_boxes.tensor, ib.pred_boxes.tensor, atol=1e-3)
+            assert torch.allclose(ia.scores, ib.scores, atol=1e-4) and torch.equal(ia.pred_classes, ib.pred_classes)
+            assert torch.allclose(ia.pred_bbox3D, ib.pred_bbox3D, atol=1e-3)
+        assert len(graphed2) == 2 and not torch.equal(graphed2[0]["instances"].scores, graphed[0]["instances"].scores)
+    finally:
+        model._graphed_eval = None
+        model.roi_heads.box_predictor.test_score_thresh = thr
+        model.train()
