@@ -167,7 +167,7 @@ def rpn_losses(rpn, anchors, logits, deltas, labels, midx, gt: GTBatch):
 _PCONST = {}
 
 
-def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes):
+def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes, training=True):
     """RPN.predict_proposals / find_top_rpn_proposals (detectron2 [third-party], restated in proposal_generator/rpn.py)
     with a padded result: boxes (B,K,4), scores (B,K) (-inf = empty slot).  anchors (A,4) and deltas (B,A,4) are the
     level-concatenated tensors.  Only the per-level top-k candidates are decoded (one fused launch: decode, clip,
@@ -176,7 +176,7 @@ def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes):
         B = deltas.shape[0]
         dev = deltas.device
         sizes = [int(t.shape[1]) for t in logits_per_level]
-        ks = [min(n, rpn.pre_nms_topk[True]) for n in sizes]
+        ks = [min(n, rpn.pre_nms_topk[training]) for n in sizes]
         maxn, L = max(ks), len(ks)
         ckey = (tuple(tuple(s) for s in image_sizes), tuple(sizes), tuple(ks), str(dev))
         cached = _PCONST.get(ckey)
@@ -199,7 +199,7 @@ def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes):
                                                         t.weights, t.scale_clamp, img_hw, rpn.min_box_size)
         keep = ops.nms_grouped(nms_boxes.view(B * L, maxn, 4), counts, rpn.nms_thresh).view(B, -1) & valid
         flat_scores = torch.where(keep, scores.view(B, -1), torch.full((), float("-inf"), device=dev))
-        k_post = min(rpn.post_nms_topk[True], flat_scores.shape[1])
+        k_post = min(rpn.post_nms_topk[training], flat_scores.shape[1])
         top_scores, top_idx = flat_scores.topk(k_post, dim=1)
         return torch.gather(boxes, 1, top_idx[:, :, None].expand(-1, -1, 4)), top_scores
 

@@ -170,6 +170,21 @@ class RPN(nn.Module):
 
     @torch.no_grad()
     def predict_proposals(self, anchors, pred_objectness_logits, pred_anchor_deltas, image_sizes):
+        if pred_anchor_deltas[0].is_cuda and hasattr(ops, "rpn_decode_select"):
+            # device path: ONE batched top-k over the levels, only the candidates are decoded (fused kernel), grouped
+            # NMS, post-NMS top-k; a single host sync for the per-image proposal counts
+            from ..dense_train import rpn_proposals_padded
+            boxes, scores = rpn_proposals_padded(self, torch.cat([a.tensor for a in anchors]), pred_objectness_logits,
+                                                 torch.cat([d.detach() for d in pred_anchor_deltas], 1), image_sizes,
+                                                 training=self.training)
+            counts = torch.isfinite(scores).sum(1).tolist()
+            results = []
+            for i, n in enumerate(counts):
+                res = Instances(image_sizes[i])
+                res.proposal_boxes = Boxes(boxes[i, :n])
+                res.objectness_logits = scores[i, :n]
+                results.append(res)
+            return results
         pred_proposals = self._decode_proposals(anchors, pred_anchor_deltas)
         return find_top_rpn_proposals(pred_proposals, [t.detach() for t in pred_objectness_logits], image_sizes,
                                       self.nms_thresh, self.pre_nms_topk[self.training],

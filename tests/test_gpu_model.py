@@ -450,3 +450,33 @@ def test_eval_graph_matches_eager_inference(built):
         model._graphed_eval = None
         model.roi_heads.box_predictor.test_score_thresh = thr
         model.train()
+
+
+def test_eval_proposals_device_path_equals_list_path(built):
+    """RPN.predict_proposals: fused device path (batched top-k, decode of the candidates only, grouped NMS) against the
+    reference-shaped per-level path (decode everything, find_top_rpn_proposals) on the same head outputs."""
+    cfg, model, opt, syn, solver = built
+    ops = importlib.import_module("3dod_amd.hipops")
+    model.eval()
+    try:
+        batch = syn.make_batch(2, 31, with_gt=False)
+        with torch.no_grad():
+            images, x = model.preprocess_image(batch)
+            feats = model.backbone(x)
+            pg = model.proposal_generator
+            fl = [feats[f] for f in pg.in_features]
+            anchors = pg.anchor_generator([(f.shape[1], f.shape[2]) for f in fl], DEV)
+            logits, deltas = pg.rpn_head(fl)
+            a = pg.predict_proposals(anchors, logits, deltas, images.image_sizes)
+            f = ops.rpn_decode_select
+            try:
+                del ops.rpn_decode_select
+                b = pg.predict_proposals(anchors, logits, deltas, images.image_sizes)
+            finally:
+                ops.rpn_decode_select = f
+        for pa, pb in zip(a, b):
+            assert len(pa) == len(pb) > 0
+            assert torch.allclose(pa.objectness_logits, pb.objectness_logits, atol=1e-6)
+            assert torch.allclose(pa.proposal_boxes.tensor, pb.proposal_boxes.tensor, atol=1e-3)
+    finally:
+        model.train()
