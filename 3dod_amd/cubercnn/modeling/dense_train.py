@@ -133,8 +133,11 @@ def rpn_label_and_sample(rpn, anchors, gt: GTBatch):
                                                rpn.anchor_matcher.labels, 1e-4)
     n_s = rpn.batch_size_per_image
     k_pos = int(n_s * rpn.positive_fraction)
-    pkey, pidx = keys[0].topk(min(k_pos, A), dim=1)
-    nkey, nidx = keys[1].topk(min(n_s, A), dim=1)
+    # one top-k launch for both key sets (positives need the first k_pos of theirs; sorted output)
+    kk = min(max(k_pos, n_s), A)
+    tkey, tidx = keys.view(2 * B, A).topk(kk, dim=1)
+    pkey, pidx = tkey[:B, :min(k_pos, A)], tidx[:B, :min(k_pos, A)]
+    nkey, nidx = tkey[B:, :min(n_s, A)], tidx[B:, :min(n_s, A)]
     # rpn.py:75 (forced arg-max anchors) is already in `out`; rpn.py:93-104 (ignore regions) inside the scatter
     ops.rpn_scatter(out, pidx, pkey, nidx, nkey, n_s, ioa, rpn.ignore_thresh)
     return out, midx, matched_ious
@@ -226,8 +229,10 @@ def roi_label_and_sample(rh, prop_boxes, prop_scores, gt: GTBatch):
                                  rh.ignore_thresh, 1e-4)
     n_s = rh.batch_size_per_image
     k_fg = min(int(n_s * rh.positive_fraction), R)
-    fkey, fidx = keys[0].topk(k_fg, dim=1)
-    bkey, bidx = keys[1].topk(min(n_s, R), dim=1)
+    kk = min(max(k_fg, n_s), R)                       # one top-k launch for the foreground and background keys
+    tkey, tidx = keys.view(2 * B, R).topk(kk, dim=1)
+    fkey, fidx = tkey[:B, :k_fg], tidx[:B, :k_fg]
+    bkey, bidx = tkey[B:, :min(n_s, R)], tidx[B:, :min(n_s, R)]
     # at most n_s picks are valid; the stable compaction keeps "foreground first" (the k_fg leading slots hold every
     # valid foreground pick)
     s_boxes, s_valid, s_cls, s_gt, counts = ops.roi_compact(fidx, fkey, bidx, bkey, n_s, boxes, cls, midx)

@@ -25,7 +25,19 @@ def _chk(rc, what):
     _lib.check(rc, what)
 
 
+_KEEP, _KEEP_POS = [None] * 128, [0]
+
+
 def _p(t):
+    """device pointer of `t` (NULL for None).  Wrappers write `_p(x.contiguous())` inline: when that makes a temporary,
+    it would be released as soon as this returns and the NEXT temporary of the same argument list could be handed the
+    same block before the kernel is even launched (two non-contiguous inputs -> garbage).  The last 128 tensors whose
+    pointers were taken are therefore kept alive in a ring; by the time a slot is recycled its kernel has long been
+    enqueued on the stream, after which the caching allocator's stream ordering makes reuse safe."""
+    if t is not None:
+        i = _KEEP_POS[0]
+        _KEEP[i] = t
+        _KEEP_POS[0] = (i + 1) & 127
     return _lib.ptr(t)
 
 
