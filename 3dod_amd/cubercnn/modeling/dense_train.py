@@ -75,49 +75,6 @@ def camera_meta(rh, Ks, im_scales_ratio, im_dims, device):
     return (meta.pin_memory() if device.type == "cuda" else meta).to(device, non_blocking=True)
 
 
-def _area(b):
-    return (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
-
-
-def pairwise_inter(gt, boxes):
-    """gt (B,G,4), boxes (B,R,4) or (R,4) -> (B,G,R) intersection areas."""
-    if boxes.dim() == 2:
-        boxes = boxes.unsqueeze(0)
-    lt = torch.max(gt[:, :, None, :2], boxes[:, None, :, :2])
-    rb = torch.min(gt[:, :, None, 2:], boxes[:, None, :, 2:])
-    wh = (rb - lt).clamp_(min=0)
-    return wh[..., 0] * wh[..., 1]
-
-
-def pairwise_iou_b(gt, boxes):
-    inter = pairwise_inter(gt, boxes)
-    b = boxes.unsqueeze(0) if boxes.dim() == 2 else boxes
-    union = _area(gt)[:, :, None] + _area(b)[:, None, :] - inter
-    return torch.where(inter > 0, inter / union, torch.zeros((), device=gt.device))
-
-
-def pairwise_ioa_b(gt, boxes):
-    inter = pairwise_inter(gt, boxes)
-    b = boxes.unsqueeze(0) if boxes.dim() == 2 else boxes
-    return torch.where(inter > 0, inter / _area(b)[:, None, :], torch.zeros((), device=gt.device))
-
-
-def _keys(weights, cand, eps=1e-4):
-    """multinomial-without-replacement keys: (w + eps) / Exp(1) for candidates, 0 otherwise."""
-    e = torch.empty_like(weights).exponential_(1.0)
-    return torch.where(cand, (weights + eps) / e, torch.zeros((), device=weights.device))
-
-
-def _take(keys, k, limit=None):
-    """top-k keys -> (idx (B,k), valid (B,k)); valid = real candidate and (if given) within the first `limit` picks."""
-    k = min(k, keys.shape[1])
-    v, idx = keys.topk(k, dim=1)
-    valid = v > 0
-    if limit is not None:
-        valid = valid & (torch.arange(k, device=keys.device)[None, :] < limit[:, None])
-    return idx, valid
-
-
 # ------------------------------------------------------------------------------------------- RPN
 def rpn_label_and_sample(rpn, anchors, gt: GTBatch):
     """RPNWithIgnore.label_and_sample_anchors (rpn.py:41-110) for the whole batch.  anchors (A,4).

@@ -287,7 +287,7 @@ class ROIHeads3D(StandardROIHeads):
         n = sum(len(b) for b in proposal_boxes_scaled)
         if n == 0:
             return instances if not self.training else (instances, {})
-        if (not self.training) and feats[0].is_cuda and hasattr(ops, "cube_decode_infer") and self.use_confidence > 0 \
+        if (not self.training) and box_classes.is_cuda and hasattr(ops, "cube_decode_infer") and self.use_confidence > 0 \
                 and (self.dims_priors_func == 'exp' or not self.dims_priors_enabled):
             return self._infer_cube_fused(feats, instances, proposal_boxes_scaled, proposal_boxes, box_classes, Ks,
                                           im_current_dims, im_scales_ratio)
