@@ -471,6 +471,7 @@ struct WgP {
     int N, Hin, Win, Cin, Hout, Wout, Cout, stride, pad, Kdim, M, cshift;
     int steps_per_split;    // 32-pixel steps handled by one split
     int tm, tn, xcd;        // tile counts (the grid is 1-D: tm * tn * splits blocks)
+    unsigned x_bytes, dy_bytes;   // extents for the buffer-load descriptors
     float* dbias;           // optional [Cout]: += column sums of dy (bias gradient), accumulated by the first k-tile's blocks
 };
 
@@ -544,7 +545,6 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_wgrad(WgP p) {
             pwo[i] = rem - pho[i] * p.Wout;
         }
     }
-    const u16* pdy = p.dy + (size_t)first * 32 * p.Cout + c0;      // dy rows of the next sub-step to load
     int mrow = first * 32;
     const int mend = min(p.M, step1 * 32);                         // rows of later splits / past M contribute zeros
     uint4 rq[KU][2], rp[KU][NP];
@@ -556,28 +556,30 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_wgrad(WgP p) {
             while (pwo[i] >= p.Wout) { pwo[i] -= p.Wout; ++pho[i]; }
             while (pho[i] >= p.Hout) { pho[i] -= p.Hout; ++pn[i]; }
         }
-        pdy += (size_t)pixels * p.Cout;
         mrow += pixels;
     };
+    // branch-free gathers like the forward kernel: raw buffer loads, masked elements read zero through an
+    // out-of-range 32-bit offset
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
     auto load_stage = [&]() {
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
             const int hi = pho[i] * p.stride - p.pad + qr, wi = pwo[i] * p.stride - p.pad + qs;
-            if (qvalid && pn[i] < p.N && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win)
-                v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(pn[i] * p.Hin + hi) * p.Win + wi) * p.Cin + qch);
-            rq[u][i] = v;
+            const bool ok = qvalid && pn[i] < p.N && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+            const unsigned off = (unsigned)(((pn[i] * p.Hin + hi) * p.Win + wi) * p.Cin + qch) * 2u;
+            rq[u][i] = buf_load16(rx, ok ? off : OOB);
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int idx = tid + CONV_T * i;
             const int prow = idx / CPR, pc = idx - prow * CPR;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < 32 * CPR && mrow + prow < mend && c0 + pc * 8 < p.Cout)
-                v = *reinterpret_cast<const uint4*>(pdy + (size_t)prow * p.Cout + pc * 8);
-            rp[u][i] = v;
+            const bool ok = idx < 32 * CPR && mrow + prow < mend && c0 + pc * 8 < p.Cout;
+            const unsigned off = (unsigned)((mrow + prow) * p.Cout + c0 + pc * 8) * 2u;
+            rp[u][i] = buf_load16(rdy, ok ? off : OOB);
         }
         advance(32);
       }
@@ -763,6 +765,7 @@ static int conv2d_bwd_weight_impl(cr_ctx* ctx, const void* dy, const void* x, fl
     p.Wout = (W + 2 * pad - ks) / stride + 1;
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = N * p.Hout * p.Wout;
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cin);
+    p.x_bytes = (unsigned)((size_t)N * H * W * Cin * 2); p.dy_bytes = (unsigned)((size_t)p.M * Cout * 2);
     if (!accumulate) {
         const int64_t nz = (int64_t)Cout * p.Kdim;
         hipLaunchKernelGGL(k_fill_zero_f32, dim3((unsigned)cr_cdiv(nz, 256)), dim3(256), 0, ctx->stream, dw, nz);
