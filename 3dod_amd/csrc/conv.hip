@@ -715,6 +715,14 @@ static int launch_wgrad_ks(cr_ctx* ctx, WgP& p) {
     const int block_cap = TM >= 64 ? 576 : 2048;
     int splits = nsteps / (16 * kg);
     if (splits > block_cap / tiles) splits = block_cap / tiles;
+    if (kg == 1 && TM >= 64) {
+        // large grids: exactly one resident wave of blocks (3 per CU = 768) when every block still gets >= 64 pixel steps
+        // to hide its atomics behind; otherwise at least 40 steps per block (the atomics of every extra split cost as
+        // much as ~2 steps of MFMA work on the 64x64 maps)
+        const int s_full = 768 / tiles;
+        if (s_full >= 1 && nsteps / s_full >= 64) splits = s_full;
+        else if (splits > nsteps / 40) splits = nsteps / 40;
+    }
     if (splits < 1) splits = 1;
     if (tiles * splits < 256) {     // far fewer blocks than CUs: trade steps per block (down to ~8) for more blocks
         int lo = nsteps < 4 ? nsteps : 4;
