@@ -93,7 +93,7 @@ class RCNN3D(nn.Module):
         H, W = batch.shape[-2:]
         if any(tuple(s) != (H, W) for s in il.image_sizes):
             # detectron2 pads AFTER normalisation (zeros in normalised space)
-            mask = torch.zeros((len(images), H, W, 1), dtype=x.dtype, device=x.device)
+            mask = torch.zeros((len(il.image_sizes), H, W, 1), dtype=x.dtype, device=x.device)
             for i, (h, w) in enumerate(il.image_sizes):
                 mask[i, :h, :w] = 1
             x = x * mask

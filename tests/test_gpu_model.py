@@ -480,3 +480,34 @@ def test_eval_proposals_device_path_equals_list_path(built):
             assert torch.allclose(pa.proposal_boxes.tensor, pb.proposal_boxes.tensor, atol=1e-3)
     finally:
         model.train()
+
+
+def test_train_step_other_resolutions(built):
+    """the kernels' tile / split / wave-group heuristics and the labelling path on shapes other than the benchmark's:
+    384x384 images, and a batch of 300x448 crops (non-square, zero-padded to 320 rows for the FPN's size divisibility)."""
+    cfg, model, opt, syn, solver = built
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    model.train()
+    model._graphed = None
+    step = solver.TrainStep(cfg, model, opt, world_size=1)
+    b1 = syn.make_batch(2, 41, size=384)
+    b2 = syn.make_batch(2, 42, size=448)
+    for d in b2:                                                    # crop to 300 x 448, keep the objects that survive
+        d["image"] = d["image"][:, :300, :].contiguous()
+        d["height"] = 300
+        inst = d["instances"]
+        keep = inst.gt_boxes.tensor[:, 1] < 280
+        new = d2.Instances((300, 448))
+        bx = inst.gt_boxes.tensor[keep].clone()
+        bx[:, 3] = bx[:, 3].clamp(max=299)
+        new.gt_boxes = d2.Boxes(bx)
+        new.gt_classes = inst.gt_classes[keep]
+        new.gt_boxes3D = inst.gt_boxes3D[keep]
+        new.gt_poses = inst.gt_poses[keep]
+        d["instances"] = new
+    with d2.EventStorage(0):
+        for b in (b1, b2, b1):
+            step(b)
+            rep = step.report()
+            assert rep["total_loss"] == rep["total_loss"] and abs(rep["total_loss"]) < 1e4, rep
+    assert rep["iterations_explode"] == 0
