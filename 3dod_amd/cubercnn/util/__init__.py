@@ -1,1 +1,2 @@
+from .util import *  # noqa: F401,F403
 from .math_util import *  # noqa: F401,F403

@@ -2,6 +2,9 @@
 fused device kernels live in 3dod_amd.geometry).  Restates cubercnn/util/math_util.py of the
 reference; the pytorch3d transforms it imports are restated from their published definition
 [third-party: pytorch3d.transforms.rotation_6d_to_matrix / axis_angle_to_matrix]."""
+import math
+from collections import defaultdict
+
 import torch
 import torch.nn.functional as F
 
@@ -117,3 +120,116 @@ def R_to_allocentric(K, R, u=None, v=None):
 
 def scaled_sigmoid(vals, min=0.0, max=1.0):
     return min + (max - min) * torch.sigmoid(vals)
+
+
+def approx_eval_resolution(h, w, scale_min=0, scale_max=1e10):
+    """math_util.py:288-316: resolution an h x w image is evaluated at (shortest edge -> scale_min, then capped so the
+    longest edge <= scale_max); returns (h, w, factor original -> network)."""
+    h0 = h
+    s = scale_min / min(h, w)
+    h, w = h * s, w * s
+    s = min(scale_max / max(h, w), 1.0)
+    h, w = h * s, w * s
+    return h, w, h / h0
+
+
+def _mean_std(x):
+    """pandas semantics: sample standard deviation (ddof = 1), NaN when undefined."""
+    import numpy as np
+    x = np.asarray(x, dtype=np.float64)
+    mean = float(x.mean()) if x.size else float('nan')
+    std = float(x.std(ddof=1)) if x.size > 1 else float('nan')
+    return [mean, std]
+
+
+def compute_priors(cfg, datasets, max_cluster_rounds=1000, min_points_for_std=5, n_bins=None, category_names=None):
+    """math_util.py:318-524: statistics of the training annotations the cube head starts from: per-category mean/std
+    of the 3D dimensions, of depth z (in VIRTUAL depth when MODEL.ROI_CUBE_HEAD.VIRTUAL_DEPTH) and of y, global z / y
+    statistics, and -- for CLUSTER_BINS > 1 -- depth statistics per 2D-scale cluster (1-D k-means on the box diagonal at
+    test resolution).  `datasets` is an `Omni3D` index; `category_names` defaults to the model's thing_classes."""
+    import numpy as np
+    from ...d2lite.data import BoxMode, MetadataCatalog
+    anns = datasets.loadAnns(datasets.getAnnIds())
+    if category_names is None:
+        category_names = MetadataCatalog.get('omni3d_model').thing_classes
+    H = cfg.MODEL.ROI_CUBE_HEAD
+    smin, smax = cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST
+
+    rows = defaultdict(list)            # category -> [w3d, h3d, l3d, y3d, z3d, scale]
+    all_z, all_y = [], []
+    for ann in anns:
+        name = ann['category_name'].lower()
+        img = datasets.imgs[ann['image_id']]
+        fy, im_h, im_w = img['K'][1][1], img['height'], img['width']
+        if cfg.DATASETS.MODAL_2D_BOXES and 'bbox2D_tight' in ann and ann['bbox2D_tight'][0] != -1:
+            box = ann['bbox2D_tight']
+        elif cfg.DATASETS.TRUNC_2D_BOXES and 'bbox2D_trunc' in ann and not all(v == -1 for v in ann['bbox2D_trunc']):
+            box = ann['bbox2D_trunc']
+        elif 'bbox2D_proj' in ann:
+            box = ann['bbox2D_proj']
+        else:
+            continue
+        _, _, w, h = BoxMode.convert(box, BoxMode.XYXY_ABS, BoxMode.XYWH_ABS)
+        _, y3d, z3d = ann['center_cam']
+        w3d, h3d, l3d = ann['dimensions']
+        test_h, _, sf = approx_eval_resolution(im_h, im_w, smin, smax)
+        h, w = h * sf, w * sf
+        if H.VIRTUAL_DEPTH:
+            z3d = z3d * (1 / compute_virtual_scale_from_focal_spaces(fy, im_h, H.VIRTUAL_FOCAL, test_h))
+        if (not ann['ignore']) and name in category_names:
+            rows[name].append([w3d, h3d, l3d, y3d, z3d, math.sqrt(h ** 2 + w ** 2)])
+            all_z.append(z3d)
+            all_y.append(y3d)
+
+    if n_bins is None:
+        n_bins = H.CLUSTER_BINS
+    dims_per_cat, z_per_cat, y_per_cat, bins = [], [], [], []
+    for cat in category_names:
+        d = np.asarray(rows.get(cat, []), dtype=np.float64).reshape(-1, 6)
+        n = len(d)
+        if n > 0:
+            ms = [_mean_std(d[:, i]) for i in range(3)]
+            dims_per_cat.append([[m[0] for m in ms], [m[1] for m in ms]])
+            z_per_cat.append(_mean_std(d[:, 4]))
+            y_per_cat.append(_mean_std(d[:, 3]))
+        else:                                            # placeholder statistics for a category without samples
+            dims_per_cat.append([[1.0, 1.0, 1.0], [1.0, 1.0, 1.0]])
+            z_per_cat.append([50, 50])
+            y_per_cat.append([1, 10])
+        if n_bins <= 1:
+            continue
+        if n < min_points_for_std:
+            print('Warning {} category has only {} valid samples...'.format(cat, n))
+            lo, hi = cfg.MODEL.ANCHOR_GENERATOR.SIZES[0][0], cfg.MODEL.ANCHOR_GENERATOR.SIZES[-1][-1]
+            base = (hi / lo) ** (1 / (n_bins - 1))
+            centres = [lo * (base ** i) for i in range(n_bins)]
+            z_bins = [[b, 15] for b in np.arange(100, 1, -(100 - 1) / n_bins)]
+            assert len(z_bins) == n_bins, 'Broken default bin scaling.'
+            bins.append((cat, centres, z_bins))
+            continue
+        scales = torch.tensor(d[:, 5], dtype=torch.float32)
+
+        def members(assign, quality, b):
+            m = assign == b
+            if m.sum() < min_points_for_std:             # thin cluster: borrow its nearest points
+                m[quality[:, b].topk(min_points_for_std)[1]] = True
+            return m
+
+        base = (scales.max() / scales.min()) ** (1 / (n_bins - 1))
+        centres = torch.tensor([float(scales.min() * (base ** i)) for i in range(n_bins)], dtype=torch.float32)
+        best = -np.inf
+        for _ in range(max_cluster_rounds):
+            quality = -(centres.unsqueeze(0) - scales.unsqueeze(1)).abs()
+            score, assign_round = quality.max(1)
+            round_score = score.mean().item()
+            if np.round(round_score, 5) > best:
+                best, assign = round_score, assign_round
+                centres = torch.tensor([scales[members(assign, quality, b)].mean().item() for b in range(n_bins)],
+                                       dtype=torch.float32)
+            else:
+                break
+        z_bins = [_mean_std(d[members(assign, quality, b).numpy(), 4]) for b in range(n_bins)]
+        bins.append((cat, centres.numpy().tolist(), z_bins))
+
+    return {'priors_dims_per_cat': dims_per_cat, 'priors_z3d_per_cat': z_per_cat, 'priors_y3d_per_cat': y_per_cat,
+            'priors_bins': bins, 'priors_y3d': _mean_std(all_y), 'priors_z3d': _mean_std(all_z)}
