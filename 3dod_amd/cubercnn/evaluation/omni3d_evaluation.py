@@ -3,8 +3,9 @@
 summarize :1555-1700; the protocol is pycocotools' COCOeval [third-party], restated).
 
 Scope: in-memory ground truth / detection records -> the 13 summary numbers of each mode.  3D IoU goes
-through the exact-IoU kernel (geometry.box3d_overlap = cr_box3d_overlap) instead of pytorch3d.  Dataset / json plumbing
-(Omni3DEvaluator, inference_on_dataset, result tables) belongs to the data path (N2) and is not built.
+through the exact-IoU kernel (geometry.box3d_overlap = cr_box3d_overlap) instead of pytorch3d.  The dataset plumbing on
+top of it (instances_to_coco_json, Omni3DEvaluator, Omni3DEvaluationHelper, inference_on_dataset) is at the end of the
+file; the logging tables of utils_logperf are not built.
 
 Record fields (as written by instances_to_coco_json, :971-1014, and the Omni3D json): image_id, category_id, id,
 bbox [x,y,w,h], area, bbox3D (8,3) corners, depth; detections add score; ground truth adds ignore2D / ignore3D."""
@@ -69,6 +70,8 @@ class Omni3Deval:
         for i, d in enumerate(dts):
             d = dict(d)
             d.setdefault("id", i + 1)
+            if "area" not in d and "bbox" in d:
+                d["area"] = d["bbox"][2] * d["bbox"][3]
             self._dts[d["image_id"], d["category_id"]].append(d)
         self.params.imgIds = sorted({k[0] for k in list(self._gts) + list(self._dts)})
         self.params.catIds = sorted({k[1] for k in list(self._gts) + list(self._dts)})
@@ -193,3 +196,266 @@ class Omni3Deval:
                               [self._mean(1, rng=L[i]) for i in (1, 2, 3)] +
                               [self._mean(0, max_det=d) for d in p.maxDets] + [self._mean(0, rng=L[i]) for i in (1, 2, 3)])
         return self.stats
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dataset plumbing (reference: Omni3DEvaluator :644-935, Omni3DEvaluationHelper :168-520, inference_on_dataset :523-641,
+# instances_to_coco_json :971-1014).  Result tables / histograms (utils_logperf) are logging only and not built.
+# ---------------------------------------------------------------------------------------------------------------------
+METRICS = {"2D": ["AP", "AP50", "AP75", "AP95", "APs", "APm", "APl"],
+           "3D": ["AP", "AP15", "AP25", "AP50", "APn", "APm", "APf"]}
+
+
+def instances_to_coco_json(instances, img_id):
+    """:971-1014: CPU `Instances` of one image -> list of result records (bbox XYWH; `depth` = mean z of the 8 corners;
+    unit placeholders when the model has no 3D head)."""
+    n = len(instances)
+    if n == 0:
+        return []
+    b = instances.pred_boxes.tensor.numpy().astype(np.float64).copy()
+    b[:, 2:] -= b[:, :2]
+    boxes, scores, classes = b.tolist(), instances.scores.tolist(), instances.pred_classes.tolist()
+    if instances.has("pred_bbox3D"):
+        bbox3D, center_cam = instances.pred_bbox3D.tolist(), instances.pred_center_cam.tolist()
+        center_2D, dims, pose = instances.pred_center_2D.tolist(), instances.pred_dimensions.tolist(), instances.pred_pose.tolist()
+    else:
+        bbox3D, center_cam = np.ones([n, 8, 3]).tolist(), np.ones([n, 3]).tolist()
+        center_2D, dims, pose = np.ones([n, 2]).tolist(), np.ones([n, 3]).tolist(), np.ones([n, 3, 3]).tolist()
+    return [{"image_id": img_id, "category_id": classes[k], "bbox": boxes[k], "score": scores[k],
+             "depth": float(np.array(bbox3D[k])[:, 2].mean()), "bbox3D": bbox3D[k], "center_cam": center_cam[k],
+             "center_2D": center_2D[k], "dimensions": dims[k], "pose": pose[k]} for k in range(n)]
+
+
+def _per_category(ev, names):
+    """AP x100 per category from precision[T,R,K,A,M] at area 'all', maxDets[-1]"""
+    out = {}
+    pr = ev.eval["precision"]
+    assert len(names) == pr.shape[2], (len(names), pr.shape)
+    for k, name in enumerate(names):
+        s = pr[:, :, k, 0, -1]
+        s = s[s > -1]
+        out["AP-" + name] = float(s.mean() * 100) if s.size else float("nan")
+    return out
+
+
+def _headline(ev, mode):
+    return {m: float(ev.stats[i] * 100) if ev.stats[i] >= 0 else float("nan") for i, m in enumerate(METRICS[mode])}
+
+
+class Omni3DEvaluator:
+    """:644-935.  Ground truth = the dataset's json through `Omni3D([json], filter_settings)`; predictions arrive with
+    the MODEL's contiguous class ids, are mapped back to Omni3D category ids and restricted to the categories this
+    dataset annotates."""
+
+    def __init__(self, dataset_name, tasks=None, distributed=True, output_dir=None, *, max_dets_per_image=None,
+                 use_fast_impl=False, eval_prox=False, only_2d=False, filter_settings=None, iou3d_fn=None):
+        from ...d2lite.data import MetadataCatalog
+        from ..data.datasets import Omni3D
+        self._output_dir, self._eval_prox, self._only_2d = output_dir, eval_prox, only_2d
+        self._filter_settings, self._iou3d_fn = filter_settings, iou3d_fn
+        self._max_dets_per_image = [1, 10, 100 if max_dets_per_image is None else max_dets_per_image]
+        self._metadata = MetadataCatalog.get(dataset_name)
+        self._omni_api = Omni3D([self._metadata.json_file], filter_settings)
+        self._do_evaluation = "annotations" in self._omni_api.dataset
+        self._predictions, self._results, self.evals = [], {}, {}
+        if self._metadata.get("thing_classes") is None:
+            # normally filled when the dataset is first loaded (load_omni3d_json, datasets.py:375-383); evaluating
+            # stored predictions without building a loader must not depend on that having happened
+            cats = sorted(self._omni_api.dataset["categories"], key=lambda c: c["id"])
+            self._metadata.thing_classes = [c["name"] for c in cats]
+            self._metadata.thing_dataset_id_to_contiguous_id = \
+                MetadataCatalog.get('omni3d_model').thing_dataset_id_to_contiguous_id
+
+    def reset(self):
+        self._predictions = []
+
+    def process(self, inputs, outputs):
+        for inp, out in zip(inputs, outputs):
+            pred = {"image_id": inp["image_id"], "K": inp["K"], "width": inp["width"], "height": inp["height"]}
+            if "p2" in inp:
+                pred["p2"] = inp["p2"]
+            inst = out["instances"]
+            pred["instances"] = inst if type(inst) == list else instances_to_coco_json(inst.to("cpu"), inp["image_id"])
+            self._predictions.append(pred)
+
+    def evaluate(self, img_ids=None):
+        import copy
+        import itertools
+        import json
+        import os
+        from ...d2lite.data import MetadataCatalog
+        self._results = {}
+        if len(self._predictions) == 0:
+            return {}
+        results = copy.deepcopy(list(itertools.chain(*[p["instances"] for p in self._predictions])))
+        global_names = MetadataCatalog.get('omni3d_model').thing_classes
+        id_map = self._metadata.thing_dataset_id_to_contiguous_id
+        contiguous = list(id_map.values())
+        assert min(contiguous) == 0 and max(contiguous) == len(contiguous) - 1
+        reverse = {v: k for k, v in id_map.items()}
+        kept = []
+        for r in results:
+            c = r["category_id"]
+            assert c < len(contiguous), f"A prediction has class={c}, but the dataset only has {len(contiguous)} classes"
+            r["category_id"] = reverse[c]
+            if global_names[c] in self._metadata.thing_classes:       # out-of-vocabulary for this dataset: dropped
+                kept.append(r)
+        if self._output_dir:
+            os.makedirs(self._output_dir, exist_ok=True)
+            with open(os.path.join(self._output_dir, "omni_instances_results.json"), "w") as f:
+                json.dump(kept, f)
+        if not self._do_evaluation or not kept:
+            return copy.deepcopy(self._results)
+        gts = self._omni_api.dataset["annotations"]
+        for i, r in enumerate(kept):                                   # pycocotools loadRes for boxes
+            r["area"], r["id"], r["iscrowd"] = r["bbox"][2] * r["bbox"][3], i + 1, 0
+        cat_ids, all_imgs = sorted(self._omni_api.getCatIds()), sorted(self._omni_api.getImgIds())
+        for mode in (["2D"] if self._only_2d else ["2D", "3D"]):
+            ev = Omni3Deval(gts, kept, mode=mode, eval_prox=self._eval_prox, iou3d_fn=self._iou3d_fn)
+            ev.params.catIds = cat_ids
+            ev.params.imgIds = list(img_ids) if img_ids is not None else all_imgs
+            ev.params.maxDets = list(self._max_dets_per_image)
+            ev.evaluate().accumulate().summarize()
+            res = _headline(ev, mode)
+            names = self._metadata.get("thing_classes")
+            if names is not None and len(names) > 1:
+                res.update(_per_category(ev, names))
+            self._results["bbox_" + mode] = res
+            self.evals[mode] = ev
+        return copy.deepcopy(self._results)
+
+
+class Omni3DEvaluationHelper:
+    """:168-520: one evaluator per dataset split, plus the pooled ("<Concat>") numbers and the Omni3D / indoor /
+    outdoor averages, computed from the per-image evaluations already made (no IoU is recomputed)."""
+
+    def __init__(self, dataset_names, filter_settings, output_folder, iter_label='-', only_2d=False, iou3d_fn=None):
+        import os
+        from collections import OrderedDict
+        from ...d2lite.data import MetadataCatalog
+        from ..data.datasets import simple_register
+        self.dataset_names, self.filter_settings, self.output_folder = dataset_names, filter_settings, output_folder
+        self.iter_label, self.only_2d = iter_label, only_2d
+        self.evaluators, self.results = OrderedDict(), OrderedDict()
+        self.results_analysis, self.results_omni3d = OrderedDict(), OrderedDict()
+        self.overall_imgIds, self.overall_catIds = set(), set()
+        self.output_folders = {n: os.path.join(output_folder, n) for n in dataset_names}
+        for n in dataset_names:
+            if MetadataCatalog.get(n).get('json_file') is None:
+                simple_register(n, filter_settings, filter_empty=False)
+            ev = Omni3DEvaluator(n, output_dir=self.output_folders[n], filter_settings=filter_settings, only_2d=only_2d,
+                                 eval_prox=('Objectron' in n or 'SUNRGBD' in n), distributed=False, iou3d_fn=iou3d_fn)
+            ev.reset()
+            self.evaluators[n] = ev
+            self.overall_imgIds.update(ev._omni_api.getImgIds())
+            self.overall_catIds.update(ev._omni_api.getCatIds())
+
+    def add_predictions(self, dataset_name, predictions):
+        self.evaluators[dataset_name]._predictions += predictions
+
+    def save_predictions(self, dataset_name):
+        import os
+        import torch
+        os.makedirs(self.output_folders[dataset_name], exist_ok=True)
+        torch.save(self.evaluators[dataset_name]._predictions,
+                   os.path.join(self.output_folders[dataset_name], "instances_predictions.pth"))
+
+    def evaluate(self, dataset_name):
+        from ..data.builtin import get_omni3d_categories
+        if dataset_name not in self.results:
+            self.results[dataset_name] = self.evaluators[dataset_name].evaluate()
+        res = self.results[dataset_name]
+        if "bbox_2D" not in res:
+            return res
+        names = self.filter_settings['category_names']
+        cats = {c for c in names if 'AP-' + c in res['bbox_2D']}
+        mean = lambda mode, cs: float(np.mean([res['bbox_' + mode]['AP-' + c] for c in cs])) if cs else float("nan")
+        g2 = mean("2D", cats)
+        g3 = float("nan") if self.only_2d else mean("3D", cats)
+        o2 = o3 = float("nan")
+        try:
+            own = get_omni3d_categories(dataset_name)
+        except ValueError:
+            own = None
+        if own is not None and len(own - cats) == 0:
+            o2 = mean("2D", own)
+            o3 = float("nan") if self.only_2d else mean("3D", own)
+        self.results_omni3d[dataset_name] = {"iters": self.iter_label, "AP2D": o2, "AP3D": o3}
+        r3 = res.get('bbox_3D', {})
+        nan = float("nan")
+        self.results_analysis[dataset_name] = {
+            "iters": self.iter_label, "AP2D": g2, "AP3D": g3, "AP3D@15": r3.get('AP15', nan), "AP3D@25": r3.get('AP25', nan),
+            "AP3D@50": r3.get('AP50', nan), "AP3D-N": r3.get('APn', nan), "AP3D-M": r3.get('APm', nan), "AP3D-F": r3.get('APf', nan)}
+        return res
+
+    def _pooled(self, mode):
+        """accumulate over the union of all datasets' per-image evaluations"""
+        ev = Omni3Deval([], [], mode=mode)
+        ev.params.catIds, ev.params.imgIds = list(self.overall_catIds), list(self.overall_imgIds)
+        ev.evalImgs = {}
+        for e in self.evaluators.values():
+            if mode in e.evals:
+                ev.evalImgs.update({k: v for k, v in e.evals[mode].evalImgs.items() if v is not None})
+        for c in ev.params.catIds:
+            for a in range(len(ev.params.areaRng)):
+                for i in ev.params.imgIds:
+                    ev.evalImgs.setdefault((c, a, i), None)
+        ev.accumulate().summarize()
+        return ev
+
+    def summarize_all(self):
+        from ...d2lite.data import MetadataCatalog
+        from ..data.builtin import get_omni3d_categories
+        for n in self.dataset_names:
+            if n not in self.results:
+                self.evaluate(n)
+        meta = MetadataCatalog.get('omni3d_model')
+        ordered = [meta.thing_classes[meta.thing_dataset_id_to_contiguous_id[c]] for c in self.overall_catIds]
+        cats = set(ordered)
+        res = {}
+        for mode in (["2D"] if self.only_2d else ["2D", "3D"]):
+            ev = self._pooled(mode)
+            res[mode] = {**_headline(ev, mode), **_per_category(ev, ordered)}
+        nan = float("nan")
+        mean = lambda mode, cs: float(np.mean([res[mode]['AP-' + c] for c in cs])) if mode in res else nan
+        r3 = res.get("3D", {})
+        self.results_analysis["<Concat>"] = {
+            "iters": self.iter_label, "AP2D": mean("2D", cats), "AP3D": mean("3D", cats), "AP3D@15": r3.get('AP15', nan),
+            "AP3D@25": r3.get('AP25', nan), "AP3D@50": r3.get('AP50', nan), "AP3D-N": r3.get('APn', nan),
+            "AP3D-M": r3.get('APm', nan), "AP3D-F": r3.get('APf', nan)}
+        for label, key in (("Omni3D_Out", "omni3d_out"), ("Omni3D_In", "omni3d_in"), ("Omni3D", "omni3d")):
+            group = get_omni3d_categories(key)
+            full = len(group - cats) == 0
+            self.results_omni3d[label] = {"iters": self.iter_label, "AP2D": mean("2D", group) if full else nan,
+                                          "AP3D": mean("3D", group) if full else nan}
+        self.results_concat = res
+        return self.results_analysis, self.results_omni3d
+
+
+def inference_on_dataset(model, data_loader):
+    """:523-641: runs `model` (eval mode, no grad) over this rank's loader and returns the prediction records; with
+    torch.distributed initialised the records of all ranks are gathered on rank 0 (other ranks get [])."""
+    import itertools
+    import torch
+    import torch.distributed as dist
+    was_training = getattr(model, "training", False)
+    if hasattr(model, "eval"):
+        model.eval()
+    out = []
+    try:
+        with torch.no_grad():
+            for inputs in data_loader:
+                outputs = model(inputs)
+                for inp, o in zip(inputs, outputs):
+                    out.append({"image_id": inp["image_id"], "K": inp["K"], "width": inp["width"], "height": inp["height"],
+                                "instances": instances_to_coco_json(o["instances"].to("cpu"), inp["image_id"])})
+    finally:
+        if was_training:
+            model.train()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        gathered = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+        dist.gather_object(out, gathered, dst=0)
+        if dist.get_rank() != 0:
+            return []
+        out = list(itertools.chain(*gathered))
+    return out

@@ -57,6 +57,10 @@ def make_cfg(config_file=None, overrides=()):
     return cfg
 
 
+_SYNTH_CATEGORY_IDS = {n: 3 * i + 2 for i, n in enumerate(
+    ("bed", "car", "chair", "lamp", "sofa", "table", "truck", "dontcare"))}
+
+
 def make_omni3d_dataset(root, name="Synth_train", n_images=6, seed=0, sizes=((480, 640), (512, 512), (640, 400)),
                         categories=("bed", "car", "chair", "sofa", "table", "truck"), dataset_id=90, source="synthetic",
                         first_image_id=1000, with_maps=True, extra_category=None):
@@ -82,7 +86,9 @@ def make_omni3d_dataset(root, name="Synth_train", n_images=6, seed=0, sizes=((48
         os.makedirs(os.path.join(root, "depth_maps"), exist_ok=True)
         os.makedirs(os.path.join(root, "ground_maps"), exist_ok=True)
     cat_names = list(categories) + ([extra_category] if extra_category else [])
-    cats = [{"id": 3 * i + 2, "name": n, "supercategory": "object"} for i, n in enumerate(cat_names)]
+    # category ids are global across files (as in Omni3D): fixed by name, not by position in this file
+    cats = [{"id": _SYNTH_CATEGORY_IDS.get(n, 900 + i), "name": n, "supercategory": "object"} for i, n in enumerate(cat_names)]
+    cats.sort(key=lambda c: c["id"])
     images, annos = [], []
     aid = first_image_id * 100
     corner_signs = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1],

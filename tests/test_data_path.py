@@ -286,3 +286,84 @@ def test_builtin_categories():
     assert "toilet" in data.get_omni3d_categories("Hypersim_val") and "toilet" not in data.get_omni3d_categories("Hypersim_test")
     with pytest.raises(ValueError):
         data.get_omni3d_categories("nope")
+
+
+def test_evaluator_over_datasets(gold, dataset_root, monkeypatch, tmp_path):
+    """json ground truth -> Omni3DEvaluator / Omni3DEvaluationHelper: detections equal to the valid ground truth score
+    AP2D = AP3D = 100 per dataset and pooled; class ids travel contiguous -> Omni3D ids; classes a dataset does not
+    annotate are dropped; a shifted copy at lower score does not hurt, a confident false positive does."""
+    from oracle import iou3d as oiou
+    ev_mod = importlib.import_module("3dod_amd.cubercnn.evaluation")
+    work, rel = dataset_root
+    monkeypatch.chdir(work)
+    fs = copy.deepcopy(gold["settings"]["default"])
+    omni = _registered(work, rel, gold, fs)
+    names = [g["name"] for g in gold["gen"]]
+    meta = D.MetadataCatalog.get("omni3d_model")
+    id_map = meta.thing_dataset_id_to_contiguous_id
+
+    def iou3d(d, g):
+        return oiou.box3d_overlap(np.asarray(d, np.float64), np.asarray(g, np.float64))[1]
+
+    def predictions(name, extra_fp=False, oov=False):
+        api = data.Omni3D([os.path.join("datasets", "Omni3D", name + ".json")], copy.deepcopy(fs))
+        by_img = {}
+        for a in api.dataset["annotations"]:
+            inst = {"image_id": a["image_id"], "category_id": id_map[a["category_id"]], "bbox": list(a["bbox"]),
+                    "score": 0.9, "depth": a["depth"], "bbox3D": a["bbox3D"]}
+            by_img.setdefault(a["image_id"], []).append(inst)
+            shifted = copy.deepcopy(inst)
+            shifted["score"] = 0.2
+            shifted["bbox"][0] += 3.0
+            by_img[a["image_id"]].append(shifted)
+            if extra_fp:
+                fp = copy.deepcopy(inst)
+                fp["score"] = 0.99
+                fp["bbox"] = [5.0, 5.0, 12.0, 9.0]
+                fp["bbox3D"] = (np.asarray(a["bbox3D"]) + 40.0).tolist()
+                by_img[a["image_id"]].append(fp)
+            if oov:                      # a class of the model that this dataset does not annotate
+                o = copy.deepcopy(inst)
+                o["category_id"], o["score"] = id_map[2], 1.0          # 'bed' (id 2) is not in Synth_b_train
+                by_img[a["image_id"]].append(o)
+        return [{"image_id": i, "K": api.imgs[i]["K"], "width": api.imgs[i]["width"], "height": api.imgs[i]["height"],
+                 "instances": v} for i, v in by_img.items()]
+
+    helper = ev_mod.Omni3DEvaluationHelper(names, fs, str(tmp_path), iter_label="t", iou3d_fn=iou3d)
+    helper.add_predictions(names[0], predictions(names[0]))
+    helper.add_predictions(names[1], predictions(names[1], oov=True))
+    for n in names:
+        res = helper.evaluate(n)
+        assert res["bbox_2D"]["AP"] == pytest.approx(100.0) and res["bbox_3D"]["AP"] == pytest.approx(100.0), res
+        assert os.path.exists(os.path.join(str(tmp_path), n, "omni_instances_results.json"))
+    assert "AP-bed" in helper.results[names[0]]["bbox_2D"] and "AP-bed" not in helper.results[names[1]]["bbox_2D"]
+    with open(os.path.join(str(tmp_path), names[1], "omni_instances_results.json")) as f:
+        saved = json.load(f)
+    assert saved and all(r["category_id"] in (5, 8) for r in saved)          # Omni3D ids of car / chair; 'bed' dropped
+    analysis, omni_tab = helper.summarize_all()
+    assert analysis["<Concat>"]["AP2D"] == pytest.approx(100.0) and analysis["<Concat>"]["AP3D"] == pytest.approx(100.0)
+    assert math.isnan(omni_tab["Omni3D"]["AP3D"])                             # not all 50 categories present
+    assert analysis[names[0]]["AP3D@25"] == pytest.approx(100.0)
+
+    worse = ev_mod.Omni3DEvaluationHelper(names[:1], fs, str(tmp_path / "fp"), iou3d_fn=iou3d)
+    worse.add_predictions(names[0], predictions(names[0], extra_fp=True))
+    res = worse.evaluate(names[0])
+    assert 20.0 < res["bbox_2D"]["AP"] < 80.0 and 20.0 < res["bbox_3D"]["AP"] < 80.0, res
+
+
+def test_instances_to_coco_json():
+    ev_mod = importlib.import_module("3dod_amd.cubercnn.evaluation")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    inst = d2.Instances((100, 200))
+    inst.pred_boxes = d2.Boxes(torch.tensor([[10., 20., 50., 80.], [0., 0., 5., 5.]]))
+    inst.scores = torch.tensor([0.9, 0.1])
+    inst.pred_classes = torch.tensor([3, 1])
+    out = ev_mod.instances_to_coco_json(inst, 77)
+    assert out[0]["bbox"] == [10.0, 20.0, 40.0, 60.0] and out[0]["image_id"] == 77 and out[1]["category_id"] == 1
+    assert out[0]["depth"] == 1.0 and np.array(out[0]["bbox3D"]).shape == (8, 3)          # placeholders without a 3D head
+    corners = torch.arange(48, dtype=torch.float32).reshape(2, 8, 3)
+    inst.pred_bbox3D, inst.pred_center_cam, inst.pred_center_2D = corners, torch.ones(2, 3), torch.ones(2, 2)
+    inst.pred_dimensions, inst.pred_pose = torch.ones(2, 3), torch.eye(3).expand(2, 3, 3)
+    out = ev_mod.instances_to_coco_json(inst, 78)
+    assert out[1]["depth"] == pytest.approx(float(corners[1, :, 2].mean()))
+    assert ev_mod.instances_to_coco_json(inst[torch.zeros(2, dtype=torch.bool)], 1) == []
