@@ -1,0 +1,240 @@
+"""ROIHeads3DScore -- the weakly supervised 3D head (reference: cubercnn/modeling/roi_heads/roi_heads.py:664-1946,
+configs/Omni_combined.yaml): the box branch and the cube head are those of ROIHeads3D, but the cube branch is trained
+from 2D boxes, a metric depth map and a ground mask instead of 3D labels:
+
+    iou                 GIoU between the GT 2D box and the hull of the projected cuboid
+    pose_alignment      cuboids of one image should share their orientation
+    pose_ground(2)      the cuboid's up-axis (or whole frame) should match the RANSAC ground normal
+    z / z_pseudo_gt_*   depth from the 2D box area / from the depth map under the box (median) or its centre
+    dims                hinge on the class prior of (w, h, l)
+
+All of them are batched tensor expressions over the foreground RoIs (weak_losses.py); the per-box depth median and the
+plane fit are HIP kernels.  The 'segmentation' and 'depth' losses need SAM masks of every object
+(roi_heads.py:881-883, generate_ground_segmentations.init_segmentation) -- the segmentation model is out of scope
+ and both are rejected at construction.
+"""
+from typing import Dict
+
+import torch
+
+from ....d2lite import ROI_HEADS_REGISTRY, Boxes, Instances, ShapeSpec, get_event_storage
+from ...util import math_util as util
+from . import weak_losses as W
+from .roi_heads import ROIHeads3D, select_foreground_proposals
+
+SQRT_2_CONSTANT = 1.4142135623730951
+POSSIBLE_LOSSES = ['dims', 'pose_alignment', 'pose_ground', 'pose_ground2', 'iou', 'segmentation', 'z', 'z_pseudo_gt_patch',
+                   'z_pseudo_gt_center', 'depth']
+
+
+@ROI_HEADS_REGISTRY.register()
+class ROIHeads3DScore(ROIHeads3D):
+    def __init__(self, cfg, input_shape: Dict[str, ShapeSpec], priors=None):
+        super().__init__(cfg, input_shape, priors=priors)
+        c = cfg.MODEL.ROI_CUBE_HEAD
+        self.loss_w_iou = c.LOSS_W_IOU
+        self.loss_w_seg = c.LOSS_W_SEG
+        self.loss_w_normal_vec = c.LOSS_W_NORMAL_VEC
+        self.loss_w_depth = c.LOSS_W_DEPTH
+        self.loss_functions = list(cfg.loss_functions)
+        assert all(x in POSSIBLE_LOSSES for x in self.loss_functions), \
+            f'loss functions must be in {POSSIBLE_LOSSES}, but was {self.loss_functions}'
+        if 'segmentation' in self.loss_functions or 'depth' in self.loss_functions:
+            raise NotImplementedError("the 'segmentation' and 'depth' losses need the SAM segmentor (SURVEY 8(f) N4), which "
+                                      "is not built; remove them from cfg.loss_functions")
+        self.segmentor = None
+        # test hooks: CPU restatements (oracle/weak.py) of the two kernels; None = the HIP path, which refuses CPU tensors
+        self._median_fn = None
+        self._plane_cls = None
+        self._ransac_triples = None
+
+    # ------------------------------------------------------------------ forward (roi_heads.py:854-914)
+    def forward(self, images, images_raw, ground_maps, depth_maps, features, proposals, Ks, im_scales_ratio, targets=None):
+        im_dims = [tuple(s) for s in images.image_sizes]
+        if self.training:
+            proposals = self.label_and_sample_proposals(proposals, targets)
+            losses = self._forward_box(features, proposals)
+            if self.loss_w_3d > 0:
+                instances_3d, losses_cube = self._forward_cube(features, proposals, Ks, im_dims, im_scales_ratio, None, None,
+                                                               ground_maps, depth_maps)
+                losses.update(losses_cube)
+            else:
+                instances_3d = None
+            return instances_3d, losses
+        return ROIHeads3D.forward(self, images, features, proposals, Ks, im_scales_ratio, targets)
+
+    # ------------------------------------------------------------------ cube branch (roi_heads.py:1319-1820)
+    def _forward_cube(self, features, instances, Ks, im_current_dims, im_scales_ratio, masks_all_images=None,
+                      first_occurrence_indices=None, ground_maps=None, depth_maps=None):
+        if not self.training:
+            # the decode of the two heads is the same code (roi_heads.py:1351-1501 == 2271-2436)
+            return ROIHeads3D._forward_cube(self, features, instances, Ks, im_current_dims, im_scales_ratio)
+        feats = [features[f] for f in self.in_features]
+        losses = {}
+        self.normalize_factor = max(sum([i.gt_classes.numel() for i in instances]), 1.0)
+        proposals, _ = select_foreground_proposals(instances, self.num_classes)
+        proposal_boxes = [x.proposal_boxes for x in proposals]
+        pred_boxes = [x.pred_boxes for x in proposals]
+        box_classes = torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals) else torch.empty(0)
+        gt_boxes3D = torch.cat([p.gt_boxes3D for p in proposals], dim=0)
+        gt_poses = torch.cat([p.gt_poses for p in proposals], dim=0)
+        assert len(gt_poses) == len(gt_boxes3D) == len(box_classes)
+
+        proposal_boxes_scaled = self.scale_proposals(proposal_boxes)
+        n = sum(len(b) for b in proposal_boxes_scaled)
+        if n == 0:
+            return instances, {}
+        cube_features = self.cube_pooler(feats, proposal_boxes_scaled).flatten(1)
+        device = cube_features.device
+        num_boxes_per_image = [len(i) for i in proposals]
+
+        Ks_dev = [torch.as_tensor(K, dtype=torch.float32) for K in Ks]
+        rep = lambda vals: torch.cat([v.unsqueeze(0).repeat([num] + [1] * v.dim())
+                                      for v, num in zip(vals, num_boxes_per_image)]).to(device)
+        Ks_scaled_per_box = rep([Ks_dev[i] / im_scales_ratio[i] for i in range(len(Ks_dev))])
+        Ks_scaled_per_box[:, -1, -1] = 1
+        focal_lengths_per_box = rep([K[1, 1] for K in Ks_dev])
+        im_ratios_per_box = rep([torch.tensor(float(r)) for r in im_scales_ratio])
+        im_scales_per_box = rep([torch.tensor(float(d[0])) for d in im_current_dims])
+        im_scales_original_per_box = im_scales_per_box * im_ratios_per_box
+        if self.virtual_depth:
+            virtual_to_real = util.compute_virtual_scale_from_focal_spaces(
+                focal_lengths_per_box, im_scales_original_per_box, self.virtual_focal, im_scales_per_box)
+        else:
+            virtual_to_real = 1.0
+
+        src_boxes = torch.cat([b.tensor for b in proposal_boxes], dim=0)
+        src_widths = src_boxes[:, 2] - src_boxes[:, 0]
+        src_heights = src_boxes[:, 3] - src_boxes[:, 1]
+        src_ctr_x = src_boxes[:, 0] + 0.5 * src_widths
+        src_ctr_y = src_boxes[:, 1] + 0.5 * src_heights
+        clamp_dims = [list(im_current_dims[i]) for i, num in enumerate(num_boxes_per_image) for _ in range(num)]
+
+        cube_2d_deltas, cube_z, cube_dims, cube_pose, cube_uncert = self.cube_head(cube_features)
+        fg_inds = torch.arange(n, device=device)
+        cube_z = cube_z[fg_inds, box_classes, :]
+        cube_dims = cube_dims[fg_inds, box_classes, :]
+        cube_pose = cube_pose[fg_inds, box_classes, :, :]
+        if self.use_confidence:
+            cube_uncert = cube_uncert[fg_inds, box_classes]
+        cube_2d_deltas = cube_2d_deltas[fg_inds, box_classes, :]
+
+        cube_x = src_ctr_x + src_widths * cube_2d_deltas[:, 0]
+        cube_y = src_ctr_y + src_heights * cube_2d_deltas[:, 1]
+        cube_xy = torch.cat((cube_x.unsqueeze(1), cube_y.unsqueeze(1)), dim=1)
+        cube_dims_norm = cube_dims
+        prior_dims_mean = prior_dims_std = None
+        if self.dims_priors_enabled:
+            prior_dims = self.priors_dims_per_cat.detach()[0][box_classes]
+            prior_dims_mean, prior_dims_std = prior_dims[:, 0, :], prior_dims[:, 1, :]
+            if self.dims_priors_func == 'sigmoid':
+                cube_dims = util.scaled_sigmoid(cube_dims_norm, min=(prior_dims_mean - 3 * prior_dims_std).clip(0.0),
+                                                max=(prior_dims_mean + 3 * prior_dims_std))
+            elif self.dims_priors_func == 'exp':
+                cube_dims = torch.exp(cube_dims_norm.clip(max=5)) * prior_dims_mean
+        else:
+            cube_dims = torch.exp(cube_dims_norm.clip(max=5))
+        if self.allocentric_pose:
+            cube_pose = util.R_from_allocentric(Ks_scaled_per_box, cube_pose, u=cube_x.detach(), v=cube_y.detach())
+        cube_z = cube_z.squeeze(1)
+        if self.virtual_depth:
+            cube_z = cube_z * virtual_to_real
+
+        prefix = 'Cube/'
+        storage = get_event_storage()
+        K = Ks_scaled_per_box
+        gt_2d, gt_z, gt_dims = gt_boxes3D[:, :2], gt_boxes3D[:, 2], gt_boxes3D[:, 3:6]
+
+        # predicted cuboids in metres and their 2D hulls (Cubes + cubes_to_box per RoI in the reference, :1547-1583)
+        cube_x3d = cube_z * (cube_x - K[:, 0, 2]) / K[:, 0, 0]
+        cube_y3d = cube_z * (cube_y - K[:, 1, 2]) / K[:, 1, 1]
+        cubes = torch.cat((cube_x3d.unsqueeze(1), cube_y3d.unsqueeze(1), cube_z.unsqueeze(1), cube_dims,
+                           cube_pose.reshape(n, 9)), dim=1)
+        proj_boxes = W.corners_to_boxes(W.project_cubes_to_corners(cubes.unsqueeze(1), K, clamp_dims))[:, 0]
+        gt_boxes = torch.cat([x.gt_boxes.tensor for x in proposals])
+
+        loss_iou = loss_pose = loss_z = loss_dims_w = loss_dims_h = loss_dims_l = None
+        loss_pseudo_gt_z = loss_ground_rot = None
+        if 'iou' in self.loss_functions:
+            loss_iou = W.generalized_box_iou_loss(gt_boxes, proj_boxes, reduction='none').view(n, -1).mean(dim=1)
+        if 'pose_alignment' in self.loss_functions:
+            loss_pose = W.pose_alignment_loss(cube_pose, num_boxes_per_image)
+        if loss_pose is not None:
+            loss_pose = loss_pose.repeat(n)
+        if 'pose_ground' in self.loss_functions or 'pose_ground2' in self.loss_functions:
+            conf = torch.tensor([0.1 if tuple(s) == (1, 1) else 1.0 for s in ground_maps.image_sizes], device=device)
+            per_image = torch.tensor(num_boxes_per_image, device=device)
+            normals = W.ground_normals(ground_maps, depth_maps, K, id_samples=self._ransac_triples,
+                                       plane_cls=self._plane_cls)
+            normals = normals.repeat_interleave(per_image, 0)
+            valid_ground_maps_conf = conf.repeat_interleave(per_image, 0)
+            if 'pose_ground' in self.loss_functions:
+                loss_ground_rot = 1 - torch.nn.functional.cosine_similarity(normals, cube_pose[:, 1, :], dim=1).abs()
+                loss_ground_rot = loss_ground_rot * valid_ground_maps_conf
+            if 'pose_ground2' in self.loss_functions:
+                loss_ground_rot = 1 - W.so3_relative_angle(cube_pose, W.normal_to_rotation(normals), cos_angle=True)
+                loss_ground_rot = loss_ground_rot * valid_ground_maps_conf
+        if 'z_pseudo_gt_patch' in self.loss_functions:
+            target = W.pseudo_gt_z_box(depth_maps, proj_boxes, num_boxes_per_image, median_fn=self._median_fn)
+            loss_pseudo_gt_z = self.l1_loss(cube_z, target)
+        elif 'z_pseudo_gt_center' in self.loss_functions:
+            loss_pseudo_gt_z = self.l1_loss(cube_z, W.pseudo_gt_z_point(depth_maps, cube_xy, num_boxes_per_image))
+        if 'z' in self.loss_functions:
+            loss_z = W.z_search_loss(gt_boxes, cubes, K, clamp_dims, proj_boxes)
+        if 'dims' in self.loss_functions:
+            loss_dims_w, loss_dims_h, loss_dims_l = W.dim_hinge_loss(prior_dims_mean, prior_dims_std, cube_dims)
+
+        with torch.no_grad():
+            total = 0
+            for l, w in ((loss_iou, self.loss_w_iou), (loss_pose, self.loss_w_pose), (loss_z, self.loss_w_z),
+                         (loss_pseudo_gt_z, self.loss_w_z), (loss_dims_w, self.loss_w_dims), (loss_dims_h, self.loss_w_dims),
+                         (loss_dims_l, self.loss_w_dims)):
+                if l is not None:
+                    total = total + l * w
+            if loss_ground_rot is not None:      # weighted by the confidence a second time, as in the reference (:1663)
+                total = total + loss_ground_rot * self.loss_w_normal_vec * valid_ground_maps_conf
+            z_error = (cube_z - gt_z).abs()
+            storage.put_scalar(prefix + 'z_error', z_error.mean(), smoothing_hint=False)
+            storage.put_scalar(prefix + 'dims_error', (cube_dims - gt_dims).abs().mean(), smoothing_hint=False)
+            storage.put_scalar(prefix + 'xy_error', (cube_xy - gt_2d).abs().mean(), smoothing_hint=False)
+            storage.put_scalar(prefix + 'z_close', (z_error < 0.20).float().mean(), smoothing_hint=False)
+            inter_wh = (torch.min(gt_boxes[:, 2:], proj_boxes[:, 2:]) - torch.max(gt_boxes[:, :2], proj_boxes[:, :2])).clamp(min=0)
+            inter = inter_wh[:, 0] * inter_wh[:, 1]
+            area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+            iou2d = torch.where(inter > 0, inter / (area(gt_boxes) + area(proj_boxes) - inter), torch.zeros_like(inter))
+            storage.put_scalar(prefix + '2D IoU', iou2d.mean(), smoothing_hint=False)
+            if not isinstance(total, int):
+                storage.put_scalar(prefix + 'total_3D_loss', self.loss_w_3d * self.safely_reduce_losses(total),
+                                   smoothing_hint=False)
+
+        named = [('loss_iou', loss_iou, self.loss_w_iou), ('loss_pose', loss_pose, self.loss_w_pose),
+                 ('loss_normal_vec', loss_ground_rot, self.loss_w_normal_vec), ('loss_z', loss_z, self.loss_w_z),
+                 ('loss_pseudo_gt_z', loss_pseudo_gt_z, self.loss_w_z), ('loss_dims_w', loss_dims_w, self.loss_w_dims),
+                 ('loss_dims_h', loss_dims_h, self.loss_w_dims), ('loss_dims_l', loss_dims_l, self.loss_w_dims)]
+        if self.use_confidence > 0:
+            uncert_sf = SQRT_2_CONSTANT * torch.exp(-cube_uncert)
+            named = [(k, l * uncert_sf if l is not None else None, w) for k, l, w in named]
+            losses.update({prefix + 'uncert': self.use_confidence * self.safely_reduce_losses(cube_uncert.clone())})
+            storage.put_scalar(prefix + 'conf', torch.exp(-cube_uncert.detach()).mean(), smoothing_hint=False)
+        for k, l, w in named:
+            if l is not None:
+                losses[prefix + k] = self.safely_reduce_losses(l) * w * self.loss_w_3d
+
+        # ---- packing of the decoded cuboids (roi_heads.py:1763-1815)
+        cube_3D = torch.cat((torch.stack((cube_x3d, cube_y3d, cube_z)).T, cube_dims,
+                             cube_xy * im_ratios_per_box.unsqueeze(1)), dim=1)
+        if self.use_confidence:
+            cube_3D = torch.cat((cube_3D, torch.exp(-cube_uncert).unsqueeze(1)), dim=1)
+        pred_instances = [Instances(image_size) for image_size in im_current_dims]
+        for cube_3D_i, cube_pose_i, inst, cls_i, boxes_i in zip(cube_3D.split(num_boxes_per_image),
+                                                                cube_pose.split(num_boxes_per_image), pred_instances,
+                                                                box_classes.split(num_boxes_per_image), pred_boxes):
+            inst.scores = cube_3D_i[:, -1]
+            inst.pred_classes = cls_i
+            inst.pred_boxes = boxes_i
+            inst.pred_bbox3D = util.get_cuboid_verts_faces(cube_3D_i[:, :6], cube_pose_i)[0]
+            inst.pred_center_cam = cube_3D_i[:, :3]
+            inst.pred_center_2D = cube_3D_i[:, 6:8]
+            inst.pred_dimensions = cube_3D_i[:, 3:6]
+            inst.pred_pose = cube_pose_i
+        return pred_instances, losses

@@ -132,3 +132,19 @@ def box3d_overlap(boxes1, boxes2):
     _lib.check(lib.cr_box3d_overlap(_lib.ctx_for(b1.device), _lib.ptr(b1), _lib.ptr(b2), N, M, _lib.ptr(vol), _lib.ptr(iou)),
                "cr_box3d_overlap")
     return vol, iou
+
+
+def box_median(depth, boxes, img):
+    """lower median (torch.median) of depth[img[i], y1:y2, x1:x2]: depth (B,H,W) f32, boxes (n,4) int32 (x1,y1,x2,y2),
+    img (n) int32 -> (n,) f32, NaN for an empty window.  One radix-select block per box (cr_box_median) instead of the
+    per-box loop of cubercnn/modeling/roi_heads/roi_heads.py:1216-1218."""
+    lib = _lib.load()
+    if not depth.is_cuda:
+        raise _lib.CrError("box_median: expected CUDA(HIP) tensors; 3dod_amd has no CPU path")
+    d = depth.float().contiguous()
+    assert d.dim() == 3 and boxes.dim() == 2 and boxes.shape[1] == 4 and img.shape[0] == boxes.shape[0]
+    b, im = boxes.to(torch.int32).contiguous(), img.to(torch.int32).contiguous()
+    out = torch.empty(b.shape[0], dtype=torch.float32, device=d.device)
+    _lib.check(lib.cr_box_median(_lib.ctx_for(d.device), _lib.ptr(d), d.shape[0], d.shape[1], d.shape[2], _lib.ptr(b),
+                                 _lib.ptr(im), b.shape[0], _lib.ptr(out)), "cr_box_median")
+    return out

@@ -99,6 +99,13 @@ int cr_propose(cr_ctx* ctx, const float* boxes, int64_t N, const float* depth, i
 int cr_ransac_plane(cr_ctx* ctx, const float* pts, int64_t Q, const int32_t* triples, int64_t T,
                     float thresh, float* out_neg_eq, int32_t* out_counts, int32_t* out_best);
 
+/* Lower median (torch.median's choice) of depth[img[i], y1:y2, x1:x2] for n integer windows (x1,y1,x2,y2), clipped to
+ * the map like a Python slice; NaN for an empty window.  depth (B,H,W) f32 contiguous; boxes (n,4) int32; img (n) int32.
+ * Replaces the per-box torch.median loop of ROIHeads3DScore.pseudo_gt_z_box_loss
+ * (cubercnn/modeling/roi_heads/roi_heads.py:1196-1232, loop at :1216-1218).  Bit-exact (selection, no arithmetic). */
+int cr_box_median(cr_ctx* ctx, const float* depth, int B, int H, int W, const int32_t* boxes, const int32_t* img, int n,
+                  float* out);
+
 /* ---- convolution stack (bf16 MFMA, f32 accumulate, NHWC) ---------------- */
 /* Activations are NHWC bf16 (channels padded to a multiple of 8).  Conv weights
  * are [Cout][ks*ks][Cin] = the physical (channels_last) layout of a

@@ -1,0 +1,187 @@
+"""Golden vectors for the weakly supervised 3D head: runs the REFERENCE's own ROIHeads3DScore._forward_cube
+(cubercnn/modeling/roi_heads/roi_heads.py:1319-1820) and its loss methods (pose_loss :1055, normal_vector_from_maps
+:1076, z_loss :1151, pseudo_gt_z_box_loss :1196, dim_loss :1234, pseudo_gt_z_point_loss :1256, normal_to_rotation
+:1306) on CPU in training mode, with the pooler / cube head replaced by given tensors, and records the losses, their
+gradients w.r.t. the head outputs, the RANSAC triples the reference drew (random.sample) and the decoded instances.
+
+Third-party symbols are stood in by this repo's restatements (detectron2 Instances / Boxes / pairwise_iou, torchvision
+generalized_box_iou_loss, pytorch3d so3_relative_angle / rotation_6d_to_matrix / axis_angle_to_matrix): parity unpinned
+at those boundaries.  Cubes, cubes_to_box, Plane.fit_parallel, so3_relative_angle_batched and everything inside
+ROIHeads3DScore are the reference's code.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_weakhead.py
+"""
+import importlib
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import _refimport  # noqa: E402
+
+ns = _refimport.load()          # geometry modules with Boxes / pairwise_iou stand-ins patched in
+d2 = importlib.import_module("3dod_amd.d2lite")
+my_util = importlib.import_module("3dod_amd.cubercnn.util.math_util")
+my_rh = importlib.import_module("3dod_amd.cubercnn.modeling.roi_heads.roi_heads")
+my_weak = importlib.import_module("3dod_amd.cubercnn.modeling.roi_heads.weak_losses")
+syn = importlib.import_module("3dod_amd.synthetic")
+
+from cubercnn.util import math_util as ref_math          # noqa: E402  (reference)
+ref_math.axis_angle_to_matrix = my_util.axis_angle_to_matrix
+import cubercnn.modeling.roi_heads.roi_heads as ref_rh   # noqa: E402  (reference)
+import ProposalNetwork.utils.plane as ref_plane          # noqa: E402  (reference, pure torch)
+
+ref_rh.Instances = d2.Instances
+ref_rh.Boxes = d2.Boxes
+ref_rh.select_foreground_proposals = my_rh.select_foreground_proposals
+ref_rh.generalized_box_iou_loss = my_weak.generalized_box_iou_loss
+ref_rh.so3_relative_angle = my_weak.so3_relative_angle
+ref_rh.Plane_cuda = ref_plane.Plane
+ref_rh.util.R_from_allocentric = ref_math.R_from_allocentric
+storage = d2.EventStorage(1)            # iter 1: the 3D-IoU logging branch (pytorch3d) is not taken
+ref_rh.get_event_storage = lambda: storage
+torch.set_num_threads(1)
+
+# record the triples the reference's RANSAC draws
+TRIPLES = []
+_orig_sample = random.sample
+
+
+def _recording_sample(population, k):
+    out = _orig_sample(population, k)
+    TRIPLES[-1].append(out)
+    return out
+
+
+class _RecordingPlane(ref_plane.Plane):
+    def fit_parallel(self, pts, thresh=0.05, minPoints=100, maxIteration=1000):
+        TRIPLES.append([])
+        ref_plane.random.sample = _recording_sample
+        try:
+            return super().fit_parallel(pts, thresh=thresh, minPoints=minPoints, maxIteration=maxIteration)
+        finally:
+            ref_plane.random.sample = _orig_sample
+
+
+ref_rh.Plane_cuda = _RecordingPlane
+
+
+def scene_maps(batch, g, size=512):
+    """depth of a ground plane 1.5 m below the camera with a back wall at 8 m, some noise; ground masks for images 0
+    and 2, image 1 has none (the (1,1) dummy of rcnn3d.py:381-384)."""
+    depth, ground = [], []
+    for i, b in enumerate(batch):
+        f = b["K"][0][0]
+        v = torch.arange(size, dtype=torch.float32).view(-1, 1).expand(size, size)
+        z = torch.where(v > size / 2 + 8, 1.5 * f / (v - size / 2).clamp(min=1.0), torch.full_like(v, 8.0)).clamp(max=8.0)
+        z = z + torch.randn(size, size, generator=g) * 0.01
+        depth.append(z)
+        ground.append((v > size / 2 + 40) if i != 1 else torch.tensor([[1]]))
+    depth_maps = d2.ImageList(torch.stack(depth), [(size, size)] * len(batch))
+    gt = torch.zeros(len(batch), size, size, dtype=torch.bool)
+    for i, m in enumerate(ground):
+        gt[i, :m.shape[0], :m.shape[1]] = m.bool()
+    ground_maps = d2.ImageList(gt, [tuple(m.shape) for m in ground])
+    return depth_maps, ground_maps
+
+
+def make_case(seed, K_classes=50):
+    g = torch.Generator().manual_seed(seed)
+    batch = syn.make_batch(3, seed)
+    ratios = [1.0, 1.25, 0.8]
+    instances, Ks = [], []
+    n_per = [7, 1, 9]                      # the middle image has one box: pose_loss skips it
+    for b, n in zip(batch, n_per):
+        gt = b["instances"]
+        idx = torch.randint(0, len(gt), (n,), generator=g)
+        inst = d2.Instances((512, 512))
+        inst.proposal_boxes = d2.Boxes(gt.gt_boxes.tensor[idx] + torch.randn(n, 4, generator=g) * 6)
+        inst.pred_boxes = d2.Boxes(gt.gt_boxes.tensor[idx] + torch.randn(n, 4, generator=g) * 3)
+        inst.gt_boxes = d2.Boxes(gt.gt_boxes.tensor[idx])
+        inst.gt_classes = gt.gt_classes[idx]
+        inst.gt_boxes3D = gt.gt_boxes3D[idx]
+        inst.gt_poses = gt.gt_poses[idx]
+        instances.append(inst)
+        Ks.append(torch.tensor(b["K"]))
+    n = sum(n_per)
+    head = {"deltas": torch.randn(n, K_classes, 2, generator=g) * 0.1,
+            "z": torch.randn(n, K_classes, 1, generator=g) * 0.5 + 3.0,
+            "dims": torch.randn(n, K_classes, 3, generator=g) * 0.3,
+            "pose6": torch.randn(n, K_classes, 6, generator=g),
+            "uncert": (torch.randn(n, K_classes, generator=g) * 0.5 + 1.0).clip(0.01)}
+    priors = torch.rand(1, K_classes, 2, 3, generator=g) * 0.8 + 0.3
+    depth_maps, ground_maps = scene_maps(batch, g)
+    return instances, Ks, ratios, head, priors, depth_maps, ground_maps
+
+
+def run(seed, loss_functions):
+    instances, Ks, ratios, head, priors, depth_maps, ground_maps = make_case(seed)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in head.items()}
+    pose = my_util.rotation_6d_to_matrix(leaves["pose6"].view(-1, 6)).view(leaves["pose6"].shape[0], -1, 3, 3)
+    n = leaves["z"].shape[0]
+    self = types.SimpleNamespace()
+    cfgv = dict(in_features=["p2"], training=True, num_classes=50, scale_roi_boxes=0.0, virtual_depth=True,
+                virtual_focal=512.0, cluster_bins=1, use_confidence=1.0, dims_priors_enabled=True,
+                dims_priors_func="exp", allocentric_pose=True, z_type="direct", disentangled_loss=True,
+                chamfer_pose=True, loss_w_3d=1.0, loss_w_iou=1.0, loss_w_seg=2.5, loss_w_pose=7.0,
+                loss_w_normal_vec=20.0, loss_w_z=1.0, loss_w_dims=20.0, loss_w_depth=1.0, inverse_z_weight=False,
+                loss_functions=loss_functions)
+    for k, v in cfgv.items():
+        setattr(self, k, v)
+    self.priors_dims_per_cat = priors
+    self.cube_pooler = lambda feats, boxes: torch.zeros(n, 4)
+    self.cube_head = lambda x: (leaves["deltas"], leaves["z"], leaves["dims"], pose, leaves["uncert"])
+    C = ref_rh.ROIHeads3DScore
+    for name in ("l1_loss", "chamfer_loss", "scale_proposals", "safely_reduce_losses", "pose_loss",
+                 "normal_vector_from_maps", "z_loss", "pseudo_gt_z_box_loss", "dim_loss", "pseudo_gt_z_point_loss",
+                 "normal_to_rotation"):
+        setattr(self, name, types.MethodType(getattr(C, name), self))
+    im_dims = [(512, 512)] * 3
+    first_occurrence = {}
+    for inst in instances:
+        for e in inst.gt_boxes3D[:, 0].tolist():
+            first_occurrence.setdefault(e, len(first_occurrence))
+    TRIPLES.clear()
+    random.seed(seed)
+    pred_instances, losses = C._forward_cube(self, {"p2": None}, instances, Ks, im_dims, ratios, None, first_occurrence,
+                                             ground_maps, depth_maps)
+    rec = {"in_" + k: v.numpy() for k, v in head.items()}
+    rec.update(priors=priors.numpy(), ratios=np.array(ratios, np.float32), Ks=torch.stack(Ks).numpy(),
+               n_per=np.array([len(i) for i in instances]),
+               proposal_boxes=torch.cat([i.proposal_boxes.tensor for i in instances]).numpy(),
+               pred_boxes=torch.cat([i.pred_boxes.tensor for i in instances]).numpy(),
+               gt_boxes=torch.cat([i.gt_boxes.tensor for i in instances]).numpy(),
+               gt_classes=torch.cat([i.gt_classes for i in instances]).numpy(),
+               gt_boxes3D=torch.cat([i.gt_boxes3D for i in instances]).numpy(),
+               gt_poses=torch.cat([i.gt_poses for i in instances]).numpy(),
+               depth_seed=np.array(seed), ground_sizes=np.array(ground_maps.image_sizes),
+               loss_functions=np.array(loss_functions))
+    if TRIPLES:
+        rec["triples"] = np.array(TRIPLES, dtype=np.int32)           # (images, 1000, 3)
+    total = sum(losses.values())
+    total.backward()
+    for k, v in losses.items():
+        rec["loss_" + k.replace("/", "_")] = v.detach().numpy()
+    for k, v in leaves.items():
+        rec["grad_" + k] = v.grad.numpy()
+    for f in ("pred_bbox3D", "pred_center_cam", "pred_center_2D", "pred_dimensions", "pred_pose", "scores"):
+        rec["out_" + f] = torch.cat([i.get(f) for i in pred_instances]).detach().numpy()
+    rec["notes"] = ("reference ROIHeads3DScore._forward_cube (roi_heads.py:1319-1820), training; depth / ground maps are "
+                    "re-created from `depth_seed` by tests (scene_maps); third-party stand-ins: parity unpinned there")
+    return rec
+
+
+if __name__ == "__main__":
+    a = run(21, ['dims', 'pose_alignment', 'pose_ground', 'iou', 'z', 'z_pseudo_gt_patch'])
+    b = run(22, ['dims', 'pose_ground2', 'iou', 'z_pseudo_gt_center'])
+    np.savez_compressed(os.path.join(HERE, "weakhead_a.npz"), **a)
+    np.savez_compressed(os.path.join(HERE, "weakhead_b.npz"), **b)
+    for name, r in (("a", a), ("b", b)):
+        print(name, {k: np.asarray(v).reshape(-1).tolist() for k, v in r.items() if k.startswith("loss_")})
