@@ -128,11 +128,15 @@ class RCNN3D(nn.Module):
             return forward_train(self, im_dims, features, head_outputs, GTBatch(gt_instances, dev),
                                  camera_meta(self.roi_heads, Ks, im_scales_ratio, im_dims, dev))
         proposals, proposal_losses = self.proposal_generator(images, features, gt_instances, head_outputs=head_outputs)
-        instances, detector_losses = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, gt_instances)
+        instances, detector_losses = self._run_roi_heads(images, features, proposals, Ks, im_scales_ratio, gt_instances,
+                                                         batched_inputs)
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)
         return losses
+
+    def _run_roi_heads(self, images, features, proposals, Ks, im_scales_ratio, targets, batched_inputs):
+        return self.roi_heads(images, features, proposals, Ks, im_scales_ratio, targets)
 
     def inference(self, batched_inputs, detected_instances=None, do_postprocess: bool = True):
         assert not self.training
@@ -152,10 +156,10 @@ class RCNN3D(nn.Module):
         Ks = [torch.FloatTensor(info['K']) for info in batched_inputs]
         if type(batched_inputs == list) and np.any(['oracle2D' in b for b in batched_inputs]):
             oracles = [b['oracle2D'] for b in batched_inputs]
-            results, _ = self.roi_heads(images, features, oracles, Ks, im_scales_ratio, None)
+            results, _ = self._run_roi_heads(images, features, oracles, Ks, im_scales_ratio, None, batched_inputs)
         else:
             proposals, _ = self.proposal_generator(images, features, None, head_outputs=head_outputs)
-            results, _ = self.roi_heads(images, features, proposals, Ks, im_scales_ratio, None)
+            results, _ = self._run_roi_heads(images, features, proposals, Ks, im_scales_ratio, None, batched_inputs)
         if do_postprocess:
             return RCNN3D._postprocess(results, batched_inputs, images.image_sizes)
         return results
@@ -185,6 +189,33 @@ class RCNN3D(nn.Module):
                     out.append({"instances": o})
                 return out
         return [{"instances": detector_postprocess(r, h, w)} for r, (h, w) in zip(instances, sizes)]
+
+
+@META_ARCH_REGISTRY.register()
+class RCNN3D_combined_features(RCNN3D):
+    """rcnn3d.py:266-456: Cube R-CNN trained without 3D labels -- the RoI heads (`ROIHeads3DScore`) additionally get the
+    per-image metric depth map and ground mask (padded to one size, `ImageList` keeps the true sizes; an image without a
+    ground mask carries the (1,1) dummy of :381-384).  The depth-feature concatenation of `cat_depth_features`
+    (MODEL.DEPTH_ON, Depth-Anything backbone) is off in every shipped config and not built."""
+
+    def __init__(self, cfg, priors=None):
+        super().__init__(cfg, priors=priors)
+        if cfg.MODEL.get("DEPTH_ON", False):
+            raise NotImplementedError("MODEL.DEPTH_ON needs the Depth-Anything feature extractor, which is not built")
+        self.depth_model = None
+        self.only_2d = cfg.MODEL.ROI_CUBE_HEAD.LOSS_W_3D == 0.0
+        self.dense_train = False          # the fused static-shape path implements ROIHeads3D's supervised losses only
+
+    def _maps(self, batched_inputs, key):
+        return ImageList.from_tensors([b[key].to(self.device) for b in batched_inputs])
+
+    def _run_roi_heads(self, images, features, proposals, Ks, im_scales_ratio, targets, batched_inputs):
+        ground_maps = depth_maps = None
+        if self.training and not self.only_2d:
+            depth_maps = self._maps(batched_inputs, "depth_map")
+            filled = [dict(b, ground_map=torch.tensor([[1]])) if b.get("ground_map") is None else b for b in batched_inputs]
+            ground_maps = self._maps(filled, "ground_map")
+        return self.roi_heads(images, None, ground_maps, depth_maps, features, proposals, Ks, im_scales_ratio, targets)
 
 
 @META_ARCH_REGISTRY.register()
