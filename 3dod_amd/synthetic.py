@@ -42,6 +42,21 @@ def make_batch(n_images, seed, size=512, num_classes=50, min_obj=4, max_obj=16, 
     return batch
 
 
+def add_scene_maps(batch, seed, ground_every=1):
+    """adds the inputs of the weakly supervised model to a `make_batch` batch: `depth_map` (h,w) float32 = a ground plane
+    1.5 m below the camera with a back wall at 8 m plus 1 cm noise, `ground_map` (h,w) bool (None for every image whose
+    index is not a multiple of `ground_every`, like an image without ground segmentation)."""
+    g = torch.Generator().manual_seed(seed)
+    for i, d in enumerate(batch):
+        h, w = d["image"].shape[-2:]
+        f = d["K"][0][0]
+        v = torch.arange(h, dtype=torch.float32).view(-1, 1).expand(h, w)
+        z = torch.where(v > h / 2 + 8, 1.5 * f / (v - h / 2).clamp(min=1.0), torch.full_like(v, 8.0)).clamp(max=8.0)
+        d["depth_map"] = (z + torch.randn(h, w, generator=g) * 0.01).contiguous()
+        d["ground_map"] = (v > h / 2 + 40).contiguous() if i % ground_every == 0 else None
+    return batch
+
+
 def make_cfg(config_file=None, overrides=()):
     """get_cfg + get_cfg_defaults + yaml + overrides, like tools/train_net.py:335-353 of the reference."""
     import os

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- measures the hot path on N MI355X GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|geometry]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|geometry|inference|weak]
 
 N>1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -174,12 +174,54 @@ def bench_inference(args, rank, world, dev):
                        "global_batch": B * world, "parallelism": f"dp{world}", "detections_per_step": n_det / max(args.steps, 1)}}
 
 
+def bench_weak(args, rank, world, dev):
+    """BASELINE.json configs[4] without its Depth-Anything backbone (not built): the weakly supervised Cube R-CNN
+    (configs/Omni_combined.yaml: RCNN3D_combined_features + ROIHeads3DScore, losses from 2D boxes + depth / ground maps),
+    2 synthetic 512x512 images per GPU (16 on 8 GPUs) with precomputed depth and ground maps -> images/s of the train step."""
+    bt = importlib.import_module("bench_train")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    B = 2
+    cfg, model, opt, syn, solver = bt.build(dev, world=world, config="Omni_combined.yaml", lr=0.015 * B * world / 25.0)
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast(opt.flat_p, 0)
+    batches = [syn.add_scene_maps(syn.make_batch(B, 777 + rank * 1000 + i), 99 + i, ground_every=2) for i in range(4)]
+    for b in batches:
+        for d in b:
+            d["image"], d["instances"], d["depth_map"] = d["image"].to(dev), d["instances"].to(dev), d["depth_map"].to(dev)
+            if d["ground_map"] is not None:
+                d["ground_map"] = d["ground_map"].to(dev)
+    step = solver.TrainStep(cfg, model, opt, world_size=world)
+    if os.environ.get("CR_GRAPHS", "dense") != "none":
+        model.enable_graphs(batches[0])
+        opt.zero_grad()
+    with d2.EventStorage(1):
+        for i in range(args.warmup):
+            step(batches[i % len(batches)])
+        barrier(world)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(batches[i % len(batches)])
+        barrier(world)
+        dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+        rep = step.report()
+    return {"metric": "images/sec weakly supervised Cube R-CNN train step (BASELINE configs[4], precomputed depth maps)",
+            "value": B * world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "RCNN3D_combined_features + ROIHeads3DScore train step, 2 img/GPU 512x512, losses "
+                                   + ",".join(cfg.loss_functions) + "; no Depth-Anything backbone (MODEL.DEPTH_ON False)",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": rep.get("total_loss"),
+                       "skipped_steps": rep.get("iterations_explode"),
+                       "valid": bool(rep.get("iterations_explode") == 0 and rep.get("total_loss") == rep.get("total_loss"))}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="train", choices=["train", "geometry", "inference"])
+    ap.add_argument("--workload", default="train", choices=["train", "geometry", "inference", "weak"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
@@ -192,6 +234,8 @@ def main():
         res = bench_geometry(args, rank, world, dev)
     elif args.workload == "inference":
         res = bench_inference(args, rank, world, dev)
+    elif args.workload == "weak":
+        res = bench_weak(args, rank, world, dev)
     else:
         bt = importlib.import_module("bench_train")
         res = bt.bench_train(args, rank, world, dev)

@@ -12,7 +12,7 @@ IMS_PER_GPU = 4
 TRAIN_GFLOP_PER_IMAGE = 309.0  # BASELINE.md section 2 (fwd 51.5 GMAC x 2 x 3)
 
 
-def build(dev, seed=0, lr=None, world=1):
+def build(dev, seed=0, lr=None, world=1, config=None, extra=()):
     # linear LR scaling rule of the reference (README.md:230-245): configs/Base.yaml's 0.02 is for 32 images/batch
     if lr is None:
         lr = 0.02 * IMS_PER_GPU * world / 32.0
@@ -21,11 +21,11 @@ def build(dev, seed=0, lr=None, world=1):
     solver = importlib.import_module("3dod_amd.cubercnn.solver")
     # CR_CONFIG selects another model config of configs/ (e.g. cubercnn_ResNet34_FPN.yaml); the default is the
     # BASELINE one (Base_Omni3D.yaml = DLA34-FPN)
-    cfg_file = os.environ.get("CR_CONFIG")
+    cfg_file = config or os.environ.get("CR_CONFIG")
     if cfg_file and not os.path.isabs(cfg_file):
         cfg_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", cfg_file)
     cfg = syn.make_cfg(cfg_file, overrides=["MODEL.DEVICE", str(dev), "VIS_PERIOD", 0, "log", False,
-                                  "SOLVER.IMS_PER_BATCH", 32, "SOLVER.BASE_LR", lr])
+                                  "SOLVER.IMS_PER_BATCH", 32, "SOLVER.BASE_LR", lr] + list(extra))
     torch.manual_seed(seed)
     model = modeling.build_model(cfg)
     model.train()
