@@ -21,13 +21,18 @@ class Plane:
         return torch.stack((i0, i1, i2), 1).to(torch.int32)
 
     def fit_parallel(self, pts: torch.Tensor, thresh=0.05, minPoints=100, maxIteration=1000, id_samples=None,
-                     generator=None):
-        """returns (-equation (4,), inlier indices) like the reference."""
+                     generator=None, need_inliers=True):
+        """returns (-equation (4,), inlier indices) like the reference; need_inliers=False skips the index list (its
+        length is data dependent, i.e. a host sync) for callers that only want the plane."""
         n_points = pts.shape[0]
         if id_samples is None:
             id_samples = self.sample_triples(n_points, maxIteration, pts.device, generator)
         neg_eq, counts, best = geo.ransac_plane(pts.float().contiguous(), id_samples, thresh, validate=False)
         eq = -neg_eq
+        self.equation = eq
+        if not need_inliers:
+            self.inliers = None
+            return neg_eq, None
         dist = (eq[0] * pts[:, 0] + eq[1] * pts[:, 1] + eq[2] * pts[:, 2] + eq[3]) / torch.sqrt(eq[0] ** 2 + eq[1] ** 2 + eq[2] ** 2)
         self.inliers = torch.where(torch.abs(dist) <= thresh)[0]
         self.equation = eq

@@ -313,3 +313,43 @@ def forward_train(model, image_sizes, features, head_outputs, gt: GTBatch, meta)
     if rh.loss_w_3d > 0:
         losses.update(cube_head_losses(rh, features, samp, pred_boxes, gt, meta, pooled=cube_pooled))
     return losses
+
+
+def forward_train_weak(model, image_sizes, features, head_outputs, gt: GTBatch, Ks, im_scales_ratio, ground_maps, depth_maps):
+    """RCNN3D_combined_features.forward in training mode (rcnn3d.py:362-414): RPN losses, proposals, RoI sampling and
+    the box head exactly as `forward_train` (fused, static shapes, no host sync); the weak cube losses of
+    ROIHeads3DScore then run on the COMPACTED foreground RoIs -- their number per image is the one value the host
+    waits for in this step."""
+    rpn, rh = model.proposal_generator, model.roi_heads
+    dev = features[rpn.in_features[0]].device
+    feats = [features[f] for f in rpn.in_features]
+    grid_sizes = [(f.shape[1], f.shape[2]) for f in feats]
+    anchors_lv = rpn.anchor_generator(grid_sizes, dev)
+    anchors = torch.cat([a.tensor for a in anchors_lv])
+    logits_lv, deltas_lv = head_outputs if head_outputs is not None else rpn.rpn_head(feats)
+    logits, deltas = torch.cat(logits_lv, 1), torch.cat(deltas_lv, 1)
+    with torch.no_grad():
+        labels, midx, _ = rpn_label_and_sample(rpn, anchors, gt)
+    losses = rpn_losses(rpn, anchors, logits, deltas, labels, midx, gt)
+    pboxes, pscores = rpn_proposals_padded(rpn, anchors, logits_lv, deltas, image_sizes)
+    samp = roi_label_and_sample(rh, pboxes, pscores, gt)
+    box_pooled, cube_pooled = pool_roi_features(rh, features, samp)
+    lb, _ = box_head_losses(rh, features, samp, gt, pooled=box_pooled)
+    losses.update(lb)
+    if rh.loss_w_3d <= 0:
+        return losses
+    B, kf = samp["valid"].shape[0], samp["k_fg"]
+    cls = samp["classes"][:, :kf]
+    fg = samp["valid"][:, :kf] & (cls >= 0) & (cls < rh.num_classes)
+    counts = fg.sum(1).tolist()                                   # host sync
+    if sum(counts) == 0:
+        return losses
+    sel = torch.nonzero(fg.reshape(-1)).squeeze(1)                # image-major order
+    img = torch.div(sel, kf, rounding_mode="floor")
+    pick = lambda t: t[:, :kf].reshape(B * kf, *t.shape[2:])[sel]
+    gidx = pick(samp["gt_idx"])
+    lc, _, _ = rh.weak_losses_flat(cube_pooled.flatten(1)[sel], pick(samp["classes"]), pick(samp["boxes"]), gt.boxes[img, gidx],
+                                   gt.boxes3D[img, gidx], gt.poses[img, gidx], counts, Ks, image_sizes, im_scales_ratio,
+                                   ground_maps, depth_maps)
+    losses.update(lc)
+    return losses

@@ -122,11 +122,7 @@ class RCNN3D(nn.Module):
         else:
             gt_instances = None
         if self.dense_train and gt_instances is not None:
-            from ..dense_train import forward_train, GTBatch, camera_meta
-            dev = self.device
-            im_dims = [tuple(s) for s in images.image_sizes]
-            return forward_train(self, im_dims, features, head_outputs, GTBatch(gt_instances, dev),
-                                 camera_meta(self.roi_heads, Ks, im_scales_ratio, im_dims, dev))
+            return self._forward_dense(images, features, head_outputs, gt_instances, Ks, im_scales_ratio, batched_inputs)
         proposals, proposal_losses = self.proposal_generator(images, features, gt_instances, head_outputs=head_outputs)
         instances, detector_losses = self._run_roi_heads(images, features, proposals, Ks, im_scales_ratio, gt_instances,
                                                          batched_inputs)
@@ -137,6 +133,14 @@ class RCNN3D(nn.Module):
 
     def _run_roi_heads(self, images, features, proposals, Ks, im_scales_ratio, targets, batched_inputs):
         return self.roi_heads(images, features, proposals, Ks, im_scales_ratio, targets)
+
+    def _forward_dense(self, images, features, head_outputs, gt_instances, Ks, im_scales_ratio, batched_inputs):
+        """static-shape, sync-free training forward (modeling/dense_train.py)"""
+        from ..dense_train import forward_train, GTBatch, camera_meta
+        dev = self.device
+        im_dims = [tuple(s) for s in images.image_sizes]
+        return forward_train(self, im_dims, features, head_outputs, GTBatch(gt_instances, dev),
+                             camera_meta(self.roi_heads, Ks, im_scales_ratio, im_dims, dev))
 
     def inference(self, batched_inputs, detected_instances=None, do_postprocess: bool = True):
         assert not self.training
@@ -204,18 +208,29 @@ class RCNN3D_combined_features(RCNN3D):
             raise NotImplementedError("MODEL.DEPTH_ON needs the Depth-Anything feature extractor, which is not built")
         self.depth_model = None
         self.only_2d = cfg.MODEL.ROI_CUBE_HEAD.LOSS_W_3D == 0.0
-        self.dense_train = False          # the fused static-shape path implements ROIHeads3D's supervised losses only
+        # dense_train = True: RPN, sampling and the box head run on the fused static-shape path, the weak cube losses on the
+        # compacted foreground RoIs; False: the instance-list path written like the reference (both are tested)
 
     def _maps(self, batched_inputs, key):
         return ImageList.from_tensors([b[key].to(self.device) for b in batched_inputs])
 
+    def _scene_maps(self, batched_inputs):
+        if self.only_2d:
+            return None, None
+        depth_maps = self._maps(batched_inputs, "depth_map")
+        filled = [dict(b, ground_map=torch.tensor([[1]])) if b.get("ground_map") is None else b for b in batched_inputs]
+        return self._maps(filled, "ground_map"), depth_maps
+
     def _run_roi_heads(self, images, features, proposals, Ks, im_scales_ratio, targets, batched_inputs):
-        ground_maps = depth_maps = None
-        if self.training and not self.only_2d:
-            depth_maps = self._maps(batched_inputs, "depth_map")
-            filled = [dict(b, ground_map=torch.tensor([[1]])) if b.get("ground_map") is None else b for b in batched_inputs]
-            ground_maps = self._maps(filled, "ground_map")
+        ground_maps, depth_maps = self._scene_maps(batched_inputs) if self.training else (None, None)
         return self.roi_heads(images, None, ground_maps, depth_maps, features, proposals, Ks, im_scales_ratio, targets)
+
+    def _forward_dense(self, images, features, head_outputs, gt_instances, Ks, im_scales_ratio, batched_inputs):
+        from ..dense_train import forward_train_weak, GTBatch
+        ground_maps, depth_maps = self._scene_maps(batched_inputs)
+        im_dims = [tuple(s) for s in images.image_sizes]
+        return forward_train_weak(self, im_dims, features, head_outputs, GTBatch(gt_instances, self.device), Ks,
+                                  im_scales_ratio, ground_maps, depth_maps)
 
 
 @META_ARCH_REGISTRY.register()

@@ -85,17 +85,58 @@ class ROIHeads3DScore(ROIHeads3D):
         if n == 0:
             return instances, {}
         cube_features = self.cube_pooler(feats, proposal_boxes_scaled).flatten(1)
-        device = cube_features.device
         num_boxes_per_image = [len(i) for i in proposals]
+        losses, cube_3D, cube_pose = self.weak_losses_flat(
+            cube_features, box_classes, torch.cat([b.tensor for b in proposal_boxes], dim=0),
+            torch.cat([x.gt_boxes.tensor for x in proposals]), gt_boxes3D, gt_poses, num_boxes_per_image, Ks,
+            im_current_dims, im_scales_ratio, ground_maps, depth_maps)
 
-        Ks_dev = [torch.as_tensor(K, dtype=torch.float32) for K in Ks]
-        rep = lambda vals: torch.cat([v.unsqueeze(0).repeat([num] + [1] * v.dim())
-                                      for v, num in zip(vals, num_boxes_per_image)]).to(device)
-        Ks_scaled_per_box = rep([Ks_dev[i] / im_scales_ratio[i] for i in range(len(Ks_dev))])
-        Ks_scaled_per_box[:, -1, -1] = 1
-        focal_lengths_per_box = rep([K[1, 1] for K in Ks_dev])
-        im_ratios_per_box = rep([torch.tensor(float(r)) for r in im_scales_ratio])
-        im_scales_per_box = rep([torch.tensor(float(d[0])) for d in im_current_dims])
+        # ---- packing of the decoded cuboids (roi_heads.py:1763-1815)
+        pred_instances = [Instances(image_size) for image_size in im_current_dims]
+        for cube_3D_i, cube_pose_i, inst, cls_i, boxes_i in zip(cube_3D.split(num_boxes_per_image),
+                                                                cube_pose.split(num_boxes_per_image), pred_instances,
+                                                                box_classes.split(num_boxes_per_image), pred_boxes):
+            inst.scores = cube_3D_i[:, -1]
+            inst.pred_classes = cls_i
+            inst.pred_boxes = boxes_i
+            inst.pred_bbox3D = util.get_cuboid_verts_faces(cube_3D_i[:, :6], cube_pose_i)[0]
+            inst.pred_center_cam = cube_3D_i[:, :3]
+            inst.pred_center_2D = cube_3D_i[:, 6:8]
+            inst.pred_dimensions = cube_3D_i[:, 3:6]
+            inst.pred_pose = cube_pose_i
+        return pred_instances, losses
+
+    def weak_losses_flat(self, cube_features, box_classes, src_boxes, gt_boxes, gt_boxes3D, gt_poses, num_boxes_per_image,
+                         Ks, im_current_dims, im_scales_ratio, ground_maps, depth_maps):
+        """decode + the weak losses on a flat, image-major list of n foreground RoIs (roi_heads.py:1366-1760).
+        cube_features (n, C*7*7); box_classes (n); src_boxes / gt_boxes (n,4); gt_boxes3D (n,9); gt_poses (n,3,3);
+        num_boxes_per_image: host ints.  Returns (losses, cube_3D (n,9), cube_pose (n,3,3))."""
+        losses = {}
+        n = cube_features.shape[0]
+        device = cube_features.device
+
+        # every per-image constant the branch needs goes to the device in ONE small copy and is gathered per box:
+        # K / ratio (9), fy of the original K, ratio, image height, clamp bounds of the projection (4), ground confidence
+        B = len(num_boxes_per_image)
+        rows = []
+        for i in range(B):
+            k = torch.as_tensor(Ks[i], dtype=torch.float32) / im_scales_ratio[i]
+            k[-1, -1] = 1
+            d = im_current_dims[i]
+            gconf = 1.0
+            if ground_maps is not None and tuple(ground_maps.image_sizes[i]) == (1, 1):
+                gconf = 0.1
+            rows.append(k.flatten().tolist() + [float(torch.as_tensor(Ks[i])[1][1]), float(im_scales_ratio[i]), float(d[0])]
+                        + [float(v) for v in W._int_clamp_bounds(d[0]) + W._int_clamp_bounds(d[1])] + [gconf])
+        table = torch.tensor(rows, dtype=torch.float32)
+        img_host = torch.tensor([i for i, num in enumerate(num_boxes_per_image) for _ in range(num)], dtype=torch.int64)
+        if device.type == "cuda":
+            table, img_host = table.pin_memory(), img_host.pin_memory()
+        table, img = table.to(device, non_blocking=True), img_host.to(device, non_blocking=True)
+        per_box = table[img]
+        Ks_scaled_per_box = per_box[:, :9].reshape(n, 3, 3)
+        focal_lengths_per_box, im_ratios_per_box, im_scales_per_box = per_box[:, 9], per_box[:, 10], per_box[:, 11]
+        clamp_bounds = per_box[:, 12:16]
         im_scales_original_per_box = im_scales_per_box * im_ratios_per_box
         if self.virtual_depth:
             virtual_to_real = util.compute_virtual_scale_from_focal_spaces(
@@ -103,12 +144,10 @@ class ROIHeads3DScore(ROIHeads3D):
         else:
             virtual_to_real = 1.0
 
-        src_boxes = torch.cat([b.tensor for b in proposal_boxes], dim=0)
         src_widths = src_boxes[:, 2] - src_boxes[:, 0]
         src_heights = src_boxes[:, 3] - src_boxes[:, 1]
         src_ctr_x = src_boxes[:, 0] + 0.5 * src_widths
         src_ctr_y = src_boxes[:, 1] + 0.5 * src_heights
-        clamp_dims = [list(im_current_dims[i]) for i, num in enumerate(num_boxes_per_image) for _ in range(num)]
 
         cube_2d_deltas, cube_z, cube_dims, cube_pose, cube_uncert = self.cube_head(cube_features)
         fg_inds = torch.arange(n, device=device)
@@ -150,9 +189,7 @@ class ROIHeads3DScore(ROIHeads3D):
         cube_y3d = cube_z * (cube_y - K[:, 1, 2]) / K[:, 1, 1]
         cubes = torch.cat((cube_x3d.unsqueeze(1), cube_y3d.unsqueeze(1), cube_z.unsqueeze(1), cube_dims,
                            cube_pose.reshape(n, 9)), dim=1)
-        proj_boxes = W.corners_to_boxes(W.project_cubes_to_corners(cubes.unsqueeze(1), K, clamp_dims))[:, 0]
-        gt_boxes = torch.cat([x.gt_boxes.tensor for x in proposals])
-
+        proj_boxes = W.corners_to_boxes(W.project_cubes_to_corners(cubes.unsqueeze(1), K, clamp_bounds))[:, 0]
         loss_iou = loss_pose = loss_z = loss_dims_w = loss_dims_h = loss_dims_l = None
         loss_pseudo_gt_z = loss_ground_rot = None
         if 'iou' in self.loss_functions:
@@ -162,12 +199,10 @@ class ROIHeads3DScore(ROIHeads3D):
         if loss_pose is not None:
             loss_pose = loss_pose.repeat(n)
         if 'pose_ground' in self.loss_functions or 'pose_ground2' in self.loss_functions:
-            conf = torch.tensor([0.1 if tuple(s) == (1, 1) else 1.0 for s in ground_maps.image_sizes], device=device)
-            per_image = torch.tensor(num_boxes_per_image, device=device)
             normals = W.ground_normals(ground_maps, depth_maps, K, id_samples=self._ransac_triples,
                                        plane_cls=self._plane_cls)
-            normals = normals.repeat_interleave(per_image, 0)
-            valid_ground_maps_conf = conf.repeat_interleave(per_image, 0)
+            normals = normals[img]
+            valid_ground_maps_conf = per_box[:, 16]
             if 'pose_ground' in self.loss_functions:
                 loss_ground_rot = 1 - torch.nn.functional.cosine_similarity(normals, cube_pose[:, 1, :], dim=1).abs()
                 loss_ground_rot = loss_ground_rot * valid_ground_maps_conf
@@ -175,12 +210,12 @@ class ROIHeads3DScore(ROIHeads3D):
                 loss_ground_rot = 1 - W.so3_relative_angle(cube_pose, W.normal_to_rotation(normals), cos_angle=True)
                 loss_ground_rot = loss_ground_rot * valid_ground_maps_conf
         if 'z_pseudo_gt_patch' in self.loss_functions:
-            target = W.pseudo_gt_z_box(depth_maps, proj_boxes, num_boxes_per_image, median_fn=self._median_fn)
+            target = W.pseudo_gt_z_box(depth_maps, proj_boxes, img, median_fn=self._median_fn)
             loss_pseudo_gt_z = self.l1_loss(cube_z, target)
         elif 'z_pseudo_gt_center' in self.loss_functions:
-            loss_pseudo_gt_z = self.l1_loss(cube_z, W.pseudo_gt_z_point(depth_maps, cube_xy, num_boxes_per_image))
+            loss_pseudo_gt_z = self.l1_loss(cube_z, W.pseudo_gt_z_point(depth_maps, cube_xy, img))
         if 'z' in self.loss_functions:
-            loss_z = W.z_search_loss(gt_boxes, cubes, K, clamp_dims, proj_boxes)
+            loss_z = W.z_search_loss(gt_boxes, cubes, K, clamp_bounds, proj_boxes)
         if 'dims' in self.loss_functions:
             loss_dims_w, loss_dims_h, loss_dims_l = W.dim_hinge_loss(prior_dims_mean, prior_dims_std, cube_dims)
 
@@ -220,21 +255,8 @@ class ROIHeads3DScore(ROIHeads3D):
             if l is not None:
                 losses[prefix + k] = self.safely_reduce_losses(l) * w * self.loss_w_3d
 
-        # ---- packing of the decoded cuboids (roi_heads.py:1763-1815)
         cube_3D = torch.cat((torch.stack((cube_x3d, cube_y3d, cube_z)).T, cube_dims,
                              cube_xy * im_ratios_per_box.unsqueeze(1)), dim=1)
         if self.use_confidence:
             cube_3D = torch.cat((cube_3D, torch.exp(-cube_uncert).unsqueeze(1)), dim=1)
-        pred_instances = [Instances(image_size) for image_size in im_current_dims]
-        for cube_3D_i, cube_pose_i, inst, cls_i, boxes_i in zip(cube_3D.split(num_boxes_per_image),
-                                                                cube_pose.split(num_boxes_per_image), pred_instances,
-                                                                box_classes.split(num_boxes_per_image), pred_boxes):
-            inst.scores = cube_3D_i[:, -1]
-            inst.pred_classes = cls_i
-            inst.pred_boxes = boxes_i
-            inst.pred_bbox3D = util.get_cuboid_verts_faces(cube_3D_i[:, :6], cube_pose_i)[0]
-            inst.pred_center_cam = cube_3D_i[:, :3]
-            inst.pred_center_2D = cube_3D_i[:, 6:8]
-            inst.pred_dimensions = cube_3D_i[:, 3:6]
-            inst.pred_pose = cube_pose_i
-        return pred_instances, losses
+        return losses, cube_3D, cube_pose

@@ -60,18 +60,26 @@ def _int_clamp_bounds(c):
     return int(-c / 2 + 1), int(c - 1 + c)
 
 
-def project_cubes_to_corners(cubes, K, clamp_dims):
-    """cubes (n,P,15), K (n,3,3), clamp_dims: list of n (c0, c1) -> clamped projected corners (n,P,8,2).
-    x is clamped with c0, y with c1 (the reference passes (H, W) of the image here: roi_heads.py:1419-1423,1551)."""
+def clamp_bounds_of(clamp_dims, device):
+    """(n,4) [x_lo, x_hi, y_lo, y_hi] for a list of n (c0, c1): x is clamped with c0, y with c1 (the reference passes
+    (H, W) of the image here: roi_heads.py:1419-1423,1551)."""
+    return torch.tensor([_int_clamp_bounds(c[0]) + _int_clamp_bounds(c[1]) for c in clamp_dims], dtype=torch.float32,
+                        device=device)
+
+
+def project_cubes_to_corners(cubes, K, bounds):
+    """cubes (n,P,15), K (n,3,3), bounds (n,4) from clamp_bounds_of (or the list of (c0, c1) itself)
+    -> clamped projected corners (n,P,8,2)."""
     n, P = cubes.shape[:2]
+    if not isinstance(bounds, torch.Tensor):
+        bounds = clamp_bounds_of(bounds, cubes.device)
     verts = util.get_cuboid_verts_faces(cubes[..., :6].reshape(-1, 6), cubes[..., 6:].reshape(-1, 3, 3))[0]
     Kr = K[:, None].expand(n, P, 3, 3).reshape(-1, 3, 3)
     pc = torch.matmul(Kr, verts.transpose(2, 1))
     pc = (pc[:, :2, :] / pc[:, 2, :].unsqueeze(-2)).transpose(2, 1).reshape(n, P, 8, 2)
-    bx = torch.tensor([_int_clamp_bounds(c[0]) for c in clamp_dims], dtype=pc.dtype, device=pc.device).view(n, 1, 1, 2)
-    by = torch.tensor([_int_clamp_bounds(c[1]) for c in clamp_dims], dtype=pc.dtype, device=pc.device).view(n, 1, 1, 2)
-    x = torch.clamp(pc[..., 0], bx[..., 0], bx[..., 1])
-    y = torch.clamp(pc[..., 1], by[..., 0], by[..., 1])
+    b = bounds.to(pc.dtype).view(n, 1, 1, 4)
+    x = torch.clamp(pc[..., 0], b[..., 0], b[..., 1])
+    y = torch.clamp(pc[..., 1], b[..., 2], b[..., 3])
     return torch.stack((x, y), dim=-1)
 
 
@@ -122,12 +130,10 @@ def ground_normals(ground_maps, depth_maps, Ks, use_nth=5, id_samples=None, gene
         u, v = torch.meshgrid(torch.arange(width, device=dev), torch.arange(height, device=dev), indexing='xy')
         x = (u - width / 2) * z / fx
         y = (v - height / 2) * z / fy
-        if gsize != (1, 1):
-            sel = ground_maps[i][::use_nth, ::use_nth] > 0
-        else:
-            sel = torch.ones(tuple(depth_maps.image_sizes[i]), device=dev)[::use_nth, ::use_nth] > 0
-        pts = torch.stack((x[sel], y[sel], z[sel]), dim=-1)
-        best_eq, _ = plane_cls().fit_parallel(pts, thresh=0.05, maxIteration=1000,
+        pts = torch.stack((x, y, z), dim=-1).reshape(-1, 3)
+        if gsize != (1, 1):           # only the ground-mask points (their number is data dependent: one host sync)
+            pts = pts[torch.nonzero((ground_maps[i][::use_nth, ::use_nth] > 0).reshape(-1)).squeeze(1)]
+        best_eq, _ = plane_cls().fit_parallel(pts, thresh=0.05, maxIteration=1000, need_inliers=False,
                                               **({"id_samples": id_samples[i]} if id_samples is not None else {}),
                                               **({"generator": generator} if generator is not None else {}))
         nv = best_eq[:-1]
@@ -153,7 +159,7 @@ def normal_to_rotation(normal):
     return torch.cat([t0, t1, normal], dim=1).reshape((n, 3, 3))
 
 
-def z_search_loss(gt_boxes, cubes, K, clamp_dims, proj_boxes, max_count=50):
+def z_search_loss(gt_boxes, cubes, K, bounds, proj_boxes, max_count=50):
     """:1151-1194: move each cube along z in 50 steps of 0.1 m (away when its projection is larger than the 2D box,
     closer otherwise), take the step whose projected area is closest to the 2D box's, loss = |z - z_step| / 2
     (a constant w.r.t. the network: both terms carry z); RoIs failing the centre test get 0.1 * 50 / 2.
@@ -171,7 +177,7 @@ def z_search_loss(gt_boxes, cubes, K, clamp_dims, proj_boxes, max_count=50):
     mod_z = cubes[:, None, 2] + sign[:, None] * values[None, :]
     mod = torch.cat((mod[..., :2], mod_z[..., None], mod[..., 3:]), dim=-1)
     with torch.no_grad():
-        boxes = corners_to_boxes(project_cubes_to_corners(mod, K, clamp_dims))
+        boxes = corners_to_boxes(project_cubes_to_corners(mod, K, bounds))
         areas = (boxes[..., 2] - boxes[..., 0]) * (boxes[..., 3] - boxes[..., 1])
         areas = areas + (areas == 0) * 10000000
         idx = torch.argmin((gt_area[:, None] - areas).abs(), dim=1)
@@ -180,9 +186,11 @@ def z_search_loss(gt_boxes, cubes, K, clamp_dims, proj_boxes, max_count=50):
     return scores / 2
 
 
-def _image_index(num_boxes_per_image, device):
-    return torch.repeat_interleave(torch.arange(len(num_boxes_per_image), device=device),
-                                   torch.tensor(num_boxes_per_image, device=device))
+def _image_index(per_image, device):
+    """per-box image index: given as such (int64 tensor) or as the host list of box counts per image"""
+    if isinstance(per_image, torch.Tensor):
+        return per_image
+    return torch.tensor([i for i, num in enumerate(per_image) for _ in range(num)], dtype=torch.int64, device=device)
 
 
 def pseudo_gt_z_point(depth_maps, xy, num_boxes_per_image):

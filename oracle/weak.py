@@ -26,7 +26,8 @@ class Plane:
     def __init__(self):
         self.inliers, self.equation = [], []
 
-    def fit_parallel(self, pts, thresh=0.05, minPoints=100, maxIteration=1000, id_samples=None, generator=None):
+    def fit_parallel(self, pts, thresh=0.05, minPoints=100, maxIteration=1000, id_samples=None, generator=None,
+                     need_inliers=True):
         n = pts.shape[0]
         if id_samples is None:
             id_samples = [random.sample(range(0, n), 3) for _ in range(maxIteration)]

@@ -63,7 +63,8 @@ def test_forward_cube_matches_reference_hip(name):
     check_case(name, torch.device("cuda:0"), (None, None))
 
 
-def test_weak_model_trains_from_the_data_path(tmp_path, monkeypatch):
+@pytest.mark.parametrize("dense", [True, False])
+def test_weak_model_trains_from_the_data_path(tmp_path, monkeypatch, dense):
     """configs/Omni_combined.yaml (RCNN3D_combined_features + ROIHeads3DScore) fed by the Omni3D loader with depth and
     ground maps: a few SGD steps with finite losses of every configured kind, then inference through the same model."""
     import os
@@ -102,6 +103,7 @@ def test_weak_model_trains_from_the_data_path(tmp_path, monkeypatch):
     torch.manual_seed(0)
     model = modeling.build_model(cfg, priors=util.compute_priors(cfg, omni)).train()
     assert type(model).__name__ == "RCNN3D_combined_features" and type(model.roi_heads).__name__ == "ROIHeads3DScore"
+    model.dense_train = dense          # fused static-shape RPN / sampling / box head, or the instance-list path
     opt = solver.build_optimizer(cfg, model)
     step = solver.TrainStep(cfg, model, opt, world_size=1)
     feed = data.DevicePrefetcher(data.build_detection_train_loader(cfg, mapper=mapper, dataset_id_to_src=id_to_src,
