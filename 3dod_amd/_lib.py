@@ -22,6 +22,11 @@ SIGNATURES = {
     "cr_propose": [P, P, c_int64, P, c_int, c_int, P, P, P, c_int64, P, c_int, P, P, P, P, P],
     "cr_ransac_plane": [P, P, c_int64, P, c_int64, c_float, P, P, P],
     "cr_box_median": [P, P, c_int, c_int, c_int, P, P, c_int, P],
+    "cr_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float],
+    "cr_layernorm": [P, P, P, P, P, c_int64, c_int, c_float],
+    "cr_gelu_inplace": [P, P, c_int64],
+    "cr_scale_residual": [P, P, P, P, P, c_int64, c_int],
+    "cr_resize_bilinear_ac": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int],
     "cr_conv2d_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int],
     "cr_conv2d_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "cr_conv2d_bwd_weight": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],

@@ -949,3 +949,53 @@ def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None
     lib = _lib.load()
     _chk(lib.cr_sgd_step(_ctx(p), _p(p), _p(g), _p(m), p.numel(), float(lr), float(momentum), float(weight_decay),
                          float(grad_scale), _p(skip_flag)), "cr_sgd_step")
+
+
+# --------------------------------------------------------------------------
+# Depth-Anything-V2 forward ops (inference only: no autograd)
+# --------------------------------------------------------------------------
+def attention(qkv, B, N, H, D, scale):
+    """qkv (B*N, 3*H*D) bf16 = output of the qkv linear -> (B*N, H*D) bf16 (cr_attention_fwd)."""
+    _need_cuda(qkv, "attention input")
+    assert qkv.dtype == bf16 and qkv.is_contiguous() and qkv.shape == (B * N, 3 * H * D)
+    out = torch.empty((B * N, H * D), dtype=bf16, device=qkv.device)
+    _chk(_lib.load().cr_attention_fwd(_ctx(qkv), _p(qkv), _p(out), B, N, H, D, float(scale)), "cr_attention_fwd")
+    return out
+
+
+def layernorm(x, gamma, beta, eps):
+    _need_cuda(x, "layernorm input")
+    assert x.dtype == bf16 and x.is_contiguous() and x.dim() == 2
+    y = torch.empty_like(x)
+    _chk(_lib.load().cr_layernorm(_ctx(x), _p(x), _p(gamma.detach().float().contiguous()),
+                                  _p(beta.detach().float().contiguous()), _p(y), x.shape[0], x.shape[1], float(eps)),
+         "cr_layernorm")
+    return y
+
+
+def gelu_(x):
+    _need_cuda(x, "gelu input")
+    assert x.dtype == bf16 and x.is_contiguous()
+    _chk(_lib.load().cr_gelu_inplace(_ctx(x), _p(x), x.numel()), "cr_gelu_inplace")
+    return x
+
+
+def scale_residual(x, y, gamma=None):
+    """x + gamma * y on (M,C) bf16"""
+    _need_cuda(x, "residual input")
+    assert x.dtype == bf16 and y.dtype == bf16 and x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
+    out = torch.empty_like(x)
+    g = gamma.detach().float().contiguous() if gamma is not None else None
+    _chk(_lib.load().cr_scale_residual(_ctx(x), _p(x), _p(y), _p(g), _p(out), x.shape[0], x.shape[1]), "cr_scale_residual")
+    return out
+
+
+def resize_bilinear_ac(x, size):
+    """F.interpolate(..., mode='bilinear', align_corners=True) on NHWC bf16"""
+    _need_cuda(x, "resize input")
+    assert x.dtype == bf16 and x.is_contiguous() and x.dim() == 4
+    B, h, w, C = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    y = torch.empty((B, Ho, Wo, C), dtype=bf16, device=x.device)
+    _chk(_lib.load().cr_resize_bilinear_ac(_ctx(x), _p(x), _p(y), B, h, w, Ho, Wo, C), "cr_resize_bilinear_ac")
+    return y

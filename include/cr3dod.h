@@ -106,6 +106,22 @@ int cr_ransac_plane(cr_ctx* ctx, const float* pts, int64_t Q, const int32_t* tri
 int cr_box_median(cr_ctx* ctx, const float* depth, int B, int H, int W, const int32_t* boxes, const int32_t* img, int n,
                   float* out);
 
+/* ---- Depth-Anything-V2 forward (DINOv2 ViT + DPT head), the ops that are not GEMMs / convolutions --------------- */
+/* softmax(q k^T * scale) v per (batch, head) on the packed output of the qkv linear: qkv (B,N,3,H,D) bf16, out (B,N,H,D)
+ * bf16, D = 64.  Flash-attention schedule on MFMA (no N x N matrix in memory).  Replaces Attention.forward /
+ * MemEffAttention.forward, depth/metric_depth/depth_anything_v2/dinov2_layers/attention.py:49-82 (xformers
+ * memory_efficient_attention [third-party] when available). */
+int cr_attention_fwd(cr_ctx* ctx, const void* qkv, void* out, int B, int N, int H, int D, float scale);
+/* nn.LayerNorm over the last dimension, x / y (M,C) bf16, gamma / beta (C) f32 (dinov2.py:96, block.py:56,68). */
+int cr_layernorm(cr_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, int64_t M, int C, float eps);
+/* exact (erf) GELU in place on n bf16 values (dinov2_layers/mlp.py:36). */
+int cr_gelu_inplace(cr_ctx* ctx, void* x, int64_t n);
+/* out = x + gamma * y, (M,C) bf16, gamma (C) f32 or NULL for 1 (LayerScale + residual, block.py:84-110). */
+int cr_scale_residual(cr_ctx* ctx, const void* x, const void* y, const float* gamma, void* out, int64_t M, int C);
+/* F.interpolate(mode="bilinear", align_corners=True) on NHWC bf16: x (B,h,w,C) -> y (B,Ho,Wo,C)
+ * (util/blocks.py:139, dpt.py:150). */
+int cr_resize_bilinear_ac(cr_ctx* ctx, const void* x, void* y, int B, int h, int w, int Ho, int Wo, int C);
+
 /* ---- convolution stack (bf16 MFMA, f32 accumulate, NHWC) ---------------- */
 /* Activations are NHWC bf16 (channels padded to a multiple of 8).  Conv weights
  * are [Cout][ks*ks][Cin] = the physical (channels_last) layout of a
