@@ -189,3 +189,30 @@ def make_omni3d_dataset(root, name="Synth_train", n_images=6, seed=0, sizes=((48
     with open(stats_path, "w") as fjson:
         json.dump(stats, fjson)
     return path
+
+
+def seeded_state_dict(model, seed):
+    """deterministic weights for ANY module from its state-dict keys and shapes alone (sorted keys, one generator): the
+    same call on the reference's module and on this repo's module of the same architecture gives both the same weights
+    without shipping a checkpoint.  Scales keep activations O(1) through deep stacks."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sorted(model.state_dict().items()):
+        if not v.dtype.is_floating_point:
+            out[k] = v.clone()
+            continue
+        r = torch.randn(v.shape, generator=g)
+        name = k.rsplit(".", 1)[-1]
+        if v.dim() >= 2 and name == "weight":
+            fan_in = v[0].numel()
+            t = r / math.sqrt(fan_in)
+        elif "norm" in k and name == "weight":
+            t = 1.0 + 0.1 * r
+        elif name == "gamma":
+            t = 1.0 + 0.1 * r
+        elif name == "bias":
+            t = 0.05 * r
+        else:                                   # position table, class / mask tokens
+            t = 0.02 * r
+        out[k] = t.to(v.dtype)
+    return out
