@@ -25,6 +25,7 @@ SIGNATURES = {
     "cr_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float],
     "cr_layernorm": [P, P, P, P, P, c_int64, c_int, c_float],
     "cr_gelu_inplace": [P, P, c_int64],
+    "cr_scale_residual_layernorm": [P, P, P, P, P, P, P, P, c_int64, c_int, c_float],
     "cr_scale_residual": [P, P, P, P, P, c_int64, c_int],
     "cr_resize_bilinear_ac": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int],
     "cr_conv2d_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int],

@@ -18,7 +18,7 @@ __device__ __forceinline__ u16 vf2bf(float f) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Attention forward, head_dim 64 (dinov2_layers/attention.py:49-62: softmax(q k^T / sqrt(d)) v on the packed qkv linear
 // output).  Flash-attention schedule on 16x16x32 bf16 MFMA, written for the wave64 operand layout:
-//   * one workgroup = 64 queries of one (batch, head), one wave = 16 queries; keys / values stream through LDS in tiles
+//   * one workgroup = 128 queries of one (batch, head), one wave = 16 queries; keys / values stream through LDS in tiles
 //     of 64 (K row-major [key][d], V transposed [d][key]);
 //   * S^T = K Q^T: the MFMA result holds, per lane, 16 scores of ONE query (column lane & 15) -> the row maximum and the
 //     row sum need the lane's own values plus two xor-shuffles (lanes l, l^16, l^32, l^48 share a query);
@@ -32,14 +32,23 @@ __device__ __forceinline__ u16 vf2bf(float f) {
 #define ATT_TK 64
 #define ATT_KPAD 8              // LDS row padding (elements): 144-byte rows, conflict-free 16-byte reads
 
-__global__ __launch_bounds__(256) void k_attention_fwd(const u16* __restrict__ qkv, u16* __restrict__ out, int B, int N,
-                                                       int H, float scale) {
+#define ATT_WAVES 8              // 8 waves x 16 queries share one K/V tile: 128 queries per workgroup
+#define ATT_T (64 * ATT_WAVES)
+#define ATT_TQ (16 * ATT_WAVES)
+
+__global__ __launch_bounds__(ATT_T) void k_attention_fwd(const u16* __restrict__ qkv, u16* __restrict__ out, int B, int N,
+                                                         int H, float scale, int qtiles) {
     __shared__ __attribute__((aligned(16))) u16 sK[ATT_TK][ATT_D + ATT_KPAD];      // [key][d]
     __shared__ __attribute__((aligned(16))) u16 sVt[ATT_D][ATT_TK + ATT_KPAD];     // [d][key]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
-    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    // workgroups are dispatched round-robin over the 8 XCDs (each with its own L2): renumber them so that the query
+    // tiles of one (batch, head) -- which stream the same K / V -- are neighbours on ONE XCD instead of one per XCD
+    const int nblk = gridDim.x, per = nblk >> 3, body = per << 3;
+    const int lb = (int)blockIdx.x < body ? ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bh = lb / qtiles, qt = lb - bh * qtiles;
+    const int b = bh / H, h = bh - b * H;
+    const int q0 = qt * ATT_TQ + wave * 16;
     const size_t row_stride = (size_t)3 * H * ATT_D;
     const u16* base = qkv + (size_t)b * N * row_stride + (size_t)h * ATT_D;
     const u16* Kb = base + (size_t)H * ATT_D;
@@ -62,41 +71,71 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const u16* __restrict__ q
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (N + ATT_TK - 1) / ATT_TK;
+    // staging: 64 keys x 64 d = 512 chunks of 8 elements over the workgroup; the global loads of tile t+1 are issued before
+    // the MFMAs of tile t (registers), so their latency overlaps the compute instead of sitting between two barriers
+    constexpr int NCH = 512 / ATT_T;     // 16-byte chunks of K (and of V) per thread and tile
+    uint4 rk[NCH], rv[NCH];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + ATT_T * i;
+            const int key = t * ATT_TK + (idx >> 3), d8 = (idx & 7) * 8;
+            rk[i] = make_uint4(0, 0, 0, 0);
+            rv[i] = make_uint4(0, 0, 0, 0);
+            if (key < N) {
+                rk[i] = *reinterpret_cast<const uint4*>(Kb + (size_t)key * row_stride + d8);
+                rv[i] = *reinterpret_cast<const uint4*>(Vb + (size_t)key * row_stride + d8);
+            }
+        }
+    };
+    load_tile(0);
     for (int t = 0; t < ntiles; ++t) {
         const int k0 = t * ATT_TK;
         __syncthreads();                               // previous tile fully consumed
-        // stage K (row-major) and V (transposed): 64 keys x 64 d = 512 chunks of 8 elements, 2 per thread
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + ATT_T * i;
             const int key = idx >> 3, d8 = (idx & 7) * 8;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (k0 + key < N) {
-                kv = *reinterpret_cast<const uint4*>(Kb + (size_t)(k0 + key) * row_stride + d8);
-                vv = *reinterpret_cast<const uint4*>(Vb + (size_t)(k0 + key) * row_stride + d8);
-            }
-            *reinterpret_cast<uint4*>(&sK[key][d8]) = kv;
-            const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+            *reinterpret_cast<uint4*>(&sK[key][d8]) = rk[i];
+            const unsigned w[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+            // column swizzle key ^ 8*(d/8 % 8): the 8 lanes that hold the same key write rows 8 apart, which would all
+            // fall on one LDS bank (row stride 36 dwords); the reads below apply the same XOR (it keeps aligned groups
+            // of 4 keys together)
+            const int kx = key ^ (((d8 >> 3) & 7) << 3);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sVt[d8 + 2 * e][key] = (u16)(w[e] & 0xffff);
-                sVt[d8 + 2 * e + 1][key] = (u16)(w[e] >> 16);
+                sVt[d8 + 2 * e][kx] = (u16)(w[e] & 0xffff);
+                sVt[d8 + 2 * e + 1][kx] = (u16)(w[e] >> 16);
             }
         }
         __syncthreads();
+        if (t + 1 < ntiles) load_tile(t + 1);
 
-        // S^T blocks: rows = keys 16*kb + 4g + e, column = query c
+        // S^T blocks: rows = keys 16*kb + 4g + e, column = query c.  All K fragments are fetched from LDS first and the 8
+        // MFMAs issued back to back over 4 independent accumulators (a read -> wait -> MFMA chain per fragment exposes
+        // the LDS latency 8 times per tile)
+        bf16x8 kf[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+                kf[s][kb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sK[16 * kb + c][32 * s + 8 * g]));
         f32x4 s4[4];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < 4; ++kb) s4[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][kb], qf[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sK[16 * kb + c][32 * s + 8 * g]));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], acc, 0, 0, 0);
+        for (int kb = 0; kb < 4; ++kb) s4[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1][kb], qf[1], s4[kb], 0, 0, 0);
+        // V^T fragments for the second product: issued now, consumed after the softmax arithmetic
+        bf16x8 vf[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const int sw = ((2 * db + (c >> 3)) & 7) << 3;
+                const uint2 v0 = *reinterpret_cast<const uint2*>(&sVt[16 * db + c][(32 * s + 4 * g) ^ sw]);
+                const uint2 v1 = *reinterpret_cast<const uint2*>(&sVt[16 * db + c][(32 * s + 16 + 4 * g) ^ sw]);
+                vf[s][db] = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
             }
-            s4[kb] = acc;
-        }
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
@@ -135,12 +174,7 @@ __global__ __launch_bounds__(256) void k_attention_fwd(const u16* __restrict__ q
         for (int s = 0; s < 2; ++s) {
             const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pk[2 * s][0], pk[2 * s][1], pk[2 * s + 1][0], pk[2 * s + 1][1]));
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const uint2 v0 = *reinterpret_cast<const uint2*>(&sVt[16 * db + c][32 * s + 4 * g]);
-                const uint2 v1 = *reinterpret_cast<const uint2*>(&sVt[16 * db + c][32 * s + 16 + 4 * g]);
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
-                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[db], 0, 0, 0);
-            }
+            for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[s][db], pf, o[db], 0, 0, 0);
         }
     }
     l_run += __shfl_xor(l_run, 16, 64);
@@ -164,9 +198,10 @@ extern "C" int cr_attention_fwd(cr_ctx* ctx, const void* qkv, void* out, int B, 
     CR_CHECK_ARG(D == ATT_D, "cr_attention_fwd: head dimension %d is not built (64 only)", D);
     if ((int64_t)B * N == 0) return CR_OK;
     CR_CHECK_ARG(qkv && out, "cr_attention_fwd: NULL pointer");
-    CR_CHECK_ARG((int64_t)B * H <= 65535, "cr_attention_fwd: B*H too large");
-    hipLaunchKernelGGL(k_attention_fwd, dim3((unsigned)cr_cdiv(N, 64), (unsigned)(B * H)), dim3(256), 0, ctx->stream,
-                       (const u16*)qkv, (u16*)out, B, N, H, scale);
+    const int qtiles = (int)cr_cdiv(N, ATT_TQ);
+    CR_CHECK_ARG((int64_t)B * H * qtiles < (1ll << 31), "cr_attention_fwd: grid too large");
+    hipLaunchKernelGGL(k_attention_fwd, dim3((unsigned)(B * H * qtiles)), dim3(ATT_T), 0, ctx->stream, (const u16*)qkv,
+                       (u16*)out, B, N, H, scale, qtiles);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -175,6 +210,7 @@ extern "C" int cr_attention_fwd(cr_ctx* ctx, const void* qkv, void* out, int B, 
 // LayerNorm over the last dimension (nn.LayerNorm(eps=1e-6), dinov2.py:96): one wave per row, float32 statistics
 // (mean, then the centred second moment), bf16 in / out.
 // ---------------------------------------------------------------------------------------------------------------------
+template <int NCH>      // 16-byte chunks per lane: C <= 512 * NCH
 __global__ __launch_bounds__(256) void k_layernorm(const u16* __restrict__ x, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, u16* __restrict__ y, int64_t M, int C,
                                                    float eps) {
@@ -182,43 +218,146 @@ __global__ __launch_bounds__(256) void k_layernorm(const u16* __restrict__ x, co
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const u16* xr = x + row * C;
+    float v[NCH][8];
     float s = 0.f;
-    for (int i = lane * 8; i < C; i += 512) {
-        const uint4 v = *reinterpret_cast<const uint4*>(xr + i);
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s += vbf2f((u16)(w[e] & 0xffff)) + vbf2f((u16)(w[e] >> 16));
+    for (int k = 0; k < NCH; ++k) {
+        const int i = lane * 8 + 512 * k;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (i < C) u = *reinterpret_cast<const uint4*>(xr + i);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[k][2 * e] = vbf2f((u16)(w[e] & 0xffff));
+            v[k][2 * e + 1] = vbf2f((u16)(w[e] >> 16));
+            s += v[k][2 * e] + v[k][2 * e + 1];
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     const float mean = s / (float)C;
     float q = 0.f;
-    for (int i = lane * 8; i < C; i += 512) {
-        const uint4 v = *reinterpret_cast<const uint4*>(xr + i);
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float a = vbf2f((u16)(w[e] & 0xffff)) - mean, b2 = vbf2f((u16)(w[e] >> 16)) - mean;
-            q += a * a + b2 * b2;
+    for (int k = 0; k < NCH; ++k) {
+        if (lane * 8 + 512 * k < C) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = v[k][e] - mean;
+                q += a * a;
+            }
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
     const float inv = rsqrtf(q / (float)C + eps);
     u16* yr = y + row * C;
-    for (int i = lane * 8; i < C; i += 512) {
-        const uint4 v = *reinterpret_cast<const uint4*>(xr + i);
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
-        unsigned o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int cidx = i + 2 * e;
-            const float a = (vbf2f((u16)(w[e] & 0xffff)) - mean) * inv * gamma[cidx] + beta[cidx];
-            const float b2 = (vbf2f((u16)(w[e] >> 16)) - mean) * inv * gamma[cidx + 1] + beta[cidx + 1];
-            o[e] = (unsigned)vf2bf(a) | ((unsigned)vf2bf(b2) << 16);
+    for (int k = 0; k < NCH; ++k) {
+        const int i = lane * 8 + 512 * k;
+        if (i < C) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + i), g1 = *reinterpret_cast<const float4*>(gamma + i + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(beta + i), b1 = *reinterpret_cast<const float4*>(beta + i + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            unsigned o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = (v[k][2 * e] - mean) * inv * gg[2 * e] + bb[2 * e];
+                const float b2 = (v[k][2 * e + 1] - mean) * inv * gg[2 * e + 1] + bb[2 * e + 1];
+                o[e] = (unsigned)vf2bf(a) | ((unsigned)vf2bf(b2) << 16);
+            }
+            *reinterpret_cast<uint4*>(yr + i) = make_uint4(o[0], o[1], o[2], o[3]);
         }
-        *reinterpret_cast<uint4*>(yr + i) = make_uint4(o[0], o[1], o[2], o[3]);
     }
+}
+
+// x_new = x + ls * y (LayerScale + residual) and h = LayerNorm(x_new) in one pass over the row: the statistics are taken
+// from the bf16-rounded x_new, i.e. exactly what k_scale_residual followed by k_layernorm produces.
+template <int NCH>
+__global__ __launch_bounds__(256) void k_scale_residual_layernorm(const u16* __restrict__ x, const u16* __restrict__ yv,
+                                                                  const float* __restrict__ ls, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, u16* __restrict__ xo,
+                                                                  u16* __restrict__ ho, int64_t M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const u16* xr = x + row * C;
+    const u16* yr = yv + row * C;
+    u16* xor_ = xo + row * C;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int i = lane * 8 + 512 * k;
+        if (i < C) {
+            const uint4 a = *reinterpret_cast<const uint4*>(xr + i), b = *reinterpret_cast<const uint4*>(yr + i);
+            const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+            unsigned o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float l0 = ls ? ls[i + 2 * e] : 1.f, l1 = ls ? ls[i + 2 * e + 1] : 1.f;
+                const u16 r0 = vf2bf(vbf2f((u16)(aw[e] & 0xffff)) + l0 * vbf2f((u16)(bw[e] & 0xffff)));
+                const u16 r1 = vf2bf(vbf2f((u16)(aw[e] >> 16)) + l1 * vbf2f((u16)(bw[e] >> 16)));
+                o[e] = (unsigned)r0 | ((unsigned)r1 << 16);
+                v[k][2 * e] = vbf2f(r0);
+                v[k][2 * e + 1] = vbf2f(r1);
+                s += v[k][2 * e] + v[k][2 * e + 1];
+            }
+            *reinterpret_cast<uint4*>(xor_ + i) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        if (lane * 8 + 512 * k < C) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = v[k][e] - mean;
+                q += a * a;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float inv = rsqrtf(q / (float)C + eps);
+    u16* hr = ho + row * C;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int i = lane * 8 + 512 * k;
+        if (i < C) {
+            unsigned o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = (v[k][2 * e] - mean) * inv * gamma[i + 2 * e] + beta[i + 2 * e];
+                const float b2 = (v[k][2 * e + 1] - mean) * inv * gamma[i + 2 * e + 1] + beta[i + 2 * e + 1];
+                o[e] = (unsigned)vf2bf(a) | ((unsigned)vf2bf(b2) << 16);
+            }
+            *reinterpret_cast<uint4*>(hr + i) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+extern "C" int cr_scale_residual_layernorm(cr_ctx* ctx, const void* x, const void* y, const float* ls, const float* gamma,
+                                           const float* beta, void* x_out, void* h_out, int64_t M, int C, float eps) {
+    CR_CHECK_ARG(ctx && M >= 0 && C > 0 && C % 8 == 0 && C <= 2048, "cr_scale_residual_layernorm: bad dims M=%lld C=%d", (long long)M, C);
+    if (M == 0) return CR_OK;
+    CR_CHECK_ARG(x && y && gamma && beta && x_out && h_out, "cr_scale_residual_layernorm: NULL pointer");
+    const dim3 grid((unsigned)cr_cdiv(M, 4));
+#define SRLN_LAUNCH(NCH_)                                                                                             \
+    hipLaunchKernelGGL(k_scale_residual_layernorm<NCH_>, grid, dim3(256), 0, ctx->stream, (const u16*)x, (const u16*)y, ls, \
+                       gamma, beta, (u16*)x_out, (u16*)h_out, M, C, eps)
+    if (C <= 512) SRLN_LAUNCH(1);
+    else if (C <= 1024) SRLN_LAUNCH(2);
+    else SRLN_LAUNCH(4);
+#undef SRLN_LAUNCH
+    CR_LAUNCH_CHECK();
+    return CR_OK;
 }
 
 extern "C" int cr_layernorm(cr_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, int64_t M, int C,
@@ -226,8 +365,14 @@ extern "C" int cr_layernorm(cr_ctx* ctx, const void* x, const float* gamma, cons
     CR_CHECK_ARG(ctx && M >= 0 && C > 0 && C % 8 == 0, "cr_layernorm: bad dims M=%lld C=%d", (long long)M, C);
     if (M == 0) return CR_OK;
     CR_CHECK_ARG(x && gamma && beta && y, "cr_layernorm: NULL pointer");
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)cr_cdiv(M, 4)), dim3(256), 0, ctx->stream, (const u16*)x, gamma, beta,
-                       (u16*)y, M, C, eps);
+    CR_CHECK_ARG(C <= 2048, "cr_layernorm: C=%d > 2048 is not built", C);
+    const dim3 grid((unsigned)cr_cdiv(M, 4));
+    if (C <= 512)
+        hipLaunchKernelGGL(k_layernorm<1>, grid, dim3(256), 0, ctx->stream, (const u16*)x, gamma, beta, (u16*)y, M, C, eps);
+    else if (C <= 1024)
+        hipLaunchKernelGGL(k_layernorm<2>, grid, dim3(256), 0, ctx->stream, (const u16*)x, gamma, beta, (u16*)y, M, C, eps);
+    else
+        hipLaunchKernelGGL(k_layernorm<4>, grid, dim3(256), 0, ctx->stream, (const u16*)x, gamma, beta, (u16*)y, M, C, eps);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -94,13 +94,19 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio), bias=ffn_bias)
         self.ls2 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
 
-    def forward(self, x, B, N):
+    def forward(self, x, B, N, h=None, next_norm=None):
+        """x: residual stream; h: LayerNorm1(x) if the previous block already produced it.  Returns (x_out, h_next):
+        h_next = next_norm(x_out) when `next_norm` is given -- every "x + ls * branch" is fused with the LayerNorm that
+        follows it (the second one of this block, or the first of the next block)."""
         g1 = self.ls1.gamma if isinstance(self.ls1, LayerScale) else None
         g2 = self.ls2.gamma if isinstance(self.ls2, LayerScale) else None
-        h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = ops.scale_residual(x, self.attn(h, B, N), g1)
-        h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return ops.scale_residual(x, self.mlp(h), g2)
+        if h is None:
+            h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x, h = ops.scale_residual_layernorm(x, self.attn(h, B, N), g1, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        m = self.mlp(h)
+        if next_norm is None:
+            return ops.scale_residual(x, m, g2), None
+        return ops.scale_residual_layernorm(x, m, g2, next_norm.weight, next_norm.bias, next_norm.eps)
 
 
 class DinoVisionTransformer(nn.Module):
@@ -183,8 +189,10 @@ class DinoVisionTransformer(nn.Module):
             tok, B, N = self.prepare_tokens(x)
             take = range(len(self.blocks) - n, len(self.blocks)) if isinstance(n, int) else n
             outs = []
+            h = None
             for i, blk in enumerate(self.blocks):
-                tok = blk(tok, B, N)
+                nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
+                tok, h = blk(tok, B, N, h, nxt)
                 if i in take:
                     outs.append(tok)
             assert len(outs) == len(take), f"only {len(outs)} / {len(take)} blocks found"

@@ -592,13 +592,26 @@ def prepared_fc_weight(weight, chw=None):
     return ent[1]
 
 
+def _bf16_copy(t):
+    """bf16 copy of a small f32 parameter (bias), cached on the tensor per version / weight epoch like the weights"""
+    ent = getattr(t, "_cr_b16", None)
+    tag = (t._version, _WEIGHT_EPOCH[0], t.data_ptr())
+    if ent is None or ent[0] != tag:
+        ent = (tag, t.detach().to(bf16))
+        try:
+            t._cr_b16 = ent
+        except Exception:
+            pass
+    return ent[1]
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, chw):
         _need_cuda(x, "linear input")
         wb = prepared_fc_weight(weight, chw)
         xb = x.to(bf16)
-        y = torch.addmm(bias.detach().to(bf16), xb, wb.t()) if bias is not None else torch.mm(xb, wb.t())
+        y = torch.addmm(_bf16_copy(bias), xb, wb.t()) if bias is not None else torch.mm(xb, wb.t())
         ctx.save_for_backward(xb, wb)
         ctx.refs = (weight, bias, chw, x.dtype)
         return y
@@ -988,6 +1001,18 @@ def scale_residual(x, y, gamma=None):
     g = gamma.detach().float().contiguous() if gamma is not None else None
     _chk(_lib.load().cr_scale_residual(_ctx(x), _p(x), _p(y), _p(g), _p(out), x.shape[0], x.shape[1]), "cr_scale_residual")
     return out
+
+
+def scale_residual_layernorm(x, y, ls, gamma, beta, eps):
+    """(x + ls * y, LayerNorm(x + ls * y)) on (M,C) bf16 in one kernel"""
+    _need_cuda(x, "residual input")
+    assert x.dtype == bf16 and y.dtype == bf16 and x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
+    xo, ho = torch.empty_like(x), torch.empty_like(x)
+    l = ls.detach().float().contiguous() if ls is not None else None
+    _chk(_lib.load().cr_scale_residual_layernorm(_ctx(x), _p(x), _p(y), _p(l), _p(gamma.detach().float().contiguous()),
+                                                 _p(beta.detach().float().contiguous()), _p(xo), _p(ho), x.shape[0],
+                                                 x.shape[1], float(eps)), "cr_scale_residual_layernorm")
+    return xo, ho
 
 
 def resize_bilinear_ac(x, size):

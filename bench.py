@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- measures the hot path on N MI355X GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|geometry|inference|weak]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|geometry|inference|weak|depth]
 
 N>1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -216,12 +216,65 @@ def bench_weak(args, rank, world, dev):
                        "valid": bool(rep.get("iterations_explode") == 0 and rep.get("total_loss") == rep.get("total_loss"))}}
 
 
+def depth_model_gflop(N_img, depth, D, heads_out, features, ph, pw):
+    """algorithmic GFLOP of one Depth-Anything-V2 forward per image: ViT blocks (24 N D^2 + 4 N^2 D per layer), patch
+    embedding, DPT head convolutions / deconvolutions (2 * MACs)."""
+    N = ph * pw + 1
+    f = depth * (24.0 * N * D * D + 4.0 * N * N * D) + 2.0 * ph * pw * 588 * D
+    oc = heads_out
+    res = [(ph * 4, pw * 4), (ph * 2, pw * 2), (ph, pw), ((ph + 1) // 2, (pw + 1) // 2)]
+    for i in range(4):
+        f += 2.0 * ph * pw * D * oc[i]                                      # 1x1 projects
+        f += 2.0 * res[i][0] * res[i][1] * oc[i] * 9 * features             # layerN_rn 3x3
+    f += 2.0 * ph * pw * oc[0] * oc[0] * 16 + 2.0 * ph * pw * oc[1] * oc[1] * 4 + 2.0 * res[3][0] * res[3][1] * oc[3] * oc[3] * 9
+    rcu = lambda hw: 2 * 2.0 * hw[0] * hw[1] * features * features * 9
+    f += rcu(res[3]) + 2 * rcu(res[2]) + 2 * rcu(res[1]) + 2 * rcu(res[0])   # refinenet4 has one unit, the others two
+    for hw in (res[2], res[1], res[0], (ph * 8, pw * 8)):
+        f += 2.0 * hw[0] * hw[1] * features * features                       # out_conv 1x1 after each up-sampling
+    f += 2.0 * (ph * 8) * (pw * 8) * features * 9 * (features // 2)
+    f += 2.0 * (ph * 14) * (pw * 14) * ((features // 2) * 9 * 32 + 32)
+    return f / 1e9
+
+
+def bench_depth(args, rank, world, dev):
+    """The depth backbone of BASELINE.json configs[4] on its own: Depth-Anything-V2 ViT-L + DPT head, 518x518 inputs,
+    random-init weights (no checkpoint offline), 4 images per GPU per step -> images/s and the achieved fraction of the
+    bf16 MFMA peak over the whole forward (GEMMs are hipBLASLt, attention / convolutions / norms are this library's)."""
+    dav2 = importlib.import_module("3dod_amd.depth_anything_v2")
+    syn = importlib.import_module("3dod_amd.synthetic")
+    B, S = 4, 518
+    torch.manual_seed(0)
+    model = dav2.DepthAnythingV2("vitl")
+    model.load_state_dict(syn.seeded_state_dict(model, 0))
+    model = model.to(dev).eval()
+    xs = [torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(10 + rank * 7 + i)).to(dev) for i in range(2)]
+    for i in range(args.warmup):
+        model(xs[i % 2])
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        d = model(xs[i % 2])
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    assert bool(torch.isfinite(d).all())
+    gflop = depth_model_gflop(B, 24, 1024, [256, 512, 1024, 1024], 256, S // 14, S // 14)
+    ach = gflop * B / (dt / args.steps) / 1e3
+    return {"metric": "images/sec Depth-Anything-V2 ViT-L forward (depth backbone of BASELINE configs[4])",
+            "value": B * world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Depth-Anything-V2 ViT-L + DPT head forward, 4 img/GPU 518x518 (1370 tokens), seeded random weights",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "gflop_per_image": gflop},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                         "traffic": None, "scope": "whole forward (algorithmic flops / wall time)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="train", choices=["train", "geometry", "inference", "weak"])
+    ap.add_argument("--workload", default="train", choices=["train", "geometry", "inference", "weak", "depth"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
@@ -236,6 +289,8 @@ def main():
         res = bench_inference(args, rank, world, dev)
     elif args.workload == "weak":
         res = bench_weak(args, rank, world, dev)
+    elif args.workload == "depth":
+        res = bench_depth(args, rank, world, dev)
     else:
         bt = importlib.import_module("bench_train")
         res = bt.bench_train(args, rank, world, dev)

@@ -114,6 +114,10 @@ int cr_box_median(cr_ctx* ctx, const float* depth, int B, int H, int W, const in
 int cr_attention_fwd(cr_ctx* ctx, const void* qkv, void* out, int B, int N, int H, int D, float scale);
 /* nn.LayerNorm over the last dimension, x / y (M,C) bf16, gamma / beta (C) f32 (dinov2.py:96, block.py:56,68). */
 int cr_layernorm(cr_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, int64_t M, int C, float eps);
+/* x_out = x + ls * y and h_out = LayerNorm(x_out) in one pass (the end of one residual branch and the norm that opens
+ * the next, block.py:84-110); ls may be NULL (= 1).  Same values as cr_scale_residual followed by cr_layernorm. */
+int cr_scale_residual_layernorm(cr_ctx* ctx, const void* x, const void* y, const float* ls, const float* gamma,
+                                const float* beta, void* x_out, void* h_out, int64_t M, int C, float eps);
 /* exact (erf) GELU in place on n bf16 values (dinov2_layers/mlp.py:36). */
 int cr_gelu_inplace(cr_ctx* ctx, void* x, int64_t n);
 /* out = x + gamma * y, (M,C) bf16, gamma (C) f32 or NULL for 1 (LayerScale + residual, block.py:84-110). */

@@ -80,3 +80,17 @@ def test_resize_bilinear_align_corners(h, w, Ho, Wo, C):
     ref = F.interpolate(x.float().permute(0, 3, 1, 2), (Ho, Wo), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
     assert y.shape == ref.shape
     assert float((y.float() - ref).abs().max()) < 0.02 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("M,C", [(3, 64), (1370, 1024), (9, 1536)])
+def test_fused_residual_layernorm_equals_the_two_kernels(M, C):
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(M, C, generator=g).to(torch.bfloat16).to(DEV)
+    y = torch.randn(M, C, generator=g).to(torch.bfloat16).to(DEV)
+    ls, gam, bet = (torch.randn(C, generator=g).to(DEV) for _ in range(3))
+    xo, ho = ops.scale_residual_layernorm(x, y, ls, gam, bet, 1e-6)
+    x2 = ops.scale_residual(x, y, ls)
+    h2 = ops.layernorm(x2, gam, bet, 1e-6)
+    assert torch.equal(xo, x2) and torch.equal(ho, h2)
+    xo, ho = ops.scale_residual_layernorm(x, y, None, gam, bet, 1e-6)
+    assert torch.equal(xo, ops.scale_residual(x, y)) and torch.equal(ho, ops.layernorm(xo, gam, bet, 1e-6))
