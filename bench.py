@@ -195,22 +195,45 @@ def bench_weak(args, rank, world, dev):
     if os.environ.get("CR_GRAPHS", "dense") != "none":
         model.enable_graphs(batches[0])
         opt.zero_grad()
+    live = os.environ.get("CR_LIVE_DEPTH", "0") == "1"
+    if live:
+        # the multi-model pipeline of configs[4]: the depth maps are not precomputed but come from the Depth-Anything-V2
+        # ViT-L forward on the same images inside the timed step (resize to 518, ImageNet normalisation, resize back)
+        dav2 = importlib.import_module("3dod_amd.depth_anything_v2")
+        depth_model = dav2.DepthAnythingV2("vitl")
+        depth_model.load_state_dict(syn.seeded_state_dict(depth_model, 0))
+        depth_model = depth_model.to(dev).eval()
+        mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+
+        def with_live_depth(batch):
+            import torch.nn.functional as F
+            with torch.no_grad():
+                rgb = torch.stack([d["image"] for d in batch]).flip(1).float() / 255.0              # BGR uint8 -> RGB [0,1]
+                x = F.interpolate((rgb - mean) / std, (518, 518), mode="bilinear", align_corners=False)
+                depth = depth_model(x)
+                depth = F.interpolate(depth[:, None], rgb.shape[-2:], mode="bilinear", align_corners=True)[:, 0]
+            return [dict(d, depth_map=depth[i]) for i, d in enumerate(batch)]
+    else:
+        with_live_depth = lambda batch: batch
     with d2.EventStorage(1):
         for i in range(args.warmup):
-            step(batches[i % len(batches)])
+            step(with_live_depth(batches[i % len(batches)]))
         barrier(world)
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(batches[i % len(batches)])
+            step(with_live_depth(batches[i % len(batches)]))
         barrier(world)
         dt = max_over_ranks(time.perf_counter() - t0, world, dev)
         rep = step.report()
-    return {"metric": "images/sec weakly supervised Cube R-CNN train step (BASELINE configs[4], precomputed depth maps)",
+    return {"metric": "images/sec weakly supervised Cube R-CNN train step (BASELINE configs[4], "
+                      + ("live Depth-Anything-V2 depth maps)" if live else "precomputed depth maps)"),
             "value": B * world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "RCNN3D_combined_features + ROIHeads3DScore train step, 2 img/GPU 512x512, losses "
-                                   + ",".join(cfg.loss_functions) + "; no Depth-Anything backbone (MODEL.DEPTH_ON False)",
+                                   + ",".join(cfg.loss_functions) + ("; depth maps from the Depth-Anything-V2 ViT-L forward "
+                                   "inside the step (CR_LIVE_DEPTH=1)" if live else "; precomputed depth maps (as the reference trains)"),
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": rep.get("total_loss"),
                        "skipped_steps": rep.get("iterations_explode"),
                        "valid": bool(rep.get("iterations_explode") == 0 and rep.get("total_loss") == rep.get("total_loss"))}}
