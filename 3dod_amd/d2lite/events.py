@@ -10,7 +10,10 @@ class EventStorage:
 
     def put_scalar(self, name, value, smoothing_hint=True):
         self.scalars[name] = value          # may be a 0-d device tensor: no host sync here
-        self.history.setdefault(name, []).append((self.iter, value))
+        h = self.history.setdefault(name, [])
+        h.append((self.iter, value))
+        if len(h) > 64:                      # a window, not the whole run (values may be device tensors)
+            del h[:-32]
 
     def put_scalars(self, **kw):
         for k, v in kw.items():

@@ -1,0 +1,104 @@
+"""do_train on the GPU: schedule applied, periodic / final checkpoints written, and a run resumed from a checkpoint ends
+where the uninterrupted run ends (same data order, restored RNG, momentum, schedule and divergence bookkeeping; kernels
+with float atomics make the match close, not bitwise)."""
+import importlib
+import itertools
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+syn = importlib.import_module("3dod_amd.synthetic")
+modeling = importlib.import_module("3dod_amd.cubercnn.modeling")
+solver = importlib.import_module("3dod_amd.cubercnn.solver")
+
+
+def batches(dev, n=8):
+    out = []
+    for i in range(n):
+        b = syn.make_batch(2, 50 + i, size=256)
+        for d in b:
+            d["image"], d["instances"] = d["image"].to(dev), d["instances"].to(dev)
+        out.append(b)
+    return out
+
+
+def run(cfg_over, out_dir, data, start, resume):
+    dev = torch.device("cuda:0")
+    cfg = syn.make_cfg(overrides=["MODEL.DEVICE", str(dev), "VIS_PERIOD", 0, "log", False, "SOLVER.BASE_LR", 0.002,
+                                  "SOLVER.WARMUP_ITERS", 4, "SOLVER.STEPS", (5,), "SOLVER.CHECKPOINT_PERIOD", 3,
+                                  "OUTPUT_DIR", out_dir] + cfg_over)
+    torch.manual_seed(0)
+    model = modeling.build_model(cfg)
+    ok = solver.do_train(cfg, model, itertools.islice(itertools.cycle(data), start, None), resume=resume, world_size=1,
+                         rank=0, check_period=1)
+    return ok, model, cfg
+
+
+def test_do_train_checkpoint_and_resume(tmp_path):
+    dev = torch.device("cuda:0")
+    data = batches(dev)
+    ok, full, _ = run(["SOLVER.MAX_ITER", 6], str(tmp_path / "a"), data, 0, False)
+    assert ok and sorted(os.listdir(tmp_path / "a")) == ["last_checkpoint", "model_final.pth", "model_recent.pth"]
+    ck = torch.load(tmp_path / "a" / "model_final.pth", map_location="cpu", weights_only=True)
+    assert ck["iteration"] == 5 and ck["scheduler"]["last_iter"] == 6 and "momentum_buffer" in ck["optimizer"]
+    assert float(ck["train_step"]["iterations_success"]) + float(ck["train_step"]["iterations_explode"]) == 6
+    # interrupted after 3 iterations, then resumed to 6
+    ok, _, _ = run(["SOLVER.MAX_ITER", 3], str(tmp_path / "b"), data, 0, False)
+    assert ok
+    start = torch.load(tmp_path / "b" / "model_final.pth", map_location="cpu", weights_only=True)["model"]   # state after 3 steps
+    ok, resumed, _ = run(["SOLVER.MAX_ITER", 6], str(tmp_path / "b"), data, 3, True)
+    assert ok
+    ck2 = torch.load(tmp_path / "b" / "model_final.pth", map_location="cpu", weights_only=True)
+    assert ck2["iteration"] == 5 and ck2["scheduler"]["last_iter"] == 6
+    def dist(m1, m2):
+        num = den = 0.0
+        for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+            if a.dtype.is_floating_point:
+                num += float((a.float() - b.float()).pow(2).sum())
+                den += float(a.float().pow(2).sum())
+        return (num / den) ** 0.5
+
+    # the yardstick is the run-to-run spread of the SAME uninterrupted run: float atomics reorder sums, and a last-bit
+    # change can flip which anchors / RoIs the IoU-weighted sampling picks, which changes the update itself
+    ok, again, _ = run(["SOLVER.MAX_ITER", 6], str(tmp_path / "c"), data, 0, False)
+    spread = dist(full, again)
+    d = dist(full, resumed)
+    print("run-to-run spread", spread, "resumed vs full", d)
+    assert d < max(3.0 * spread, 1e-4), (d, spread)
+    # and the resumed run really moved on from the checkpoint it started from
+    moved = sum(float((resumed.state_dict()[k].float().cpu() - v.float()).abs().sum()) for k, v in start.items() if v.dtype.is_floating_point)
+    assert moved > 0
+
+
+def test_train_net_driver_end_to_end(tmp_path, monkeypatch):
+    """tools/train_net.py main(): synthetic Omni3D files -> priors -> model -> do_train (loader + prefetcher, schedule,
+    checkpoint) -> do_test (inference on the test split, AP tables), then --eval-only from the written checkpoint."""
+    import sys
+    import types
+    D = importlib.import_module("3dod_amd.d2lite.data")
+    root = tmp_path / "datasets"
+    root.mkdir()
+    syn.make_omni3d_dataset(str(root), name="Synth_train", n_images=10, seed=8)
+    syn.make_omni3d_dataset(str(root), name="Synth_val", n_images=4, seed=9, first_image_id=3000)
+    monkeypatch.chdir(tmp_path)
+    for n in list(D.DatasetCatalog):
+        D.DatasetCatalog.remove(n)
+    for n in ("omni3d_model", "Synth_train", "Synth_val"):
+        D.MetadataCatalog.pop(n, None)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    tn = importlib.import_module("train_net")
+    cats = ["bed", "car", "chair", "sofa", "table", "truck"]
+    opts = ["DATASETS.TRAIN", ("Synth_train",), "DATASETS.TEST", ("Synth_val",), "DATASETS.CATEGORY_NAMES", cats,
+            "SOLVER.IMS_PER_BATCH", 2, "SOLVER.MAX_ITER", 4, "SOLVER.CHECKPOINT_PERIOD", 2, "SOLVER.BASE_LR", 0.001,
+            "SOLVER.WARMUP_ITERS", 2, "DATALOADER.NUM_WORKERS", 0, "INPUT.MIN_SIZE_TRAIN", (256,), "INPUT.MAX_SIZE_TRAIN", 512,
+            "INPUT.MIN_SIZE_TEST", 256, "INPUT.MAX_SIZE_TEST", 512, "VIS_PERIOD", 0, "log", False, "OUTPUT_DIR", str(tmp_path / "out"),
+            "TEST.EVAL_PERIOD", 0, "MODEL.DEVICE", "cuda:0"]
+    args = types.SimpleNamespace(config_file=None, resume=False, eval_only=False, opts=opts)
+    analysis = tn.main(args)
+    assert "Synth_val" in analysis and "<Concat>" in analysis
+    assert os.path.exists(tmp_path / "out" / "model_final.pth") and os.path.exists(tmp_path / "out" / "category_meta.json")
+    args = types.SimpleNamespace(config_file=None, resume=True, eval_only=True, opts=opts)
+    again = tn.main(args)
+    assert set(again) == set(analysis)
