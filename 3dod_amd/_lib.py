@@ -22,6 +22,7 @@ SIGNATURES = {
     "cr_propose": [P, P, c_int64, P, c_int, c_int, P, P, P, c_int64, P, c_int, P, P, P, P, P],
     "cr_ransac_plane": [P, P, c_int64, P, c_int64, c_float, P, P, P],
     "cr_box_median": [P, P, c_int, c_int, c_int, P, P, c_int, P],
+    "cr_fold_bn": [P, P, P, P, P, P, c_float, P, P, c_int, c_int],
     "cr_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float],
     "cr_layernorm": [P, P, P, P, P, c_int64, c_int, c_float],
     "cr_gelu_inplace": [P, P, c_int64],

@@ -813,6 +813,31 @@ __global__ void k_cast_f32_bf16(const float* __restrict__ src, u16* __restrict__
     }
 }
 
+// Inference-time BatchNorm folding: a frozen BatchNorm after a convolution is a per-output-channel affine map, so
+// wf[co][:] = w[co][:] * s[co] (bf16) and bias[co] = beta[co] - mean[co] * s[co] with s = gamma / sqrt(var + eps) turn
+// conv + BN (+ residual, ReLU) into ONE convolution with a bias epilogue: no statistics, no second pass over the
+// activations.  One launch per layer (weights may have changed since the last call; the result is tiny).
+__global__ __launch_bounds__(256) void k_fold_bn(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, const float* __restrict__ mean,
+                                                 const float* __restrict__ var, float eps, u16* __restrict__ wf,
+                                                 float* __restrict__ bias, int Cout, int K) {
+    const int co = blockIdx.x;
+    const float s = gamma[co] * rsqrtf(var[co] + eps);
+    if (threadIdx.x == 0) bias[co] = beta[co] - mean[co] * s;
+    const float* wr = w + (size_t)co * K;
+    u16* o = wf + (size_t)co * K;
+    for (int i = threadIdx.x; i < K; i += 256) o[i] = f2bf(wr[i] * s);
+}
+
+extern "C" int cr_fold_bn(cr_ctx* ctx, const float* w, const float* gamma, const float* beta, const float* mean,
+                          const float* var, float eps, void* wf, float* bias, int Cout, int K) {
+    CR_CHECK_ARG(ctx && w && gamma && beta && mean && var && wf && bias && Cout > 0 && K > 0, "cr_fold_bn: bad args");
+    hipLaunchKernelGGL(k_fold_bn, dim3((unsigned)Cout), dim3(256), 0, ctx->stream, w, gamma, beta, mean, var, eps, (u16*)wf,
+                       bias, Cout, K);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
 extern "C" int cr_cast_f32_to_bf16(cr_ctx* ctx, const float* src, void* dst, int64_t n) {
     CR_CHECK_ARG(ctx && n >= 0, "cr_cast_f32_to_bf16: bad args");
     if (n == 0) return CR_OK;

@@ -218,8 +218,8 @@ class _ConvBN(torch.autograd.Function):
                                _p(out), M, Cout, int(relu), float(eps), float(momentum), _p(mi), _p(running_mean),
                                _p(running_var)), "cr_bn_fwd")
         else:
-            # frozen statistics: fold into an affine epilogue (scale*x + shift) done by the BN kernel with
-            # mean/invstd taken from the running buffers
+            # frozen statistics with gradients enabled (freeze_bn fine-tuning; plain inference takes conv_bn_folded): an
+            # affine epilogue (scale*x + shift) done by the BN kernel with mean/invstd taken from the running buffers
             y_raw = conv_fwd_raw(x, wb, Cout, k, stride, pad)
             M = y_raw.numel() // Cout
             mi = torch.stack([running_mean, torch.rsqrt(running_var + eps)]).contiguous()
@@ -264,8 +264,25 @@ class _ConvBN(torch.autograd.Function):
         return dx, dw, ret_g, ret_b, dres, None, None, None, None, None, None, None, None
 
 
+def conv_bn_folded(x, weight, gamma, beta, running_mean, running_var, stride=1, pad=0, relu=True, residual=None, eps=1e-5):
+    """inference: frozen BatchNorm folded into the convolution's weights and bias (cr_fold_bn), residual and ReLU in the
+    conv epilogue -- one kernel per layer instead of conv + scale/shift arithmetic + a second pass over the output"""
+    _need_cuda(x, "conv input")
+    weight = as_krsc(weight)
+    Cout, _, k, _ = weight.shape
+    K_ = weight.numel() // Cout
+    wf = torch.empty((Cout, K_), dtype=bf16, device=x.device)
+    bias_f = torch.empty((Cout,), dtype=f32, device=x.device)
+    _chk(_lib.load().cr_fold_bn(_ctx(x), _p(weight.detach()), _p(gamma.detach()), _p(beta.detach()), _p(running_mean),
+                                _p(running_var), float(eps), _p(wf), _p(bias_f), Cout, K_), "cr_fold_bn")
+    return conv_fwd_raw(x, wf, Cout, k, stride, pad, bias=bias_f, residual=residual, relu=relu)
+
+
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride=1, pad=0, relu=True, residual=None,
                 eps=1e-5, momentum=0.1, training=True):
+    if not training and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or gamma.requires_grad
+                                                          or (residual is not None and residual.requires_grad))):
+        return conv_bn_folded(x, weight, gamma, beta, running_mean, running_var, stride, pad, relu, residual, eps)
     return _ConvBN.apply(x, as_krsc(weight), gamma, beta, residual, running_mean, running_var, stride, pad, relu, eps,
                          momentum, training)
 

@@ -147,6 +147,13 @@ int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, in
 /* dw f32 (Cout, ks*ks*Cin); accumulate=0 zeroes it first (shared RPN-head weights accumulate over levels). */
 int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
                          int Cout, int ks, int stride, int pad, int accumulate);
+/* Fold a frozen BatchNorm2d into the preceding convolution for inference: wf (Cout, K) bf16 = w * gamma / sqrt(var + eps),
+ * bias (Cout) f32 = beta - mean * gamma / sqrt(var + eps); w (Cout, K) f32 in the kernels' [Cout][kh][kw][Cin] order.
+ * conv(x, wf) + bias (+ residual, ReLU in the conv epilogue) == BatchNorm(conv(x, w)) in eval mode
+ * (cubercnn/modeling/backbone/dla.py:40-68: conv -> bn -> relu with BatchNorm = nn.BatchNorm2d in eval()). */
+int cr_fold_bn(cr_ctx* ctx, const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
+               float eps, void* wf, float* bias, int Cout, int K);
+
 /* same, plus dbias[Cout] += sum over output pixels of dy (bias gradient of the FPN / RPN-head convs), accumulated inside
  * the same kernel from the dy tiles it stages anyway (dbias must be zeroed or hold the running gradient). */
 int cr_conv2d_bwd_weight_bias(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,

@@ -310,3 +310,25 @@ def test_linear_fc(chw):
     ops.bump_weight_epoch()
     y2 = ops.linear(xd.detach(), wd2, None, chw=chw)
     assert relerr(y2.float().cpu(), (yo.detach() - b) * 2) < 2e-2
+
+
+def test_folded_batchnorm_inference_matches_unfolded():
+    """eval-mode conv+BN(+residual, ReLU): the folded single-convolution path (no_grad) against the affine-epilogue path
+    (grad enabled) and against the float32 definition"""
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 24, 20, 64, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(128, 64, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    gamma, beta = (torch.rand(128, generator=g) + 0.5).to(dev).requires_grad_(), (torch.randn(128, generator=g) * 0.2).to(dev).requires_grad_()
+    mean, var = (torch.randn(128, generator=g) * 0.3).to(dev), (torch.rand(128, generator=g) + 0.2).to(dev)
+    res = torch.randn(2, 12, 10, 128, generator=g).to(torch.bfloat16).to(dev)
+    with torch.no_grad():
+        folded = ops.conv_bn_act(x, w, gamma, beta, mean, var, stride=2, pad=1, relu=True, residual=res, training=False)
+    unfolded = ops.conv_bn_act(x, w, gamma, beta, mean, var, stride=2, pad=1, relu=True, residual=res, training=False)
+    assert unfolded.requires_grad and not folded.requires_grad
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w.detach().to(torch.bfloat16).float(), None, 2, 1)
+    ref = F.relu(F.batch_norm(y, mean, var, gamma.detach(), beta.detach(), False, 0.0, 1e-5) + res.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    for out in (folded, unfolded.detach()):
+        assert float((out.float() - ref).norm() / ref.norm()) < 1e-2
+    assert float((folded.float() - unfolded.detach().float()).norm() / ref.norm()) < 1e-2
