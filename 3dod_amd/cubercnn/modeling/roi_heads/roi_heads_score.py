@@ -251,9 +251,18 @@ class ROIHeads3DScore(ROIHeads3D):
             named = [(k, l * uncert_sf if l is not None else None, w) for k, l, w in named]
             losses.update({prefix + 'uncert': self.use_confidence * self.safely_reduce_losses(cube_uncert.clone())})
             storage.put_scalar(prefix + 'conf', torch.exp(-cube_uncert.detach()).mean(), smoothing_hint=False)
-        for k, l, w in named:
-            if l is not None:
-                losses[prefix + k] = self.safely_reduce_losses(l) * w * self.loss_w_3d
+        # safely_reduce_losses of every term in one masked reduction over the stacked (terms, n) matrix
+        live = [(k, l, w) for k, l, w in named if l is not None]
+        if live:
+            L = torch.stack([l for _, l, _ in live])
+            valid = torch.isfinite(L)
+            cnt = valid.sum(1)
+            tot = torch.where(valid, L, torch.zeros_like(L)).sum(1)
+            red = torch.where(cnt > 0, tot / cnt.clamp(min=1), L.mean(1) * 0.0)
+            wts = torch.tensor([w * self.loss_w_3d for _, _, w in live], dtype=red.dtype).to(red.device, non_blocking=True)
+            red = red * wts
+            for i, (k, _, _) in enumerate(live):
+                losses[prefix + k] = red[i]
 
         cube_3D = torch.cat((torch.stack((cube_x3d, cube_y3d, cube_z)).T, cube_dims,
                              cube_xy * im_ratios_per_box.unsqueeze(1)), dim=1)

@@ -20,6 +20,20 @@ _SY = (-1, -1, 1, 1, -1, -1, 1, 1)     # y <- h : -h/2 for {0,1,4,5}
 _SZ = (-1, -1, -1, -1, 1, 1, 1, 1)     # z <- w : -w/2 for {0,1,2,3}
 
 
+_CUBOID_CONST = {}
+
+
+def _cuboid_constants(dev):
+    """corner sign table and triangle list, made once per device (no host-to-device copy per call)"""
+    c = _CUBOID_CONST.get(str(dev))
+    if c is None:
+        signs = torch.tensor([_SX, _SY, _SZ], dtype=torch.float32, device=dev)
+        faces = torch.tensor([[0, 1, 2], [2, 3, 0], [1, 5, 6], [6, 2, 1], [4, 0, 3], [3, 7, 4], [5, 4, 7], [7, 6, 5],
+                              [4, 5, 1], [1, 0, 4], [3, 2, 6], [6, 7, 3]], device=dev).float()
+        c = _CUBOID_CONST[str(dev)] = (signs, faces)
+    return c
+
+
 def get_cuboid_verts_faces(box3d=None, R=None):
     """math_util.py:142-245.  box3d (n,6) [X,Y,Z,W,H,L], R (n,3,3) -> verts (n,8,3), faces (n,12,3)."""
     if box3d is None:
@@ -33,18 +47,14 @@ def get_cuboid_verts_faces(box3d=None, R=None):
         if R is not None:
             R = R.unsqueeze(0)
     n = len(box3d)
-    dev = box3d.device
-    sx = torch.tensor(_SX, dtype=torch.float32, device=dev)
-    sy = torch.tensor(_SY, dtype=torch.float32, device=dev)
-    sz = torch.tensor(_SZ, dtype=torch.float32, device=dev)
-    verts = torch.stack((sx[None] * (box3d[:, 5:6] / 2), sy[None] * (box3d[:, 4:5] / 2),
-                         sz[None] * (box3d[:, 3:4] / 2)), dim=1)          # (n,3,8)
+    signs, faces0 = _cuboid_constants(box3d.device)                       # (3,8) half-extent signs for (l, h, w); (12,3)
+    half = torch.stack((box3d[:, 5], box3d[:, 4], box3d[:, 3]), dim=1) * 0.5
+    verts = signs[None] * half[:, :, None]                                # (n,3,8)
     if R is not None:
         verts = R @ verts
     verts = verts + box3d[:, :3].unsqueeze(2)
     verts = verts.transpose(1, 2)
-    faces = torch.tensor([[0, 1, 2], [2, 3, 0], [1, 5, 6], [6, 2, 1], [4, 0, 3], [3, 7, 4], [5, 4, 7], [7, 6, 5],
-                          [4, 5, 1], [1, 0, 4], [3, 2, 6], [6, 7, 3]], device=dev).float().unsqueeze(0).repeat([n, 1, 1])
+    faces = faces0.unsqueeze(0).expand(n, 12, 3)
     if squeeze:
         verts = verts.squeeze()
         faces = faces.squeeze()
@@ -105,17 +115,19 @@ def _ray_rotation(K, u, v):
 def R_from_allocentric(K, R_view, u=None, v=None):
     """math_util.py:802-830 (tensor branch): R = M @ R_view where the viewing-ray angle > 0."""
     M, valid = _ray_rotation(K, u, v)
-    R = R_view.clone()
-    R[valid] = torch.bmm(M[valid], R_view[valid])
-    return R
+    # branch-free (boolean indexing costs a host sync per use): rows on the optical axis keep R_view; their M (0/0) is
+    # replaced by the identity before the product so that no NaN reaches the gradient of the unselected branch
+    sel = valid[:, None, None]
+    M = torch.where(sel, M, torch.eye(3, dtype=M.dtype, device=M.device).expand_as(M))
+    return torch.where(sel, torch.bmm(M, R_view), R_view)
 
 
 def R_to_allocentric(K, R, u=None, v=None):
     """math_util.py:746-776 (tensor branch)."""
     M, valid = _ray_rotation(K, u, v)
-    R_view = R.clone()
-    R_view[valid] = torch.bmm(M[valid].transpose(2, 1), R[valid])
-    return R_view
+    sel = valid[:, None, None]
+    M = torch.where(sel, M, torch.eye(3, dtype=M.dtype, device=M.device).expand_as(M))
+    return torch.where(sel, torch.bmm(M.transpose(2, 1), R), R)
 
 
 def scaled_sigmoid(vals, min=0.0, max=1.0):
