@@ -4,7 +4,8 @@
 // (roi_heads.py:1196-1232), which the reference computes with one torch.median call per box in a Python loop.
 // One block per box; exact selection of the lower median (torch.median's choice for an even count) by a 4-pass
 // 8-bit radix select over the order-preserving integer image of the float bits: every pass histograms the window's
-// elements that still match the prefix found so far (LDS atomics), a single wave scans the 256 bins.  The window is
+// elements that still match the prefix found so far (LDS atomics on run-length-compressed counts), a single wave scans
+// the 256 bins.  The window is
 // re-read from L2 four times (a 512x512 map is 1 MB); no sorting, no scratch memory.  Integer work, bit-exact.
 #include "cr_common.h"
 
@@ -16,7 +17,8 @@ __device__ __forceinline__ float ord2f(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-__global__ __launch_bounds__(256) void k_box_median(const float* __restrict__ depth, int B, int H, int W,
+#define MED_T 1024
+__global__ __launch_bounds__(MED_T) void k_box_median(const float* __restrict__ depth, int B, int H, int W,
                                                     const int* __restrict__ boxes, const int* __restrict__ img, int n,
                                                     float* __restrict__ out) {
     __shared__ unsigned hist[256];
@@ -37,15 +39,30 @@ __global__ __launch_bounds__(256) void k_box_median(const float* __restrict__ de
     if (tid == 0) { s_prefix = 0u; s_k = (unsigned)((cnt - 1) >> 1); }
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        hist[tid] = 0u;
+        if (tid < 256) hist[tid] = 0u;
         __syncthreads();
         const unsigned prefix = s_prefix;
         const unsigned hi_mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-        for (int i = tid; i < cnt; i += 256) {
-            const int r = i / bw, c = i - r * bw;
-            const unsigned key = f2ord(base[(size_t)r * W + c]);
-            if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        // run-length accumulation: neighbouring depths share their high bytes, so in the first passes nearly every
+        // element of a thread falls into the same bin -- counting the run in a register and touching LDS only when the
+        // bin changes removes the (otherwise fully serialised) same-address atomics
+        int cur = -1;
+        unsigned run = 0;
+        for (int r = tid >> 6; r < bh; r += MED_T / 64) {                 // one wave per row, lanes along the row
+            const float* row = base + (size_t)r * W;
+            for (int c = tid & 63; c < bw; c += 64) {
+                const unsigned key = f2ord(row[c]);
+                const int bin = (key & hi_mask) == prefix ? (int)((key >> shift) & 255u) : -1;
+                if (bin == cur) {
+                    ++run;
+                } else {
+                    if (cur >= 0) atomicAdd(&hist[cur], run);
+                    cur = bin;
+                    run = 1;
+                }
+            }
         }
+        if (cur >= 0) atomicAdd(&hist[cur], run);
         __syncthreads();
         if (tid < 64) {
             // wave scan over 256 bins: each lane owns 4 consecutive bins
@@ -78,7 +95,7 @@ extern "C" int cr_box_median(cr_ctx* ctx, const float* depth, int B, int H, int 
     if (n == 0) return CR_OK;
     CR_CHECK_ARG(depth && boxes && img && out, "cr_box_median: NULL pointer");
     CR_CHECK_ARG((int64_t)H * W < (1ll << 31), "cr_box_median: map too large");
-    hipLaunchKernelGGL(k_box_median, dim3(n), dim3(256), 0, ctx->stream, depth, B, H, W, boxes, img, n, out);
+    hipLaunchKernelGGL(k_box_median, dim3(n), dim3(MED_T), 0, ctx->stream, depth, B, H, W, boxes, img, n, out);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
