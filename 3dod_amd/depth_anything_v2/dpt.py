@@ -127,3 +127,43 @@ class DepthAnythingV2(nn.Module):
         feats = self.pretrained.get_intermediate_layers(x, self.intermediate_layer_idx[self.encoder], return_class_token=True)
         depth = self.depth_head(feats, patch_h, patch_w) * self.max_depth
         return depth.squeeze(1)
+
+
+    # ------------------------------------------------------------------ raw images (dpt.py:191-222)
+    @staticmethod
+    def _net_size(h, w, input_size=518, multiple=14):
+        """util/transform.py Resize(resize_method='lower_bound', keep_aspect_ratio=True, ensure_multiple_of=14): scale so
+        that both sides are at least `input_size`, then round each side to a multiple of 14 (never below input_size)"""
+        import numpy as np
+        scale = max(input_size / h, input_size / w)
+
+        def constrain(x):
+            y = int(np.round(x / multiple) * multiple)
+            if y < input_size:
+                y = int(np.ceil(x / multiple) * multiple)
+            return y
+        return constrain(scale * h), constrain(scale * w)
+
+    def image2tensor(self, raw_image, input_size=518):
+        """raw_image: (H,W,3) uint8 BGR (numpy or tensor) -> ((1,3,h',w') normalised RGB on the model's device, (H,W)).
+        The reference resizes with cv2.INTER_CUBIC on the host; here the resize is torch's bicubic on the GPU
+        [cv2 absent: parity unpinned for the resampling]."""
+        import torch.nn.functional as F
+        dev = next(self.parameters()).device
+        img = torch.as_tensor(raw_image).to(dev)
+        h, w = img.shape[:2]
+        x = img.flip(-1).permute(2, 0, 1).float()[None] / 255.0
+        nh, nw = self._net_size(h, w, input_size)
+        x = F.interpolate(x, (nh, nw), mode="bicubic", align_corners=False)
+        mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+        return (x - mean) / std, (h, w)
+
+    @torch.no_grad()
+    def infer_image(self, raw_image, input_size=518):
+        """(H,W,3) uint8 BGR -> (H,W) float32 numpy depth in metres, like the reference's infer_image"""
+        import torch.nn.functional as F
+        image, (h, w) = self.image2tensor(raw_image, input_size)
+        depth = self.forward(image)
+        depth = F.interpolate(depth[:, None], (h, w), mode="bilinear", align_corners=True)[0, 0]
+        return depth.cpu().numpy()

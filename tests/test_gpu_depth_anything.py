@@ -53,3 +53,31 @@ def test_other_input_sizes_and_state_dict_keys():
     assert "depth_head.resize_layers.0.weight" in keys and "depth_head.scratch.output_conv2.2.weight" in keys
     with pytest.raises(RuntimeError):
         model(torch.randn(1, 3, 28, 28))          # CPU tensor: no CPU path
+
+
+def test_infer_image_and_depth_map_tool(tmp_path):
+    """raw BGR image -> metric depth at the image's size; tools/generate_depth_maps.py writes the .npz files the weak
+    losses' data path reads"""
+    import sys
+    dev = torch.device("cuda:0")
+    assert dav2.DepthAnythingV2._net_size(480, 640) == (518, 686) and dav2.DepthAnythingV2._net_size(518, 518) == (518, 518)
+    assert dav2.DepthAnythingV2._net_size(375, 1242) == (518, 1722)
+    model = build(2, dev)
+    img = np.random.default_rng(0).integers(0, 256, (60, 90, 3), dtype=np.uint8)
+    d = model.infer_image(img, input_size=70)
+    assert d.shape == (60, 90) and d.dtype == np.float32 and np.isfinite(d).all() and d.min() >= 0 and d.max() <= 20
+    root = tmp_path / "datasets"
+    root.mkdir()
+    jf = syn.make_omni3d_dataset(str(root), name="Synth_train", n_images=3, seed=1, with_maps=False)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    tool = importlib.import_module("generate_depth_maps")
+    model.infer_image.__func__.__defaults__ = (70,)            # small network input for the test
+    try:
+        n = tool.generate(model, [jf], root=str(root))
+    finally:
+        model.infer_image.__func__.__defaults__ = (518,)
+    assert n == 3 and tool.generate(model, [jf], root=str(root)) == 0        # second run: nothing left to do
+    import json
+    for info in json.load(open(jf))["images"]:
+        with np.load(root / "depth_maps" / f"{info['id']}.npz") as f:
+            assert f["depth"].shape == (info["height"], info["width"]) and f["depth"].dtype == np.float32
