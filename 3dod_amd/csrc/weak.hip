@@ -99,3 +99,154 @@ extern "C" int cr_box_median(cr_ctx* ctx, const float* depth, int B, int H, int 
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Convex hull of the 8 projected cuboid corners in the order the reference produces it (jarvis_march,
+// ProposalNetwork/utils/utils.py:424-470, incl. its handling of duplicate points :427-433 and its tie rules), one thread
+// per RoI.  out_order (n,8): indices into the (bumped) points, hull vertices first; out_count (n); out_bump (n,8): the
+// constant the reference adds to BOTH coordinates of a duplicated point.  The march is capped at 8 steps (a hull of 8
+// points has at most 8 vertices; the reference would loop forever on inputs that never return to the start).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void k_hull8(const float* __restrict__ pts, int n, int* __restrict__ out_order, int* __restrict__ out_count,
+                        float* __restrict__ out_bump) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float x[8], y[8], bump[8];
+    for (int i = 0; i < 8; ++i) { x[i] = pts[(r * 8 + i) * 2]; y[i] = pts[(r * 8 + i) * 2 + 1]; bump[i] = 0.f; }
+    // duplicates: every index i that equals some later point; the k-th such index (ascending) gets + (k+1)
+    int k = 0;
+    for (int i = 0; i < 7; ++i) {
+        bool dup = false;
+        for (int j = i + 1; j < 8; ++j) dup |= (x[i] == x[j] && y[i] == y[j]);
+        if (dup) { ++k; bump[i] = (float)k; }
+    }
+    for (int i = 0; i < 8; ++i) { x[i] += bump[i]; y[i] += bump[i]; out_bump[r * 8 + i] = bump[i]; }
+    // start: smallest x, among equals the largest y (first one on a further tie)
+    float minx = x[0];
+    for (int i = 1; i < 8; ++i) minx = fminf(minx, x[i]);
+    int start = -1, ncand = 0;
+    for (int i = 0; i < 8; ++i)
+        if (x[i] == minx) {
+            ++ncand;
+            if (start < 0 || y[i] > y[start]) start = i;
+        }
+    if (ncand == 1)
+        for (int i = 0; i < 8; ++i) if (x[i] == minx) { start = i; break; }
+    int res[9];
+    int m = 0;
+    res[m++] = start;
+    int l = start;
+    for (int step = 0; step < 8; ++step) {
+        int q = (l + 1) % 8;
+        for (int i = 0; i < 8; ++i) {
+            if (i == l) continue;
+            const float d = (x[i] - x[l]) * (y[q] - y[l]) - (y[i] - y[l]) * (x[q] - x[l]);
+            const float di = (x[i] - x[l]) * (x[i] - x[l]) + (y[i] - y[l]) * (y[i] - y[l]);
+            const float dq = (x[q] - x[l]) * (x[q] - x[l]) + (y[q] - y[l]) * (y[q] - y[l]);
+            if (d > 0.f || (d == 0.f && di > dq)) q = i;
+        }
+        l = q;
+        if (l == start) break;
+        if (m < 8) res[m++] = q; else break;
+    }
+    out_count[r] = m;
+    for (int i = 0; i < 8; ++i) out_order[r * 8 + i] = i < m ? res[m - 1 - i] : 0;      // the reference returns the flipped list
+}
+
+extern "C" int cr_hull8(cr_ctx* ctx, const float* pts, int n, int32_t* order, int32_t* count, float* bump) {
+    CR_CHECK_ARG(ctx && n >= 0, "cr_hull8: bad args");
+    if (n == 0) return CR_OK;
+    CR_CHECK_ARG(pts && order && count && bump, "cr_hull8: NULL pointer");
+    hipLaunchKernelGGL(k_hull8, dim3((unsigned)cr_cdiv(n, 64)), dim3(64), 0, ctx->stream, pts, n, order, count, bump);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Soft polygon mask + focal loss of `segment_loss` (roi_heads.py:1030-1053 with fill_polygon, utils.py:472-502):
+//   m(px) = prod_e clamp((X - v1x)(v2y - v1y) - (Y - v1y)(v2x - v1x), 0, 1) over the hull edges e = (v1 -> v2),
+//   loss  = mean_px sigmoid_focal_loss(inputs = gt mask (0/1 used as a logit), targets = m; alpha 0.25, gamma 2)
+// -- yes, the ground-truth mask is the `inputs` argument in the reference.  One pass per RoI over the H x W pixels, forward
+// and the gradient w.r.t. the (<= 8) hull vertices in the same kernel (the reference materialises 8 full-size float masks
+// per RoI).  Ties of the clamp (argument exactly 0 or 1) pass half the gradient, like torch.max / torch.min.
+// grid (n, chunks); loss (n) and grad (n,8,2) are accumulated with atomics and must be zeroed by the caller.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_polygon_focal(const float* __restrict__ hull, const int* __restrict__ count,
+                                                       const unsigned char* __restrict__ masks, const int* __restrict__ mask_idx,
+                                                       int H, int W, float* __restrict__ loss, float* __restrict__ grad,
+                                                       int want_grad) {
+    __shared__ float red[4][17];
+    const int r = blockIdx.x;
+    const int k = count[r];
+    float vx[8], vy[8];
+    for (int e = 0; e < 8; ++e) { vx[e] = hull[(r * 8 + e) * 2]; vy[e] = hull[(r * 8 + e) * 2 + 1]; }
+    const unsigned char* mk = masks + (size_t)mask_idx[r] * H * W;
+    const int total = H * W;
+    float acc = 0.f, g[16];
+    for (int i = 0; i < 16; ++i) g[i] = 0.f;
+    const float inv_total = 1.f / (float)total;
+    for (int p = blockIdx.y * 256 + threadIdx.x; p < total; p += gridDim.y * 256) {
+        const float Y = (float)(p / W), X = (float)(p - (p / W) * W);
+        float c[8], dc[8], m = 1.f;
+        for (int e = 0; e < 8; ++e) {
+            c[e] = 1.f; dc[e] = 0.f;
+            if (e < k) {
+                const int e2 = e + 1 == k ? 0 : e + 1;
+                const float raw = (X - vx[e]) * (vy[e2] - vy[e]) - (Y - vy[e]) * (vx[e2] - vx[e]);
+                c[e] = fminf(fmaxf(raw, 0.f), 1.f);
+                dc[e] = (raw > 0.f && raw < 1.f) ? 1.f : ((raw == 0.f || raw == 1.f) ? 0.5f : 0.f);
+                m *= c[e];
+            }
+        }
+        const float x = mk[p] ? 1.f : 0.f;
+        const float ps = 1.f / (1.f + __expf(-x));
+        const float ce = fmaxf(x, 0.f) - x * m + log1pf(__expf(-fabsf(x)));
+        const float pt = ps * m + (1.f - ps) * (1.f - m);
+        const float om = 1.f - pt;
+        const float at = 0.25f * m + 0.75f * (1.f - m);
+        acc += at * ce * om * om * inv_total;
+        if (want_grad) {
+            const float dL = (-0.5f * ce * om * om + at * (-x) * om * om + at * ce * 2.f * om * (-(2.f * ps - 1.f))) * inv_total;
+            for (int e = 0; e < 8; ++e) {
+                if (e < k && dc[e] != 0.f) {
+                    float others = 1.f;
+                    for (int j = 0; j < 8; ++j) if (j != e && j < k) others *= c[j];
+                    const float dr = dL * others * dc[e];
+                    const int e2 = e + 1 == k ? 0 : e + 1;
+                    g[2 * e] += dr * (-(vy[e2] - vy[e]) + (Y - vy[e]));
+                    g[2 * e + 1] += dr * (-(X - vx[e]) + (vx[e2] - vx[e]));
+                    g[2 * e2] += dr * (-(Y - vy[e]));
+                    g[2 * e2 + 1] += dr * (X - vx[e]);
+                }
+            }
+        }
+    }
+    // block reduction of 17 values
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float vals[17];
+    vals[0] = acc;
+    for (int i = 0; i < 16; ++i) vals[1 + i] = g[i];
+    for (int i = 0; i < 17; ++i) {
+        float v = vals[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 17) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x == 0) atomicAdd(&loss[r], v);
+        else if (want_grad) atomicAdd(&grad[r * 16 + threadIdx.x - 1], v);
+    }
+}
+
+extern "C" int cr_polygon_focal(cr_ctx* ctx, const float* hull, const int32_t* count, const unsigned char* masks,
+                                const int32_t* mask_idx, int n, int H, int W, float* loss, float* grad) {
+    CR_CHECK_ARG(ctx && n >= 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 30), "cr_polygon_focal: bad args");
+    if (n == 0) return CR_OK;
+    CR_CHECK_ARG(hull && count && masks && mask_idx && loss, "cr_polygon_focal: NULL pointer");
+    const int chunks = (int)(cr_cdiv((int64_t)H * W, 256 * 16) < 64 ? cr_cdiv((int64_t)H * W, 256 * 16) : 64);
+    hipLaunchKernelGGL(k_polygon_focal, dim3((unsigned)n, (unsigned)(chunks < 1 ? 1 : chunks)), dim3(256), 0, ctx->stream, hull,
+                       count, masks, mask_idx, H, W, loss, grad, grad != nullptr);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

@@ -315,7 +315,8 @@ def forward_train(model, image_sizes, features, head_outputs, gt: GTBatch, meta)
     return losses
 
 
-def forward_train_weak(model, image_sizes, features, head_outputs, gt: GTBatch, Ks, im_scales_ratio, ground_maps, depth_maps):
+def forward_train_weak(model, image_sizes, features, head_outputs, gt: GTBatch, Ks, im_scales_ratio, ground_maps, depth_maps,
+                       masks=None, mask_keys=None):
     """RCNN3D_combined_features.forward in training mode (rcnn3d.py:362-414): RPN losses, proposals, RoI sampling and
     the box head exactly as `forward_train` (fused, static shapes, no host sync); the weak cube losses of
     ROIHeads3DScore then run on the COMPACTED foreground RoIs -- their number per image is the one value the host
@@ -350,6 +351,6 @@ def forward_train_weak(model, image_sizes, features, head_outputs, gt: GTBatch, 
     gidx = pick(samp["gt_idx"])
     lc, _, _ = rh.weak_losses_flat(cube_pooled.flatten(1)[sel], pick(samp["classes"]), pick(samp["boxes"]), gt.boxes[img, gidx],
                                    gt.boxes3D[img, gidx], gt.poses[img, gidx], counts, Ks, image_sizes, im_scales_ratio,
-                                   ground_maps, depth_maps)
+                                   ground_maps, depth_maps, masks, mask_keys)
     losses.update(lc)
     return losses

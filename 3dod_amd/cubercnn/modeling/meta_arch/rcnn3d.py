@@ -221,16 +221,24 @@ class RCNN3D_combined_features(RCNN3D):
         filled = [dict(b, ground_map=torch.tensor([[1]])) if b.get("ground_map") is None else b for b in batched_inputs]
         return self._maps(filled, "ground_map"), depth_maps
 
+    def _images_raw(self, batched_inputs):
+        """rcnn3d.py:369: the un-normalised RGB images, padded to one size (only needed by a segmentor)"""
+        if not (self.training and getattr(self.roi_heads, "needs_masks", False)):
+            return None
+        return ImageList.from_tensors([b["image"].to(self.device)[[2, 1, 0]] for b in batched_inputs])
+
     def _run_roi_heads(self, images, features, proposals, Ks, im_scales_ratio, targets, batched_inputs):
         ground_maps, depth_maps = self._scene_maps(batched_inputs) if self.training else (None, None)
-        return self.roi_heads(images, None, ground_maps, depth_maps, features, proposals, Ks, im_scales_ratio, targets)
+        return self.roi_heads(images, self._images_raw(batched_inputs), ground_maps, depth_maps, features, proposals, Ks,
+                              im_scales_ratio, targets)
 
     def _forward_dense(self, images, features, head_outputs, gt_instances, Ks, im_scales_ratio, batched_inputs):
         from ..dense_train import forward_train_weak, GTBatch
         ground_maps, depth_maps = self._scene_maps(batched_inputs)
         im_dims = [tuple(s) for s in images.image_sizes]
+        masks, keys = self.roi_heads.object_masks(self._images_raw(batched_inputs), gt_instances)
         return forward_train_weak(self, im_dims, features, head_outputs, GTBatch(gt_instances, self.device), Ks,
-                                  im_scales_ratio, ground_maps, depth_maps)
+                                  im_scales_ratio, ground_maps, depth_maps, masks, keys)
 
 
 @META_ARCH_REGISTRY.register()

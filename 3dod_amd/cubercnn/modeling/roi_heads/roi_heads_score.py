@@ -9,9 +9,11 @@ from 2D boxes, a metric depth map and a ground mask instead of 3D labels:
     dims                hinge on the class prior of (w, h, l)
 
 All of them are batched tensor expressions over the foreground RoIs (weak_losses.py); the per-box depth median and the
-plane fit are HIP kernels.  The 'segmentation' and 'depth' losses need SAM masks of every object
-(roi_heads.py:881-883, generate_ground_segmentations.init_segmentation) -- the segmentation model is out of scope
- and both are rejected at construction.
+plane fit are HIP kernels.
+    segmentation        hull of the projected corners as a soft polygon mask vs the object's mask (focal loss; one fused kernel)
+    depth               depth extent of the cuboid vs the 10..90 % depth range under the object's mask
+The last two need a mask per object: the reference runs SAM-HQ on the GT boxes (roi_heads.py:881-883); that model is out
+of scope, so the masks come from a pluggable `segmentor` callable.
 """
 from typing import Dict
 
@@ -39,10 +41,13 @@ class ROIHeads3DScore(ROIHeads3D):
         self.loss_functions = list(cfg.loss_functions)
         assert all(x in POSSIBLE_LOSSES for x in self.loss_functions), \
             f'loss functions must be in {POSSIBLE_LOSSES}, but was {self.loss_functions}'
-        if 'segmentation' in self.loss_functions or 'depth' in self.loss_functions:
-            raise NotImplementedError("the 'segmentation' and 'depth' losses need the SAM segmentor (SURVEY 8(f) N4), which "
-                                      "is not built; remove them from cfg.loss_functions")
+        # 'segmentation' / 'depth' need one mask per ground-truth object.  The reference gets them from SAM-HQ prompted with
+        # the GT boxes (object_masks, roi_heads.py:1000-1016; init_segmentation); that model is not built,
+        # so the masks come from a pluggable callable: segmentor(images_raw (B,3,H,W) uint8 RGB, targets) -> list per
+        # image of (N_i,1,H,W) bool tensors.  Without one these two losses raise at the first training step.
         self.segmentor = None
+        self._hull_fn = None
+        self._focal_fn = None
         # test hooks: CPU restatements (oracle/weak.py) of the two kernels; None = the HIP path, which refuses CPU tensors
         self._median_fn = None
         self._plane_cls = None
@@ -55,13 +60,33 @@ class ROIHeads3DScore(ROIHeads3D):
             proposals = self.label_and_sample_proposals(proposals, targets)
             losses = self._forward_box(features, proposals)
             if self.loss_w_3d > 0:
-                instances_3d, losses_cube = self._forward_cube(features, proposals, Ks, im_dims, im_scales_ratio, None, None,
+                masks, keys = self.object_masks(images_raw, targets)
+                instances_3d, losses_cube = self._forward_cube(features, proposals, Ks, im_dims, im_scales_ratio, masks, keys,
                                                                ground_maps, depth_maps)
                 losses.update(losses_cube)
             else:
                 instances_3d = None
             return instances_3d, losses
         return ROIHeads3D.forward(self, images, features, proposals, Ks, im_scales_ratio, targets)
+
+    @property
+    def needs_masks(self):
+        return 'segmentation' in self.loss_functions or 'depth' in self.loss_functions
+
+    def object_masks(self, images_raw, targets):
+        """roi_heads.py:864-885,1000-1016: (masks (Nm,H,W) uint8 over all GT objects of the batch in target order, the
+        gt_boxes3D[:, 0] value of each -- the key the reference looks masks up by) or (None, None)."""
+        if not self.needs_masks:
+            return None, None
+        if self.segmentor is None:
+            raise RuntimeError("cfg.loss_functions asks for 'segmentation' / 'depth' but no segmentor is set: assign a callable "
+                               "(images_raw, targets) -> per-image (N,1,H,W) masks to model.roi_heads.segmentor")
+        raw = images_raw.tensor if hasattr(images_raw, "tensor") else images_raw
+        per_image = self.segmentor(raw, targets)
+        masks = torch.cat([m.reshape(-1, *m.shape[-2:]) for m in per_image]).to(torch.uint8).contiguous()
+        keys = torch.cat([t.gt_boxes3D[:, 0] for t in targets])
+        assert masks.shape[0] == keys.shape[0], "one mask per ground-truth object"
+        return masks, keys
 
     # ------------------------------------------------------------------ cube branch (roi_heads.py:1319-1820)
     def _forward_cube(self, features, instances, Ks, im_current_dims, im_scales_ratio, masks_all_images=None,
@@ -86,10 +111,15 @@ class ROIHeads3DScore(ROIHeads3D):
             return instances, {}
         cube_features = self.cube_pooler(feats, proposal_boxes_scaled).flatten(1)
         num_boxes_per_image = [len(i) for i in proposals]
+        masks, mask_keys = masks_all_images, first_occurrence_indices
+        if isinstance(masks, (list, tuple)):                      # the reference's form: list of (1,H,W) masks + {key: index}
+            masks = torch.cat([m.reshape(-1, *m.shape[-2:]) for m in masks]).to(torch.uint8).contiguous()
+            mask_keys = torch.tensor([k for k, _ in sorted(mask_keys.items(), key=lambda kv: kv[1])], dtype=torch.float32,
+                                     device=masks.device)
         losses, cube_3D, cube_pose = self.weak_losses_flat(
             cube_features, box_classes, torch.cat([b.tensor for b in proposal_boxes], dim=0),
             torch.cat([x.gt_boxes.tensor for x in proposals]), gt_boxes3D, gt_poses, num_boxes_per_image, Ks,
-            im_current_dims, im_scales_ratio, ground_maps, depth_maps)
+            im_current_dims, im_scales_ratio, ground_maps, depth_maps, masks, mask_keys)
 
         # ---- packing of the decoded cuboids (roi_heads.py:1763-1815)
         pred_instances = [Instances(image_size) for image_size in im_current_dims]
@@ -107,7 +137,7 @@ class ROIHeads3DScore(ROIHeads3D):
         return pred_instances, losses
 
     def weak_losses_flat(self, cube_features, box_classes, src_boxes, gt_boxes, gt_boxes3D, gt_poses, num_boxes_per_image,
-                         Ks, im_current_dims, im_scales_ratio, ground_maps, depth_maps):
+                         Ks, im_current_dims, im_scales_ratio, ground_maps, depth_maps, masks=None, mask_keys=None):
         """decode + the weak losses on a flat, image-major list of n foreground RoIs (roi_heads.py:1366-1760).
         cube_features (n, C*7*7); box_classes (n); src_boxes / gt_boxes (n,4); gt_boxes3D (n,9); gt_poses (n,3,3);
         num_boxes_per_image: host ints.  Returns (losses, cube_3D (n,9), cube_pose (n,3,3))."""
@@ -127,7 +157,8 @@ class ROIHeads3DScore(ROIHeads3D):
             if ground_maps is not None and tuple(ground_maps.image_sizes[i]) == (1, 1):
                 gconf = 0.1
             rows.append(k.flatten().tolist() + [float(torch.as_tensor(Ks[i])[1][1]), float(im_scales_ratio[i]), float(d[0])]
-                        + [float(v) for v in W._int_clamp_bounds(d[0]) + W._int_clamp_bounds(d[1])] + [gconf])
+                        + [float(v) for v in W._int_clamp_bounds(d[0]) + W._int_clamp_bounds(d[1])] + [gconf]
+                        + [float(int(d[0] - 1)), float(int(d[1] - 1))])
         table = torch.tensor(rows, dtype=torch.float32)
         img_host = torch.tensor([i for i, num in enumerate(num_boxes_per_image) for _ in range(num)], dtype=torch.int64)
         if device.type == "cuda":
@@ -189,9 +220,20 @@ class ROIHeads3DScore(ROIHeads3D):
         cube_y3d = cube_z * (cube_y - K[:, 1, 2]) / K[:, 1, 1]
         cubes = torch.cat((cube_x3d.unsqueeze(1), cube_y3d.unsqueeze(1), cube_z.unsqueeze(1), cube_dims,
                            cube_pose.reshape(n, 9)), dim=1)
-        proj_boxes = W.corners_to_boxes(W.project_cubes_to_corners(cubes.unsqueeze(1), K, clamp_bounds))[:, 0]
+        corners2d = W.project_cubes_to_corners(cubes.unsqueeze(1), K, clamp_bounds)
+        proj_boxes = W.corners_to_boxes(corners2d)[:, 0]
         loss_iou = loss_pose = loss_z = loss_dims_w = loss_dims_h = loss_dims_l = None
-        loss_pseudo_gt_z = loss_ground_rot = None
+        loss_pseudo_gt_z = loss_ground_rot = loss_seg = loss_depth = None
+        if masks is not None and self.needs_masks:
+            mask_idx = W.mask_index_of(gt_boxes3D[:, 0], mask_keys.to(gt_boxes3D.dtype))
+            if 'segmentation' in self.loss_functions:
+                # corners clamped into the image (x with dims[0]-1, y with dims[1]-1, as in the reference :1572-1575)
+                bube = torch.stack((torch.minimum(corners2d[:, 0, :, 0].clamp(min=0), per_box[:, 17:18]),
+                                    torch.minimum(corners2d[:, 0, :, 1].clamp(min=0), per_box[:, 18:19])), dim=-1)
+                loss_seg = W.segment_loss(masks, bube, mask_idx, self._hull_fn, self._focal_fn)
+            if 'depth' in self.loss_functions:
+                corners_z = util.get_cuboid_verts_faces(cubes[:, :6], cube_pose)[0][..., 2]
+                loss_depth = W.depth_range_loss(masks, mask_idx, depth_maps, corners_z, gt_boxes, img)
         if 'iou' in self.loss_functions:
             loss_iou = W.generalized_box_iou_loss(gt_boxes, proj_boxes, reduction='none').view(n, -1).mean(dim=1)
         if 'pose_alignment' in self.loss_functions:
@@ -221,7 +263,8 @@ class ROIHeads3DScore(ROIHeads3D):
 
         with torch.no_grad():
             total = 0
-            for l, w in ((loss_iou, self.loss_w_iou), (loss_pose, self.loss_w_pose), (loss_z, self.loss_w_z),
+            for l, w in ((loss_iou, self.loss_w_iou), (loss_seg, self.loss_w_seg), (loss_depth, self.loss_w_depth),
+                         (loss_pose, self.loss_w_pose), (loss_z, self.loss_w_z),
                          (loss_pseudo_gt_z, self.loss_w_z), (loss_dims_w, self.loss_w_dims), (loss_dims_h, self.loss_w_dims),
                          (loss_dims_l, self.loss_w_dims)):
                 if l is not None:
@@ -243,7 +286,8 @@ class ROIHeads3DScore(ROIHeads3D):
                                    smoothing_hint=False)
 
         named = [('loss_iou', loss_iou, self.loss_w_iou), ('loss_pose', loss_pose, self.loss_w_pose),
-                 ('loss_normal_vec', loss_ground_rot, self.loss_w_normal_vec), ('loss_z', loss_z, self.loss_w_z),
+                 ('loss_normal_vec', loss_ground_rot, self.loss_w_normal_vec), ('loss_seg', loss_seg, self.loss_w_seg),
+                 ('loss_depth', loss_depth, self.loss_w_depth), ('loss_z', loss_z, self.loss_w_z),
                  ('loss_pseudo_gt_z', loss_pseudo_gt_z, self.loss_w_z), ('loss_dims_w', loss_dims_w, self.loss_w_dims),
                  ('loss_dims_h', loss_dims_h, self.loss_w_dims), ('loss_dims_l', loss_dims_l, self.loss_w_dims)]
         if self.use_confidence > 0:

@@ -234,3 +234,48 @@ def dim_hinge_loss(prior_mean, prior_std, dimensions):
         return None, None, None
     s = ((dimensions - prior_mean).abs() / prior_std - 1.0).clamp(min=0)
     return s[:, 0], s[:, 1], s[:, 2]
+
+
+# ---------------------------------------------------------------------------------------------- losses that need masks
+def mask_index_of(roi_keys, mask_keys):
+    """`first_occurrence_indices` of roi_heads.py:866-881 without the host dictionary: the mask of a RoI is the FIRST object
+    (over all images, in target order) whose gt_boxes3D[:, 0] equals the RoI's -- objects sharing that value share a
+    mask, as in the reference."""
+    hit = roi_keys[:, None] == mask_keys[None, :]
+    return torch.argmax(hit.to(torch.int32), dim=1)
+
+
+def segment_loss(masks, bube_corners, mask_idx, hull_fn=None, focal_fn=None):
+    """:1030-1053 (loss='focal'): hull of the 8 projected corners -> soft polygon mask -> sigmoid focal loss against the
+    object's mask (the mask is the `inputs` argument of the focal loss, as in the reference), mean over the pixels.
+    masks (Nm,H,W) uint8; bube_corners (n,8,2) already clamped to the image; mask_idx (n)."""
+    if hull_fn is None or focal_fn is None:
+        from .... import geometry as geo
+        hull_fn, focal_fn = hull_fn or geo.hull8, focal_fn or geo.polygon_focal
+    order, count, bump = hull_fn(bube_corners)
+    pts = bube_corners + bump[..., None]
+    hull = torch.gather(pts, 1, order[..., None].expand(-1, -1, 2))
+    return focal_fn(hull, count, masks, mask_idx)
+
+
+def depth_range_loss(masks, mask_idx, depth_maps, corners_z, gt_boxes, img):
+    """:1281-1304: |(q90 - q10 of the depth under the object's mask) - (depth extent of the predicted cuboid)|; the
+    depth map is resampled (bilinear, align_corners) to the mask's size when they differ; an empty mask falls back to the
+    2D box.  One small sort per RoI, like the reference (torch.quantile)."""
+    import torch.nn.functional as F
+    pred = corners_z.max(dim=1).values - corners_z.min(dim=1).values
+    gts = []
+    cache = {}
+    for r in range(pred.shape[0]):
+        i = int(img[r])
+        m = masks[mask_idx[r]].bool()
+        if i not in cache:
+            d = depth_maps[i]
+            cache[i] = d if d.shape == m.shape else F.interpolate(d[None, None], size=m.shape, mode='bilinear', align_corners=True)[0, 0]
+        d = cache[i]
+        vals = d[m]
+        if vals.numel() == 0:
+            b = gt_boxes[r].long()
+            vals = d[b[1]:b[3], b[0]:b[2]]
+        gts.append(torch.quantile(vals.flatten(), 0.9) - torch.quantile(vals.flatten(), 0.1))
+    return (torch.stack(gts) - pred).abs()

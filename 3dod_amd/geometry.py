@@ -148,3 +148,46 @@ def box_median(depth, boxes, img):
     _lib.check(lib.cr_box_median(_lib.ctx_for(d.device), _lib.ptr(d), d.shape[0], d.shape[1], d.shape[2], _lib.ptr(b),
                                  _lib.ptr(im), b.shape[0], _lib.ptr(out)), "cr_box_median")
     return out
+
+
+def hull8(points):
+    """convex hull of each RoI's 8 projected corners in the reference's order (cr_hull8): points (n,8,2) f32 ->
+    order (n,8) int64, count (n) int32, bump (n,8) f32"""
+    lib = _lib.load()
+    if not points.is_cuda:
+        raise _lib.CrError("hull8: expected CUDA(HIP) tensors; 3dod_amd has no CPU path")
+    p = points.detach().float().contiguous()
+    n = p.shape[0]
+    order = torch.empty((n, 8), dtype=torch.int32, device=p.device)
+    count = torch.empty((n,), dtype=torch.int32, device=p.device)
+    bump = torch.empty((n, 8), dtype=torch.float32, device=p.device)
+    _lib.check(lib.cr_hull8(_lib.ctx_for(p.device), _lib.ptr(p), n, _lib.ptr(order), _lib.ptr(count), _lib.ptr(bump)), "cr_hull8")
+    return order.long(), count, bump
+
+
+class _PolygonFocal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hull, count, masks, mask_idx):
+        lib = _lib.load()
+        h = hull.detach().float().contiguous()
+        n = h.shape[0]
+        loss = torch.zeros((n,), dtype=torch.float32, device=h.device)
+        grad = torch.zeros((n, 8, 2), dtype=torch.float32, device=h.device) if hull.requires_grad else None
+        _lib.check(lib.cr_polygon_focal(_lib.ctx_for(h.device), _lib.ptr(h), _lib.ptr(count), _lib.ptr(masks), _lib.ptr(mask_idx), n,
+                                        masks.shape[1], masks.shape[2], _lib.ptr(loss), _lib.ptr(grad) if grad is not None else None),
+                   "cr_polygon_focal")
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.grad * g.view(-1, 1, 1)) if ctx.grad is not None else None, None, None, None
+
+
+def polygon_focal(hull, count, masks, mask_idx):
+    """segment_loss per RoI (cr_polygon_focal): hull (n,8,2) ordered vertices (differentiable), count (n) int32,
+    masks (Nm,H,W) uint8, mask_idx (n) int32 -> (n,) float32"""
+    if not hull.is_cuda:
+        raise _lib.CrError("polygon_focal: expected CUDA(HIP) tensors; 3dod_amd has no CPU path")
+    assert masks.dtype == torch.uint8 and masks.dim() == 3 and masks.is_contiguous()
+    return _PolygonFocal.apply(hull, count.to(torch.int32).contiguous(), masks, mask_idx.to(torch.int32).contiguous())

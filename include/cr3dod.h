@@ -106,6 +106,17 @@ int cr_ransac_plane(cr_ctx* ctx, const float* pts, int64_t Q, const int32_t* tri
 int cr_box_median(cr_ctx* ctx, const float* depth, int B, int H, int W, const int32_t* boxes, const int32_t* img, int n,
                   float* out);
 
+/* Convex hull of each RoI's 8 projected corners in the reference's order and tie rules (jarvis_march,
+ * ProposalNetwork/utils/utils.py:424-470): pts (n,8,2) f32 -> order (n,8) int32 (hull vertices first), count (n) int32,
+ * bump (n,8) f32 = the constant the reference adds to both coordinates of duplicated points (:427-433). */
+int cr_hull8(cr_ctx* ctx, const float* pts, int n, int32_t* order, int32_t* count, float* bump);
+/* segment_loss of ROIHeads3DScore (roi_heads.py:1030-1053) for n RoIs: soft polygon mask of the hull (fill_polygon,
+ * utils.py:472-502) against the object's mask through sigmoid_focal_loss(inputs = mask, targets = polygon), mean over the
+ * H x W pixels.  hull (n,8,2) f32 ordered vertices, count (n); masks (Nm,H,W) uint8, mask_idx (n) int32.
+ * loss (n) f32 and grad (n,8,2) f32 (d loss / d hull vertex, or NULL) are ACCUMULATED: zero them first. */
+int cr_polygon_focal(cr_ctx* ctx, const float* hull, const int32_t* count, const unsigned char* masks, const int32_t* mask_idx,
+                     int n, int H, int W, float* loss, float* grad);
+
 /* ---- Depth-Anything-V2 forward (DINOv2 ViT + DPT head), the ops that are not GEMMs / convolutions --------------- */
 /* softmax(q k^T * scale) v per (batch, head) on the packed output of the qkv linear: qkv (B,N,3,H,D) bf16, out (B,N,H,D)
  * bf16, D = 64.  Flash-attention schedule on MFMA (no N x N matrix in memory).  Replaces Attention.forward /

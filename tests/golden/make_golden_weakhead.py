@@ -45,6 +45,20 @@ ref_rh.generalized_box_iou_loss = my_weak.generalized_box_iou_loss
 ref_rh.so3_relative_angle = my_weak.so3_relative_angle
 ref_rh.Plane_cuda = ref_plane.Plane
 ref_rh.util.R_from_allocentric = ref_math.R_from_allocentric
+
+
+def _sigmoid_focal_loss(inputs, targets, alpha=0.25, gamma=2, reduction="none"):
+    """torchvision.ops.sigmoid_focal_loss [third-party, restated]"""
+    p = torch.sigmoid(inputs)
+    ce = torch.nn.functional.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss
+
+
+ref_rh.sigmoid_focal_loss = _sigmoid_focal_loss
 storage = d2.EventStorage(1)            # iter 1: the 3D-IoU logging branch (pytorch3d) is not taken
 ref_rh.get_event_storage = lambda: storage
 torch.set_num_threads(1)
@@ -121,7 +135,25 @@ def make_case(seed, K_classes=50):
     return instances, Ks, ratios, head, priors, depth_maps, ground_maps
 
 
-def run(seed, loss_functions):
+def object_masks(batch, size=512):
+    """one mask per ground-truth object of every image (target order): its 2D box shrunk by 15 %, with a corner cut off;
+    the object with index 1 of every image gets an EMPTY mask (the depth loss then falls back to the box)"""
+    masks, keys = [], []
+    for b in batch:
+        gt = b["instances"]
+        for j, (box, k) in enumerate(zip(gt.gt_boxes.tensor.tolist(), gt.gt_boxes3D[:, 0].tolist())):
+            x1, y1, x2, y2 = box
+            cx, cy, w, h = (x1 + x2) / 2, (y1 + y2) / 2, (x2 - x1) * 0.85, (y2 - y1) * 0.85
+            m = torch.zeros(1, size, size, dtype=torch.bool)
+            if j != 1:
+                m[0, int(cy - h / 2):int(cy + h / 2), int(cx - w / 2):int(cx + w / 2)] = True
+                m[0, int(cy - h / 2):int(cy - h / 4), int(cx - w / 2):int(cx - w / 4)] = False
+            masks.append(m)
+            keys.append(k)
+    return masks, keys
+
+
+def run(seed, loss_functions, with_masks=False):
     instances, Ks, ratios, head, priors, depth_maps, ground_maps = make_case(seed)
     leaves = {k: v.clone().requires_grad_(True) for k, v in head.items()}
     pose = my_util.rotation_6d_to_matrix(leaves["pose6"].view(-1, 6)).view(leaves["pose6"].shape[0], -1, 3, 3)
@@ -141,7 +173,7 @@ def run(seed, loss_functions):
     C = ref_rh.ROIHeads3DScore
     for name in ("l1_loss", "chamfer_loss", "scale_proposals", "safely_reduce_losses", "pose_loss",
                  "normal_vector_from_maps", "z_loss", "pseudo_gt_z_box_loss", "dim_loss", "pseudo_gt_z_point_loss",
-                 "normal_to_rotation"):
+                 "normal_to_rotation", "segment_loss", "depth_range_loss", "dice_loss"):
         setattr(self, name, types.MethodType(getattr(C, name), self))
     im_dims = [(512, 512)] * 3
     first_occurrence = {}
@@ -150,7 +182,14 @@ def run(seed, loss_functions):
             first_occurrence.setdefault(e, len(first_occurrence))
     TRIPLES.clear()
     random.seed(seed)
-    pred_instances, losses = C._forward_cube(self, {"p2": None}, instances, Ks, im_dims, ratios, None, first_occurrence,
+    masks_all = None
+    if with_masks:
+        batch = syn.make_batch(3, seed)
+        masks_all, keys = object_masks(batch)
+        first_occurrence = {}
+        for k in keys:                                   # roi_heads.py:866-881
+            first_occurrence.setdefault(k, len(first_occurrence))
+    pred_instances, losses = C._forward_cube(self, {"p2": None}, instances, Ks, im_dims, ratios, masks_all, first_occurrence,
                                              ground_maps, depth_maps)
     rec = {"in_" + k: v.numpy() for k, v in head.items()}
     rec.update(priors=priors.numpy(), ratios=np.array(ratios, np.float32), Ks=torch.stack(Ks).numpy(),
@@ -161,7 +200,7 @@ def run(seed, loss_functions):
                gt_classes=torch.cat([i.gt_classes for i in instances]).numpy(),
                gt_boxes3D=torch.cat([i.gt_boxes3D for i in instances]).numpy(),
                gt_poses=torch.cat([i.gt_poses for i in instances]).numpy(),
-               depth_seed=np.array(seed), ground_sizes=np.array(ground_maps.image_sizes),
+               depth_seed=np.array(seed), ground_sizes=np.array(ground_maps.image_sizes), with_masks=np.array(with_masks),
                loss_functions=np.array(loss_functions))
     if TRIPLES:
         rec["triples"] = np.array(TRIPLES, dtype=np.int32)           # (images, 1000, 3)
@@ -181,7 +220,9 @@ def run(seed, loss_functions):
 if __name__ == "__main__":
     a = run(21, ['dims', 'pose_alignment', 'pose_ground', 'iou', 'z', 'z_pseudo_gt_patch'])
     b = run(22, ['dims', 'pose_ground2', 'iou', 'z_pseudo_gt_center'])
+    c = run(23, ['segmentation', 'depth', 'iou', 'dims'], with_masks=True)
     np.savez_compressed(os.path.join(HERE, "weakhead_a.npz"), **a)
     np.savez_compressed(os.path.join(HERE, "weakhead_b.npz"), **b)
-    for name, r in (("a", a), ("b", b)):
+    np.savez_compressed(os.path.join(HERE, "weakhead_c.npz"), **c)
+    for name, r in (("a", a), ("b", b), ("c", c)):
         print(name, {k: np.asarray(v).reshape(-1).tolist() for k, v in r.items() if k.startswith("loss_")})

@@ -52,6 +52,23 @@ def replay_generator(seed, K_classes=50, n_per=(7, 1, 9)):
     return g, batch
 
 
+def object_masks(batch, size=512):
+    """must mirror tests/golden/make_golden_weakhead.py:object_masks"""
+    masks, keys = [], []
+    for b in batch:
+        gt = b["instances"]
+        for j, (box, k) in enumerate(zip(gt.gt_boxes.tensor.tolist(), gt.gt_boxes3D[:, 0].tolist())):
+            x1, y1, x2, y2 = box
+            cx, cy, w, h = (x1 + x2) / 2, (y1 + y2) / 2, (x2 - x1) * 0.85, (y2 - y1) * 0.85
+            m = torch.zeros(1, size, size, dtype=torch.bool)
+            if j != 1:
+                m[0, int(cy - h / 2):int(cy + h / 2), int(cx - w / 2):int(cx + w / 2)] = True
+                m[0, int(cy - h / 2):int(cy - h / 4), int(cx - w / 2):int(cx - w / 4)] = False
+            masks.append(m)
+            keys.append(k)
+    return masks, keys
+
+
 def build_head(rec, dev, hooks):
     """an ROIHeads3DScore shell (no conv trunk: pooler and cube head are replaced by the recorded head outputs)"""
     self = score.ROIHeads3DScore.__new__(score.ROIHeads3DScore)
@@ -65,7 +82,9 @@ def build_head(rec, dev, hooks):
         setattr(self, k, v)
     self.train()
     self.priors_dims_per_cat = torch.nn.Parameter(torch.tensor(rec["priors"], device=dev))
-    self._median_fn, self._plane_cls = hooks
+    self._median_fn, self._plane_cls = hooks[:2]
+    self._hull_fn, self._focal_fn = hooks[2:] if len(hooks) > 2 else (None, None)
+    self.segmentor = None
     self._ransac_triples = [torch.as_tensor(t, device=dev) for t in rec["triples"]] if "triples" in rec else None
     return self
 
@@ -97,8 +116,15 @@ def run_case(name, dev, hooks):
         instances.append(inst)
         start += m
     Ks_t = [torch.tensor(k) for k in rec["Ks"]]
+    masks = first = None
+    if "with_masks" in rec and bool(rec["with_masks"]):
+        mlist, keys = object_masks(batch)
+        masks = [m.to(dev) for m in mlist]
+        first = {}
+        for k in keys:
+            first.setdefault(k, len(first))
     with d2.EventStorage(1) as storage:
-        pred, losses = self._forward_cube({"p2": None}, instances, Ks_t, [(512, 512)] * 3, rec["ratios"].tolist(), None, None,
+        pred, losses = self._forward_cube({"p2": None}, instances, Ks_t, [(512, 512)] * 3, rec["ratios"].tolist(), masks, first,
                                           ground_maps, depth_maps)
         sum(losses.values()).sum().backward()
     return rec, pred, losses, leaves
@@ -120,10 +146,10 @@ def check_case(name, dev, hooks, tol=2e-4):
         assert np.allclose(got, rec["out_" + f], rtol=1e-4, atol=1e-4), f
 
 
-@pytest.mark.parametrize("name", ["weakhead_a.npz", "weakhead_b.npz"])
+@pytest.mark.parametrize("name", ["weakhead_a.npz", "weakhead_b.npz", "weakhead_c.npz"])
 def test_forward_cube_matches_reference_cpu(name):
     from oracle import weak as ow
-    check_case(name, torch.device("cpu"), (ow.box_median, ow.Plane))
+    check_case(name, torch.device("cpu"), (ow.box_median, ow.Plane, ow.hull8, ow.polygon_focal))
 
 
 def test_product_path_refuses_cpu():
