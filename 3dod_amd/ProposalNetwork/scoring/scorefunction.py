@@ -46,3 +46,25 @@ def score_point_cloud(point_cloud, cubes, K=None, segmentation_mask=None):
              (pc[:, 1].view(-1, 1) > lo[1]) & (pc[:, 1].view(-1, 1) < hi[1]) & \
              (pc[:, 2].view(-1, 1) > lo[2]) & (pc[:, 2].view(-1, 1) < hi[2])
     return inside.sum(0)
+
+
+def _segment_terms(segmentation_mask, bube_corners, counts_fn=None):
+    """intersection / union of every proposal's rasterised hull with the object mask on the [::4, ::4] grid"""
+    corners = bube_corners.to(device=segmentation_mask.device).squeeze(0)
+    counts = (counts_fn or geo.segment_counts)(corners, segmentation_mask, 4)
+    inter = counts[:, 1].to(torch.float32)
+    union = (counts[:, 0] + (segmentation_mask[::4, ::4] != 0).sum() - counts[:, 1]).to(torch.float32)
+    return inter, union
+
+
+def score_segmentation(segmentation_mask, bube_corners, counts_fn=None):
+    """scorefunction.py:88-105 with mask_iou (utils.py:230-239), MABO only: IoU of the proposal's filled convex hull and
+    the object mask, both sampled every 4th pixel; 0 where they do not intersect.  (1,P,8,2) corners -> (P,)"""
+    inter, union = _segment_terms(segmentation_mask, bube_corners, counts_fn)
+    return torch.where(inter > 0, inter / union.clamp(min=1), torch.zeros_like(inter))
+
+
+def score_mod_segmentation(segmentation_mask, bube_corners, counts_fn=None):
+    """scorefunction.py:107-124 with mod_mask_iou (utils.py:241-250): intersection^5 / union (not a standard IoU)"""
+    inter, union = _segment_terms(segmentation_mask, bube_corners, counts_fn)
+    return torch.where(inter > 0, inter ** 5 / union.clamp(min=1), torch.zeros_like(inter))

@@ -250,3 +250,98 @@ extern "C" int cr_polygon_focal(cr_ctx* ctx, const float* hull, const int32_t* c
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Mask scores of the 1000 proposals of one object (MABO diagnostics): score_segmentation / score_mod_segmentation,
+// ProposalNetwork/scoring/scorefunction.py:88-126 with mask_iou / mod_mask_iou, ProposalNetwork/utils/utils.py:230-250.
+// The reference rasterises every proposal on the host: cv2.convexHull(8 projected corners) -> int32 -> cv2.fillPoly on a
+// full-size canvas -> [::4, ::4] -> intersection / union with the object mask [cv2: third-party, absent; restated].
+// Here one workgroup per proposal: gift-wrapped hull of the 8 points (float), vertices truncated to int32 like the numpy
+// cast, and a sample (4i, 4j) belongs to the filled polygon iff it lies inside or ON the closed integer polygon (exact
+// integer cross products); only the samples in the polygon's bounding box are visited.  cv2.fillPoly additionally paints
+// the Bresenham lines of the edges, which can add samples up to half a pixel outside the exact polygon -- at a stride of 4
+// these are rare; parity with cv2 is unpinned.
+// counts (P,2) int32 = {samples in polygon, samples in polygon AND mask}; the IoU arithmetic is done by the caller.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_segment_counts(const float* __restrict__ corners, int P, const unsigned char* __restrict__ mask,
+                                                        int H, int W, int stride, int* __restrict__ counts) {
+    __shared__ int hx[8], hy[8], hk, bb[4];
+    __shared__ int s_cnt[2];
+    const int p = blockIdx.x;
+    if (threadIdx.x == 0) {
+        float x[8], y[8];
+        bool finite = true;
+        for (int i = 0; i < 8; ++i) {
+            x[i] = corners[(p * 8 + i) * 2]; y[i] = corners[(p * 8 + i) * 2 + 1];
+            finite &= (x[i] == x[i]) && (y[i] == y[i]) && fabsf(x[i]) < 1e9f && fabsf(y[i]) < 1e9f;
+        }
+        int m = 0;
+        if (finite) {
+            int start = 0;
+            for (int i = 1; i < 8; ++i) if (x[i] < x[start] || (x[i] == x[start] && y[i] < y[start])) start = i;
+            int l = start;
+            for (int step = 0; step < 8; ++step) {
+                hx[m] = (int)x[l]; hy[m] = (int)y[l]; ++m;                 // (int): truncation toward zero, like astype(int32)
+                int q = -1;
+                for (int i = 0; i < 8; ++i) {
+                    if (x[i] == x[l] && y[i] == y[l]) continue;            // the point itself and its duplicates
+                    if (q < 0) { q = i; continue; }
+                    const float d = (x[i] - x[l]) * (y[q] - y[l]) - (y[i] - y[l]) * (x[q] - x[l]);
+                    const float di = (x[i] - x[l]) * (x[i] - x[l]) + (y[i] - y[l]) * (y[i] - y[l]);
+                    const float dq = (x[q] - x[l]) * (x[q] - x[l]) + (y[q] - y[l]) * (y[q] - y[l]);
+                    if (d > 0.f || (d == 0.f && di > dq)) q = i;
+                }
+                if (q < 0 || (x[q] == x[start] && y[q] == y[start])) break;
+                l = q;
+            }
+        }
+        hk = m;
+        int x0 = 1 << 30, x1 = -(1 << 30), y0 = 1 << 30, y1 = -(1 << 30);
+        for (int i = 0; i < m; ++i) { x0 = min(x0, hx[i]); x1 = max(x1, hx[i]); y0 = min(y0, hy[i]); y1 = max(y1, hy[i]); }
+        bb[0] = max(x0, 0); bb[1] = min(x1, W - 1); bb[2] = max(y0, 0); bb[3] = min(y1, H - 1);
+        s_cnt[0] = 0; s_cnt[1] = 0;
+    }
+    __syncthreads();
+    const int k = hk;
+    int in_poly = 0, in_both = 0;
+    if (k >= 1 && bb[0] <= bb[1] && bb[2] <= bb[3]) {
+        const int i0 = (bb[0] + stride - 1) / stride, i1 = bb[1] / stride, j0 = (bb[2] + stride - 1) / stride, j1 = bb[3] / stride;
+        const int nx = i1 - i0 + 1, ny = j1 - j0 + 1;
+        if (nx > 0 && ny > 0) {
+            for (int t = threadIdx.x; t < nx * ny; t += 256) {
+                const int X = (i0 + t % nx) * stride, Y = (j0 + t / nx) * stride;
+                bool pos = true, neg = true;
+                if (k == 1) {
+                    pos = neg = (X == hx[0] && Y == hy[0]);
+                } else {
+                    for (int e = 0; e < k; ++e) {
+                        const int e2 = e + 1 == k ? 0 : e + 1;
+                        const long long cr = (long long)(hx[e2] - hx[e]) * (Y - hy[e]) - (long long)(hy[e2] - hy[e]) * (X - hx[e]);
+                        pos &= cr >= 0; neg &= cr <= 0;
+                    }
+                    if (k == 2 && pos && neg) {                        // on the line: inside the segment's box only
+                        pos = neg = X >= min(hx[0], hx[1]) && X <= max(hx[0], hx[1]) && Y >= min(hy[0], hy[1]) && Y <= max(hy[0], hy[1]);
+                    }
+                }
+                if (pos || neg) {
+                    ++in_poly;
+                    in_both += mask[(size_t)Y * W + X] ? 1 : 0;
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { in_poly += __shfl_xor(in_poly, off, 64); in_both += __shfl_xor(in_both, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt[0], in_poly); atomicAdd(&s_cnt[1], in_both); }
+    __syncthreads();
+    if (threadIdx.x == 0) { counts[2 * p] = s_cnt[0]; counts[2 * p + 1] = s_cnt[1]; }
+}
+
+extern "C" int cr_segment_counts(cr_ctx* ctx, const float* corners, int P, const unsigned char* mask, int H, int W, int stride,
+                                 int32_t* counts) {
+    CR_CHECK_ARG(ctx && P >= 0 && H > 0 && W > 0 && stride > 0, "cr_segment_counts: bad args");
+    if (P == 0) return CR_OK;
+    CR_CHECK_ARG(corners && mask && counts, "cr_segment_counts: NULL pointer");
+    hipLaunchKernelGGL(k_segment_counts, dim3((unsigned)P), dim3(256), 0, ctx->stream, corners, P, mask, H, W, stride, counts);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

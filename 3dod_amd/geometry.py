@@ -191,3 +191,18 @@ def polygon_focal(hull, count, masks, mask_idx):
         raise _lib.CrError("polygon_focal: expected CUDA(HIP) tensors; 3dod_amd has no CPU path")
     assert masks.dtype == torch.uint8 and masks.dim() == 3 and masks.is_contiguous()
     return _PolygonFocal.apply(hull, count.to(torch.int32).contiguous(), masks, mask_idx.to(torch.int32).contiguous())
+
+
+def segment_counts(corners2d, mask, stride=4):
+    """per proposal: samples (stride*i, stride*j) inside the filled hull of its 8 projected corners, and how many of
+    those the object mask covers (cr_segment_counts): corners2d (P,8,2) f32, mask (H,W) bool/uint8 -> (P,2) int64"""
+    lib = _lib.load()
+    if not corners2d.is_cuda:
+        raise _lib.CrError("segment_counts: expected CUDA(HIP) tensors; 3dod_amd has no CPU path")
+    c = corners2d.detach().float().contiguous()
+    m = mask.to(device=c.device, dtype=torch.uint8).contiguous()
+    P = c.shape[0]
+    out = torch.empty((P, 2), dtype=torch.int32, device=c.device)
+    _lib.check(lib.cr_segment_counts(_lib.ctx_for(c.device), _lib.ptr(c), P, _lib.ptr(m), m.shape[0], m.shape[1], int(stride),
+                                     _lib.ptr(out)), "cr_segment_counts")
+    return out.long()

@@ -117,6 +117,14 @@ int cr_hull8(cr_ctx* ctx, const float* pts, int n, int32_t* order, int32_t* coun
 int cr_polygon_focal(cr_ctx* ctx, const float* hull, const int32_t* count, const unsigned char* masks, const int32_t* mask_idx,
                      int n, int H, int W, float* loss, float* grad);
 
+/* Raster counts behind score_segmentation / score_mod_segmentation (ProposalNetwork/scoring/scorefunction.py:88-126;
+ * cv2.convexHull + cv2.fillPoly + [::stride, ::stride] + mask_iou, utils.py:230-250) for the P proposals of one object:
+ * corners (P,8,2) f32 projected corners, mask (H,W) uint8 -> counts (P,2) int32 = {polygon samples, polygon AND mask
+ * samples} on the grid (stride*i, stride*j); a sample is in the polygon iff inside or on the closed hull with vertices
+ * truncated to int32. */
+int cr_segment_counts(cr_ctx* ctx, const float* corners, int P, const unsigned char* mask, int H, int W, int stride,
+                      int32_t* counts);
+
 /* ---- Depth-Anything-V2 forward (DINOv2 ViT + DPT head), the ops that are not GEMMs / convolutions --------------- */
 /* softmax(q k^T * scale) v per (batch, head) on the packed output of the qkv linear: qkv (B,N,3,H,D) bf16, out (B,N,H,D)
  * bf16, D = 64.  Flash-attention schedule on MFMA (no N x N matrix in memory).  Replaces Attention.forward /

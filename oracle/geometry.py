@@ -435,3 +435,71 @@ def fix_ground_normal(nv):
     if nv[1] < 0:
         nv = nv * -1
     return nv
+
+
+# --------------------------------------------------------------------------
+# mask scores (MABO): hull raster counts on the [::stride, ::stride] grid
+# --------------------------------------------------------------------------
+def segment_counts(corners2d, mask, stride=4):
+    """restatement of cv2.convexHull -> int32 -> cv2.fillPoly -> [::stride, ::stride] used by score_segmentation
+    (ProposalNetwork/scoring/scorefunction.py:88-105) [cv2: third-party, absent]: a grid sample belongs to the polygon
+    iff it lies inside or on the closed convex hull of the 8 points, hull vertices truncated to int.  -> (P,2) int64
+    {polygon samples, polygon AND mask samples}."""
+    c = np.asarray(corners2d, dtype=F32)
+    m = np.asarray(mask) != 0
+    H, W = m.shape
+    out = np.zeros((c.shape[0], 2), dtype=np.int64)
+    ys, xs = np.meshgrid(np.arange(0, H, stride), np.arange(0, W, stride), indexing="ij")
+    for p in range(c.shape[0]):
+        pts = c[p]
+        if not np.isfinite(pts).all() or np.abs(pts).max() >= 1e9:
+            continue
+        hull = _hull_ccw(pts)
+        hv = np.array([[int(x), int(y)] for x, y in hull], dtype=np.int64)          # int(): truncation toward zero
+        k = len(hv)
+        if k == 1:
+            inside = (xs == hv[0, 0]) & (ys == hv[0, 1])
+        else:
+            pos = np.ones_like(xs, dtype=bool)
+            neg = np.ones_like(xs, dtype=bool)
+            for e in range(k):
+                a, b = hv[e], hv[(e + 1) % k]
+                cr = (b[0] - a[0]) * (ys - a[1]) - (b[1] - a[1]) * (xs - a[0])
+                pos &= cr >= 0
+                neg &= cr <= 0
+            inside = pos | neg
+            if k == 2:
+                inside &= (xs >= hv[:, 0].min()) & (xs <= hv[:, 0].max()) & (ys >= hv[:, 1].min()) & (ys <= hv[:, 1].max())
+        out[p, 0] = inside.sum()
+        out[p, 1] = (inside & m[::stride, ::stride]).sum()
+    return out
+
+
+def _hull_ccw(pts):
+    """convex hull vertices of a few float32 points by gift wrapping with exact float32 cross products (collinear:
+    farthest), starting at the lowest x (then lowest y)"""
+    pts = np.asarray(pts, dtype=F32)
+    n = len(pts)
+    start = 0
+    for i in range(1, n):
+        if pts[i, 0] < pts[start, 0] or (pts[i, 0] == pts[start, 0] and pts[i, 1] < pts[start, 1]):
+            start = i
+    hull, l = [], start
+    for _ in range(n):
+        hull.append(pts[l])
+        q = -1
+        for i in range(n):
+            if pts[i, 0] == pts[l, 0] and pts[i, 1] == pts[l, 1]:
+                continue
+            if q < 0:
+                q = i
+                continue
+            d = F32(F32(pts[i, 0] - pts[l, 0]) * F32(pts[q, 1] - pts[l, 1])) - F32(F32(pts[i, 1] - pts[l, 1]) * F32(pts[q, 0] - pts[l, 0]))
+            di = F32(F32(pts[i, 0] - pts[l, 0]) ** 2) + F32(F32(pts[i, 1] - pts[l, 1]) ** 2)
+            dq = F32(F32(pts[q, 0] - pts[l, 0]) ** 2) + F32(F32(pts[q, 1] - pts[l, 1]) ** 2)
+            if d > 0 or (d == 0 and di > dq):
+                q = i
+        if q < 0 or (pts[q, 0] == pts[start, 0] and pts[q, 1] == pts[start, 1]):
+            break
+        l = q
+    return hull

@@ -143,3 +143,40 @@ def test_iou_3d_and_score_point_cloud():
     want = torch.stack([((p[:, 0] > lo[0][k]) & (p[:, 0] < hi[0][k]) & (p[:, 1] > lo[1][k]) & (p[:, 1] < hi[1][k]) &
                          (p[:, 2] > lo[2][k]) & (p[:, 2] < hi[2][k])).sum() for k in range(P)])
     assert torch.equal(s.cpu(), want) and s.dtype == torch.int64
+
+
+def test_mask_scores_kernel_against_oracle():
+    """score_segmentation / score_mod_segmentation (MABO): raster counts of cr_segment_counts equal the oracle's, and the
+    scores equal mask_iou / mod_mask_iou of the reference's definition computed from those counts"""
+    import importlib
+    import numpy as np
+    import torch
+    from oracle import geometry as og
+    geo = importlib.import_module("3dod_amd.geometry")
+    sf = importlib.import_module("3dod_amd.ProposalNetwork.scoring.scorefunction")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    P, H, W = 400, 240, 320
+    ctr = rng.uniform([-40, -40], [W + 40, H + 40], (P, 1, 2))
+    pts = (ctr + rng.normal(0, 1, (P, 8, 2)) * rng.uniform(2, 90, (P, 1, 1))).astype(np.float32)
+    pts[:60] = np.round(pts[:60])                                   # integer vertices, collinear cases
+    pts[60:90, :, 0] = np.clip(pts[60:90, :, 0], -int(W / 2) + 1, 2 * W - 1)      # clamped like projected corners
+    pts[90:100, 4:] = pts[90:100, :4]                               # duplicated corners
+    pts[100:105] = pts[100:105, :1]                                 # all eight identical
+    pts[105, 2, 1] = np.nan
+    mask = np.zeros((H, W), dtype=bool)
+    yy, xx = np.ogrid[:H, :W]
+    mask[((yy - 120) / 70.0) ** 2 + ((xx - 150) / 110.0) ** 2 < 1] = True
+    want = og.segment_counts(pts, mask, 4)
+    got = geo.segment_counts(torch.tensor(pts, device=dev), torch.tensor(mask, device=dev), 4).cpu().numpy()
+    assert (got == want).all(), np.nonzero((got != want).any(1))[0][:10]
+    assert (want[:, 0] > 0).sum() > 300 and (want[:, 1] > 0).sum() > 100
+    seg = torch.tensor(mask, device=dev)
+    s = sf.score_segmentation(seg, torch.tensor(pts, device=dev)[None]).cpu().numpy()
+    m = sf.score_mod_segmentation(seg, torch.tensor(pts, device=dev)[None]).cpu().numpy()
+    n_seg = int(mask[::4, ::4].sum())
+    inter, union = want[:, 1].astype(np.float64), (want[:, 0] + n_seg - want[:, 1]).astype(np.float64)
+    exp_s = np.where(inter > 0, inter / np.maximum(union, 1), 0)
+    exp_m = np.where(inter > 0, inter ** 5 / np.maximum(union, 1), 0)
+    assert np.allclose(s, exp_s, rtol=1e-6) and np.allclose(m, exp_m, rtol=1e-5)
+    assert s.max() <= 1.0 and s.max() > 0.3
