@@ -4,6 +4,7 @@
 // Token activations are (B*N, C) bf16 row-major; image-shaped activations NHWC bf16 like the rest of the library.
 #include "cr_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -32,12 +33,12 @@ __device__ __forceinline__ u16 vf2bf(float f) {
 #define ATT_TK 64
 #define ATT_KPAD 8              // LDS row padding (elements): 144-byte rows, conflict-free 16-byte reads
 
-#define ATT_WAVES 8              // 8 waves x 16 queries share one K/V tile: 128 queries per workgroup
-#define ATT_T (64 * ATT_WAVES)
-#define ATT_TQ (16 * ATT_WAVES)
-
-__global__ __launch_bounds__(ATT_T) void k_attention_fwd(const u16* __restrict__ qkv, u16* __restrict__ out, int B, int N,
-                                                         int H, float scale, int qtiles) {
+// WAVES waves per workgroup share one K/V tile; every wave owns QB blocks of 16 queries (QB = 2: each K / V^T fragment
+// fetched from LDS feeds two MFMAs).
+template <int QB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_attention_fwd(const u16* __restrict__ qkv, u16* __restrict__ out, int B, int N,
+                                                              int H, float scale, int qtiles) {
+    constexpr int T = 64 * WAVES, TQ = 16 * QB * WAVES;
     __shared__ __attribute__((aligned(16))) u16 sK[ATT_TK][ATT_D + ATT_KPAD];      // [key][d]
     __shared__ __attribute__((aligned(16))) u16 sVt[ATT_D][ATT_TK + ATT_KPAD];     // [d][key]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -48,37 +49,43 @@ __global__ __launch_bounds__(ATT_T) void k_attention_fwd(const u16* __restrict__
     const int lb = (int)blockIdx.x < body ? ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int bh = lb / qtiles, qt = lb - bh * qtiles;
     const int b = bh / H, h = bh - b * H;
-    const int q0 = qt * ATT_TQ + wave * 16;
+    const int q0 = qt * TQ + wave * 16 * QB;
     const size_t row_stride = (size_t)3 * H * ATT_D;
     const u16* base = qkv + (size_t)b * N * row_stride + (size_t)h * ATT_D;
     const u16* Kb = base + (size_t)H * ATT_D;
     const u16* Vb = base + (size_t)2 * H * ATT_D;
 
-    // Q fragments (B operand): query q0 + c, d = 32*s + 8*g .. +7
-    bf16x8 qf[2];
-    {
-        const int q = q0 + c;
+    // Q fragments (B operand): query q0 + 16*qb + c, d = 32*s + 8*g .. +7
+    bf16x8 qf[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0 + 16 * qb + c;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (q < N) v = *reinterpret_cast<const uint4*>(base + (size_t)q * row_stride + 32 * s + 8 * g);
-            qf[s] = __builtin_bit_cast(bf16x8, v);
+            qf[qb][s] = __builtin_bit_cast(bf16x8, v);
         }
     }
-    f32x4 o[4];
+    f32x4 o[QB][4];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -INFINITY;
+        l_run[qb] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[qb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     const int ntiles = (N + ATT_TK - 1) / ATT_TK;
     // staging: 64 keys x 64 d = 512 chunks of 8 elements over the workgroup; the global loads of tile t+1 are issued before
     // the MFMAs of tile t (registers), so their latency overlaps the compute instead of sitting between two barriers
-    constexpr int NCH = 512 / ATT_T;     // 16-byte chunks of K (and of V) per thread and tile
+    constexpr int NCH = 512 / T;
     uint4 rk[NCH], rv[NCH];
     auto load_tile = [&](int t) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + ATT_T * i;
+            const int idx = tid + T * i;
             const int key = t * ATT_TK + (idx >> 3), d8 = (idx & 7) * 8;
             rk[i] = make_uint4(0, 0, 0, 0);
             rv[i] = make_uint4(0, 0, 0, 0);
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(ATT_T) void k_attention_fwd(const u16* __restrict__
         __syncthreads();                               // previous tile fully consumed
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int idx = tid + ATT_T * i;
+            const int idx = tid + T * i;
             const int key = idx >> 3, d8 = (idx & 7) * 8;
             *reinterpret_cast<uint4*>(&sK[key][d8]) = rk[i];
             const unsigned w[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
@@ -111,8 +118,8 @@ __global__ __launch_bounds__(ATT_T) void k_attention_fwd(const u16* __restrict__
         __syncthreads();
         if (t + 1 < ntiles) load_tile(t + 1);
 
-        // S^T blocks: rows = keys 16*kb + 4g + e, column = query c.  All K fragments are fetched from LDS first and the 8
-        // MFMAs issued back to back over 4 independent accumulators (a read -> wait -> MFMA chain per fragment exposes
+        // S^T blocks: rows = keys 16*kb + 4g + e, column = query c.  All K fragments are fetched from LDS first and the
+        // MFMAs issued back to back over independent accumulators (a read -> wait -> MFMA chain per fragment exposes
         // the LDS latency 8 times per tile)
         bf16x8 kf[2][4];
 #pragma unroll
@@ -120,11 +127,17 @@ __global__ __launch_bounds__(ATT_T) void k_attention_fwd(const u16* __restrict__
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
                 kf[s][kb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sK[16 * kb + c][32 * s + 8 * g]));
-        f32x4 s4[4];
+        f32x4 s4[QB][4];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) s4[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][kb], qf[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) s4[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1][kb], qf[1], s4[kb], 0, 0, 0);
+            for (int kb = 0; kb < 4; ++kb)
+                s4[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][kb], qf[qb][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+                s4[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1][kb], qf[qb][1], s4[qb][kb], 0, 0, 0);
         // V^T fragments for the second product: issued now, consumed after the softmax arithmetic
         bf16x8 vf[2][4];
 #pragma unroll
@@ -136,59 +149,66 @@ __global__ __launch_bounds__(ATT_T) void k_attention_fwd(const u16* __restrict__
                 const uint2 v1 = *reinterpret_cast<const uint2*>(&sVt[16 * db + c][(32 * s + 16 + 4 * g) ^ sw]);
                 vf[s][db] = __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
             }
-        float mx = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = -INFINITY;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = k0 + 16 * kb + 4 * g + e;
-                const float v = key < N ? s4[kb][e] * scale : -INFINITY;
-                s4[kb][e] = v;
-                mx = fmaxf(mx, v);
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + 16 * kb + 4 * g + e;
+                    const float v = key < N ? s4[qb][kb][e] * scale : -INFINITY;
+                    s4[qb][kb][e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qb], mx);      // finite: every tile has at least one valid key
+            const float alpha = __expf(m_run[qb] - m_new); // first tile: exp(-inf) = 0
+            float psum = 0.f;
+            unsigned pk[4][2];                             // P as bf16 pairs, [kb][e/2]
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                float p[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p[e] = __expf(s4[qb][kb][e] - m_new);
+                    psum += p[e];
+                }
+                pk[kb][0] = (unsigned)vf2bf(p[0]) | ((unsigned)vf2bf(p[1]) << 16);
+                pk[kb][1] = (unsigned)vf2bf(p[2]) | ((unsigned)vf2bf(p[3]) << 16);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);          // finite: every tile has at least one valid key
-        const float alpha = __expf(m_run - m_new);     // first tile: exp(-inf) = 0
-        float psum = 0.f;
-        unsigned pk[4][2];                             // P as bf16 pairs, [kb][e/2]
+            l_run[qb] = l_run[qb] * alpha + psum;
+            m_run[qb] = m_new;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            float p[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                p[e] = __expf(s4[kb][e] - m_new);
-                psum += p[e];
+            for (int i = 0; i < 4; ++i) {
+                o[qb][i][0] *= alpha; o[qb][i][1] *= alpha; o[qb][i][2] *= alpha; o[qb][i][3] *= alpha;
             }
-            pk[kb][0] = (unsigned)vf2bf(p[0]) | ((unsigned)vf2bf(p[1]) << 16);
-            pk[kb][1] = (unsigned)vf2bf(p[2]) | ((unsigned)vf2bf(p[3]) << 16);
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+            // O^T[d, q] += sum_keys V^T[d, key] P^T[key, q]; step s covers key blocks 2s and 2s+1
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha;
-        }
-        // O^T[d, q] += sum_keys V^T[d, key] P^T[key, q]; step s covers key blocks 2s and 2s+1
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pk[2 * s][0], pk[2 * s][1], pk[2 * s + 1][0], pk[2 * s + 1][1]));
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pk[2 * s][0], pk[2 * s][1], pk[2 * s + 1][0], pk[2 * s + 1][1]));
-#pragma unroll
-            for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[s][db], pf, o[db], 0, 0, 0);
+                for (int db = 0; db < 4; ++db) o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[s][db], pf, o[qb][db], 0, 0, 0);
+            }
         }
     }
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
-    const int q = q0 + c;
-    if (q < N) {
-        const float inv = 1.f / l_run;
-        u16* dst = out + ((size_t)b * N + q) * ((size_t)H * ATT_D) + (size_t)h * ATT_D;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            uint2 pkd;
-            pkd.x = (unsigned)vf2bf(o[db][0] * inv) | ((unsigned)vf2bf(o[db][1] * inv) << 16);
-            pkd.y = (unsigned)vf2bf(o[db][2] * inv) | ((unsigned)vf2bf(o[db][3] * inv) << 16);
-            *reinterpret_cast<uint2*>(dst + 16 * db + 4 * g) = pkd;
+    for (int qb = 0; qb < QB; ++qb) {
+        float l = l_run[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int q = q0 + 16 * qb + c;
+        if (q < N) {
+            const float inv = 1.f / l;
+            u16* dst = out + ((size_t)b * N + q) * ((size_t)H * ATT_D) + (size_t)h * ATT_D;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                uint2 pkd;
+                pkd.x = (unsigned)vf2bf(o[qb][db][0] * inv) | ((unsigned)vf2bf(o[qb][db][1] * inv) << 16);
+                pkd.y = (unsigned)vf2bf(o[qb][db][2] * inv) | ((unsigned)vf2bf(o[qb][db][3] * inv) << 16);
+                *reinterpret_cast<uint2*>(dst + 16 * db + 4 * g) = pkd;
+            }
         }
     }
 }
@@ -198,10 +218,13 @@ extern "C" int cr_attention_fwd(cr_ctx* ctx, const void* qkv, void* out, int B, 
     CR_CHECK_ARG(D == ATT_D, "cr_attention_fwd: head dimension %d is not built (64 only)", D);
     if ((int64_t)B * N == 0) return CR_OK;
     CR_CHECK_ARG(qkv && out, "cr_attention_fwd: NULL pointer");
-    const int qtiles = (int)cr_cdiv(N, ATT_TQ);
+    // measured on ViT-L (4 x 16 heads x 1370 tokens): <QB=1, 8 waves> 86 us, <2, 4> 98 us, <2, 8> 102 us -- the second query
+    // block per wave costs more in registers / occupancy than it saves in LDS fragment reads
+    constexpr int QB = 1, WAVES = 8;
+    const int qtiles = (int)cr_cdiv(N, 16 * QB * WAVES);
     CR_CHECK_ARG((int64_t)B * H * qtiles < (1ll << 31), "cr_attention_fwd: grid too large");
-    hipLaunchKernelGGL(k_attention_fwd, dim3((unsigned)(B * H * qtiles)), dim3(ATT_T), 0, ctx->stream, (const u16*)qkv,
-                       (u16*)out, B, N, H, scale, qtiles);
+    hipLaunchKernelGGL((k_attention_fwd<QB, WAVES>), dim3((unsigned)(B * H * qtiles)), dim3(64 * WAVES), 0, ctx->stream,
+                       (const u16*)qkv, (u16*)out, B, N, H, scale, qtiles);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
