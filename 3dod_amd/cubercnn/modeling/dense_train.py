@@ -225,8 +225,13 @@ def pool_roi_features(rh, features, samp):
         half = (cb[..., 2:3] - cb[..., 0:1]) * (0.5 * rh.scale_roi_boxes)
         cb = torch.cat([ctr - half, ctr + half], -1)
     bp, cp = rh.box_pooler, rh.cube_pooler
-    if rh.loss_w_3d > 0 and tuple(rh.box_in_features) == tuple(rh.in_features) and bp.scales == cp.scales and \
-            bp.output_size == cp.output_size:
+    same = rh.loss_w_3d > 0 and tuple(rh.box_in_features) == tuple(rh.in_features) and bp.scales == cp.scales and \
+        bp.output_size == cp.output_size
+    if same and not rh.scale_roi_boxes > 0 and hasattr(ops, "shared_prefix"):
+        # the 3D head's RoIs ARE the first kf RoIs of the box head: pool once, share (forward and backward)
+        out = ops.roi_align_pyramid([features[f] for f in rh.in_features], _rois(samp["boxes"]), bp.scales, bp.output_size)
+        return ops.shared_prefix(out, B, S, kf)
+    if same:
         feats = [features[f] for f in rh.in_features]
         out = ops.roi_align_pyramid(feats, torch.cat([_rois(samp["boxes"]), _rois(cb)], 0), bp.scales, bp.output_size)
         return out[:B * S], out[B * S:]

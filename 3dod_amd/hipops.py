@@ -536,6 +536,32 @@ class _ROIAlign(torch.autograd.Function):
         return (None, None, None) + tuple(g.to(bf16) for g in grads)
 
 
+class _SharedPrefix(torch.autograd.Function):
+    """(B*S, ...) pooled RoI features -> (the same tensor, a copy of the first kf RoIs of every image).  The 3D head pools
+    exactly the foreground slots the box head already pooled, so they are pooled ONCE; backward adds the 3D head's gradient
+    into the box head's gradient tile in place (one small kernel) instead of scattering 20 % more RoIs with atomics."""
+
+    @staticmethod
+    def forward(ctx, pooled, B, S, kf):
+        ctx.dims = (B, S, kf)
+        v = pooled.view(B, S, -1)
+        return pooled.view_as(pooled), v[:, :kf].reshape((B * kf,) + tuple(pooled.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, g_all, g_head):
+        B, S, kf = ctx.dims
+        if g_all is None:
+            g_all = torch.zeros((B * S,) + tuple(g_head.shape[1:]), dtype=g_head.dtype, device=g_head.device)
+        g_all = g_all.contiguous()
+        if g_head is not None:
+            g_all.view(B, S, -1)[:, :kf] += g_head.reshape(B, kf, -1).to(g_all.dtype)
+        return g_all, None, None, None
+
+
+def shared_prefix(pooled, B, S, kf):
+    return _SharedPrefix.apply(pooled, B, S, kf)
+
+
 def roi_align_pyramid(feats, rois, scales, out_size):
     """feats: list of NHWC bf16 maps (fine -> coarse); rois (R,5) f32 [batch,x1,y1,x2,y2]."""
     return _ROIAlign.apply(rois.to(f32), tuple(scales), out_size, *feats)
