@@ -102,3 +102,33 @@ def test_train_net_driver_end_to_end(tmp_path, monkeypatch):
     args = types.SimpleNamespace(config_file=None, resume=True, eval_only=True, opts=opts)
     again = tn.main(args)
     assert set(again) == set(analysis)
+
+
+def test_demo_on_a_folder_of_images(tmp_path):
+    """tools/demo.py: folder of images -> one json of detections per image (camera heuristics of the reference demo)"""
+    import json
+    import sys
+    import types
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    demo = importlib.import_module("demo")
+    assert demo.camera(480, 640) == [[960.0, 0.0, 320.0], [0.0, 960.0, 240.0], [0.0, 0.0, 1.0]]
+    assert demo.camera(480, 640, 500.0, (300.0, 200.0))[0] == [500.0, 0.0, 300.0]
+    folder = tmp_path / "imgs"
+    folder.mkdir()
+    rng = np.random.default_rng(0)
+    for i, hw in enumerate(((240, 320), (300, 200))):
+        Image.fromarray(rng.integers(0, 256, hw + (3,), dtype=np.uint8)).save(folder / f"im{i}.png")
+    (folder / "notes.txt").write_text("not an image")
+    cfg = syn.make_cfg(overrides=["MODEL.DEVICE", "cuda:0", "VIS_PERIOD", 0, "log", False, "INPUT.MIN_SIZE_TEST", 256,
+                                  "INPUT.MAX_SIZE_TEST", 512, "MODEL.ROI_HEADS.NUM_CLASSES", 5])
+    torch.manual_seed(0)
+    model = modeling.build_model(cfg)
+    files = sorted(str(p) for p in folder.iterdir())
+    out = demo.run(cfg, model, files, str(tmp_path / "out"), ["a", "b", "c", "d", "e"], threshold=0.0)
+    assert [os.path.basename(p) for p in out] == ["im0.json", "im1.json"]
+    rec = json.load(open(out[1]))
+    assert rec["K"][0][0] == 4.0 * 300 / 2 and rec["K"][0][2] == 100.0
+    for d in rec["detections"]:
+        assert d["category"] in "abcde" and len(d["bbox3D"]) == 6 and np.array(d["corners3D"]).shape == (8, 3)
