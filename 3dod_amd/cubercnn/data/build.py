@@ -142,7 +142,7 @@ def build_detection_test_loader(cfg=None, dataset_name=None, *, dataset=None, ma
         sampler = D.InferenceSampler(len(dataset), rank=rank, world_size=world_size)
     batch_sampler = tud.BatchSampler(sampler, batch_size=batch_size, drop_last=False)
     return tud.DataLoader(dataset, num_workers=num_workers, batch_sampler=batch_sampler,
-                          collate_fn=D.trivial_batch_collator)
+                          collate_fn=D.trivial_batch_collator, worker_init_fn=D.worker_init_reset_seed)
 
 
 def dataset_id_maps(datasets, num_classes, id_map):

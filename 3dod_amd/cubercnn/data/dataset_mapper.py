@@ -77,6 +77,9 @@ class DatasetMapper3D:
 
         if "annotations" in dataset_dict:
             K = np.array(dataset_dict['K'])
+            if self.dataset_id_to_unknown_cats is None:
+                raise RuntimeError("DatasetMapper3D.dataset_id_to_unknown_cats is not set (tools/train_net.py:147 assigns it "
+                                   "after building the loader; see cubercnn.data.build.dataset_id_maps)")
             unknown = self.dataset_id_to_unknown_cats[dataset_dict['dataset_id']]
             annos = [transform_instance_annotations(obj, transforms, K=K)
                      for obj in dataset_dict.pop("annotations") if obj.get("iscrowd", 0) == 0]

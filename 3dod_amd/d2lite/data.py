@@ -548,6 +548,15 @@ def trivial_batch_collator(batch):
     return batch
 
 
+def worker_init_reset_seed(worker_id):
+    """detectron2.data.build.worker_init_reset_seed: loader workers are forked with identical numpy / random states, so
+    every worker would draw the same augmentation sequence; reseed them from torch's per-worker seed"""
+    import random
+    seed = (torch.initial_seed() % (2 ** 31)) + worker_id
+    np.random.seed(seed % (2 ** 31))
+    random.seed(seed)
+
+
 def _first(batch):
     return batch[0]
 
@@ -563,7 +572,8 @@ def build_batch_data_loader(dataset, sampler, total_batch_size, *, aspect_ratio_
     batch_size = total_batch_size // world_size
     stream = _SampledIterable(dataset, sampler)
     if aspect_ratio_grouping:
-        loader = tud.DataLoader(stream, num_workers=num_workers, batch_size=None, collate_fn=None)
+        loader = tud.DataLoader(stream, num_workers=num_workers, batch_size=None, collate_fn=None,
+                                worker_init_fn=worker_init_reset_seed)
         return AspectRatioGroupedDataset(loader, batch_size)
     return tud.DataLoader(stream, batch_size=batch_size, drop_last=True, num_workers=num_workers,
-                          collate_fn=trivial_batch_collator)
+                          collate_fn=trivial_batch_collator, worker_init_fn=worker_init_reset_seed)

@@ -367,3 +367,28 @@ def test_instances_to_coco_json():
     out = ev_mod.instances_to_coco_json(inst, 78)
     assert out[1]["depth"] == pytest.approx(float(corners[1, :, 2].mean()))
     assert ev_mod.instances_to_coco_json(inst[torch.zeros(2, dtype=torch.bool)], 1) == []
+
+
+def test_loader_workers_draw_different_augmentations(gold, dataset_root, monkeypatch):
+    """two loader workers must not replay the same numpy random stream (flip / scale choices)"""
+    work, rel = dataset_root
+    monkeypatch.chdir(work)
+    fs = copy.deepcopy(gold["settings"]["default"])
+    omni = _registered(work, rel, gold, fs)
+    names = [g["name"] for g in gold["gen"]]
+    cfg = syn.make_cfg(overrides=["DATASETS.TRAIN", tuple(names), "SOLVER.IMS_PER_BATCH", 2, "DATALOADER.NUM_WORKERS", 2,
+                                  "DATALOADER.ASPECT_RATIO_GROUPING", False, "INPUT.MIN_SIZE_TRAIN", tuple(range(128, 257, 8)),
+                                  "INPUT.MAX_SIZE_TRAIN", 512])
+    meta = D.MetadataCatalog.get("omni3d_model")
+    unknown, id_to_src = data.build.dataset_id_maps(omni, cfg.MODEL.ROI_HEADS.NUM_CLASSES, meta.thing_dataset_id_to_contiguous_id)
+    mapper = data.DatasetMapper3D(cfg, is_train=True)
+    with pytest.raises(RuntimeError, match="dataset_id_to_unknown_cats"):
+        mapper(D.DatasetCatalog.get(names[0])[0])
+    mapper.dataset_id_to_unknown_cats = unknown
+    torch.manual_seed(0)
+    it = iter(data.build_detection_train_loader(cfg, mapper=mapper, dataset_id_to_src=id_to_src, rank=0, world_size=1))
+    sizes = [min(d["image"].shape[1:]) for _ in range(6) for d in next(it)]
+    # worker 0 produces batches 0, 2, 4 and worker 1 batches 1, 3, 5: with cloned RNG states the two would pick the same
+    # sequence of short edges
+    w0, w1 = sizes[0:2] + sizes[4:6] + sizes[8:10], sizes[2:4] + sizes[6:8] + sizes[10:12]
+    assert w0 != w1, (w0, w1)
