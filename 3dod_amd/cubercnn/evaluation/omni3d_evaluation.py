@@ -438,20 +438,37 @@ def inference_on_dataset(model, data_loader):
     import itertools
     import torch
     import torch.distributed as dist
+    import logging
+    import time
     was_training = getattr(model, "training", False)
     if hasattr(model, "eval"):
         model.eval()
     out = []
+    t_data = t_compute = t_eval = 0.0
+    n_iter = 0
     try:
         with torch.no_grad():
+            t0 = time.perf_counter()
             for inputs in data_loader:
+                t1 = time.perf_counter()
                 outputs = model(inputs)
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                t2 = time.perf_counter()
                 for inp, o in zip(inputs, outputs):
                     out.append({"image_id": inp["image_id"], "K": inp["K"], "width": inp["width"], "height": inp["height"],
                                 "instances": instances_to_coco_json(o["instances"].to("cpu"), inp["image_id"])})
+                t3 = time.perf_counter()
+                t_data, t_compute, t_eval, n_iter = t_data + (t1 - t0), t_compute + (t2 - t1), t_eval + (t3 - t2), n_iter + 1
+                t0 = t3
     finally:
         if was_training:
             model.train()
+    if n_iter:
+        # the reference's accounting (:549-632): data / compute / packing seconds per iteration on this rank
+        logging.getLogger(__name__).info(
+            "Inference done {} iterations. Dataloading: {:.4f} s/iter. Inference: {:.4f} s/iter. Eval: {:.4f} s/iter.".format(
+                n_iter, t_data / n_iter, t_compute / n_iter, t_eval / n_iter))
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         gathered = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
         dist.gather_object(out, gathered, dst=0)

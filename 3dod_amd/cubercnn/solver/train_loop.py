@@ -14,7 +14,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from ...d2lite import EventStorage
+from ...d2lite import EventStorage, JSONWriter, CommonMetricPrinter
 from .build import TrainStep, build_optimizer, freeze_bn
 
 logger = logging.getLogger(__name__)
@@ -199,6 +199,9 @@ def do_train(cfg, model, data_loader, resume=False, world_size=None, rank=None, 
     dev = optimizer.flat_p.device
     iteration = start_iter
     data_iter = iter(data_loader)
+    # default_writers of the reference (train_net.py:140): stdout + OUTPUT_DIR/metrics.json, on rank 0
+    writers = [CommonMetricPrinter(max_iter), JSONWriter(os.path.join(cfg.OUTPUT_DIR, "metrics.json"))] \
+        if rank == 0 and cfg.OUTPUT_DIR else []
     with EventStorage(start_iter) as storage:
         while iteration < max_iter:
             storage.iter = iteration
@@ -212,7 +215,9 @@ def do_train(cfg, model, data_loader, resume=False, world_size=None, rank=None, 
                 ok, bad = rep["iterations_success"], rep["iterations_explode"]
                 total = max(ok + bad, 1.0)
                 skipped_now = bool(step.last["skipped"].item())
-                storage.put_scalars(total_loss=rep["total_loss"], lr=scheduler.get_last_lr()[0])
+                storage.put_scalars(lr=scheduler.get_last_lr()[0], **{k: v for k, v in rep.items() if not k.startswith("iterations_")})
+                for w in writers:
+                    w.write(storage)
                 retry = torch.tensor(float(bad / total >= cfg.MODEL.STABILIZE > 0 and total > cfg.SOLVER.CHECKPOINT_PERIOD / 2),
                                      device=dev)
                 if world_size > 1:
@@ -230,4 +235,7 @@ def do_train(cfg, model, data_loader, resume=False, world_size=None, rank=None, 
                 if not skipped_now and bad / total < 0.5 * cfg.MODEL.STABILIZE or cfg.MODEL.STABILIZE <= 0:
                     periodic.step(iteration)
             iteration += 1
+    for w in writers:
+        if hasattr(w, "close"):
+            w.close()
     return True

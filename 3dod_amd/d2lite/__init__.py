@@ -10,4 +10,4 @@ from .registry import Registry, META_ARCH_REGISTRY, BACKBONE_REGISTRY, PROPOSAL_
     ROI_HEADS_REGISTRY, ROI_BOX_HEAD_REGISTRY, RPN_HEAD_REGISTRY, ANCHOR_GENERATOR_REGISTRY
 from .structures import Boxes, Instances, ImageList, ShapeSpec, pairwise_iou, pairwise_ioa, cat
 from .box_ops import Box2BoxTransform, Matcher, DefaultAnchorGenerator, subsample_labels_d2
-from .events import EventStorage, get_event_storage
+from .events import EventStorage, get_event_storage, JSONWriter, CommonMetricPrinter

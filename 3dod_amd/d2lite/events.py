@@ -37,6 +37,46 @@ class EventStorage:
         _STACK.pop()
 
 
+class JSONWriter:
+    """detectron2.utils.events.JSONWriter [third-party, restated]: one json object per call with the latest value of every
+    scalar in the storage, appended to `metrics.json`."""
+
+    def __init__(self, json_file):
+        import os
+        os.makedirs(os.path.dirname(json_file) or ".", exist_ok=True)
+        self._file = open(json_file, "a")
+
+    def write(self, storage=None):
+        import json
+        storage = storage or get_event_storage()
+        rec = {"iteration": storage.iter}
+        for k, v in storage.scalars.items():
+            try:
+                rec[k] = float(v)
+            except (TypeError, ValueError):
+                pass
+        self._file.write(json.dumps(rec, sort_keys=True) + "\n")
+        self._file.flush()
+
+    def close(self):
+        self._file.close()
+
+
+class CommonMetricPrinter:
+    """one log line per call: iteration, total loss, the individual losses, learning rate"""
+
+    def __init__(self, max_iter=None, logger=None):
+        import logging
+        self.max_iter, self.logger = max_iter, logger or logging.getLogger("cubercnn.events")
+
+    def write(self, storage=None):
+        storage = storage or get_event_storage()
+        s = storage.latest()
+        losses = "  ".join("{}: {:.4g}".format(k, v) for k, v in sorted(s.items()) if "loss" in k.lower() and k != "total_loss")
+        self.logger.info(" iter: {}  total_loss: {:.4g}  {}  lr: {:.5g}".format(
+            storage.iter, s.get("total_loss", float("nan")), losses, s.get("lr", float("nan"))))
+
+
 _DEFAULT = EventStorage()
 
 

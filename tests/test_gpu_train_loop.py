@@ -40,7 +40,11 @@ def test_do_train_checkpoint_and_resume(tmp_path):
     dev = torch.device("cuda:0")
     data = batches(dev)
     ok, full, _ = run(["SOLVER.MAX_ITER", 6], str(tmp_path / "a"), data, 0, False)
-    assert ok and sorted(os.listdir(tmp_path / "a")) == ["last_checkpoint", "model_final.pth", "model_recent.pth"]
+    assert ok and sorted(os.listdir(tmp_path / "a")) == ["last_checkpoint", "metrics.json", "model_final.pth", "model_recent.pth"]
+    import json
+    lines = [json.loads(l) for l in open(tmp_path / "a" / "metrics.json")]
+    assert [l["iteration"] for l in lines] == list(range(6)) and all("total_loss" in l and "lr" in l and "rpn/cls" in l for l in lines)
+    assert lines[0]["lr"] < lines[3]["lr"]                        # warm-up
     ck = torch.load(tmp_path / "a" / "model_final.pth", map_location="cpu", weights_only=True)
     assert ck["iteration"] == 5 and ck["scheduler"]["last_iter"] == 6 and "momentum_buffer" in ck["optimizer"]
     assert float(ck["train_step"]["iterations_success"]) + float(ck["train_step"]["iterations_explode"]) == 6
