@@ -169,24 +169,36 @@ extern "C" int cr_hull8(cr_ctx* ctx, const float* pts, int n, int32_t* order, in
 // -- yes, the ground-truth mask is the `inputs` argument in the reference.  One pass per RoI over the H x W pixels, forward
 // and the gradient w.r.t. the (<= 8) hull vertices in the same kernel (the reference materialises 8 full-size float masks
 // per RoI).  Ties of the clamp (argument exactly 0 or 1) pass half the gradient, like torch.max / torch.min.
-// grid (n, chunks); loss (n) and grad (n,8,2) are accumulated with atomics and must be zeroed by the caller.
+// One workgroup per RoI over the hull's bounding box; mask_ones (Nm) = number of set pixels of every mask.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_polygon_focal(const float* __restrict__ hull, const int* __restrict__ count,
                                                        const unsigned char* __restrict__ masks, const int* __restrict__ mask_idx,
-                                                       int H, int W, float* __restrict__ loss, float* __restrict__ grad,
-                                                       int want_grad) {
-    __shared__ float red[4][17];
+                                                       const int* __restrict__ mask_ones, int H, int W,
+                                                       float* __restrict__ loss, float* __restrict__ grad, int want_grad) {
+    __shared__ float red[4][18];
     const int r = blockIdx.x;
     const int k = count[r];
     float vx[8], vy[8];
     for (int e = 0; e < 8; ++e) { vx[e] = hull[(r * 8 + e) * 2]; vy[e] = hull[(r * 8 + e) * 2 + 1]; }
-    const unsigned char* mk = masks + (size_t)mask_idx[r] * H * W;
+    const int mi = mask_idx[r];
+    const unsigned char* mk = masks + (size_t)mi * H * W;
+    // Outside the hull's bounding box some edge has a negative argument, so the polygon value is exactly 0 there and the
+    // focal term depends on the mask bit alone (two constants) with zero gradient: only the box is visited.
+    float fx0 = vx[0], fx1 = vx[0], fy0 = vy[0], fy1 = vy[0];
+    for (int e = 1; e < 8; ++e)
+        if (e < k) { fx0 = fminf(fx0, vx[e]); fx1 = fmaxf(fx1, vx[e]); fy0 = fminf(fy0, vy[e]); fy1 = fmaxf(fy1, vy[e]); }
+    const bool finite = (fx0 == fx0) && (fx1 == fx1) && (fy0 == fy0) && (fy1 == fy1) && k >= 1;
+    const int bx0 = finite ? max((int)floorf(fmaxf(fx0, -1.f)) - 1, 0) : 0, bx1 = finite ? min((int)ceilf(fminf(fx1, (float)W)) + 1, W - 1) : W - 1;
+    const int by0 = finite ? max((int)floorf(fmaxf(fy0, -1.f)) - 1, 0) : 0, by1 = finite ? min((int)ceilf(fminf(fy1, (float)H)) + 1, H - 1) : H - 1;
+    const int bw = max(bx1 - bx0 + 1, 0), bh = max(by1 - by0 + 1, 0);
     const int total = H * W;
-    float acc = 0.f, g[16];
+    float acc = 0.f, ones_in = 0.f, g[16];
     for (int i = 0; i < 16; ++i) g[i] = 0.f;
     const float inv_total = 1.f / (float)total;
-    for (int p = blockIdx.y * 256 + threadIdx.x; p < total; p += gridDim.y * 256) {
-        const float Y = (float)(p / W), X = (float)(p - (p / W) * W);
+    for (int q = threadIdx.x; q < bw * bh; q += 256) {
+        const int yy = by0 + q / bw, xx = bx0 + (q - (q / bw) * bw);
+        const int p = yy * W + xx;
+        const float Y = (float)yy, X = (float)xx;
         float c[8], dc[8], m = 1.f;
         for (int e = 0; e < 8; ++e) {
             c[e] = 1.f; dc[e] = 0.f;
@@ -199,6 +211,7 @@ __global__ __launch_bounds__(256) void k_polygon_focal(const float* __restrict__
             }
         }
         const float x = mk[p] ? 1.f : 0.f;
+        ones_in += x;
         const float ps = 1.f / (1.f + __expf(-x));
         const float ce = fmaxf(x, 0.f) - x * m + log1pf(__expf(-fabsf(x)));
         const float pt = ps * m + (1.f - ps) * (1.f - m);
@@ -221,32 +234,44 @@ __global__ __launch_bounds__(256) void k_polygon_focal(const float* __restrict__
             }
         }
     }
-    // block reduction of 17 values
+    // block reduction of 18 values: loss inside the box, 16 gradients, mask ones inside the box
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float vals[17];
+    float vals[18];
     vals[0] = acc;
     for (int i = 0; i < 16; ++i) vals[1 + i] = g[i];
-    for (int i = 0; i < 17; ++i) {
+    vals[17] = ones_in;
+    for (int i = 0; i < 18; ++i) {
         float v = vals[i];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
     if (threadIdx.x < 17) {
-        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (threadIdx.x == 0) atomicAdd(&loss[r], v);
-        else if (want_grad) atomicAdd(&grad[r * 16 + threadIdx.x - 1], v);
+        float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x == 0) {
+            // pixels outside the box: polygon value 0 -> focal(x, 0) = 0.75 * ce(x) * sigmoid(x)^2
+            const float in_ones = red[0][17] + red[1][17] + red[2][17] + red[3][17];
+            const float out_ones = (float)mask_ones[mi] - in_ones;
+            const float out_zeros = (float)(total - bw * bh) - out_ones;
+            const float L0 = 0.75f * 0.69314718056f * 0.25f;
+            const float p1 = 1.f / (1.f + __expf(-1.f));
+            const float L1 = 0.75f * (1.f + log1pf(__expf(-1.f))) * p1 * p1;
+            v += (L0 * out_zeros + L1 * out_ones) * inv_total;
+            loss[r] = v;
+        } else if (want_grad) {
+            grad[r * 16 + threadIdx.x - 1] = v;
+        }
     }
 }
 
 extern "C" int cr_polygon_focal(cr_ctx* ctx, const float* hull, const int32_t* count, const unsigned char* masks,
-                                const int32_t* mask_idx, int n, int H, int W, float* loss, float* grad) {
+                                const int32_t* mask_idx, const int32_t* mask_ones, int n, int H, int W, float* loss,
+                                float* grad) {
     CR_CHECK_ARG(ctx && n >= 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 30), "cr_polygon_focal: bad args");
     if (n == 0) return CR_OK;
-    CR_CHECK_ARG(hull && count && masks && mask_idx && loss, "cr_polygon_focal: NULL pointer");
-    const int chunks = (int)(cr_cdiv((int64_t)H * W, 256 * 16) < 64 ? cr_cdiv((int64_t)H * W, 256 * 16) : 64);
-    hipLaunchKernelGGL(k_polygon_focal, dim3((unsigned)n, (unsigned)(chunks < 1 ? 1 : chunks)), dim3(256), 0, ctx->stream, hull,
-                       count, masks, mask_idx, H, W, loss, grad, grad != nullptr);
+    CR_CHECK_ARG(hull && count && masks && mask_idx && mask_ones && loss, "cr_polygon_focal: NULL pointer");
+    hipLaunchKernelGGL(k_polygon_focal, dim3((unsigned)n), dim3(256), 0, ctx->stream, hull, count, masks, mask_idx, mask_ones, H,
+                       W, loss, grad, grad != nullptr);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -171,11 +171,12 @@ class _PolygonFocal(torch.autograd.Function):
         lib = _lib.load()
         h = hull.detach().float().contiguous()
         n = h.shape[0]
-        loss = torch.zeros((n,), dtype=torch.float32, device=h.device)
-        grad = torch.zeros((n, 8, 2), dtype=torch.float32, device=h.device) if hull.requires_grad else None
-        _lib.check(lib.cr_polygon_focal(_lib.ctx_for(h.device), _lib.ptr(h), _lib.ptr(count), _lib.ptr(masks), _lib.ptr(mask_idx), n,
-                                        masks.shape[1], masks.shape[2], _lib.ptr(loss), _lib.ptr(grad) if grad is not None else None),
-                   "cr_polygon_focal")
+        loss = torch.empty((n,), dtype=torch.float32, device=h.device)
+        grad = torch.empty((n, 8, 2), dtype=torch.float32, device=h.device) if hull.requires_grad else None
+        ones = (masks != 0).sum((1, 2)).to(torch.int32).contiguous()
+        _lib.check(lib.cr_polygon_focal(_lib.ctx_for(h.device), _lib.ptr(h), _lib.ptr(count), _lib.ptr(masks), _lib.ptr(mask_idx),
+                                        _lib.ptr(ones), n, masks.shape[1], masks.shape[2], _lib.ptr(loss),
+                                        _lib.ptr(grad) if grad is not None else None), "cr_polygon_focal")
         ctx.grad = grad
         return loss
 

@@ -112,10 +112,11 @@ int cr_box_median(cr_ctx* ctx, const float* depth, int B, int H, int W, const in
 int cr_hull8(cr_ctx* ctx, const float* pts, int n, int32_t* order, int32_t* count, float* bump);
 /* segment_loss of ROIHeads3DScore (roi_heads.py:1030-1053) for n RoIs: soft polygon mask of the hull (fill_polygon,
  * utils.py:472-502) against the object's mask through sigmoid_focal_loss(inputs = mask, targets = polygon), mean over the
- * H x W pixels.  hull (n,8,2) f32 ordered vertices, count (n); masks (Nm,H,W) uint8, mask_idx (n) int32.
- * loss (n) f32 and grad (n,8,2) f32 (d loss / d hull vertex, or NULL) are ACCUMULATED: zero them first. */
+ * H x W pixels.  hull (n,8,2) f32 ordered vertices, count (n); masks (Nm,H,W) uint8, mask_idx (n) int32, mask_ones (Nm)
+ * int32 = set pixels per mask (only the hull's bounding box is visited; outside it the term is a constant per mask bit).
+ * loss (n) f32 and grad (n,8,2) f32 (d loss / d hull vertex, or NULL) are written. */
 int cr_polygon_focal(cr_ctx* ctx, const float* hull, const int32_t* count, const unsigned char* masks, const int32_t* mask_idx,
-                     int n, int H, int W, float* loss, float* grad);
+                     const int32_t* mask_ones, int n, int H, int W, float* loss, float* grad);
 
 /* Raster counts behind score_segmentation / score_mod_segmentation (ProposalNetwork/scoring/scorefunction.py:88-126;
  * cv2.convexHull + cv2.fillPoly + [::stride, ::stride] + mask_iou, utils.py:230-250) for the P proposals of one object:
