@@ -184,7 +184,15 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
     const bool have_rect = rect_pts != nullptr;
     if (have_rect && tid < 8) s_rect[tid] = rect_pts[obj * 8 + tid];
 
-    float v_iou[CPT], v_gauss[CPT], v_diff[CPT], v_s[CPT];
+    // per-cube intermediates that live across the two per-object reductions: in LDS ([quantity][cube], conflict-free),
+    // not in CPT-sized register arrays -- with the cube loop rolled the kernel needs ~half the VGPRs and twice the waves
+    // are resident per SIMD
+    __shared__ float s_v[4][CPT * GEO_T];
+    float* const v_iou = s_v[0] + tid;
+    float* const v_gauss = s_v[1] + tid;
+    float* const v_diff = s_v[2] + tid;
+    float* const v_s = s_v[3] + tid;
+#define VAT(arr, c) arr[(c) * GEO_T]
     double sum_mnx = 0, sum_mxx = 0, sum_mny = 0, sum_mxy = 0;
 
     // ---------------- pass A: corners, boxes, iou, gauss, ratio diff (+ chamfer if rect given)
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
             }
         }
         __syncthreads();
-#pragma unroll
+#pragma unroll 1
         for (int c = 0; c < CPT; ++c) {
             const int base = c * GEO_T;
             if (base < P) {                          // block-uniform
@@ -253,15 +261,15 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
                     h = (h != h) ? h : fmaxf(h, 0.0f);
                     const float inter = w * h;
                     const float iou = inter / ((a1 + a2) - inter);
-                    v_iou[c] = inter > 0.0f ? iou : 0.0f;
+                    VAT(v_iou, c) = inter > 0.0f ? iou : 0.0f;
                     // size prior (scorefunction.py:151-152), dims are (w,h,l) = cu[3..5]
                     const float z0 = (cu[3] - mu0) / sg0, z1 = (cu[4] - mu1) / sg1, z2 = (cu[5] - mu2) / sg2;
                     const float e0 = cr_exp_f32(-0.5f * (z0 * z0));
                     const float e1 = cr_exp_f32(-0.5f * (z1 * z1));
                     const float e2 = cr_exp_f32(-0.5f * (z2 * z2));
-                    v_gauss[c] = ((e0 + e1) + e2) / 3.0f;
+                    VAT(v_gauss, c) = ((e0 + e1) + e2) / 3.0f;
                     const float pr = (b2 - b0) / (b3 - b1);
-                    v_diff[c] = fabsf(gt_ratio - pr);
+                    VAT(v_diff, c) = fabsf(gt_ratio - pr);
                     sum_mnx += b0; sum_mxx += b2; sum_mny += b1; sum_mxy += b3;
                 }
                 if (have_rect || pass == 1) {
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
                         const double d = nan ? (double)nan_f() : sqrt(best);
                         acc = (q == 0) ? d : acc + d;
                     }
-                    v_s[c] = (float)(acc / 4.0);
+                    VAT(v_s, c) = (float)(acc / 4.0);
                 }
             }
             __syncthreads();
@@ -293,13 +301,13 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
     // ---------------- per-object normalisers
     float lmaxd = -INFINITY, lmaxs = -INFINITY;
     bool nand = false, nans = false;
-#pragma unroll
+#pragma unroll 1
     for (int c = 0; c < CPT; ++c) {
         if (c * GEO_T + tid < P) {
-            nand |= v_diff[c] != v_diff[c];
-            nans |= v_s[c] != v_s[c];
-            lmaxd = fmaxf(lmaxd, v_diff[c]);
-            lmaxs = fmaxf(lmaxs, v_s[c]);
+            nand |= VAT(v_diff, c) != VAT(v_diff, c);
+            nans |= VAT(v_s, c) != VAT(v_s, c);
+            lmaxd = fmaxf(lmaxd, VAT(v_diff, c));
+            lmaxs = fmaxf(lmaxs, VAT(v_s, c));
         }
     }
     const bool anyv = tid < P;
@@ -309,15 +317,15 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
     // ---------------- pass B: final scores + argmax
     float bestv = 0.0f;
     int besti = -1;
-#pragma unroll
+#pragma unroll 1
     for (int c = 0; c < CPT; ++c) {
         const int p = c * GEO_T + tid;
         if (p < P) {
-            const float dim = (1.0f - v_diff[c] / maxdiff) * v_gauss[c];
-            const float cor = 1.0f - v_s[c] / maxs;
-            const float comb = (v_iou[c] * dim) * cor;
+            const float dim = (1.0f - VAT(v_diff, c) / maxdiff) * VAT(v_gauss, c);
+            const float cor = 1.0f - VAT(v_s, c) / maxs;
+            const float comb = (VAT(v_iou, c) * dim) * cor;
             const size_t gi = (size_t)obj * P + p;
-            if (out_iou) out_iou[gi] = v_iou[c];
+            if (out_iou) out_iou[gi] = VAT(v_iou, c);
             if (out_dim) out_dim[gi] = dim;
             if (out_corner) out_corner[gi] = cor;
             if (out_combined) out_combined[gi] = comb;
