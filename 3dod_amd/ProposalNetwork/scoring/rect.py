@@ -19,17 +19,14 @@ def min_area_rect(points: np.ndarray) -> np.ndarray:
         hull = pts[[np.argmin(pts @ (pts[-1] - pts[0])), np.argmax(pts @ (pts[-1] - pts[0]))]]
     edges = np.roll(hull, -1, axis=0) - hull
     ang = np.unique(np.mod(np.arctan2(edges[:, 1], edges[:, 0]), np.pi / 2))
-    best = None
-    for a in ang:
-        c, s = np.cos(a), np.sin(a)
-        Rm = np.array([[c, s], [-s, c]])
-        r = hull @ Rm.T
-        mn, mx = r.min(0), r.max(0)
-        area = (mx[0] - mn[0]) * (mx[1] - mn[1])
-        if best is None or area < best[0]:
-            box = np.array([[mn[0], mn[1]], [mx[0], mn[1]], [mx[0], mx[1]], [mn[0], mx[1]]]) @ Rm
-            best = (area, box)
-    return best[1].astype(np.float32)
+    c, s = np.cos(ang)[:, None], np.sin(ang)[:, None]                      # every candidate edge direction at once
+    rx = hull[None, :, 0] * c + hull[None, :, 1] * s
+    ry = hull[None, :, 1] * c - hull[None, :, 0] * s
+    x0, x1, y0, y1 = rx.min(1), rx.max(1), ry.min(1), ry.max(1)
+    k = int(np.argmin((x1 - x0) * (y1 - y0)))                              # first minimum in angle order
+    c, s = c[k, 0], s[k, 0]
+    box = np.array([[x0[k], y0[k]], [x1[k], y0[k]], [x1[k], y1[k]], [x0[k], y1[k]]])
+    return (box @ np.array([[c, s], [-s, c]])).astype(np.float32)
 
 
 def rect_from_mask(mask: np.ndarray):
@@ -37,9 +34,17 @@ def rect_from_mask(mask: np.ndarray):
     m = np.asarray(mask).astype(bool)
     if not m.any():
         return None
+    rows, cols = np.nonzero(m.any(1))[0], np.nonzero(m.any(0))[0]
+    r0, c0 = rows[0], cols[0]
+    m = m[r0:rows[-1] + 1, c0:cols[-1] + 1]                                # label only the mask's bounding window
     lab, n = ndimage.label(m, structure=np.ones((3, 3)))
     if n > 1:
         sizes = ndimage.sum(m, lab, index=np.arange(1, n + 1))
         m = lab == (1 + int(np.argmax(sizes)))
-    ys, xs = np.nonzero(m)
-    return min_area_rect(np.stack([xs, ys], 1))
+    # the hull of a pixel set is the hull of each occupied row's first and last pixel: <= 2H points reach the sort
+    # and Qhull instead of every mask pixel
+    rows = np.nonzero(m.any(1))[0]
+    sub = m[rows]
+    x0 = sub.argmax(1)
+    x1 = m.shape[1] - 1 - sub[:, ::-1].argmax(1)
+    return min_area_rect(np.concatenate([np.stack([x0 + c0, rows + r0], 1), np.stack([x1 + c0, rows + r0], 1)]))
