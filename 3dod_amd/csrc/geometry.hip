@@ -181,7 +181,8 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
     const float a1 = (r2 - r0) * (r3 - r1);
     const float gt_ratio = (r2 - r0) / (r3 - r1);
 
-    const bool have_rect = rect_pts != nullptr;
+    // no rectangle at all, or a NaN row for this object (empty mask, cr_mask_rects): the no-contour fallback below
+    const bool have_rect = rect_pts != nullptr && rect_pts[obj * 8] == rect_pts[obj * 8];
     if (have_rect && tid < 8) s_rect[tid] = rect_pts[obj * 8 + tid];
 
     // per-cube intermediates that live across the two per-object reductions: in LDS ([quantity][cube], conflict-free),

@@ -370,3 +370,224 @@ extern "C" int cr_segment_counts(cr_ctx* ctx, const float* corners, int P, const
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Object mask -> minimum-area rectangle of its largest 8-connected component: the host step of score_corners
+// (ProposalNetwork/scoring/scorefunction.py:58-68: cv2.findContours(RETR_EXTERNAL) -> max contourArea -> cv2.minAreaRect
+// -> cv2.boxPoints), kept on the device so the n masks never leave HBM.
+//   1. k_ccl_init    label = first pixel of the pixel's run inside its 64-pixel wave segment (ballot), -1 for background
+//   2. k_ccl_merge   union-find (atomicMin on the parent) across segment boundaries and with the row above; only the
+//                    pixels at run starts of either row issue a union, the rest are implied
+//   3. k_ccl_sizes   label := root; each run segment adds its length to sizes[root] (one atomic per segment)
+//   4. k_ccl_best    per object max over roots of (size, lowest root) -- ties go to the component that starts first in
+//                    raster order, as scipy.ndimage.label + argmax does in the host restatement (oracle/rect.py)
+//   5. k_mask_rect   one workgroup per object: row extremes of the chosen component -> left / right convex chains (two
+//                    lanes, integer turn tests) -> rotating calipers over the hull edges in f64
+// Labels are pixel indices local to the object (H*W < 2^31).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ccl_find(const int* L, int a) {
+    int p;
+    while ((p = __hip_atomic_load(L + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != a) a = p;   // parents change under us: read at L2
+    return a;
+}
+
+__device__ __forceinline__ void ccl_union(int* L, int a, int b) {
+    bool done = false;
+    while (!done) {
+        a = ccl_find(L, a);
+        b = ccl_find(L, b);
+        if (a < b) { const int old = atomicMin(L + b, a); done = old == b; b = old; }
+        else if (b < a) { const int old = atomicMin(L + a, b); done = old == a; a = old; }
+        else done = true;
+    }
+}
+
+// grid (ceil(W/256), H, n), block 256: a wave covers 64 consecutive pixels of one row
+__global__ __launch_bounds__(256) void k_ccl_init(const unsigned char* __restrict__ masks, int H, int W, int* __restrict__ labels) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const size_t base = (size_t)blockIdx.z * H * W;
+    const bool fg = x < W && masks[base + (size_t)y * W + x] != 0;
+    const unsigned long long b = __ballot(fg);
+    if (x >= W) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = ~b & ((1ull << lane) - 1ull);          // background lanes before this one
+    const int start = below ? 64 - __clzll(below) : 0;
+    labels[base + (size_t)y * W + x] = fg ? y * W + (x - lane + start) : -1;
+}
+
+__global__ __launch_bounds__(256) void k_ccl_merge(int H, int W, int* __restrict__ labels) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    int* L = labels + (size_t)blockIdx.z * H * W;
+    const int p = y * W + x;
+    if (L[p] < 0) return;
+    const bool w = x > 0 && L[p - 1] >= 0;
+    if (w && (threadIdx.x & 63) == 0) ccl_union(L, p, p - 1);              // run continues across the segment boundary
+    if (y == 0) return;
+    const int up = p - W;
+    const bool n = L[up] >= 0, nw = x > 0 && L[up - 1] >= 0, ne = x + 1 < W && L[up + 1] >= 0;
+    if (n) { if (!w || !nw) ccl_union(L, p, up); }
+    else {
+        if (nw && !w) ccl_union(L, p, up - 1);
+        if (ne) ccl_union(L, p, up + 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_sizes(int H, int W, int* __restrict__ labels, int* __restrict__ sizes) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const size_t base = (size_t)blockIdx.z * H * W;
+    int* L = labels + base;
+    const int p = y * W + x;
+    const bool fg = x < W && L[p] >= 0;
+    const unsigned long long b = __ballot(fg);
+    if (!fg) return;
+    const int root = ccl_find(L, p);
+    L[p] = root;
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 || !((b >> (lane - 1)) & 1ull)) {                         // first pixel of a run segment
+        const unsigned long long rest = ~(b >> lane);
+        atomicAdd(sizes + base + root, rest ? __ffsll((long long)rest) - 1 : 64 - lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_best(int H, int W, const int* __restrict__ labels, const int* __restrict__ sizes,
+                                                  unsigned long long* __restrict__ best) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t base = (size_t)blockIdx.z * H * W;
+    const int p = y * W + x;
+    if (labels[base + p] != p) return;
+    atomicMax(best + blockIdx.z, ((unsigned long long)(unsigned)sizes[base + p] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p));
+}
+
+#define RECT_T 1024
+// dynamic LDS: int sx0[H], sx1[H], stack[2][H], hull_x[2H], hull_y[2H]
+__global__ __launch_bounds__(RECT_T) void k_mask_rect(int H, int W, const int* __restrict__ labels,
+                                                      const unsigned long long* __restrict__ best, float* __restrict__ rects,
+                                                      unsigned char* __restrict__ valid) {
+    extern __shared__ int s_rect[];
+    int* sx0 = s_rect;
+    int* sx1 = sx0 + H;
+    int* stk = sx1 + H;
+    int* hx = stk + 2 * H;
+    int* hy = hx + 2 * H;
+    __shared__ int s_rows[2], s_cnt[3];
+    __shared__ double s_area[RECT_T / 64], s_ang[RECT_T / 64];
+    const int obj = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* out = rects + (size_t)obj * 8;
+    const unsigned long long key = best[obj];
+    if (key == 0ull) {                                                      // empty mask
+        if (tid < 8) out[tid] = __builtin_nanf("");                         // cr_cubes_project_score: fallback rectangle
+        if (tid == 0) valid[obj] = 0;
+        return;
+    }
+    const int root = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    const int* L = labels + (size_t)obj * H * W;
+    if (tid == 0) { s_rows[0] = H; s_rows[1] = -1; }
+    __syncthreads();
+    for (int r = wave; r < H; r += RECT_T / 64) {
+        int lo = W, hi = -1;
+        for (int x = lane; x < W; x += 64)
+            if (L[(size_t)r * W + x] == root) { lo = min(lo, x); hi = max(hi, x); }
+        for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        if (lane == 0) {
+            sx0[r] = hi >= 0 ? lo : -1;
+            sx1[r] = hi;
+            if (hi >= 0) { atomicMin(&s_rows[0], r); atomicMax(&s_rows[1], r); }
+        }
+    }
+    __syncthreads();
+    const int rmin = s_rows[0], rmax = s_rows[1];
+    if (tid < 2) {                                                          // lane 0: left chain, lane 1: right chain
+        int* st = stk + tid * H;
+        const int* sx = tid ? sx1 : sx0;
+        int top = 0;
+        for (int r = rmin; r <= rmax; ++r) {
+            const int x = sx[r];
+            if (x < 0) continue;                                            // (a component covers contiguous rows)
+            while (top >= 2) {
+                const int ay = st[top - 2], by = st[top - 1], ax = sx[ay], bx = sx[by];
+                const int cross = (bx - ax) * (r - ay) - (by - ay) * (x - ax);
+                if (tid ? cross <= 0 : cross >= 0) --top; else break;
+            }
+            st[top++] = r;
+        }
+        s_cnt[tid] = top;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int h = 0;
+        for (int i = 0; i < s_cnt[0]; ++i) { const int r = stk[i]; hx[h] = sx0[r]; hy[h] = r; ++h; }
+        for (int i = s_cnt[1] - 1; i >= 0; --i) {
+            const int r = stk[H + i];
+            if ((r == rmax || r == rmin) && sx0[r] == sx1[r]) continue;     // chain end shared with the left chain
+            hx[h] = sx1[r]; hy[h] = r; ++h;
+        }
+        s_cnt[2] = h;
+    }
+    __syncthreads();
+    const int h = s_cnt[2];
+    if (h == 1) {
+        if (tid < 8) out[tid] = (float)((tid & 1) ? hy[0] : hx[0]);
+        if (tid == 0) valid[obj] = 1;
+        return;
+    }
+    const double HALF_PI = 1.5707963267948966;
+    double b_area = 1.0e300, b_ang = 4.0;
+    for (int e = tid; e < h; e += RECT_T) {
+        const int e2 = e + 1 == h ? 0 : e + 1;
+        double ang = fmod(atan2((double)(hy[e2] - hy[e]), (double)(hx[e2] - hx[e])), HALF_PI);
+        if (ang < 0.0) ang += HALF_PI;
+        const double c = cos(ang), s = sin(ang);
+        double x0 = 1.0e300, x1 = -1.0e300, y0 = 1.0e300, y1 = -1.0e300;
+        for (int v = 0; v < h; ++v) {
+            const double vx = (double)hx[v], vy = (double)hy[v];
+            const double rx = vx * c + vy * s, ry = vy * c - vx * s;
+            x0 = fmin(x0, rx); x1 = fmax(x1, rx); y0 = fmin(y0, ry); y1 = fmax(y1, ry);
+        }
+        const double area = (x1 - x0) * (y1 - y0);
+        if (area < b_area || (area == b_area && ang < b_ang)) { b_area = area; b_ang = ang; }
+    }
+    for (int o = 32; o; o >>= 1) {
+        const double a2 = __shfl_xor(b_area, o), g2 = __shfl_xor(b_ang, o);
+        if (a2 < b_area || (a2 == b_area && g2 < b_ang)) { b_area = a2; b_ang = g2; }
+    }
+    if (lane == 0) { s_area[wave] = b_area; s_ang[wave] = b_ang; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < RECT_T / 64; ++w)
+            if (s_area[w] < b_area || (s_area[w] == b_area && s_ang[w] < b_ang)) { b_area = s_area[w]; b_ang = s_ang[w]; }
+        const double c = cos(b_ang), s = sin(b_ang);
+        double x0 = 1.0e300, x1 = -1.0e300, y0 = 1.0e300, y1 = -1.0e300;
+        for (int v = 0; v < h; ++v) {
+            const double vx = (double)hx[v], vy = (double)hy[v];
+            const double rx = vx * c + vy * s, ry = vy * c - vx * s;
+            x0 = fmin(x0, rx); x1 = fmax(x1, rx); y0 = fmin(y0, ry); y1 = fmax(y1, ry);
+        }
+        const double bx[4] = {x0, x1, x1, x0}, by[4] = {y0, y0, y1, y1};
+        for (int k = 0; k < 4; ++k) {                                       // back to image axes: [bx by] @ [[c s] [-s c]]
+            out[2 * k] = (float)(bx[k] * c - by[k] * s);
+            out[2 * k + 1] = (float)(bx[k] * s + by[k] * c);
+        }
+        valid[obj] = 1;
+    }
+}
+
+extern "C" int cr_mask_rects(cr_ctx* ctx, const unsigned char* masks, int n, int H, int W, int32_t* labels, int32_t* sizes,
+                             unsigned long long* best, float* rects, unsigned char* valid) {
+    CR_CHECK_ARG(ctx && n >= 0 && H > 0 && W > 0 && H <= 1900 && (int64_t)H * W < (1ll << 31) && n <= 65535,
+                 "cr_mask_rects: bad args (H <= 1900: 32 B of LDS per row; n <= 65535)");
+    if (n == 0) return CR_OK;
+    CR_CHECK_ARG(masks && labels && sizes && best && rects && valid, "cr_mask_rects: NULL pointer");
+    CR_HIP(hipMemsetAsync(sizes, 0, sizeof(int32_t) * (size_t)n * H * W, ctx->stream));
+    CR_HIP(hipMemsetAsync(best, 0, sizeof(unsigned long long) * (size_t)n, ctx->stream));
+    const dim3 grid((unsigned)cr_cdiv(W, 256), (unsigned)H, (unsigned)n), block(256);
+    hipLaunchKernelGGL(k_ccl_init, grid, block, 0, ctx->stream, masks, H, W, labels);
+    hipLaunchKernelGGL(k_ccl_merge, grid, block, 0, ctx->stream, H, W, labels);
+    hipLaunchKernelGGL(k_ccl_sizes, grid, block, 0, ctx->stream, H, W, labels, sizes);
+    hipLaunchKernelGGL(k_ccl_best, grid, block, 0, ctx->stream, H, W, (const int*)labels, (const int*)sizes, best);
+    hipLaunchKernelGGL(k_mask_rect, dim3((unsigned)n), dim3(RECT_T), sizeof(int) * 8 * (size_t)H, ctx->stream, H, W,
+                       (const int*)labels, (const unsigned long long*)best, rects, valid);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

@@ -16,7 +16,6 @@ import torch.nn as nn
 from ....d2lite import ROI_HEADS_REGISTRY, Boxes, Instances
 from .... import geometry as geo
 from ....ProposalNetwork.proposals import proposals as PN
-from ....ProposalNetwork.scoring.rect import rect_from_mask
 from ....ProposalNetwork.utils.plane import Plane
 from ....ProposalNetwork.utils.spaces import Cubes
 from .fast_rcnn import FastRCNNOutputs, batched_nms
@@ -90,7 +89,7 @@ class ROIHeads_Boxer(StandardROIHeads):
         """roi_heads.py:304-660 (use_pred_boxes branch :492-505 and the Instances packing :647-660)."""
         dev = depth_maps.device
         P = self.number_of_proposals
-        cubes_all, K_all, ref_all, mu_all, sg_all, rect_all, have_rect = [], [], [], [], [], [], True
+        cubes_all, K_all, ref_all, mu_all, sg_all, rect_all, have_rect = [], [], [], [], [], [], False
         for i, (b, cls) in enumerate(zip(boxes, classes)):
             n = len(b)
             if n == 0:
@@ -116,14 +115,10 @@ class ROIHeads_Boxer(StandardROIHeads):
             mu_all.append(mu)
             sg_all.append(sg)
             if masks is not None and masks[i] is not None:
-                m = masks[i].cpu().numpy()
-                rects = [rect_from_mask(m[j]) for j in range(n)]
-                if any(r is None for r in rects):
-                    have_rect = False
-                else:
-                    rect_all.append(torch.tensor(np.stack(rects), device=dev))
+                have_rect = True
+                rect_all.append(geo.mask_rects(masks[i].to(dev))[0])           # NaN row = empty mask -> fallback rect
             else:
-                have_rect = False
+                rect_all.append(torch.full((n, 4, 2), float("nan"), device=dev))
         out_instances = [Instances(s) for s in image_sizes]
         if not cubes_all:
             return out_instances
@@ -133,7 +128,7 @@ class ROIHeads_Boxer(StandardROIHeads):
         cubes_t = torch.cat(cubes_all)
         res = geo.cubes_project_score(cubes_t, torch.cat(K_all).contiguous(), (W, H), torch.cat(ref_all).contiguous(),
                                       torch.cat(mu_all), torch.cat(sg_all),
-                                      torch.cat(rect_all) if (have_rect and rect_all) else None, want=())
+                                      torch.cat(rect_all) if have_rect else None, want=())
         idx = res["argmax"]
         best = cubes_t[torch.arange(cubes_t.shape[0], device=dev), idx]        # (Ntot,15)
         verts = geo.cuboid_corners(best[:, :6].contiguous(), best[:, 6:].reshape(-1, 3, 3).contiguous())

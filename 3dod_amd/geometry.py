@@ -207,3 +207,21 @@ def segment_counts(corners2d, mask, stride=4):
     _lib.check(lib.cr_segment_counts(_lib.ctx_for(c.device), _lib.ptr(c), P, _lib.ptr(m), m.shape[0], m.shape[1], int(stride),
                                      _lib.ptr(out)), "cr_segment_counts")
     return out.long()
+
+
+def mask_rects(masks):
+    """minimum-area rectangle of the largest 8-connected component of every mask (cr_mask_rects; the cv2 step of
+    score_corners, scorefunction.py:58-68): masks (n,H,W) bool/uint8 on the GPU -> rects (n,4,2) f32, valid (n) bool"""
+    lib = _lib.load()
+    if not masks.is_cuda:
+        raise _lib.CrError("mask_rects: expected CUDA(HIP) tensors; 3dod_amd has no CPU path")
+    m = masks.to(torch.uint8).contiguous()
+    n, H, W = m.shape
+    dev = m.device
+    scratch = torch.empty((2, n, H, W), dtype=torch.int32, device=dev)
+    best = torch.empty((n,), dtype=torch.int64, device=dev)
+    rects = torch.empty((n, 4, 2), dtype=torch.float32, device=dev)
+    valid = torch.empty((n,), dtype=torch.uint8, device=dev)
+    _lib.check(lib.cr_mask_rects(_lib.ctx_for(dev), _lib.ptr(m), n, H, W, _lib.ptr(scratch[0]), _lib.ptr(scratch[1]),
+                                 _lib.ptr(best), _lib.ptr(rects), _lib.ptr(valid)), "cr_mask_rects")
+    return rects, valid.bool()

@@ -61,8 +61,9 @@ int cr_cuboid_corners(cr_ctx* ctx, const float* box6, const float* R, int64_t n,
  * cubes (N,P,15) = [cx,cy,cz,w,h,l,R row-major]; K (3,3) when k_per_object==0
  * else (N,3,3); im_w/im_h = the clamp tuple (W,H); ref_boxes (N,4) XYXY;
  * prior_mu / prior_sigma (N,3) in (w,h,l); rect_pts (N,4,2) = the
- * cv2.boxPoints(minAreaRect(mask contour)) quad, or NULL for the reference's
- * no-contour fallback (scorefunction.py:69-75).
+ * cv2.boxPoints(minAreaRect(mask contour)) quad (cr_mask_rects computes it), or
+ * NULL for the reference's no-contour fallback (scorefunction.py:69-75) on every
+ * object; an object whose row starts with NaN (empty mask) takes it alone.
  * Outputs (any of the first six may be NULL = not written):
  *   out_corners (N,P,8,2) out_boxes (N,P,4) out_iou/out_dim/out_corner/
  *   out_combined (N,P); out_argmax (N) int64; out_best (N) = combined[argmax].
@@ -125,6 +126,16 @@ int cr_polygon_focal(cr_ctx* ctx, const float* hull, const int32_t* count, const
  * truncated to int32. */
 int cr_segment_counts(cr_ctx* ctx, const float* corners, int P, const unsigned char* mask, int H, int W, int stride,
                       int32_t* counts);
+
+/* Minimum-area rectangle of the largest 8-connected component of each object mask: the mask -> 4-point box step of
+ * score_corners (ProposalNetwork/scoring/scorefunction.py:58-68: cv2.findContours(RETR_EXTERNAL) -> max contourArea ->
+ * cv2.minAreaRect -> cv2.boxPoints) for n masks in one call.  masks (n,H,W) uint8; rects (n,4,2) f32 (x,y) corners;
+ * valid (n) uint8 = 0 for an empty mask (the reference then falls back to the mean extent of the projected cubes,
+ * :69-75).  labels, sizes: (n,H,W) int32 scratch; best: (n) uint64 scratch.  H <= 1900.  Ties between components of equal
+ * size go to the one that starts first in raster order; between rectangles of equal area to the smaller edge angle
+ * mod pi/2. */
+int cr_mask_rects(cr_ctx* ctx, const unsigned char* masks, int n, int H, int W, int32_t* labels, int32_t* sizes,
+                  unsigned long long* best, float* rects, unsigned char* valid);
 
 /* ---- Depth-Anything-V2 forward (DINOv2 ViT + DPT head), the ops that are not GEMMs / convolutions --------------- */
 /* softmax(q k^T * scale) v per (batch, head) on the packed output of the qkv linear: qkv (B,N,3,H,D) bf16, out (B,N,H,D)

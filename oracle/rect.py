@@ -1,8 +1,9 @@
-"""The per-object mask -> 4-point rectangle step of score_corners (ProposalNetwork/scoring/scorefunction.py:58-68:
-cv2.findContours(RETR_EXTERNAL) -> largest contour -> cv2.minAreaRect -> cv2.boxPoints), restated on the host with
-numpy/scipy because OpenCV is not installed: largest 8-connected component -> convex hull of its pixel centres ->
-minimum-area enclosing rectangle by rotating calipers.  [third-party: parity unpinned w.r.t. OpenCV; the corner
-order differs from cv2.boxPoints, which the order-invariant chamfer score does not see.]"""
+"""TEST INFRASTRUCTURE (oracle): the per-object mask -> 4-point rectangle step of score_corners
+(ProposalNetwork/scoring/scorefunction.py:58-68: cv2.findContours(RETR_EXTERNAL) -> largest contour -> cv2.minAreaRect
+-> cv2.boxPoints), restated with numpy/scipy because OpenCV is not installed: largest 8-connected component -> convex
+hull of its pixel centres -> minimum-area enclosing rectangle by rotating calipers.  The checker of cr_mask_rects.
+[third-party: parity unpinned w.r.t. OpenCV -- cv2.contourArea ranks contours by polygon area, this ranks components by
+pixel count; the corner order differs from cv2.boxPoints, which the order-invariant chamfer score does not see.]"""
 import numpy as np
 from scipy import ndimage
 from scipy.spatial import ConvexHull, QhullError

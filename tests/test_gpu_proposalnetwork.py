@@ -180,3 +180,79 @@ def test_mask_scores_kernel_against_oracle():
     exp_m = np.where(inter > 0, inter ** 5 / np.maximum(union, 1), 0)
     assert np.allclose(s, exp_s, rtol=1e-6) and np.allclose(m, exp_m, rtol=1e-5)
     assert s.max() <= 1.0 and s.max() > 0.3
+
+
+def _rect_masks(H, W, seed):
+    """object masks that stress the labelling: rotated ellipses with speckle, thin lines, single pixels, a spiral (long
+    label chains), a comb, two components of equal size, the full frame and an empty mask"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[:H, :W]
+    masks = []
+    for _ in range(6):
+        a = rng.uniform(0, np.pi)
+        cx, cy = rng.uniform(0.25, 0.75) * W, rng.uniform(0.25, 0.75) * H
+        ra, rb = rng.uniform(4, 0.3 * W), rng.uniform(4, 0.2 * H)
+        u = (xx - cx) * np.cos(a) + (yy - cy) * np.sin(a)
+        v = -(xx - cx) * np.sin(a) + (yy - cy) * np.cos(a)
+        masks.append(((u / ra) ** 2 + (v / rb) ** 2 < 1) | (rng.random((H, W)) < 0.002))
+    m = np.zeros((H, W), bool); m[H // 3, W // 5] = True; masks.append(m)                    # one pixel
+    m = np.zeros((H, W), bool); m[7, 3:W - 9] = True; masks.append(m)                        # one row, crosses segments
+    m = np.zeros((H, W), bool); m[5:H - 3, W - 1] = True; masks.append(m)                    # one column at the border
+    m = np.zeros((H, W), bool); d = np.arange(min(H, W) - 4); m[d + 2, d + 1] = True; masks.append(m)   # 8-connected diagonal
+    m = np.zeros((H, W), bool); d = np.arange(min(H, W) - 4); m[d + 2, min(H, W) - 3 - d] = True; masks.append(m)
+    m = np.zeros((H, W), bool)                                                               # square spiral, 1 px wide
+    t, l, b, r = 2, 2, H - 3, W - 3
+    while b - t > 6 and r - l > 6:
+        m[t, l:r + 1] = True; m[t:b + 1, r] = True; m[b, l + 2:r + 1] = True; m[t + 2:b + 1, l + 2] = True
+        m[t + 2, l + 2:r - 1] = True
+        t, l, b, r = t + 2, l + 2, b - 2, r - 2
+    masks.append(m)
+    m = np.zeros((H, W), bool); m[10:H - 10, 4:W - 4:2] = True; m[H - 11, 4:W - 4] = True; masks.append(m)   # comb
+    m = np.zeros((H, W), bool); m[4:10, 30:40] = True; m[20:30, 8:14] = True; m[40:42, 3:5] = True; masks.append(m)  # tie
+    masks.append(np.ones((H, W), bool))
+    masks.append(np.zeros((H, W), bool))
+    m = rng.random((H, W)) < 0.45; masks.append(m)                                            # percolation-like noise
+    return np.stack(masks)
+
+
+@pytest.mark.parametrize("H,W", [(96, 130), (200, 333), (512, 512)])
+def test_mask_rects_kernel_against_oracle(H, W):
+    """cr_mask_rects (largest 8-connected component -> hull -> minimum-area rectangle) against oracle/rect.py, corner
+    by corner; the empty mask is flagged invalid and marked NaN for the scoring kernel's fallback."""
+    from oracle import rect as orect
+    geo = importlib.import_module("3dod_amd.geometry")
+    masks = _rect_masks(H, W, seed=H)
+    rects, valid = geo.mask_rects(torch.from_numpy(masks).to(DEV))
+    rects, valid = rects.cpu().numpy(), valid.cpu().numpy()
+    for j, m in enumerate(masks):
+        want = orect.rect_from_mask(m)
+        if want is None:
+            assert not valid[j] and np.isnan(rects[j]).all()
+            continue
+        assert valid[j]
+        # 2e-3 px: the f64 angle comes from the device's atan2 / sin / cos instead of libm's
+        np.testing.assert_allclose(rects[j], want, rtol=0, atol=2e-3, err_msg="mask %d" % j)
+
+
+def test_project_score_nan_rect_row_takes_fallback():
+    """an object whose rectangle row is NaN scores against the no-contour fallback rectangle (scorefunction.py:69-75)
+    while the others keep theirs"""
+    geo = importlib.import_module("3dod_amd.geometry")
+    rng = np.random.default_rng(5)
+    N, P = 4, 1000
+    cubes = np.concatenate([rng.uniform(-1, 1, (N, P, 2)), rng.uniform(2, 6, (N, P, 1)), rng.uniform(0.3, 2, (N, P, 3)),
+                            np.tile(np.eye(3).reshape(1, 1, 9), (N, P, 1))], -1).astype(np.float32)
+    K = np.tile(np.array([[400, 0, 256], [0, 400, 256], [0, 0, 1]], np.float32), (N, 1, 1))
+    ref = np.tile(np.array([200, 180, 330, 300], np.float32), (N, 1))
+    mu, sg = np.full((N, 3), 1.0, np.float32), np.full((N, 3), 0.3, np.float32)
+    rect = np.tile(np.array([[200, 180], [330, 180], [330, 300], [200, 300]], np.float32), (N, 1, 1))
+    T = lambda a: torch.from_numpy(a).to(DEV)
+    with_rect = geo.cubes_project_score(T(cubes), T(K), (512, 512), T(ref), T(mu), T(sg), T(rect))
+    no_rect = geo.cubes_project_score(T(cubes), T(K), (512, 512), T(ref), T(mu), T(sg), None)
+    mixed_rect = rect.copy()
+    mixed_rect[2] = np.nan
+    mixed = geo.cubes_project_score(T(cubes), T(K), (512, 512), T(ref), T(mu), T(sg), T(mixed_rect))
+    for k in ("combined", "corner", "argmax", "best"):
+        assert torch.equal(mixed[k][[0, 1, 3]], with_rect[k][[0, 1, 3]]), k
+        assert torch.equal(mixed[k][2], no_rect[k][2]), k
+    assert not torch.equal(with_rect["corner"][2], no_rect["corner"][2])
