@@ -38,3 +38,27 @@ def propose(reference_box, depth_image, priors, im_shape, K, number_of_proposals
     else:
         raise RuntimeError("truncated-normal rejection sampling did not converge (prior std too large for its range?)")
     return Cubes(cubes), None, None
+
+
+def propose_batched(boxes, img_idx, depth_images, priors, K, number_of_proposals, ground_normals, generator=None):
+    """propose() for the objects of a whole batch in one launch (cr_propose_batched): boxes (N,4) tensor, img_idx (N)
+    int32 image of each object, depth_images (B,H,W), priors = (mean (N,3), std (N,3)), K (B,3,3), ground_normals (B,3).
+    Returns the (N,P,15) cube tensor.  One host sync per call (the rejection sampler's exhausted flag)."""
+    dev = boxes.device
+    N, P = boxes.shape[0], int(number_of_proposals)
+    if N == 0:
+        return torch.zeros((0, P, 15), device=dev)
+    mu, sg = priors[0].to(dev).float(), priors[1].to(dev).float()
+    depth = depth_images.to(dev).float().contiguous()
+    ctr = torch.randn((3, N, P), device=dev, generator=generator)
+    yaw = torch.randint(36, (N, P), device=dev, generator=generator, dtype=torch.int32)
+    rounds = ROUNDS
+    for attempt in range(12):
+        dn = torch.randn((rounds, 3, N, P), device=dev, generator=generator)
+        cubes, exhausted = geo.propose_from_draws_batched(boxes.float().contiguous(), img_idx, depth, mu, sg,
+                                                          K.to(dev).float().contiguous(), P, dn, ctr, yaw,
+                                                          ground_normals.to(dev).float().contiguous())
+        if int(exhausted.item()) == 0:
+            return cubes
+        rounds *= 2
+    raise RuntimeError("truncated-normal rejection sampling did not converge (prior std too large for its range?)")

@@ -20,6 +20,27 @@ class Plane:
         i2 = i2 + (i2 >= hi).long()
         return torch.stack((i0, i1, i2), 1).to(torch.int32)
 
+    @staticmethod
+    def sample_triples_batched(eligible, B, n_points, n_iter, device, generator=None):
+        """sample_triples for B point sets at once without reading a count back: eligible (B,Q) bool or None (all of
+        the n_points points); every set must have >= 3 eligible points.  Returns (B,n_iter,3) int32 indices into Q."""
+        if eligible is None:
+            cnt = torch.full((B, 1), n_points, device=device, dtype=torch.int64)
+        else:
+            cnt = eligible.sum(1, keepdim=True)
+        u = torch.rand((3, B, n_iter), device=device, generator=generator, dtype=torch.float64)
+        i0 = torch.minimum((u[0] * cnt).long(), cnt - 1)
+        i1 = (i0 + 1 + torch.minimum((u[1] * (cnt - 1)).long(), cnt - 2)) % cnt
+        i2 = torch.minimum((u[2] * (cnt - 2)).long(), cnt - 3)
+        lo, hi = torch.minimum(i0, i1), torch.maximum(i0, i1)
+        i2 = i2 + (i2 >= lo).long()
+        i2 = i2 + (i2 >= hi).long()
+        tri = torch.stack((i0, i1, i2), -1)                                  # ranks among the eligible points
+        if eligible is not None:
+            order = torch.sort(eligible.to(torch.uint8), dim=1, descending=True, stable=True).indices
+            tri = torch.gather(order, 1, tri.reshape(B, -1)).reshape(B, n_iter, 3)
+        return tri.to(torch.int32)
+
     def fit_parallel(self, pts: torch.Tensor, thresh=0.05, minPoints=100, maxIteration=1000, id_samples=None,
                      generator=None, need_inliers=True):
         """returns (-equation (4,), inlier indices) like the reference; need_inliers=False skips the index list (its

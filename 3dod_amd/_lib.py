@@ -21,6 +21,8 @@ SIGNATURES = {
                                P, P, P, P, P, P, P, P],
     "cr_propose": [P, P, c_int64, P, c_int, c_int, P, P, P, c_int64, P, c_int, P, P, P, P, P],
     "cr_ransac_plane": [P, P, c_int64, P, c_int64, c_float, P, P, P],
+    "cr_ransac_plane_batched": [P, P, P, c_int, c_int64, P, c_int64, c_float, P, P, P],
+    "cr_propose_batched": [P, P, P, c_int64, P, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P, P, P, P, P],
     "cr_box_median": [P, P, c_int, c_int, c_int, P, P, c_int, P],
     "cr_fold_bn": [P, P, P, P, P, P, c_float, P, P, c_int, c_int],
     "cr_hull8": [P, P, c_int, P, P, P],

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(GEO_T) void k_propose(
     const float* __restrict__ prior_mu, const float* __restrict__ prior_sigma, const float* __restrict__ Kmat,
     int N, int P, const float* __restrict__ dim_normals, int rounds, const float* __restrict__ ctr_normals,
     const int32_t* __restrict__ yaw_idx, const float* __restrict__ normal, float* __restrict__ out_cubes,
-    int32_t* __restrict__ out_exhausted) {
+    int32_t* __restrict__ out_exhausted, const int32_t* __restrict__ img_idx) {
     __shared__ float s_sort[PROP_MAXP];
     __shared__ double s_red64[GEO_W];
     __shared__ float s_tab[36 * 9];
@@ -454,6 +454,12 @@ __global__ __launch_bounds__(GEO_T) void k_propose(
 
     const int obj = blockIdx.x, tid = threadIdx.x;
     const float b0 = boxes[obj * 4 + 0], b1 = boxes[obj * 4 + 1], b2 = boxes[obj * 4 + 2], b3 = boxes[obj * 4 + 3];
+    if (img_idx) {                         // objects of several images in one launch: per-image depth, K and normal
+        const int im = img_idx[obj];
+        depth += (size_t)im * H * W;
+        Kmat += im * 9;
+        normal += im * 3;
+    }
     const float K00 = Kmat[0], K02 = Kmat[2], K12 = Kmat[5];
 
     // 36-yaw table from the ground normal: utils.py:112-146, proposals.py:404-405
@@ -597,7 +603,27 @@ extern "C" int cr_propose(cr_ctx* ctx, const float* boxes, int64_t N, const floa
     CR_HIP(hipMemsetAsync(out_exhausted, 0, sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(k_propose, dim3((unsigned)N), dim3(GEO_T), 0, ctx->stream, boxes, depth, H, W, prior_mu,
                        prior_sigma, K, (int)N, (int)P, dim_normals, rounds, ctr_normals, yaw_idx, normal, out_cubes,
-                       out_exhausted);
+                       out_exhausted, (const int32_t*)nullptr);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+extern "C" int cr_propose_batched(cr_ctx* ctx, const float* boxes, const int32_t* img_idx, int64_t N, const float* depth,
+                                  int B, int H, int W, const float* prior_mu, const float* prior_sigma, const float* K,
+                                  int64_t P, const float* dim_normals, int rounds, const float* ctr_normals,
+                                  const int32_t* yaw_idx, const float* normals, float* out_cubes, int32_t* out_exhausted) {
+    CR_CHECK_ARG(ctx != nullptr, "cr_propose_batched: ctx is NULL");
+    CR_CHECK_ARG(N >= 0 && B >= 1, "cr_propose_batched: bad N / B");
+    if (N == 0) return CR_OK;
+    CR_CHECK_ARG(P >= 2 && P <= PROP_MAXP, "cr_propose_batched: P=%lld outside [2,%d]", (long long)P, PROP_MAXP);
+    CR_CHECK_ARG(rounds >= 1 && H > 0 && W > 0, "cr_propose_batched: bad rounds / depth shape");
+    CR_CHECK_ARG(boxes && img_idx && depth && prior_mu && prior_sigma && K && dim_normals && ctr_normals && yaw_idx &&
+                     normals && out_cubes && out_exhausted,
+                 "cr_propose_batched: NULL pointer");
+    CR_HIP(hipMemsetAsync(out_exhausted, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(k_propose, dim3((unsigned)N), dim3(GEO_T), 0, ctx->stream, boxes, depth, H, W, prior_mu,
+                       prior_sigma, K, (int)N, (int)P, dim_normals, rounds, ctr_normals, yaw_idx, normals, out_cubes,
+                       out_exhausted, img_idx);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -608,9 +634,15 @@ extern "C" int cr_propose(cr_ctx* ctx, const float* boxes, int64_t N, const floa
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(GEO_T) void k_ransac_count(const float* __restrict__ pts, int Q,
                                                          const int32_t* __restrict__ triples, float thresh,
-                                                         float* __restrict__ eqs, int32_t* __restrict__ counts) {
+                                                         float* __restrict__ eqs, int32_t* __restrict__ counts,
+                                                         const unsigned char* __restrict__ eligible) {
     __shared__ int s_cnt[GEO_W];
-    const int t = blockIdx.x, tid = threadIdx.x;
+    const int t = blockIdx.x, tid = threadIdx.x, T = gridDim.x;
+    pts += (size_t)blockIdx.y * Q * 3;      // blockIdx.y = image of a batched fit (cr_ransac_plane_batched)
+    triples += (size_t)blockIdx.y * T * 3;
+    eqs += (size_t)blockIdx.y * T * 4;
+    counts += (size_t)blockIdx.y * T;
+    if (eligible) eligible += (size_t)blockIdx.y * Q;
     const int i0 = triples[t * 3], i1 = triples[t * 3 + 1], i2 = triples[t * 3 + 2];
     const float ax = pts[i1 * 3] - pts[i0 * 3], ay = pts[i1 * 3 + 1] - pts[i0 * 3 + 1], az = pts[i1 * 3 + 2] - pts[i0 * 3 + 2];
     const float bx = pts[i2 * 3] - pts[i0 * 3], by = pts[i2 * 3 + 1] - pts[i0 * 3 + 1], bz = pts[i2 * 3 + 2] - pts[i0 * 3 + 2];
@@ -622,7 +654,7 @@ __global__ __launch_bounds__(GEO_T) void k_ransac_count(const float* __restrict_
     int cnt = 0;
     for (int q = tid; q < Q; q += GEO_T) {
         const float d = (((cx * pts[q * 3] + cy * pts[q * 3 + 1]) + cz * pts[q * 3 + 2]) + k) / den;
-        cnt += fabsf(d) <= thresh ? 1 : 0;
+        cnt += (fabsf(d) <= thresh && (!eligible || eligible[q])) ? 1 : 0;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
@@ -641,6 +673,10 @@ __global__ __launch_bounds__(GEO_T) void k_ransac_pick(const float* __restrict__
                                                         float* __restrict__ out_neg_eq, int32_t* __restrict__ out_best) {
     __shared__ int s_c[GEO_W], s_i[GEO_W];
     const int tid = threadIdx.x;
+    eqs += (size_t)blockIdx.x * T * 4;
+    counts += (size_t)blockIdx.x * T;
+    out_neg_eq += blockIdx.x * 4;
+    out_best += blockIdx.x * 2;
     int bc = -1, bi = 0x7fffffff;
     for (int t = tid; t < T; t += GEO_T) {
         const int c = counts[t];
@@ -671,9 +707,27 @@ extern "C" int cr_ransac_plane(cr_ctx* ctx, const float* pts, int64_t Q, const i
     CR_CHECK_ARG(pts && triples && out_neg_eq && out_counts && out_best, "cr_ransac_plane: NULL pointer");
     float* eqs = (float*)ctx->ws;
     hipLaunchKernelGGL(k_ransac_count, dim3((unsigned)T), dim3(GEO_T), 0, ctx->stream, pts, (int)Q, triples, thresh,
-                       eqs, out_counts);
+                       eqs, out_counts, (const unsigned char*)nullptr);
     CR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(GEO_T), 0, ctx->stream, eqs, out_counts, (int)T, out_neg_eq,
+                       out_best);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+extern "C" int cr_ransac_plane_batched(cr_ctx* ctx, const float* pts, const unsigned char* eligible, int B, int64_t Q,
+                                       const int32_t* triples, int64_t T, float thresh, float* out_neg_eq,
+                                       int32_t* out_counts, int32_t* out_best) {
+    CR_CHECK_ARG(ctx != nullptr, "cr_ransac_plane_batched: ctx is NULL");
+    CR_CHECK_ARG(B >= 0 && B <= 65535 && Q >= 3 && T >= 1, "cr_ransac_plane_batched: need B<=65535, Q>=3 points, T>=1 triples");
+    if (B == 0) return CR_OK;
+    CR_CHECK_ARG(Q <= 0x7fffffff / 3 && (int64_t)B * T <= (int64_t)(ctx->ws_bytes / 16), "cr_ransac_plane_batched: too large");
+    CR_CHECK_ARG(pts && triples && out_neg_eq && out_counts && out_best, "cr_ransac_plane_batched: NULL pointer");
+    float* eqs = (float*)ctx->ws;
+    hipLaunchKernelGGL(k_ransac_count, dim3((unsigned)T, (unsigned)B), dim3(GEO_T), 0, ctx->stream, pts, (int)Q, triples,
+                       thresh, eqs, out_counts, eligible);
+    CR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ransac_pick, dim3((unsigned)B), dim3(GEO_T), 0, ctx->stream, eqs, out_counts, (int)T, out_neg_eq,
                        out_best);
     CR_LAUNCH_CHECK();
     return CR_OK;

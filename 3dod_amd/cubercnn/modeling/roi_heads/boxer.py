@@ -23,13 +23,15 @@ from .roi_heads import StandardROIHeads
 
 
 def depth_to_points(depth, K, use_nth=5):
-    """roi_heads.py:345-356, reproduced as written: strided pixel INDICES with the full-resolution intrinsics."""
-    dp = depth[::use_nth, ::use_nth]
-    Hs, Ws = dp.shape
+    """roi_heads.py:345-356, reproduced as written: strided pixel INDICES with the full-resolution intrinsics.
+    depth (H,W) with K (3,3), or a batch (B,H,W) with K (B,3,3)."""
+    dp = depth[..., ::use_nth, ::use_nth]
+    Hs, Ws = dp.shape[-2:]
     v, u = torch.meshgrid(torch.arange(Hs, device=depth.device, dtype=torch.float32),
                           torch.arange(Ws, device=depth.device, dtype=torch.float32), indexing="ij")
-    x = (u - K[0, 2]) * dp / K[0, 0]
-    y = (v - K[1, 2]) * dp / K[1, 1]
+    k = lambda r, c: K[..., r, c, None, None] if K.dim() == 3 else K[r, c]
+    x = (u - k(0, 2)) * dp / k(0, 0)
+    y = (v - k(1, 2)) * dp / k(1, 1)
     return torch.stack((x, y, dp), -1)
 
 
@@ -86,49 +88,48 @@ class ROIHeads_Boxer(StandardROIHeads):
     @torch.no_grad()
     def _forward_cube(self, image_sizes, boxes: List[Boxes], classes, depth_maps, ground_maps, Ks, im_scales_ratio,
                       masks=None, generator=None):
-        """roi_heads.py:304-660 (use_pred_boxes branch :492-505 and the Instances packing :647-660)."""
+        """roi_heads.py:304-660 (use_pred_boxes branch :492-505 and the Instances packing :647-660).  The reference
+        walks the images one by one; here every stage (ground-plane fit, proposals, mask rectangles, scoring) is one
+        launch for the whole batch, with a single host sync (the rejection sampler's exhausted flag)."""
         dev = depth_maps.device
         P = self.number_of_proposals
-        cubes_all, K_all, ref_all, mu_all, sg_all, rect_all, have_rect = [], [], [], [], [], [], False
-        for i, (b, cls) in enumerate(zip(boxes, classes)):
-            n = len(b)
-            if n == 0:
-                continue
-            K = (torch.as_tensor(Ks[i], dtype=torch.float32) / im_scales_ratio[i]).to(dev)
-            K[-1, -1] = 1
-            prior = self.priors_dims_per_cat.detach()[0][cls]                  # (n,2,3)
-            mu, sg = prior[:, 0, :].contiguous(), prior[:, 1, :].contiguous()
-            pts = depth_to_points(depth_maps[i], K)
-            if ground_maps is not None:
-                g = ground_maps[i][::5, ::5] > 0
-                gp = pts[g]
-                gp = gp if gp.shape[0] >= 3 else pts.reshape(-1, 3)
-            else:
-                gp = pts.reshape(-1, 3)
-            neg_eq, _ = Plane().fit_parallel(gp.contiguous(), thresh=0.05, maxIteration=1000, generator=generator)
-            normal = fix_ground_normal(-neg_eq[:3])
-            H, W = image_sizes[i]
-            cubes, _, _ = PN.propose(b, depth_maps[i], (mu, sg), (W, H), K, P, ground_normal=normal, generator=generator)
-            cubes_all.append(cubes.tensor)
-            K_all.append(K.unsqueeze(0).expand(n, 3, 3))
-            ref_all.append(b.tensor)
-            mu_all.append(mu)
-            sg_all.append(sg)
-            if masks is not None and masks[i] is not None:
-                have_rect = True
-                rect_all.append(geo.mask_rects(masks[i].to(dev))[0])           # NaN row = empty mask -> fallback rect
-            else:
-                rect_all.append(torch.full((n, 4, 2), float("nan"), device=dev))
         out_instances = [Instances(s) for s in image_sizes]
-        if not cubes_all:
+        counts = [len(b) for b in boxes]
+        if sum(counts) == 0:
             return out_instances
-        sizes = {tuple(s) for s in image_sizes}
-        assert len(sizes) == 1, "one clamp window per launch: batch images of one size"
+        assert len({tuple(s) for s in image_sizes}) == 1, "one clamp window per launch: batch images of one size"
         H, W = image_sizes[0]
-        cubes_t = torch.cat(cubes_all)
-        res = geo.cubes_project_score(cubes_t, torch.cat(K_all).contiguous(), (W, H), torch.cat(ref_all).contiguous(),
-                                      torch.cat(mu_all), torch.cat(sg_all),
-                                      torch.cat(rect_all) if have_rect else None, want=())
+        B = len(boxes)
+        K_img = torch.stack([torch.as_tensor(Ks[i], dtype=torch.float32) / im_scales_ratio[i] for i in range(B)])
+        K_img[:, -1, -1] = 1
+        K_img = K_img.to(dev)
+        # numpy, not torch.repeat_interleave on the CPU: that opens an OpenMP region, whose spinning workers can eat a
+        # container's CPU quota and stall this thread for the rest of the scheduler period (~90 ms measured)
+        img_idx = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int32), counts)).to(dev)
+        ref = torch.cat([b.tensor for b in boxes]).contiguous()
+        prior = self.priors_dims_per_cat.detach()[0][torch.cat(list(classes))]   # (Ntot,2,3)
+        mu, sg = prior[:, 0, :].contiguous(), prior[:, 1, :].contiguous()
+
+        # ground normal of every image: RANSAC over its (strided) ground pixels, or over all points if it has < 3
+        pts = depth_to_points(depth_maps, K_img).reshape(B, -1, 3)
+        eligible = None
+        if ground_maps is not None:
+            eligible = (ground_maps[:, ::5, ::5] > 0).reshape(B, -1)
+            eligible = eligible | (eligible.sum(1, keepdim=True) < 3)
+        triples = Plane.sample_triples_batched(eligible, B, pts.shape[1], 1000, dev, generator)
+        neg_eq, _, _ = geo.ransac_plane_batched(pts, triples, eligible, thresh=0.05)
+        normals = fix_ground_normal(-neg_eq[:, :3].t()).t().contiguous()        # (B,3)
+
+        cubes_t = PN.propose_batched(ref, img_idx, depth_maps, (mu, sg), K_img, P, normals, generator=generator)
+        rects = None
+        if masks is not None and any(m is not None for m in masks):
+            if all(m is not None for m in masks):
+                rects = geo.mask_rects(torch.cat([m.to(dev) for m in masks]))[0]   # NaN row = empty mask -> fallback
+            else:
+                rects = torch.full((sum(counts), 4, 2), float("nan"), device=dev)
+                have = torch.cat([torch.full((n,), m is not None) for n, m in zip(counts, masks)]).to(dev)
+                rects[have] = geo.mask_rects(torch.cat([m.to(dev) for m in masks if m is not None]))[0]
+        res = geo.cubes_project_score(cubes_t, K_img[img_idx.long()].contiguous(), (W, H), ref, mu, sg, rects, want=())
         idx = res["argmax"]
         best = cubes_t[torch.arange(cubes_t.shape[0], device=dev), idx]        # (Ntot,15)
         verts = geo.cuboid_corners(best[:, :6].contiguous(), best[:, 6:].reshape(-1, 3, 3).contiguous())

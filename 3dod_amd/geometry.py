@@ -94,6 +94,55 @@ def propose_from_draws(boxes, depth, prior_mu, prior_sigma, K, P, dim_normals, c
     return cubes, exhausted
 
 
+def propose_from_draws_batched(boxes, img_idx, depth, prior_mu, prior_sigma, K, P, dim_normals, ctr_normals, yaw_idx, normals):
+    """cr_propose_batched: the objects of B images in one launch.  boxes (N,4), img_idx (N) int32, depth (B,H,W),
+    K (B,3,3), normals (B,3); draws as in propose_from_draws.  Returns (cubes (N,P,15), exhausted int tensor)."""
+    boxes = _f32c(boxes, "boxes", (None, 4))
+    N, dev = boxes.shape[0], boxes.device
+    depth = _f32c(depth, "depth", (None, None, None))
+    B, H, W = depth.shape
+    K = _f32c(K, "K", (B, 3, 3))
+    normals = _f32c(normals, "normals", (B, 3))
+    prior_mu = _f32c(prior_mu, "prior_mu", (N, 3))
+    prior_sigma = _f32c(prior_sigma, "prior_sigma", (N, 3))
+    dim_normals = _f32c(dim_normals, "dim_normals", (None, 3, N, P))
+    ctr_normals = _f32c(ctr_normals, "ctr_normals", (3, N, P))
+    yaw_idx = yaw_idx.to(torch.int32).contiguous()
+    img_idx = img_idx.to(device=dev, dtype=torch.int32).contiguous()
+    assert tuple(yaw_idx.shape) == (N, P) and tuple(img_idx.shape) == (N,)
+    cubes = torch.empty((N, P, 15), dtype=f32, device=dev)
+    exhausted = torch.zeros((1,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.cr_propose_batched(_lib.ctx_for(dev), _lib.ptr(boxes), _lib.ptr(img_idx), N, _lib.ptr(depth), B, H, W,
+                                      _lib.ptr(prior_mu), _lib.ptr(prior_sigma), _lib.ptr(K), P, _lib.ptr(dim_normals),
+                                      dim_normals.shape[0], _lib.ptr(ctr_normals), _lib.ptr(yaw_idx), _lib.ptr(normals),
+                                      _lib.ptr(cubes), _lib.ptr(exhausted)), "cr_propose_batched")
+    return cubes, exhausted
+
+
+def ransac_plane_batched(pts, triples, eligible=None, thresh=0.05):
+    """B plane fits at once (cr_ransac_plane_batched): pts (B,Q,3), triples (B,T,3) int32 indices of eligible points,
+    eligible (B,Q) bool/uint8 or None.  Returns (-equation (B,4), counts (B,T), best (B,2) = idx,count).  The caller
+    guarantees the triples are in range (they come from the device-side sampler; checking them would be a sync)."""
+    pts = _f32c(pts, "pts", (None, None, 3))
+    B, Q = pts.shape[0], pts.shape[1]
+    triples = triples.to(torch.int32).contiguous()
+    T = triples.shape[1]
+    assert tuple(triples.shape) == (B, T, 3) and triples.is_cuda
+    dev = pts.device
+    if eligible is not None:
+        eligible = eligible.to(torch.uint8).contiguous()
+        assert tuple(eligible.shape) == (B, Q)
+    neg_eq = torch.empty((B, 4), dtype=f32, device=dev)
+    counts = torch.empty((B, T), dtype=torch.int32, device=dev)
+    best = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.cr_ransac_plane_batched(_lib.ctx_for(dev), _lib.ptr(pts), _lib.ptr(eligible), B, Q, _lib.ptr(triples), T,
+                                           float(thresh), _lib.ptr(neg_eq), _lib.ptr(counts), _lib.ptr(best)),
+               "cr_ransac_plane_batched")
+    return neg_eq, counts, best
+
+
 def ransac_plane(pts, triples, thresh=0.05, validate=True):
     """K21 Plane.fit_parallel with given triples.  Returns (-equation (4,), counts (T,), best (2,) = idx,count)."""
     pts = _f32c(pts, "pts", (None, 3))
@@ -209,19 +258,39 @@ def segment_counts(corners2d, mask, stride=4):
     return out.long()
 
 
+_scratch = {}
+
+
+def _workspace(dev, nbytes):
+    """grow-only per-device scratch for kernels that need O(input) temporary storage: a fresh 100+ MB request per call
+    makes the caching allocator split and re-grow its large blocks (a ~20 ms hipMalloc every few calls).  Used on the
+    current stream only."""
+    buf = _scratch.get(dev)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _scratch.pop(dev, None)
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _scratch[dev] = buf
+    return buf
+
+
 def mask_rects(masks):
     """minimum-area rectangle of the largest 8-connected component of every mask (cr_mask_rects; the cv2 step of
-    score_corners, scorefunction.py:58-68): masks (n,H,W) bool/uint8 on the GPU -> rects (n,4,2) f32, valid (n) bool"""
+    score_corners, scorefunction.py:58-68): masks (n,H,W) bool/uint8 on the GPU -> rects (n,4,2) f32 (a NaN row for an
+    empty mask), valid (n) bool"""
     lib = _lib.load()
     if not masks.is_cuda:
         raise _lib.CrError("mask_rects: expected CUDA(HIP) tensors; 3dod_amd has no CPU path")
-    m = masks.to(torch.uint8).contiguous()
+    m = masks.contiguous()
+    m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
     n, H, W = m.shape
     dev = m.device
-    scratch = torch.empty((2, n, H, W), dtype=torch.int32, device=dev)
-    best = torch.empty((n,), dtype=torch.int64, device=dev)
+    px = n * H * W
+    ws = _workspace(dev, 8 * px + 8 * n + 16)
+    labels, sizes = ws[:4 * px], ws[4 * px:8 * px]
+    best = ws[8 * px + (-8 * px) % 16:][:8 * n]
     rects = torch.empty((n, 4, 2), dtype=torch.float32, device=dev)
     valid = torch.empty((n,), dtype=torch.uint8, device=dev)
-    _lib.check(lib.cr_mask_rects(_lib.ctx_for(dev), _lib.ptr(m), n, H, W, _lib.ptr(scratch[0]), _lib.ptr(scratch[1]),
+    _lib.check(lib.cr_mask_rects(_lib.ctx_for(dev), _lib.ptr(m), n, H, W, _lib.ptr(labels), _lib.ptr(sizes),
                                  _lib.ptr(best), _lib.ptr(rects), _lib.ptr(valid)), "cr_mask_rects")
     return rects, valid.bool()

@@ -93,12 +93,28 @@ int cr_propose(cr_ctx* ctx, const float* boxes, int64_t N, const float* depth, i
                const float* dim_normals, int rounds, const float* ctr_normals,
                const int32_t* yaw_idx, const float* normal, float* out_cubes, int32_t* out_exhausted);
 
+/* cr_propose for the objects of B images in one launch (the per-image loop of
+ * cubercnn/modeling/roi_heads/roi_heads.py:480-505): img_idx (N) int32 selects the
+ * object's depth map of depth (B,H,W), intrinsics of K (B,3,3) and ground normal
+ * of normals (B,3); everything else as cr_propose. */
+int cr_propose_batched(cr_ctx* ctx, const float* boxes, const int32_t* img_idx, int64_t N, const float* depth,
+                       int B, int H, int W, const float* prior_mu, const float* prior_sigma, const float* K,
+                       int64_t P, const float* dim_normals, int rounds, const float* ctr_normals,
+                       const int32_t* yaw_idx, const float* normals, float* out_cubes, int32_t* out_exhausted);
+
 /* K21: Plane.fit_parallel -- ProposalNetwork/utils/plane.py:79-134 with the
  * sampled index triples given.  pts (Q,3); triples (T,3) int32;
  * out_neg_eq (4) = -(a,b,c,d) as the reference returns; out_counts (T) int32
  * inlier counts (workspace + diagnostic); out_best (2) int32 = {index, count}. */
 int cr_ransac_plane(cr_ctx* ctx, const float* pts, int64_t Q, const int32_t* triples, int64_t T,
                     float thresh, float* out_neg_eq, int32_t* out_counts, int32_t* out_best);
+
+/* B independent plane fits in one launch pair (one per image of a batch, roi_heads.py:400-410): pts (B,Q,3);
+ * eligible (B,Q) uint8 or NULL = which points count as inliers (the image's ground pixels; the triples must index
+ * eligible points); triples (B,T,3); out_neg_eq (B,4); out_counts (B,T); out_best (B,2). */
+int cr_ransac_plane_batched(cr_ctx* ctx, const float* pts, const unsigned char* eligible, int B, int64_t Q,
+                            const int32_t* triples, int64_t T, float thresh, float* out_neg_eq,
+                            int32_t* out_counts, int32_t* out_best);
 
 /* Lower median (torch.median's choice) of depth[img[i], y1:y2, x1:x2] for n integer windows (x1,y1,x2,y2), clipped to
  * the map like a Python slice; NaN for an empty window.  depth (B,H,W) f32 contiguous; boxes (n,4) int32; img (n) int32.
