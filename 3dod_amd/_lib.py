@@ -27,7 +27,7 @@ SIGNATURES = {
     "cr_fold_bn": [P, P, P, P, P, P, c_float, P, P, c_int, c_int],
     "cr_hull8": [P, P, c_int, P, P, P],
     "cr_segment_counts": [P, P, c_int, P, c_int, c_int, c_int, P],
-    "cr_mask_rects": [P, P, c_int, c_int, c_int, P, P, P, P, P],
+    "cr_mask_rects": [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P],
     "cr_polygon_focal": [P, P, P, P, P, P, c_int, c_int, c_int, P, P],
     "cr_attention_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_float],
     "cr_layernorm": [P, P, P, P, P, c_int64, c_int, c_float],

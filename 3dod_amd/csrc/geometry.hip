@@ -629,42 +629,72 @@ extern "C" int cr_propose_batched(cr_ctx* ctx, const float* boxes, const int32_t
 }
 
 // ---------------------------------------------------------------------------
-// K21: parallel RANSAC plane.  One workgroup per candidate triple counts its
-// inliers over all points (points stay L2-resident: Q*12 B ~ 126 KB at 512^2).
+// K21: parallel RANSAC plane.  One workgroup per RANSAC_TPB candidate triples counts
+// their inliers over all points (points stay L2-resident: Q*12 B ~ 126 KB at 512^2).
 // ---------------------------------------------------------------------------
+#define RANSAC_TPB 8      // candidate planes per workgroup: every point read scores 8 hypotheses
 __global__ __launch_bounds__(GEO_T) void k_ransac_count(const float* __restrict__ pts, int Q,
-                                                         const int32_t* __restrict__ triples, float thresh,
+                                                         const int32_t* __restrict__ triples, int T, float thresh,
                                                          float* __restrict__ eqs, int32_t* __restrict__ counts,
                                                          const unsigned char* __restrict__ eligible) {
-    __shared__ int s_cnt[GEO_W];
-    const int t = blockIdx.x, tid = threadIdx.x, T = gridDim.x;
+    __shared__ int s_cnt[GEO_W][RANSAC_TPB];
+    __shared__ float s_pl[RANSAC_TPB][5];   // cx, cy, cz, k, den
+    const int t0 = blockIdx.x * RANSAC_TPB, tid = threadIdx.x;
     pts += (size_t)blockIdx.y * Q * 3;      // blockIdx.y = image of a batched fit (cr_ransac_plane_batched)
     triples += (size_t)blockIdx.y * T * 3;
     eqs += (size_t)blockIdx.y * T * 4;
     counts += (size_t)blockIdx.y * T;
     if (eligible) eligible += (size_t)blockIdx.y * Q;
-    const int i0 = triples[t * 3], i1 = triples[t * 3 + 1], i2 = triples[t * 3 + 2];
-    const float ax = pts[i1 * 3] - pts[i0 * 3], ay = pts[i1 * 3 + 1] - pts[i0 * 3 + 1], az = pts[i1 * 3 + 2] - pts[i0 * 3 + 2];
-    const float bx = pts[i2 * 3] - pts[i0 * 3], by = pts[i2 * 3 + 1] - pts[i0 * 3 + 1], bz = pts[i2 * 3 + 2] - pts[i0 * 3 + 2];
-    float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
-    const float nrm = sqrtf((cx * cx + cy * cy) + cz * cz);
-    cx = cx / nrm; cy = cy / nrm; cz = cz / nrm;
-    const float k = -((cx * pts[i1 * 3] + cy * pts[i1 * 3 + 1]) + cz * pts[i1 * 3 + 2]);
-    const float den = sqrtf((cx * cx + cy * cy) + cz * cz);
-    int cnt = 0;
+    if (tid < RANSAC_TPB && t0 + tid < T) {
+        const int t = t0 + tid;
+        const int i0 = triples[t * 3], i1 = triples[t * 3 + 1], i2 = triples[t * 3 + 2];
+        const float ax = pts[i1 * 3] - pts[i0 * 3], ay = pts[i1 * 3 + 1] - pts[i0 * 3 + 1], az = pts[i1 * 3 + 2] - pts[i0 * 3 + 2];
+        const float bx = pts[i2 * 3] - pts[i0 * 3], by = pts[i2 * 3 + 1] - pts[i0 * 3 + 1], bz = pts[i2 * 3 + 2] - pts[i0 * 3 + 2];
+        float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+        const float nrm = sqrtf((cx * cx + cy * cy) + cz * cz);
+        cx = cx / nrm; cy = cy / nrm; cz = cz / nrm;
+        s_pl[tid][0] = cx; s_pl[tid][1] = cy; s_pl[tid][2] = cz;
+        s_pl[tid][3] = -((cx * pts[i1 * 3] + cy * pts[i1 * 3 + 1]) + cz * pts[i1 * 3 + 2]);
+        s_pl[tid][4] = sqrtf((cx * cx + cy * cy) + cz * cz);
+    }
+    __syncthreads();
+    const int nh = min(RANSAC_TPB, T - t0);
+    float pl[RANSAC_TPB][5];
+    int cnt[RANSAC_TPB];
+#pragma unroll
+    for (int h = 0; h < RANSAC_TPB; ++h) {
+        cnt[h] = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) pl[h][j] = s_pl[h < nh ? h : 0][j];
+    }
     for (int q = tid; q < Q; q += GEO_T) {
-        const float d = (((cx * pts[q * 3] + cy * pts[q * 3 + 1]) + cz * pts[q * 3 + 2]) + k) / den;
-        cnt += (fabsf(d) <= thresh && (!eligible || eligible[q])) ? 1 : 0;
+        const float px = pts[q * 3], py = pts[q * 3 + 1], pz = pts[q * 3 + 2];
+        const bool ok = !eligible || eligible[q];
+#pragma unroll
+        for (int h = 0; h < RANSAC_TPB; ++h) {
+            // the reference tests |num / den| <= thresh.  Division is monotonic and thresh is a float, so the outcome is
+            // decided by |num| against thresh * den except within a few ulp of equality; only there is the division done.
+            const float a = fabsf(((pl[h][0] * px + pl[h][1] * py) + pl[h][2] * pz) + pl[h][3]);
+            const float b = thresh * pl[h][4];
+            bool in = a < b;
+            if (fabsf(a - b) <= b * 4.8e-7f) in = a / pl[h][4] <= thresh;
+            cnt[h] += (in && ok) ? 1 : 0;
+        }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-    if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
+    for (int h = 0; h < RANSAC_TPB; ++h) {
+        int c = cnt[h];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if ((tid & 63) == 0) s_cnt[tid >> 6][h] = c;
+    }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < nh) {
         int c = 0;
-        for (int i = 0; i < GEO_W; ++i) c += s_cnt[i];
+        for (int i = 0; i < GEO_W; ++i) c += s_cnt[i][tid];
+        const int t = t0 + tid;
         counts[t] = c;
-        eqs[t * 4] = cx; eqs[t * 4 + 1] = cy; eqs[t * 4 + 2] = cz; eqs[t * 4 + 3] = k;
+        eqs[t * 4] = s_pl[tid][0]; eqs[t * 4 + 1] = s_pl[tid][1]; eqs[t * 4 + 2] = s_pl[tid][2]; eqs[t * 4 + 3] = s_pl[tid][3];
     }
 }
 
@@ -706,8 +736,8 @@ extern "C" int cr_ransac_plane(cr_ctx* ctx, const float* pts, int64_t Q, const i
     CR_CHECK_ARG(Q <= 0x7fffffff / 3 && T <= (int64_t)(ctx->ws_bytes / 16), "cr_ransac_plane: too large");
     CR_CHECK_ARG(pts && triples && out_neg_eq && out_counts && out_best, "cr_ransac_plane: NULL pointer");
     float* eqs = (float*)ctx->ws;
-    hipLaunchKernelGGL(k_ransac_count, dim3((unsigned)T), dim3(GEO_T), 0, ctx->stream, pts, (int)Q, triples, thresh,
-                       eqs, out_counts, (const unsigned char*)nullptr);
+    hipLaunchKernelGGL(k_ransac_count, dim3((unsigned)cr_cdiv(T, RANSAC_TPB)), dim3(GEO_T), 0, ctx->stream, pts, (int)Q, triples,
+                       (int)T, thresh, eqs, out_counts, (const unsigned char*)nullptr);
     CR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ransac_pick, dim3(1), dim3(GEO_T), 0, ctx->stream, eqs, out_counts, (int)T, out_neg_eq,
                        out_best);
@@ -724,8 +754,8 @@ extern "C" int cr_ransac_plane_batched(cr_ctx* ctx, const float* pts, const unsi
     CR_CHECK_ARG(Q <= 0x7fffffff / 3 && (int64_t)B * T <= (int64_t)(ctx->ws_bytes / 16), "cr_ransac_plane_batched: too large");
     CR_CHECK_ARG(pts && triples && out_neg_eq && out_counts && out_best, "cr_ransac_plane_batched: NULL pointer");
     float* eqs = (float*)ctx->ws;
-    hipLaunchKernelGGL(k_ransac_count, dim3((unsigned)T, (unsigned)B), dim3(GEO_T), 0, ctx->stream, pts, (int)Q, triples,
-                       thresh, eqs, out_counts, eligible);
+    hipLaunchKernelGGL(k_ransac_count, dim3((unsigned)cr_cdiv(T, RANSAC_TPB), (unsigned)B), dim3(GEO_T), 0, ctx->stream, pts,
+                       (int)Q, triples, (int)T, thresh, eqs, out_counts, eligible);
     CR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ransac_pick, dim3((unsigned)B), dim3(GEO_T), 0, ctx->stream, eqs, out_counts, (int)T, out_neg_eq,
                        out_best);

@@ -402,67 +402,137 @@ __device__ __forceinline__ void ccl_union(int* L, int a, int b) {
     }
 }
 
-// grid (ceil(W/256), H, n), block 256: a wave covers 64 consecutive pixels of one row
-__global__ __launch_bounds__(256) void k_ccl_init(const unsigned char* __restrict__ masks, int H, int W, int* __restrict__ labels) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    const size_t base = (size_t)blockIdx.z * H * W;
-    const bool fg = x < W && masks[base + (size_t)y * W + x] != 0;
-    const unsigned long long b = __ballot(fg);
-    if (x >= W) return;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = ~b & ((1ull << lane) - 1ull);          // background lanes before this one
-    const int start = below ? 64 - __clzll(below) : 0;
-    labels[base + (size_t)y * W + x] = fg ? y * W + (x - lane + start) : -1;
-}
+// Window of an object = rows [y0, y1] x 256-pixel chunks from x0 covering [x0, x1] of its mask's bounding box (k_mask_bbox).
+// The labelling passes walk only the window, so they cost the masks' area, not the frame's; pixels left of x0 / right of x1
+// / above y0 are background by construction and are never read.
+struct MaskSrc {
+    const unsigned char* base;              // (n,H,W) dense, or
+    const unsigned char* const* ptrs;       // n device pointers to (H,W) masks
+    __device__ __forceinline__ const unsigned char* of(int obj, size_t hw) const { return ptrs ? ptrs[obj] : base + obj * hw; }
+};
 
-__global__ __launch_bounds__(256) void k_ccl_merge(int H, int W, int* __restrict__ labels) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    int* L = labels + (size_t)blockIdx.z * H * W;
-    const int p = y * W + x;
-    if (L[p] < 0) return;
-    const bool w = x > 0 && L[p - 1] >= 0;
-    if (w && (threadIdx.x & 63) == 0) ccl_union(L, p, p - 1);              // run continues across the segment boundary
-    if (y == 0) return;
-    const int up = p - W;
-    const bool n = L[up] >= 0, nw = x > 0 && L[up - 1] >= 0, ne = x + 1 < W && L[up + 1] >= 0;
-    if (n) { if (!w || !nw) ccl_union(L, p, up); }
-    else {
-        if (nw && !w) ccl_union(L, p, up - 1);
-        if (ne) ccl_union(L, p, up + 1);
+// bbox (n,4) int32 = {x0, y0, x1, y1}, preset to {large, large, -1, -1}.  grid (ceil(H/32), n), block 256: a wave scans 8 rows.
+__global__ __launch_bounds__(256) void k_mask_bbox(MaskSrc src, int H, int W, int* __restrict__ bbox) {
+    const int lane = threadIdx.x & 63, obj = blockIdx.y;
+    const int yb = blockIdx.x * 32 + (threadIdx.x >> 6) * 8;
+    const unsigned char* m = src.of(obj, (size_t)H * W);
+    int lo = W, hi = -1, ylo = H, yhi = -1;
+    const bool words = (W & 3) == 0 && (((size_t)m) & 3) == 0;
+#pragma unroll 8
+    for (int k = 0; k < 8; ++k) {
+        const int y = yb + k;
+        if (y >= H) break;
+        const unsigned char* row = m + (size_t)y * W;
+        bool any = false;
+        if (words) {
+            const unsigned int* r4 = (const unsigned int*)row;
+            for (int i = lane; i < W / 4; i += 64) {
+                const unsigned int v = r4[i];
+                if (v) {
+                    const int first = (v & 0xFFu) ? 0 : (v & 0xFF00u) ? 1 : (v & 0xFF0000u) ? 2 : 3;
+                    const int last = (v & 0xFF000000u) ? 3 : (v & 0xFF0000u) ? 2 : (v & 0xFF00u) ? 1 : 0;
+                    lo = min(lo, 4 * i + first); hi = max(hi, 4 * i + last); any = true;
+                }
+            }
+        } else {
+            for (int x = lane; x < W; x += 64)
+                if (row[x]) { lo = min(lo, x); hi = max(hi, x); any = true; }
+        }
+        if (any) { ylo = min(ylo, y); yhi = max(yhi, y); }
+    }
+    for (int o = 32; o; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o));
+        ylo = min(ylo, __shfl_xor(ylo, o)); yhi = max(yhi, __shfl_xor(yhi, o));
+    }
+    if (lane == 0 && hi >= 0) {
+        int* b = bbox + 4 * obj;
+        atomicMin(b + 0, lo); atomicMin(b + 1, ylo); atomicMax(b + 2, hi); atomicMax(b + 3, yhi);
     }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_sizes(int H, int W, int* __restrict__ labels, int* __restrict__ sizes) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    const size_t base = (size_t)blockIdx.z * H * W;
-    int* L = labels + base;
-    const int p = y * W + x;
-    const bool fg = x < W && L[p] >= 0;
-    const unsigned long long b = __ballot(fg);
-    if (!fg) return;
-    const int root = ccl_find(L, p);
-    L[p] = root;
+// The labelling passes: grid (CCL_ROWS, n), block 256.  Workgroup j of an object walks the window rows y0+j, y0+j+CCL_ROWS,
+// ... in chunks of 256 pixels from x0, so a wave always covers the same 64 consecutive pixels of a row in every pass (the
+// run segments of k_ccl_init) and no workgroup is spent outside the window.
+#define CCL_ROWS 16
+#define CCL_WINDOW_LOOP(...)                                                                                    \
+    const int obj = blockIdx.y;                                                                                  \
+    const int bx0 = bbox[4 * obj], by0 = bbox[4 * obj + 1], bx1 = bbox[4 * obj + 2], by1 = bbox[4 * obj + 3];   \
+    for (int y = by0 + (int)blockIdx.x; y <= by1; y += CCL_ROWS)                                                 \
+        for (int xc = bx0; xc <= bx1; xc += 256) {                                                               \
+            const int x = xc + (int)threadIdx.x;                                                                 \
+            __VA_ARGS__                                                                                          \
+        }
+
+__global__ __launch_bounds__(256) void k_ccl_init(MaskSrc src, int H, int W, const int* __restrict__ bbox,
+                                                  int* __restrict__ labels, int* __restrict__ sizes) {
+    const size_t hw = (size_t)H * W;
     const int lane = threadIdx.x & 63;
-    if (lane == 0 || !((b >> (lane - 1)) & 1ull)) {                         // first pixel of a run segment
-        const unsigned long long rest = ~(b >> lane);
-        atomicAdd(sizes + base + root, rest ? __ffsll((long long)rest) - 1 : 64 - lane);
-    }
+    CCL_WINDOW_LOOP({
+        const size_t base = obj * hw;
+        const bool fg = x < W && src.of(obj, hw)[(size_t)y * W + x] != 0;
+        const unsigned long long b = __ballot(fg);
+        if (x < W) {
+            const unsigned long long below = ~b & ((1ull << lane) - 1ull);  // background lanes before this one
+            const int start = below ? 64 - __clzll(below) : 0;
+            labels[base + (size_t)y * W + x] = fg ? y * W + (x - lane + start) : -1;
+            sizes[base + (size_t)y * W + x] = 0;
+        }
+    })
 }
 
-__global__ __launch_bounds__(256) void k_ccl_best(int H, int W, const int* __restrict__ labels, const int* __restrict__ sizes,
-                                                  unsigned long long* __restrict__ best) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    const size_t base = (size_t)blockIdx.z * H * W;
-    const int p = y * W + x;
-    if (labels[base + p] != p) return;
-    atomicMax(best + blockIdx.z, ((unsigned long long)(unsigned)sizes[base + p] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p));
+__global__ __launch_bounds__(256) void k_ccl_merge(int H, int W, const int* __restrict__ bbox, int* __restrict__ labels) {
+    CCL_WINDOW_LOOP({
+        int* L = labels + (size_t)obj * H * W;
+        const int p = y * W + x;
+        if (x < W && L[p] >= 0) {
+            const bool w = x > bx0 && L[p - 1] >= 0;
+            if (w && (threadIdx.x & 63) == 0) ccl_union(L, p, p - 1);      // run continues across the segment boundary
+            if (y > by0) {
+                const int up = p - W;
+                const bool n = L[up] >= 0, nw = x > bx0 && L[up - 1] >= 0, ne = x < bx1 && L[up + 1] >= 0;
+                if (n) { if (!w || !nw) ccl_union(L, p, up); }
+                else {
+                    if (nw && !w) ccl_union(L, p, up - 1);
+                    if (ne) ccl_union(L, p, up + 1);
+                }
+            }
+        }
+    })
 }
 
-#define RECT_T 1024
+__global__ __launch_bounds__(256) void k_ccl_sizes(int H, int W, const int* __restrict__ bbox, int* __restrict__ labels,
+                                                   int* __restrict__ sizes) {
+    const int lane = threadIdx.x & 63;
+    CCL_WINDOW_LOOP({
+        const size_t base = (size_t)obj * H * W;
+        int* L = labels + base;
+        const int p = y * W + x;
+        const bool fg = x < W && L[p] >= 0;
+        const unsigned long long b = __ballot(fg);
+        if (fg) {
+            const int root = ccl_find(L, p);
+            L[p] = root;
+            if (lane == 0 || !((b >> (lane - 1)) & 1ull)) {                 // first pixel of a run segment
+                const unsigned long long rest = ~(b >> lane);
+                atomicAdd(sizes + base + root, rest ? __ffsll((long long)rest) - 1 : 64 - lane);
+            }
+        }
+    })
+}
+
+__global__ __launch_bounds__(256) void k_ccl_best(int H, int W, const int* __restrict__ bbox, const int* __restrict__ labels,
+                                                  const int* __restrict__ sizes, unsigned long long* __restrict__ best) {
+    CCL_WINDOW_LOOP({
+        const size_t base = (size_t)obj * H * W;
+        const int p = y * W + x;
+        if (x < W && labels[base + p] == p)
+            atomicMax(best + obj, ((unsigned long long)(unsigned)sizes[base + p] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p));
+    })
+}
+
+#define RECT_T 256
 // dynamic LDS: int sx0[H], sx1[H], stack[2][H], hull_x[2H], hull_y[2H]
-__global__ __launch_bounds__(RECT_T) void k_mask_rect(int H, int W, const int* __restrict__ labels,
+__global__ __launch_bounds__(RECT_T) void k_mask_rect(int H, int W, const int* __restrict__ bbox, const int* __restrict__ labels,
                                                       const unsigned long long* __restrict__ best, float* __restrict__ rects,
                                                       unsigned char* __restrict__ valid) {
     extern __shared__ int s_rect[];
@@ -485,9 +555,10 @@ __global__ __launch_bounds__(RECT_T) void k_mask_rect(int H, int W, const int* _
     const int* L = labels + (size_t)obj * H * W;
     if (tid == 0) { s_rows[0] = H; s_rows[1] = -1; }
     __syncthreads();
-    for (int r = wave; r < H; r += RECT_T / 64) {
+    const int bx0 = bbox[4 * obj], by0 = bbox[4 * obj + 1], bx1 = bbox[4 * obj + 2], by1 = bbox[4 * obj + 3];
+    for (int r = by0 + wave; r <= by1; r += RECT_T / 64) {
         int lo = W, hi = -1;
-        for (int x = lane; x < W; x += 64)
+        for (int x = bx0 + lane; x <= bx1; x += 64)
             if (L[(size_t)r * W + x] == root) { lo = min(lo, x); hi = max(hi, x); }
         for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
         if (lane == 0) {
@@ -573,21 +644,26 @@ __global__ __launch_bounds__(RECT_T) void k_mask_rect(int H, int W, const int* _
     }
 }
 
-extern "C" int cr_mask_rects(cr_ctx* ctx, const unsigned char* masks, int n, int H, int W, int32_t* labels, int32_t* sizes,
-                             unsigned long long* best, float* rects, unsigned char* valid) {
+extern "C" int cr_mask_rects(cr_ctx* ctx, const unsigned char* masks, const unsigned char* const* mask_ptrs, int n, int H, int W,
+                             int32_t* labels, int32_t* sizes, unsigned long long* best, int32_t* bbox, float* rects,
+                             unsigned char* valid) {
     CR_CHECK_ARG(ctx && n >= 0 && H > 0 && W > 0 && H <= 1900 && (int64_t)H * W < (1ll << 31) && n <= 65535,
                  "cr_mask_rects: bad args (H <= 1900: 32 B of LDS per row; n <= 65535)");
     if (n == 0) return CR_OK;
-    CR_CHECK_ARG(masks && labels && sizes && best && rects && valid, "cr_mask_rects: NULL pointer");
-    CR_HIP(hipMemsetAsync(sizes, 0, sizeof(int32_t) * (size_t)n * H * W, ctx->stream));
+    CR_CHECK_ARG((masks != nullptr) != (mask_ptrs != nullptr), "cr_mask_rects: give either masks or mask_ptrs");
+    CR_CHECK_ARG(labels && sizes && best && bbox && rects && valid, "cr_mask_rects: NULL pointer");
     CR_HIP(hipMemsetAsync(best, 0, sizeof(unsigned long long) * (size_t)n, ctx->stream));
-    const dim3 grid((unsigned)cr_cdiv(W, 256), (unsigned)H, (unsigned)n), block(256);
-    hipLaunchKernelGGL(k_ccl_init, grid, block, 0, ctx->stream, masks, H, W, labels);
-    hipLaunchKernelGGL(k_ccl_merge, grid, block, 0, ctx->stream, H, W, labels);
-    hipLaunchKernelGGL(k_ccl_sizes, grid, block, 0, ctx->stream, H, W, labels, sizes);
-    hipLaunchKernelGGL(k_ccl_best, grid, block, 0, ctx->stream, H, W, (const int*)labels, (const int*)sizes, best);
+    CR_HIP(hipMemset2DAsync(bbox, 4 * sizeof(int32_t), 0x7f, 2 * sizeof(int32_t), (size_t)n, ctx->stream));       // x0, y0 = large
+    CR_HIP(hipMemset2DAsync(bbox + 2, 4 * sizeof(int32_t), 0xff, 2 * sizeof(int32_t), (size_t)n, ctx->stream));   // x1, y1 = -1
+    const MaskSrc src{masks, mask_ptrs};
+    const dim3 grid(CCL_ROWS, (unsigned)n), block(256);
+    hipLaunchKernelGGL(k_mask_bbox, dim3((unsigned)cr_cdiv(H, 32), (unsigned)n), block, 0, ctx->stream, src, H, W, bbox);
+    hipLaunchKernelGGL(k_ccl_init, grid, block, 0, ctx->stream, src, H, W, (const int*)bbox, labels, sizes);
+    hipLaunchKernelGGL(k_ccl_merge, grid, block, 0, ctx->stream, H, W, (const int*)bbox, labels);
+    hipLaunchKernelGGL(k_ccl_sizes, grid, block, 0, ctx->stream, H, W, (const int*)bbox, labels, sizes);
+    hipLaunchKernelGGL(k_ccl_best, grid, block, 0, ctx->stream, H, W, (const int*)bbox, (const int*)labels, (const int*)sizes, best);
     hipLaunchKernelGGL(k_mask_rect, dim3((unsigned)n), dim3(RECT_T), sizeof(int) * 8 * (size_t)H, ctx->stream, H, W,
-                       (const int*)labels, (const unsigned long long*)best, rects, valid);
+                       (const int*)bbox, (const int*)labels, (const unsigned long long*)best, rects, valid);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -254,11 +254,16 @@ class BoxNet(RCNN3D):
 
     def inference(self, batched_inputs, experiment_type=None, do_postprocess=True, generator=None):
         use_pred = (experiment_type or {}).get('use_pred_boxes', True)
-        images, x = self.preprocess_image(batched_inputs)
+        if use_pred:
+            images, x = self.preprocess_image(batched_inputs)
+        else:
+            # GT boxes: only the image sizes are used -- no stacking, no normalisation
+            from types import SimpleNamespace
+            images = SimpleNamespace(image_sizes=[tuple(b["image"].shape[-2:]) for b in batched_inputs])
         im_scales_ratio = [info['height'] / im_size[0] for (info, im_size) in zip(batched_inputs, images.image_sizes)]
         Ks = [torch.FloatTensor(info['K']) for info in batched_inputs]
-        depth = torch.stack([b["depth_map"].to(self.device).float() for b in batched_inputs])
-        ground = torch.stack([b["ground_map"].to(self.device) for b in batched_inputs]) \
+        depth = torch.stack([b["depth_map"] for b in batched_inputs]).to(self.device).float()
+        ground = torch.stack([b["ground_map"] for b in batched_inputs]).to(self.device) \
             if all(b.get("ground_map") is not None for b in batched_inputs) else None
         masks = [b.get("masks") for b in batched_inputs] if any("masks" in b for b in batched_inputs) else None
         if use_pred:
@@ -266,7 +271,8 @@ class BoxNet(RCNN3D):
             proposals, _ = self.proposal_generator(images, features, None)
         else:
             features = None
-            proposals = [b["instances"].to(self.device) for b in batched_inputs]
+            proposals = [b["instances"] if b["instances"].gt_boxes.device == self.device else b["instances"].to(self.device)
+                         for b in batched_inputs]
         results, _ = self.roi_heads(images, features, proposals, depth, ground, Ks, im_scales_ratio, masks=masks,
                                     use_pred_boxes=use_pred, generator=generator)
         if do_postprocess:

@@ -120,31 +120,35 @@ class ROIHeads_Boxer(StandardROIHeads):
         neg_eq, _, _ = geo.ransac_plane_batched(pts, triples, eligible, thresh=0.05)
         normals = fix_ground_normal(-neg_eq[:, :3].t()).t().contiguous()        # (B,3)
 
-        cubes_t = PN.propose_batched(ref, img_idx, depth_maps, (mu, sg), K_img, P, normals, generator=generator)
         rects = None
         if masks is not None and any(m is not None for m in masks):
             if all(m is not None for m in masks):
-                rects = geo.mask_rects(torch.cat([m.to(dev) for m in masks]))[0]   # NaN row = empty mask -> fallback
+                rects = geo.mask_rects([m.to(dev) for m in masks])[0]             # NaN row = empty mask -> fallback
             else:
                 rects = torch.full((sum(counts), 4, 2), float("nan"), device=dev)
                 have = torch.cat([torch.full((n,), m is not None) for n, m in zip(counts, masks)]).to(dev)
-                rects[have] = geo.mask_rects(torch.cat([m.to(dev) for m in masks if m is not None]))[0]
-        res = geo.cubes_project_score(cubes_t, K_img[img_idx.long()].contiguous(), (W, H), ref, mu, sg, rects, want=())
-        idx = res["argmax"]
-        best = cubes_t[torch.arange(cubes_t.shape[0], device=dev), idx]        # (Ntot,15)
-        verts = geo.cuboid_corners(best[:, :6].contiguous(), best[:, 6:].reshape(-1, 3, 3).contiguous())
-        off = 0
-        for i, (b, cls) in enumerate(zip(boxes, classes)):
-            n = len(b)
-            inst = out_instances[i]
-            sl = slice(off, off + n)
-            inst.pred_boxes = b
-            inst.scores = res["best"][sl]
-            inst.pred_classes = cls
-            inst.pred_bbox3D = verts[sl]
-            inst.pred_center_cam = best[sl, :3]
-            inst.pred_dimensions = best[sl, 3:6]
-            inst.pred_pose = best[sl, 6:].reshape(-1, 3, 3)
-            inst.pred_center_2D = b.get_centers()
-            off += n
-        return out_instances
+                rects[have] = geo.mask_rects([m.to(dev) for m in masks if m is not None])[0]
+        K_obj = K_img[img_idx.long()].contiguous()
+        centers = (ref[:, :2] + ref[:, 2:]) / 2                                 # Boxes.get_centers for every object
+        while True:
+            # proposals -> scores -> best cube -> Instances are all issued before the rejection sampler's flag is read, so
+            # the host never waits in the middle of the batch and its packing overlaps the kernels; a non-zero flag (rare
+            # once the round count has adapted) redoes them
+            cubes_t, exhausted = PN.propose_batched(ref, img_idx, depth_maps, (mu, sg), K_img, P, normals,
+                                                    generator=generator, defer_check=True)
+            res = geo.cubes_project_score(cubes_t, K_obj, (W, H), ref, mu, sg, rects, want=())
+            idx = res["argmax"]
+            best = cubes_t[torch.arange(cubes_t.shape[0], device=dev), idx]    # (Ntot,15)
+            verts = geo.cuboid_corners(best[:, :6].contiguous(), best[:, 6:].reshape(-1, 3, 3).contiguous())
+            ctr_cam, dims, pose = best[:, :3], best[:, 3:6], best[:, 6:].reshape(-1, 3, 3)
+            off = 0
+            for i, (b, cls) in enumerate(zip(boxes, classes)):
+                n = counts[i]
+                sl = slice(off, off + n)
+                out_instances[i] = Instances(image_sizes[i], pred_boxes=b, scores=res["best"][sl], pred_classes=cls,
+                                             pred_bbox3D=verts[sl], pred_center_cam=ctr_cam[sl], pred_dimensions=dims[sl],
+                                             pred_pose=pose[sl], pred_center_2D=centers[sl])
+                off += n
+            if int(exhausted.item()) == 0:
+                return out_instances
+            PN.note_exhausted()

@@ -132,9 +132,11 @@ class Instances:
         return self._fields[name]
 
     def set(self, name, value):
-        data_len = len(value)
-        if len(self._fields):
-            assert len(self) == data_len, f"Adding a field of length {data_len} to a Instances of length {len(self)}"
+        # shape[0] for tensors: torch.Tensor.__len__ goes through Python and this runs ~10 times per image
+        data_len = value.shape[0] if isinstance(value, torch.Tensor) else len(value)
+        if self._fields:
+            cur = len(self)
+            assert cur == data_len, f"Adding a field of length {data_len} to a Instances of length {cur}"
         self._fields[name] = value
 
     def has(self, name):
@@ -169,7 +171,7 @@ class Instances:
 
     def __len__(self):
         for v in self._fields.values():
-            return v.__len__()
+            return v.shape[0] if isinstance(v, torch.Tensor) else v.__len__()
         raise NotImplementedError("Empty Instances does not support __len__!")
 
     def __iter__(self):

@@ -276,21 +276,32 @@ def _workspace(dev, nbytes):
 
 def mask_rects(masks):
     """minimum-area rectangle of the largest 8-connected component of every mask (cr_mask_rects; the cv2 step of
-    score_corners, scorefunction.py:58-68): masks (n,H,W) bool/uint8 on the GPU -> rects (n,4,2) f32 (a NaN row for an
-    empty mask), valid (n) bool"""
+    score_corners, scorefunction.py:58-68): masks (n,H,W) bool/uint8 on the GPU, or a list of such tensors (the masks of
+    several images: passed as a pointer table, not concatenated) -> rects (n,4,2) f32 (a NaN row for an empty mask),
+    valid (n) bool"""
     lib = _lib.load()
-    if not masks.is_cuda:
+    many = isinstance(masks, (list, tuple))
+    ms = [m for m in (masks if many else [masks])]
+    if not all(m.is_cuda for m in ms):
         raise _lib.CrError("mask_rects: expected CUDA(HIP) tensors; 3dod_amd has no CPU path")
-    m = masks.contiguous()
-    m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
-    n, H, W = m.shape
-    dev = m.device
+    ms = [m.contiguous() for m in ms]
+    ms = [m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8) for m in ms]
+    H, W = ms[0].shape[-2:]
+    assert all(m.dim() == 3 and tuple(m.shape[-2:]) == (H, W) for m in ms)
+    n = sum(m.shape[0] for m in ms)
+    dev = ms[0].device
     px = n * H * W
-    ws = _workspace(dev, 8 * px + 8 * n + 16)
+    ws = _workspace(dev, 8 * px + 32 * n + 64)
     labels, sizes = ws[:4 * px], ws[4 * px:8 * px]
-    best = ws[8 * px + (-8 * px) % 16:][:8 * n]
+    tail = ws[8 * px + (-8 * px) % 16:]
+    best, bbox = tail[:8 * n], tail[8 * n:24 * n]
     rects = torch.empty((n, 4, 2), dtype=torch.float32, device=dev)
     valid = torch.empty((n,), dtype=torch.uint8, device=dev)
-    _lib.check(lib.cr_mask_rects(_lib.ctx_for(dev), _lib.ptr(m), n, H, W, _lib.ptr(labels), _lib.ptr(sizes),
-                                 _lib.ptr(best), _lib.ptr(rects), _lib.ptr(valid)), "cr_mask_rects")
+    dense, table = (ms[0], None) if len(ms) == 1 else (None, None)
+    if dense is None:
+        import numpy as np
+        table = torch.from_numpy(np.concatenate([m.data_ptr() + np.arange(m.shape[0], dtype=np.int64) * (H * W) for m in ms]))
+        table = table.to(dev)
+    _lib.check(lib.cr_mask_rects(_lib.ctx_for(dev), _lib.ptr(dense), _lib.ptr(table), n, H, W, _lib.ptr(labels), _lib.ptr(sizes),
+                                 _lib.ptr(best), _lib.ptr(bbox), _lib.ptr(rects), _lib.ptr(valid)), "cr_mask_rects")
     return rects, valid.bool()

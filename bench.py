@@ -174,6 +174,54 @@ def bench_inference(args, rank, world, dev):
                        "global_batch": B * world, "parallelism": f"dp{world}", "detections_per_step": n_det / max(args.steps, 1)}}
 
 
+def bench_boxnet(args, rank, world, dev):
+    """BASELINE.json configs[2] end to end: BoxNet on GT boxes, 64 synthetic 512x512 images x 16 objects per GPU with depth,
+    ground and object masks resident in HBM -> images/s through ground-plane RANSAC, 1000 proposals per object, mask ->
+    minimum-area rectangle, project + score + argmax and the Instances packing (`--workload geometry` times the scoring
+    kernel alone)."""
+    syn = importlib.import_module("3dod_amd.synthetic")
+    modeling = importlib.import_module("3dod_amd.cubercnn.modeling")
+    here = os.path.dirname(os.path.abspath(__file__))
+    cfg = syn.make_cfg(os.path.join(here, "configs", "BoxNet.yaml"), ["MODEL.DEVICE", str(dev), "VIS_PERIOD", 0, "log", False])
+    torch.manual_seed(0)
+    model = modeling.build_model(cfg).eval()
+    B, n_obj = 64, 16
+    batch = syn.make_batch(B, 777 + rank, min_obj=n_obj, max_obj=n_obj)
+    g = torch.Generator().manual_seed(2 + rank)
+    yy = torch.arange(512)[:, None]
+    for b in batch:
+        b["image"] = b["image"].to(dev)
+        b["instances"] = b["instances"].to(dev)
+        b["depth_map"] = (torch.rand(512, 512, generator=g) * 3 + 1).to(dev)
+        b["ground_map"] = (yy > 300).expand(512, 512).to(torch.uint8).to(dev)
+        boxes = b["instances"].gt_boxes.tensor.round().long().clamp(0, 511).cpu()
+        m = torch.zeros(len(boxes), 512, 512, dtype=torch.bool)
+        xx = torch.arange(512)[None, :]
+        for j, bb in enumerate(boxes):                     # an ellipse inscribed in the box: a non-trivial hull
+            cx, cy, rx, ry = (bb[0] + bb[2]) / 2, (bb[1] + bb[3]) / 2, (bb[2] - bb[0]) / 2 + 0.5, (bb[3] - bb[1]) / 2 + 0.5
+            m[j] = ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 <= 1
+        b["masks"] = m.to(dev)
+    nobj = sum(len(b["instances"]) for b in batch)
+    gen = torch.Generator(device=dev).manual_seed(3 + rank)
+    run = lambda: model.inference(batch, experiment_type={"use_pred_boxes": False}, generator=gen)
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            run()
+        barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier(world)
+        dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    return {"metric": "images/sec BoxNet 1000-cube proposal-and-scoring pipeline on GT boxes (BASELINE configs[2], end to end)",
+            "value": B * world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BoxNet.inference(use_pred_boxes=False): {B} images x {nobj // B} objects x 1000 cubes per GPU, "
+                                   "depth + ground + object masks in HBM", "objects_per_gpu": nobj,
+                       "cubes_per_s": nobj * 1000 * world * args.steps / dt, "parallelism": f"images sharded x{world}, no collective"}}
+
+
 def bench_weak(args, rank, world, dev):
     """BASELINE.json configs[4] without its Depth-Anything backbone (not built): the weakly supervised Cube R-CNN
     (configs/Omni_combined.yaml: RCNN3D_combined_features + ROIHeads3DScore, losses from 2D boxes + depth / ground maps),
@@ -297,7 +345,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="train", choices=["train", "geometry", "inference", "weak", "depth"])
+    ap.add_argument("--workload", default="train", choices=["train", "geometry", "inference", "weak", "depth", "boxnet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
@@ -314,6 +362,8 @@ def main():
         res = bench_weak(args, rank, world, dev)
     elif args.workload == "depth":
         res = bench_depth(args, rank, world, dev)
+    elif args.workload == "boxnet":
+        res = bench_boxnet(args, rank, world, dev)
     else:
         bt = importlib.import_module("bench_train")
         res = bt.bench_train(args, rank, world, dev)

@@ -145,13 +145,16 @@ int cr_segment_counts(cr_ctx* ctx, const float* corners, int P, const unsigned c
 
 /* Minimum-area rectangle of the largest 8-connected component of each object mask: the mask -> 4-point box step of
  * score_corners (ProposalNetwork/scoring/scorefunction.py:58-68: cv2.findContours(RETR_EXTERNAL) -> max contourArea ->
- * cv2.minAreaRect -> cv2.boxPoints) for n masks in one call.  masks (n,H,W) uint8; rects (n,4,2) f32 (x,y) corners;
- * valid (n) uint8 = 0 for an empty mask (the reference then falls back to the mean extent of the projected cubes,
- * :69-75).  labels, sizes: (n,H,W) int32 scratch; best: (n) uint64 scratch.  H <= 1900.  Ties between components of equal
- * size go to the one that starts first in raster order; between rectangles of equal area to the smaller edge angle
- * mod pi/2. */
-int cr_mask_rects(cr_ctx* ctx, const unsigned char* masks, int n, int H, int W, int32_t* labels, int32_t* sizes,
-                  unsigned long long* best, float* rects, unsigned char* valid);
+ * cv2.minAreaRect -> cv2.boxPoints) for n masks in one call.  Masks are uint8 (H,W) each, given EITHER as one dense
+ * (n,H,W) array `masks` OR as `mask_ptrs`, a device array of n device pointers (masks of several images without a
+ * gather); the other argument is NULL.  rects (n,4,2) f32 (x,y) corners, a NaN row for an empty mask (the reference
+ * then falls back to the mean extent of the projected cubes, :69-75; cr_cubes_project_score does the same on a NaN
+ * row); valid (n) uint8.  Scratch: labels, sizes (n,H,W) int32 (touched only inside each mask's bounding window),
+ * best (n) uint64, bbox (n,4) int32.  H <= 1900.  Ties between components of equal size go to the one that starts first
+ * in raster order; between rectangles of equal area to the smaller edge angle mod pi/2. */
+int cr_mask_rects(cr_ctx* ctx, const unsigned char* masks, const unsigned char* const* mask_ptrs, int n, int H, int W,
+                  int32_t* labels, int32_t* sizes, unsigned long long* best, int32_t* bbox, float* rects,
+                  unsigned char* valid);
 
 /* ---- Depth-Anything-V2 forward (DINOv2 ViT + DPT head), the ops that are not GEMMs / convolutions --------------- */
 /* softmax(q k^T * scale) v per (batch, head) on the packed output of the qkv linear: qkv (B,N,3,H,D) bf16, out (B,N,H,D)

@@ -232,6 +232,11 @@ def test_mask_rects_kernel_against_oracle(H, W):
         assert valid[j]
         # 2e-3 px: the f64 angle comes from the device's atan2 / sin / cos instead of libm's
         np.testing.assert_allclose(rects[j], want, rtol=0, atol=2e-3, err_msg="mask %d" % j)
+    # the masks of several images as a list (pointer table, uint8 and bool mixed): same rows as the dense call
+    t = torch.from_numpy(masks).to(DEV)
+    r2, v2 = geo.mask_rects([t[:5], t[5:6].to(torch.uint8) * 255, t[6:6], t[6:]])
+    assert torch.equal(v2.cpu(), torch.from_numpy(valid)) and torch.equal(torch.nan_to_num(r2.cpu(), nan=-1.0),
+                                                                         torch.nan_to_num(torch.from_numpy(rects), nan=-1.0))
 
 
 def test_project_score_nan_rect_row_takes_fallback():
