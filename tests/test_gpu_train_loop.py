@@ -136,3 +136,9 @@ def test_demo_on_a_folder_of_images(tmp_path):
     assert rec["K"][0][0] == 4.0 * 300 / 2 and rec["K"][0][2] == 100.0
     for d in rec["detections"]:
         assert d["category"] in "abcde" and len(d["bbox3D"]) == 6 and np.array(d["corners3D"]).shape == (8, 3)
+    # the drawn outputs of demo.py:141-144: <name>_boxes.jpg always, <name>_novel.jpg when something was detected
+    for i in range(2):
+        boxes_jpg = tmp_path / "out" / f"im{i}_boxes.jpg"
+        assert boxes_jpg.exists() and Image.open(boxes_jpg).size == ((320, 240), (200, 300))[i]
+        n = len(json.load(open(out[i]))["detections"])
+        assert (tmp_path / "out" / f"im{i}_novel.jpg").exists() == (n > 0)

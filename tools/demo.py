@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Cube R-CNN on a folder of images -- the counterpart of the reference's demo/demo.py (do_test :24-163) without its
-renderer: for every image the detections above --threshold are written to <OUTPUT_DIR>/<name>.json
-({category, score, bbox3D [X,Y,Z,w,h,l], pose 3x3, corners3D 8x3, center_2D, bbox2D}) instead of drawn with pytorch3d / cv2.
+"""Cube R-CNN on a folder of images -- the counterpart of the reference's demo/demo.py (do_test :24-163): for every image
+<OUTPUT_DIR>/<name>_boxes.jpg (the detections above --threshold as projected 3D wireframes with labels) and
+<name>_novel.jpg (a top-down view of the same boxes; the reference renders a mesh scene with pytorch3d), plus <name>.json
+({category, score, bbox3D [X,Y,Z,w,h,l], pose 3x3, corners3D 8x3, center_2D, bbox2D}).
 
     python tools/demo.py --config-file configs/Base_Omni3D.yaml --input-folder datasets/demo_images \\
         --threshold 0.25 MODEL.WEIGHTS output/run1/model_final.pth OUTPUT_DIR output/demo
@@ -31,6 +32,8 @@ def camera(h, w, focal_length=0.0, principal_point=()):
 
 def run(cfg, model, files, out_dir, cats, threshold=0.25, focal_length=0.0, principal_point=()):
     D = importlib.import_module("3dod_amd.d2lite.data")
+    vis = importlib.import_module("3dod_amd.cubercnn.vis")
+    U = importlib.import_module("3dod_amd.cubercnn.util.util")
     os.makedirs(out_dir, exist_ok=True)
     aug = D.AugmentationList([D.ResizeShortestEdge(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST, "choice")])
     model.eval()
@@ -61,6 +64,16 @@ def run(cfg, model, files, out_dir, cats, threshold=0.25, focal_length=0.0, prin
         with open(dst, "w") as f:
             json.dump({"file": path, "K": batched[0]["K"], "detections": out}, f)
         written.append(dst)
+        K = batched[0]["K"]
+        if out:                                        # demo.py:116-142
+            meshes = [U.mesh_cuboid(o["bbox3D"], o["pose"], color=[c / 255.0 for c in U.get_color(i)]) for i, o in enumerate(out)]
+            text = ["{} {:.2f}".format(o["category"], o["score"]) for o in out]
+            im_drawn, im_topdown, _ = vis.draw_scene_view(im, K, meshes, text=text, scale=im.shape[0], blend_weight=0.5,
+                                                          blend_weight_overlay=0.85)
+            U.imwrite(im_drawn, os.path.join(out_dir, name + "_boxes.jpg"))
+            U.imwrite(im_topdown, os.path.join(out_dir, name + "_novel.jpg"))
+        else:
+            U.imwrite(im, os.path.join(out_dir, name + "_boxes.jpg"))
         print("File: {} with {} dets".format(name, len(out)))
     return written
 
