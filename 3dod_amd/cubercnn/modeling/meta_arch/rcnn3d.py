@@ -162,7 +162,7 @@ class RCNN3D(nn.Module):
             oracles = [b['oracle2D'] for b in batched_inputs]
             results, _ = self._run_roi_heads(images, features, oracles, Ks, im_scales_ratio, None, batched_inputs)
         else:
-            proposals, _ = self.proposal_generator(images, features, None, head_outputs=head_outputs)
+            proposals, _ = self.proposal_generator(images, features, None, head_outputs=head_outputs, padded=True)
             results, _ = self._run_roi_heads(images, features, proposals, Ks, im_scales_ratio, None, batched_inputs)
         if do_postprocess:
             return RCNN3D._postprocess(results, batched_inputs, images.image_sizes)
@@ -268,7 +268,7 @@ class BoxNet(RCNN3D):
         masks = [b.get("masks") for b in batched_inputs] if any("masks" in b for b in batched_inputs) else None
         if use_pred:
             features = self.backbone(x)
-            proposals, _ = self.proposal_generator(images, features, None)
+            proposals, _ = self.proposal_generator(images, features, None, padded=True)
         else:
             features = None
             proposals = [b["instances"] if b["instances"].gt_boxes.device == self.device else b["instances"].to(self.device)

@@ -150,8 +150,10 @@ class RPN(nn.Module):
             "head": head,
         }
 
-    def forward(self, images, features: Dict[str, torch.Tensor], gt_instances=None, head_outputs=None):
-        """head_outputs: (logits, deltas) when the head already ran inside the captured dense graph."""
+    def forward(self, images, features: Dict[str, torch.Tensor], gt_instances=None, head_outputs=None, padded=False):
+        """head_outputs: (logits, deltas) when the head already ran inside the captured dense graph.  padded=True (eval,
+        device path): every image gets all post-NMS slots, empty ones with objectness -inf, and no host sync happens
+        here; the caller's box predictor drops them (FastRCNNOutputs.inference)."""
         feats = [features[f] for f in self.in_features]
         grid_sizes = [(f.shape[1], f.shape[2]) for f in feats]                     # NHWC
         anchors = self.anchor_generator(grid_sizes, feats[0].device)
@@ -165,11 +167,12 @@ class RPN(nn.Module):
             losses = self.losses(anchors, pred_objectness_logits, gt_labels, pred_anchor_deltas, gt_boxes)
         else:
             losses = {}
-        proposals = self.predict_proposals(anchors, pred_objectness_logits, pred_anchor_deltas, images.image_sizes)
+        proposals = self.predict_proposals(anchors, pred_objectness_logits, pred_anchor_deltas, images.image_sizes,
+                                           padded=padded and not self.training)
         return proposals, losses
 
     @torch.no_grad()
-    def predict_proposals(self, anchors, pred_objectness_logits, pred_anchor_deltas, image_sizes):
+    def predict_proposals(self, anchors, pred_objectness_logits, pred_anchor_deltas, image_sizes, padded=False):
         if pred_anchor_deltas[0].is_cuda and hasattr(ops, "rpn_decode_select"):
             # device path: ONE batched top-k over the levels, only the candidates are decoded (fused kernel), grouped
             # NMS, post-NMS top-k; a single host sync for the per-image proposal counts
@@ -177,6 +180,9 @@ class RPN(nn.Module):
             boxes, scores = rpn_proposals_padded(self, torch.cat([a.tensor for a in anchors]), pred_objectness_logits,
                                                  torch.cat([d.detach() for d in pred_anchor_deltas], 1), image_sizes,
                                                  training=self.training)
+            if padded:
+                return [Instances(image_sizes[i], proposal_boxes=Boxes(boxes[i]), objectness_logits=scores[i])
+                        for i in range(len(image_sizes))]
             counts = torch.isfinite(scores).sum(1).tolist()
             results = []
             for i, n in enumerate(counts):

@@ -197,7 +197,15 @@ class FastRCNNOutputs(FastRCNNOutputLayers):
 
     def inference(self, predictions, proposals):
         boxes = self.predict_boxes(predictions, proposals)
-        scores = self.predict_probs(predictions, proposals)
+        if len(proposals) and proposals[0].has("objectness_logits"):
+            # padded proposal slots of the RPN's sync-free eval path (objectness -inf) must not become detections: their
+            # scores turn NaN, which fast_rcnn_inference filters like any non-finite prediction
+            real = torch.isfinite(cat([p.objectness_logits for p in proposals], dim=0))
+            probs = F.softmax(predictions[0], dim=-1)
+            probs = torch.where(real[:, None], probs, torch.full((), float("nan"), dtype=probs.dtype, device=probs.device))
+            scores = probs.split([len(p) for p in proposals], dim=0)
+        else:
+            scores = self.predict_probs(predictions, proposals)
         image_shapes = [x.image_size for x in proposals]
         return fast_rcnn_inference(boxes, scores, image_shapes, self.test_score_thresh, self.test_nms_thresh,
                                    self.test_topk_per_image)
