@@ -180,7 +180,13 @@ class ROIHeads3DScore(ROIHeads3D):
         src_ctr_x = src_boxes[:, 0] + 0.5 * src_widths
         src_ctr_y = src_boxes[:, 1] + 0.5 * src_heights
 
-        cube_2d_deltas, cube_z, cube_dims, cube_pose, cube_uncert = self.cube_head(cube_features)
+        # the number of foreground RoIs changes every step and hipBLASLt picks a kernel per problem size (~100 us of host
+        # time for each unseen shape, x ~24 GEMMs fwd + bwd): the head runs on the rows padded to a multiple of 128, so only
+        # a couple of shapes ever occur; the padding rows are sliced off (their gradient is zero)
+        rows = -(-n // 128) * 128
+        head_in = torch.nn.functional.pad(cube_features, (0, 0, 0, rows - n)) if rows != n else cube_features
+        cube_2d_deltas, cube_z, cube_dims, cube_pose, cube_uncert = (
+            t[:n] if t is not None else None for t in self.cube_head(head_in))
         fg_inds = torch.arange(n, device=device)
         cube_z = cube_z[fg_inds, box_classes, :]
         cube_dims = cube_dims[fg_inds, box_classes, :]
