@@ -207,6 +207,7 @@ class _ConvBN(torch.autograd.Function):
         dev = x.device
         lib = _lib.load()
         if training:
+            _STATS_EPOCH[0] += 1
             N_, H_, W_, _ = x.shape
             M = N_ * ((H_ + 2 * pad - k) // stride + 1) * ((W_ + 2 * pad - k) // stride + 1)
             nparts = (M + 63) // 64            # statistics rows are per 64 pixels (independent of the tile choice)
@@ -264,18 +265,35 @@ class _ConvBN(torch.autograd.Function):
         return dx, dw, ret_g, ret_b, dres, None, None, None, None, None, None, None, None
 
 
+_STATS_EPOCH = [0]          # bumped by every eager train-mode BatchNorm forward (running statistics change through raw pointers)
+
+
 def conv_bn_folded(x, weight, gamma, beta, running_mean, running_var, stride=1, pad=0, relu=True, residual=None, eps=1e-5):
     """inference: frozen BatchNorm folded into the convolution's weights and bias (cr_fold_bn), residual and ReLU in the
-    conv epilogue -- one kernel per layer instead of conv + scale/shift arithmetic + a second pass over the output"""
+    conv epilogue -- one kernel per layer instead of conv + scale/shift arithmetic + a second pass over the output.
+    Outside graph capture the folded copies are cached on the weight tensor (keyed by the version counters of the five
+    tensors, the weight epoch and the statistics epoch); inside a capture they are recomputed, so that a replay follows
+    weights that changed since."""
     _need_cuda(x, "conv input")
     weight = as_krsc(weight)
     Cout, _, k, _ = weight.shape
     K_ = weight.numel() // Cout
-    wf = torch.empty((Cout, K_), dtype=bf16, device=x.device)
-    bias_f = torch.empty((Cout,), dtype=f32, device=x.device)
-    _chk(_lib.load().cr_fold_bn(_ctx(x), _p(weight.detach()), _p(gamma.detach()), _p(beta.detach()), _p(running_mean),
-                                _p(running_var), float(eps), _p(wf), _p(bias_f), Cout, K_), "cr_fold_bn")
-    return conv_fwd_raw(x, wf, Cout, k, stride, pad, bias=bias_f, residual=residual, relu=relu)
+    capturing = torch.cuda.is_current_stream_capturing()
+    tag = None if capturing else (weight._version, gamma._version, beta._version, running_mean._version, running_var._version,
+                                  _WEIGHT_EPOCH[0], _STATS_EPOCH[0], weight.data_ptr(), running_mean.data_ptr(), float(eps))
+    ent = None if capturing else getattr(weight, "_cr_fold", None)
+    if ent is None or ent[0] != tag:
+        wf = torch.empty((Cout, K_), dtype=bf16, device=x.device)
+        bias_f = torch.empty((Cout,), dtype=f32, device=x.device)
+        _chk(_lib.load().cr_fold_bn(_ctx(x), _p(weight.detach()), _p(gamma.detach()), _p(beta.detach()), _p(running_mean),
+                                    _p(running_var), float(eps), _p(wf), _p(bias_f), Cout, K_), "cr_fold_bn")
+        ent = (tag, wf, bias_f)
+        if not capturing:
+            try:
+                weight._cr_fold = ent
+            except Exception:
+                pass
+    return conv_fwd_raw(x, ent[1], Cout, k, stride, pad, bias=ent[2], residual=residual, relu=relu)
 
 
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride=1, pad=0, relu=True, residual=None,

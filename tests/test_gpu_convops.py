@@ -332,3 +332,37 @@ def test_folded_batchnorm_inference_matches_unfolded():
     for out in (folded, unfolded.detach()):
         assert float((out.float() - ref).norm() / ref.norm()) < 1e-2
     assert float((folded.float() - unfolded.detach().float()).norm() / ref.norm()) < 1e-2
+
+
+def test_folded_batchnorm_cache_follows_weights_and_statistics():
+    """the folded copies are cached on the weight tensor between eval calls; an in-place weight update, a train-mode forward
+    (running statistics move through raw pointers) and a weight-epoch bump each invalidate them"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 16, 16, 64, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(dev).requires_grad_(), torch.zeros(64, device=dev).requires_grad_()
+    mean, var = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+
+    def ev():
+        with torch.no_grad():
+            return ops.conv_bn_act(x, w, gamma, beta, mean, var, stride=1, pad=1, relu=False, training=False).float()
+
+    def fresh():                                           # the same computation with nothing cached
+        with torch.no_grad():
+            return ops.conv_bn_act(x, w.detach().clone(memory_format=torch.preserve_format).requires_grad_(), gamma, beta, mean,
+                                   var, stride=1, pad=1, relu=False, training=False).float()
+    y0 = ev()
+    ent = w._cr_fold
+    assert torch.equal(ev(), y0) and w._cr_fold is ent               # second call: cache hit
+    with torch.no_grad():
+        w.mul_(2.0)                                                   # version counter moves
+    y1 = ev()
+    assert w._cr_fold is not ent and torch.equal(y1, fresh()) and not torch.equal(y1, y0)
+    ent = w._cr_fold
+    ops.conv_bn_act(x * 3 + 1, w, gamma, beta, mean, var, stride=1, pad=1, relu=False, training=True)   # updates mean / var
+    y2 = ev()
+    assert w._cr_fold is not ent and torch.equal(y2, fresh()) and not torch.equal(y2, y1)
+    ent = w._cr_fold
+    ops.bump_weight_epoch()
+    assert torch.equal(ev(), y2) and w._cr_fold is not ent
