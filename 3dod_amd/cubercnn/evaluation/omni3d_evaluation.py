@@ -443,6 +443,8 @@ def inference_on_dataset(model, data_loader):
     was_training = getattr(model, "training", False)
     if hasattr(model, "eval"):
         model.eval()
+    if hasattr(model, "enable_graphs_eval") and next(iter(model.parameters())).is_cuda:
+        model.enable_graphs_eval(max_shapes=16)          # one forward graph per image resolution of the dataset
     out = []
     t_data = t_compute = t_eval = 0.0
     n_iter = 0

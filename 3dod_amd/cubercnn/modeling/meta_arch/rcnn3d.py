@@ -44,6 +44,7 @@ class RCNN3D(nn.Module):
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
         self._graphed = None
         self._graphed_eval = None
+        self._graphed_eval_cache, self._graphed_eval_max = None, 0
         # static-shape training path (modeling/dense_train.py): same rules, no host<->device syncs
         self.dense_train = True
 
@@ -55,12 +56,39 @@ class RCNN3D(nn.Module):
         self._graphed = GraphedDense(self, batch)
         return self._graphed
 
-    def enable_graphs_eval(self, sample_batched_inputs):
-        """eval-mode counterpart of enable_graphs: forward-only graph of preprocess + trunk + FPN + RPN head."""
+    def enable_graphs_eval(self, sample_batched_inputs=None, max_shapes=0):
+        """eval-mode counterpart of enable_graphs: forward-only graph of preprocess + trunk + FPN + RPN head for the
+        image-batch shape of `sample_batched_inputs`, and / or (max_shapes > 0) one graph per batch shape met during
+        inference, captured on first sight and kept for the `max_shapes` most recently used shapes -- an evaluation set has
+        a handful of resolutions, and at one image per step the eager dense region is bound by the host's launch rate."""
+        from collections import OrderedDict
         from ..graphed import GraphedDenseEval
-        il, batch = self._stack_images(sample_batched_inputs)
-        self._graphed_eval = GraphedDenseEval(self, batch)
+        self._graphed_eval_max = int(max_shapes)
+        if self._graphed_eval_cache is None:
+            self._graphed_eval_cache = OrderedDict()
+        if sample_batched_inputs is not None:
+            il, batch = self._stack_images(sample_batched_inputs)
+            self._graphed_eval = GraphedDenseEval(self, batch)
+            self._graphed_eval_cache[self._graphed_eval.shape] = self._graphed_eval
         return self._graphed_eval
+
+    def _eval_graph_for(self, batch):
+        """the captured dense region for this uint8 image batch, capturing it if the per-shape cache has room"""
+        cache = self._graphed_eval_cache
+        if cache is None:
+            return None
+        key = tuple(batch.shape)
+        ge = cache.get(key)
+        if ge is not None:
+            cache.move_to_end(key)
+            return ge if ge.matches(batch) else None
+        if self._graphed_eval_max <= 0:
+            return None
+        from ..graphed import GraphedDenseEval
+        while len(cache) >= self._graphed_eval_max:
+            cache.popitem(last=False)                       # least recently used shape
+        ge = cache[key] = GraphedDenseEval(self, batch)
+        return ge
 
     def forward_static(self, images_u8, image_sizes, gt, meta):
         """training forward from device-resident, fixed-shape inputs only (no host data, no syncs): the body of the
@@ -145,14 +173,14 @@ class RCNN3D(nn.Module):
     def inference(self, batched_inputs, detected_instances=None, do_postprocess: bool = True):
         assert not self.training
         head_outputs = None
-        ge = self._graphed_eval
-        if ge is not None:
+        ge = None
+        if self._graphed_eval_cache is not None:
             images, batch = self._stack_images(batched_inputs)
-            if all(tuple(sz) == tuple(batch.shape[-2:]) for sz in images.image_sizes) and ge.matches(batch):
+            if all(tuple(sz) == tuple(batch.shape[-2:]) for sz in images.image_sizes):
+                ge = self._eval_graph_for(batch)
+            if ge is not None:
                 features, logits, deltas = ge(batch)
                 head_outputs = (logits, deltas)
-            else:
-                ge = None
         if ge is None:
             images, x = self.preprocess_image(batched_inputs)
             features = self.backbone(x)

@@ -446,8 +446,25 @@ def test_eval_graph_matches_eager_inference(built):
             assert torch.allclose(ia.scores, ib.scores, atol=1e-4) and torch.equal(ia.pred_classes, ib.pred_classes)
             assert torch.allclose(ia.pred_bbox3D, ib.pred_bbox3D, atol=1e-3)
         assert len(graphed2) == 2 and not torch.equal(graphed2[0]["instances"].scores, graphed[0]["instances"].scores)
+        # per-shape cache: a second resolution is captured on first sight, the least recently used shape is dropped
+        with torch.no_grad():
+            model.enable_graphs_eval(max_shapes=2)
+            small = syn.make_batch(1, 25, size=256, with_gt=False)
+            out_small = model(small)
+            assert set(model._graphed_eval_cache) == {(2, 3, 512, 512), (1, 3, 256, 256)}
+            model._graphed_eval_cache.clear()
+            eager_small = model(small)                                     # cache empty again -> re-captured; compare with eager
+            model._graphed_eval_max = 0
+            model._graphed_eval_cache.clear()
+            eager_small = model(small)
+            assert len(out_small[0]["instances"]) == len(eager_small[0]["instances"])
+            assert torch.allclose(out_small[0]["instances"].scores, eager_small[0]["instances"].scores, atol=1e-4)
+            model.enable_graphs_eval(max_shapes=2)
+            model(small); model(syn.make_batch(1, 26, size=384, with_gt=False)); model(syn.make_batch(1, 27, size=320, with_gt=False))
+            assert list(model._graphed_eval_cache) == [(1, 3, 384, 384), (1, 3, 320, 320)]
     finally:
         model._graphed_eval = None
+        model._graphed_eval_cache, model._graphed_eval_max = None, 0
         model.roi_heads.box_predictor.test_score_thresh = thr
         model.train()
 
