@@ -68,6 +68,98 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 32 + ((chunk ^ ((-(row >> 2)) & 3)) << 3);
 }
 
+// Shared epilogue of the implicit-GEMM kernels: bias, BN statistics, residual, ReLU, store (4 consecutive channels per
+// lane).  sStat: >= 4*2*BN floats of LDS that nothing else uses any more (the k loop ended with a barrier).
+template <int BM, int BN, int TC, int TP, typename OutT>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[TC][TP], float* sStat, int m0, int n0, int mt,
+                                              int poff, int coff, int tid, int lane, int wave, bool lead) {
+    const bool do_stats = p.stats != nullptr;
+    if (do_stats) {
+        if (lead) for (int i = tid; i < 4 * 2 * BN; i += CONV_T) sStat[i] = 0.f;
+        __syncthreads();
+    }
+    const int g = lane >> 4, pl = lane & 15;
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        const int chl = coff + i * 16 + 4 * g;     // channel within the block tile
+        const int ch = n0 + chl;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b4[e] = p.bias[ch + e];
+        }
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int m = m0 + poff + j * 16 + pl;
+            if (m < p.M && lead) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[e];
+                if (do_stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+                }
+                const size_t o = (size_t)m * p.Cout + ch;
+                if (p.res) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + o);
+                    v[0] += bf2f((u16)(rr.x & 0xffff)); v[1] += bf2f((u16)(rr.x >> 16));
+                    v[2] += bf2f((u16)(rr.y & 0xffff)); v[3] += bf2f((u16)(rr.y >> 16));
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (sizeof(OutT) == 4) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(p.y) + o) = pk;
+                }
+            }
+        }
+        if (do_stats) {
+            // reduce over the 16 pixel lanes that share this lane's channel group
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    ssum[e] += __shfl_xor(ssum[e], off, 64);
+                    ssq[e] += __shfl_xor(ssq[e], off, 64);
+                }
+            }
+            if (pl == 0 && lead) {  // exactly one lane per (wave, channel): plain stores
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sStat[(wave * 2 + 0) * BN + chl + e] = ssum[e];
+                    sStat[(wave * 2 + 1) * BN + chl + e] = ssq[e];
+                }
+            }
+        }
+    }
+    if (do_stats) {
+        __syncthreads();
+        if (!lead) return;
+        // statistics rows are per 64 pixels so that their number does not depend on the tile choice:
+        // a 128-pixel tile writes its sums to row 2*mt and zeros to row 2*mt+1
+        const int srow = (BM == 128) ? 2 * mt : mt;
+        float* dst = p.stats + (size_t)srow * 2 * p.Cout;
+        if (BM == 128 && (size_t)(srow + 1) * 64 < (size_t)p.M + 64) {
+            float* dz = dst + 2 * p.Cout;
+            if ((int64_t)(srow + 1) * 64 < (int64_t)p.M)
+                for (int i = tid; i < BN; i += CONV_T) { dz[n0 + i] = 0.f; dz[p.Cout + n0 + i] = 0.f; }
+        }
+        for (int i = tid; i < BN; i += CONV_T) {
+            const float a = ((sStat[(0 * 2 + 0) * BN + i] + sStat[(1 * 2 + 0) * BN + i]) + sStat[(2 * 2 + 0) * BN + i]) + sStat[(3 * 2 + 0) * BN + i];
+            const float b = ((sStat[(0 * 2 + 1) * BN + i] + sStat[(1 * 2 + 1) * BN + i]) + sStat[(2 * 2 + 1) * BN + i]) + sStat[(3 * 2 + 1) * BN + i];
+            dst[n0 + i] = a;
+            dst[p.Cout + n0 + i] = b;
+        }
+    }
+}
+
 // KU = 32-wide k sub-steps per pipeline stage: small tiles on small grids are bound by the latency of one
 // global->LDS round trip per stage, so they take 4 sub-steps (BK = 128) per round trip.
 // KG = wave groups per block (intra-block split-K): layers whose grid is <= ~1 block per CU run 4 groups of 4 waves on
@@ -269,93 +361,164 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
         __syncthreads();                 // `red` is dead from here on (sStat aliases it)
     }
     const bool lead = grp == 0;          // groups 1.. only keep the epilogue's barriers company
-    // ---- epilogue: bias, BN statistics, residual, ReLU, store (4 consecutive channels per lane)
-    const bool do_stats = p.stats != nullptr;
-    if (do_stats) {
-        if (lead) for (int i = tid; i < 4 * 2 * BN; i += CONV_T) sStat[i] = 0.f;
-        __syncthreads();
-    }
-    const int g = lane >> 4, pl = lane & 15;
-#pragma unroll
-    for (int i = 0; i < TC; ++i) {
-        const int chl = coff + i * 16 + 4 * g;     // channel within the block tile
-        const int ch = n0 + chl;
-        float b4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) b4[e] = p.bias[ch + e];
-        }
-        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const int m = m0 + poff + j * 16 + pl;
-            if (m < p.M && lead) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[e];
-                if (do_stats) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
-                }
-                const size_t o = (size_t)m * p.Cout + ch;
-                if (p.res) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + o);
-                    v[0] += bf2f((u16)(rr.x & 0xffff)); v[1] += bf2f((u16)(rr.x >> 16));
-                    v[2] += bf2f((u16)(rr.y & 0xffff)); v[3] += bf2f((u16)(rr.y >> 16));
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (sizeof(OutT) == 4) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    uint2 pk;
-                    pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                    pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(p.y) + o) = pk;
-                }
-            }
-        }
-        if (do_stats) {
-            // reduce over the 16 pixel lanes that share this lane's channel group
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) {
-                    ssum[e] += __shfl_xor(ssum[e], off, 64);
-                    ssq[e] += __shfl_xor(ssq[e], off, 64);
-                }
-            }
-            if (pl == 0 && lead) {  // exactly one lane per (wave, channel): plain stores
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sStat[(wave * 2 + 0) * BN + chl + e] = ssum[e];
-                    sStat[(wave * 2 + 1) * BN + chl + e] = ssq[e];
-                }
-            }
-        }
-    }
-    if (do_stats) {
-        __syncthreads();
-        if (!lead) return;
-        // statistics rows are per 64 pixels so that their number does not depend on the tile choice:
-        // a 128-pixel tile writes its sums to row 2*mt and zeros to row 2*mt+1
-        const int srow = (BM == 128) ? 2 * mt : mt;
-        float* dst = p.stats + (size_t)srow * 2 * p.Cout;
-        if (BM == 128 && (size_t)(srow + 1) * 64 < (size_t)p.M + 64) {
-            float* dz = dst + 2 * p.Cout;
-            if ((int64_t)(srow + 1) * 64 < (int64_t)p.M)
-                for (int i = tid; i < BN; i += CONV_T) { dz[n0 + i] = 0.f; dz[p.Cout + n0 + i] = 0.f; }
-        }
-        for (int i = tid; i < BN; i += CONV_T) {
-            const float a = ((sStat[(0 * 2 + 0) * BN + i] + sStat[(1 * 2 + 0) * BN + i]) + sStat[(2 * 2 + 0) * BN + i]) + sStat[(3 * 2 + 0) * BN + i];
-            const float b = ((sStat[(0 * 2 + 1) * BN + i] + sStat[(1 * 2 + 1) * BN + i]) + sStat[(2 * 2 + 1) * BN + i]) + sStat[(3 * 2 + 1) * BN + i];
-            dst[n0 + i] = a;
-            dst[p.Cout + n0 + i] = b;
-        }
-    }
+    conv_epilogue<BM, BN, TC, TP, OutT>(p, acc, sStat, m0, n0, mt, poff, coff, tid, lane, wave, lead);
 }
+
+// ---------------------------------------------------------------------------
+// k_conv_igemm_dma: the implicit GEMM of k_conv_igemm for the LARGE 3x3 / 1x1 layers (forward and backward-data), 128-pixel
+// x BN-channel tiles, with the operand tiles fetched by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging registers) into
+// TWO 64-deep LDS buffers: a whole k stage is in flight under the MFMAs of the previous one and there is one barrier pair
+// per 64 (not 32) of k.  3x3 256->256 on 4x128x128: 138 -> 90 us (561 -> 860 TFLOP/s), bit-identical output (same MFMA
+// order: k in steps of 32, ascending).
+//   * The DMA writes lane l's 16 bytes at base + 16 l, i.e. 16 rows x four 16-B chunks in order; the conflict-free image
+//     of lds_off() (chunk' = chunk ^ f(row)) is produced on the SOURCE side: lane l fetches logical chunk (l & 3) ^ f(row).
+//   * The compiler puts `s_waitcnt vmcnt(0)` in front of every LDS read it can see while a DMA is outstanding, so the
+//     fragment reads are inline `ds_read_b128` and the waits are explicit: vmcnt(N) (this wave's N DMAs of the NEXT stage
+//     may stay in flight) + barrier before a buffer is read, lgkmcnt(0) tied to the fragment registers before the MFMAs,
+//     barrier before the buffer is refilled.
+// Requires Cin % 64 == 0 (a 64-wide k stage never straddles a filter tap) and Cout % BN == 0; bf16 output.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// generic -> LDS address space.  Kept out of the kernel template: there the cast sits in a value-dependent expression, is
+// re-checked when the template is instantiated, fails in the HOST pass (silently: device-code diagnostics are deferred)
+// and the kernel's host stub is never emitted.
+__device__ __forceinline__ lds_ptr_t to_lds(u16* p) { return (lds_ptr_t)p; }
+__device__ __forceinline__ unsigned lds_addr(u16* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
+// one LDS-DMA: 64 lanes x 16 B from base + voff[lane] (0 past the descriptor's extent) to dst + 16 lane.  Also a plain
+// function for the same reason: the target builtin inside an instantiation-dependent call is re-checked per instantiation.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, u16* dst, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+}
+
+__device__ __forceinline__ u32x4 lds_read16_asm(unsigned byte_addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+}
+
+template <int BN, int KS, int MODE>
+__global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
+    constexpr int BM = 128, BK = 64;
+    constexpr int WAVES_M = BN == 128 ? 2 : 4, WAVES_N = 4 / WAVES_M;      // as k_conv_igemm: same statistics order
+    constexpr int TP = BM / WAVES_M / 16, TC = BN / WAVES_N / 16;
+    constexpr int NBW = BN / 64;                                            // weight rows per thread (chunks of 64 rows)
+    constexpr int XS = BM * 32, WS = BN * 32;                               // elements of one 32-deep sub-block
+    constexpr int STAGE = 2 * XS + 2 * WS;                                  // X(u=0), X(u=1), W(u=0), W(u=1)
+    constexpr int NDMA = 4 + 2 * NBW;                                       // DMA instructions per thread per stage
+    __shared__ __attribute__((aligned(1024))) u16 smem[2 * STAGE];          // 64 KiB (BN=128) / 48 KiB (BN=64)
+    static_assert(4 * 2 * BN * sizeof(float) <= 2 * STAGE * sizeof(u16), "sStat must fit");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = p.Cout / BN;
+    const int bid = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int nt = bid % n_tiles, mt = bid / n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // rows this lane fetches: (tid >> 2) + 64 i  (wave w: rows 16 w .. 16 w + 15 of each 64-row half)
+    int nimg[2], hb[2], wb[2];
+    bool rv[2];
+    unsigned csrc[2];                                                        // logical chunk (bytes) fetched for row i
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 2) + 64 * i;
+        const int m = m0 + row;
+        rv[i] = m < p.M;
+        const int mm = rv[i] ? m : 0;
+        const int hw = p.Hout * p.Wout;
+        const int n = mm / hw;
+        const int rem = mm - n * hw;
+        const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+        nimg[i] = n;
+        if (MODE == 0) { hb[i] = ho * p.stride - p.pad; wb[i] = wo * p.stride - p.pad; }
+        else           { hb[i] = ho + p.pad;            wb[i] = wo + p.pad; }
+        csrc[i] = (unsigned)(((tid & 3) ^ ((-(row >> 2)) & 3)) * 16);
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned wrow[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) wrow[i] = (unsigned)((n0 + (tid >> 2) + 64 * i) * p.Kdim) * 2u + csrc[i];
+
+    const int nstage = p.Kdim / BK;
+    auto issue = [&](int st, int buf) {
+        const int k0 = st * BK;
+        const int tap = KS == 1 ? 0 : (k0 >> p.cshift), cc = KS == 1 ? k0 : (k0 & (p.Cin - 1));
+        const int r = tap / KS, s2 = tap - r * KS;
+        u16* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int hi, wi;
+            bool ok = rv[i];
+            if (MODE == 0) { hi = hb[i] + r; wi = wb[i] + s2; }
+            else {
+                const int th = hb[i] - r, tw = wb[i] - s2;
+                if (p.stride == 2) { ok = ok && (((th | tw) & 1) == 0); hi = th >> 1; wi = tw >> 1; }
+                else { hi = th; wi = tw; }
+            }
+            ok = ok && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
+            const unsigned off = (unsigned)(((nimg[i] * p.Hin + hi) * p.Win + wi) * p.Cin + cc) * 2u + csrc[i];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                dma16(rx, base + u * XS + (wave * 16 + 64 * i) * 32, ok ? off + (unsigned)u * 64u : OOB);
+        }
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                dma16(rw, base + 2 * XS + u * WS + (wave * 16 + 64 * i) * 32, wrow[i] + (unsigned)(k0 + u * 32) * 2u);
+    };
+
+    const int poff = (wave / WAVES_N) * (BM / WAVES_M), coff = (wave % WAVES_N) * (BN / WAVES_N);
+    const int fr = lane & 15, fc = lane >> 4;
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned lds0 = lds_addr(smem);                                   // byte address of smem in LDS
+    unsigned xa[TP], wa[TC];                                                // fragment byte offsets inside a sub-block
+#pragma unroll
+    for (int j = 0; j < TP; ++j) xa[j] = (unsigned)lds_off(poff + j * 16 + fr, fc) * 2u;
+#pragma unroll
+    for (int i = 0; i < TC; ++i) wa[i] = (unsigned)lds_off(coff + i * 16 + fr, fc) * 2u;
+
+    issue(0, 0);
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstage) {
+            issue(st + 1, buf ^ 1);
+            if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage st has landed (this wave's DMAs)
+            else           asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                                        // ... and every other wave's
+        const unsigned sb = lds0 + (unsigned)(buf * STAGE) * 2u;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 xf[TP], wf[TC];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) xf[j] = lds_read16_asm(sb + (unsigned)(u * XS) * 2u + xa[j]);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wf[i] = lds_read16_asm(sb + (unsigned)(2 * XS + u * WS) * 2u + wa[i]);
+            if (TP == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[TP - 2]), "+v"(xf[TP - 1]),
+                                      "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]));
+            else         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0]), "+v"(xf[TP - 1]),
+                                      "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]));
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]),
+                                                                        __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // everyone is done with `buf` before stage st+2 refills it
+    }
+    conv_epilogue<BM, BN, TC, TP, u16>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt, poff, coff, tid, lane, wave, true);
+}
+
 
 template <int BM, int BN, int KS, int MODE, int KU = 1, int KG = 1>
 static int launch_igemm_t(cr_ctx* ctx, const ConvP& p, int out_f32) {
@@ -377,8 +540,41 @@ static int xcd_enabled() {
     return v;
 }
 
+// literal template arguments from a plain function (the launch from inside a function template left the host stubs undefined)
+static void launch_dma_kernel(int bn, int ks, int mode, hipStream_t stream, const ConvP& p) {
+    const dim3 grid((unsigned)(cr_cdiv(p.M, 128) * (p.Cout / bn))), block(CONV_T);
+#define CR_DMA_CASE(B, K, M_) if (bn == B && ks == K && mode == M_) { hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_>), grid, block, 0, stream, p); return; }
+    CR_DMA_CASE(128, 3, 0) CR_DMA_CASE(128, 3, 1) CR_DMA_CASE(128, 1, 0) CR_DMA_CASE(128, 1, 1)
+    CR_DMA_CASE(64, 3, 0) CR_DMA_CASE(64, 3, 1) CR_DMA_CASE(64, 1, 0) CR_DMA_CASE(64, 1, 1)
+#undef CR_DMA_CASE
+}
+
+static int dma_enabled() {
+    static const int v = env_int("CR_CONV_DMA", 1);
+    return v;
+}
+
+// true + launched if the layer takes the LDS-DMA kernel: the layers that would run <128,128> or <128,64> tiles with KU = 1
+template <int KS, int MODE>
+static bool try_launch_dma(cr_ctx* ctx, const ConvP& p, int out_f32, int* rc) {
+    if constexpr (KS == 7) {
+        return false;
+    } else {
+        if (out_f32 || !dma_enabled() || (p.Cin & 63) != 0 || p.Cout % 64 != 0) return false;
+        const int64_t big_tiles = cr_cdiv(p.M, 128) * (p.Cout >= 128 ? p.Cout / 128 : 1);
+        if (big_tiles < 512) return false;                   // small grids keep the 64x64 / split-K kernels
+        launch_dma_kernel(p.Cout % 128 == 0 ? 128 : 64, KS, MODE, ctx->stream, p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cr_set_error("k_conv_igemm_dma launch failed: %s", hipGetErrorString(e)); *rc = CR_EHIP; }
+    else *rc = CR_OK;
+    return true;
+}
+
 template <int KS, int MODE>
 static int launch_igemm_ks(cr_ctx* ctx, const ConvP& p, int out_f32) {
+    int rc_dma = CR_OK;
+    if (try_launch_dma<KS, MODE>(ctx, p, out_f32, &rc_dma)) return rc_dma;
     // the 32x32 ... 8x8 levels at 4 images/GPU give only 8-64 tiles of 128x128: use 64x64 tiles there so that the
     // launch covers the 256 CUs (MI355X: "a launch needs >> 256 workgroups")
     const int64_t big_tiles = cr_cdiv(p.M, 128) * (p.Cout >= 128 ? p.Cout / 128 : 1);

@@ -191,6 +191,7 @@ int cr_resize_bilinear_ac(cr_ctx* ctx, const void* x, void* y, int B, int h, int
 int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout,
                   int ks, int stride, int pad, const float* bias, const void* residual, int relu,
                   float* stats, int out_f32);
+
 /* dx (N,H,W,Cin) bf16 from dy (N,Ho,Wo,Cout) bf16; wt = cr_weight_transpose(w). */
 int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int N, int H, int W, int Cin,
                        int Cout, int ks, int stride, int pad);
