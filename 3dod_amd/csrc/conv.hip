@@ -561,9 +561,12 @@ static bool try_launch_dma(cr_ctx* ctx, const ConvP& p, int out_f32, int* rc) {
         return false;
     } else {
         if (out_f32 || !dma_enabled() || (p.Cin & 63) != 0 || p.Cout % 64 != 0) return false;
+        static const int min_tiles = env_int("CR_CONV_DMA_MIN_TILES", 128), force_bn = env_int("CR_CONV_DMA_BN", 0);
         const int64_t big_tiles = cr_cdiv(p.M, 128) * (p.Cout >= 128 ? p.Cout / 128 : 1);
-        if (big_tiles < 512) return false;                   // small grids keep the 64x64 / split-K kernels
-        launch_dma_kernel(p.Cout % 128 == 0 ? 128 : 64, KS, MODE, ctx->stream, p);
+        if (big_tiles < min_tiles) return false;             // small grids keep the 64x64 / split-K kernels
+        int bn = p.Cout % 128 == 0 ? 128 : 64;
+        if (force_bn == 64 || (force_bn == 0 && bn == 128 && big_tiles < 512)) bn = 64;   // more workgroups on mid-size maps
+        launch_dma_kernel(bn, KS, MODE, ctx->stream, p);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cr_set_error("k_conv_igemm_dma launch failed: %s", hipGetErrorString(e)); *rc = CR_EHIP; }

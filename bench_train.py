@@ -129,7 +129,7 @@ def cpu_baseline_train():
 
 
 def dominant_kernel_roofline(dev, reps=20):
-    """the dominant kernel family of the step (profiles/: k_conv_wgrad<128,3> then k_conv_igemm<128,3,*>) timed live with
+    """the dominant kernel family of the step (profiles/: k_conv_wgrad<128,3> and k_conv_igemm_dma<128,3,*>) timed live with
     HIP events on the stream it is launched on, on its largest instance in the network: the FPN p2 output conv
     (3x3, 256->256, 4x128x128 pixels; 2*M*Cout*9*Cin = 77.3 GFLOP per launch and direction)."""
     ops = importlib.import_module("3dod_amd.hipops")
@@ -143,8 +143,8 @@ def dominant_kernel_roofline(dev, reps=20):
     out = {}
     sink = torch.zeros(C * C * 9, device=dev)           # accumulate target (the flat gradient in the train step)
     for name, fn in (("k_conv_wgrad<128,3>", lambda: ops.conv_bwd_weight_raw(dy, x, 3, 1, 1, sink=sink)),
-                     ("k_conv_igemm<128,3,0,bf16> (fwd)", lambda: ops.conv_fwd_raw(x, wb, C, 3, 1, 1)),
-                     ("k_conv_igemm<128,3,1,bf16> (bwd-data)", lambda: ops.conv_bwd_data_raw(dy, wt, x.shape, 3, 1, 1))):
+                     ("k_conv_igemm_dma<128,3,0> (fwd)", lambda: ops.conv_fwd_raw(x, wb, C, 3, 1, 1)),
+                     ("k_conv_igemm_dma<128,3,1> (bwd-data)", lambda: ops.conv_bwd_data_raw(dy, wt, x.shape, 3, 1, 1))):
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -161,8 +161,9 @@ def dominant_kernel_roofline(dev, reps=20):
     traffic = None
     try:
         pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_conv_traffic.json")))
-        key = {"k_conv_wgrad<128,3>": "k_conv_wgrad<128, 3", "k_conv_igemm<128,3,0,bf16> (fwd)": "k_conv_igemm<128, 128, 3, 0",
-               "k_conv_igemm<128,3,1,bf16> (bwd-data)": "k_conv_igemm<128, 128, 3, 1"}[worst]
+        # (the PMC passes predate the LDS-DMA forward / backward-data kernels: only the weight-gradient kernel has counters)
+        key = {"k_conv_wgrad<128,3>": "k_conv_wgrad<128, 3", "k_conv_igemm_dma<128,3,0> (fwd)": "k_conv_igemm_dma<128, 3, 0",
+               "k_conv_igemm_dma<128,3,1> (bwd-data)": "k_conv_igemm_dma<128, 3, 1"}[worst]
         traffic = [v["traffic_bytes"] for k, v in pmc["kernels"].items() if k.startswith(key)][0]
     except Exception:
         pass
