@@ -366,3 +366,48 @@ def test_folded_batchnorm_cache_follows_weights_and_statistics():
     ent = w._cr_fold
     ops.bump_weight_epoch()
     assert torch.equal(ev(), y2) and w._cr_fold is not ent
+
+
+DMA_CASES = [  # N, H, W, Cin, Cout, k, stride  -- all large enough for the LDS-DMA kernel (>= 128 tiles of 128 pixels)
+    (2, 128, 128, 64, 64, 3, 1), (1, 128, 128, 64, 128, 3, 1), (2, 96, 100, 128, 256, 1, 1), (2, 256, 256, 64, 64, 3, 2),
+    (1, 131, 127, 64, 256, 3, 1)]
+
+
+@pytest.mark.parametrize("case", DMA_CASES)
+def test_lds_dma_conv_equals_register_staged_kernel(case):
+    """k_conv_igemm_dma (bf16 output, large layers) against k_conv_igemm on the same layer: the f32-output form never takes
+    the DMA kernel, accumulates in the same order and shares the epilogue, so its result rounded to bf16 must be identical
+    -- with bias, residual, ReLU and the BatchNorm statistics rows.  Backward-data against the float32 definition."""
+    import torch.nn.functional as F
+    N, H, W, Cin, Cout, k, stride = case
+    pad = k // 2
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16).to(dev)
+    w4 = (torch.randn(Cout, Cin, k, k, generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)
+    wb, wt = ops.prepared_weights(w4, need_transposed=True)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    assert (N * Ho * Wo + 127) // 128 * max(Cout // 128, 1) >= 128
+    # (more than 320 tiles of 64 x 64: the register-staged path then has no intra-block split-K, whose sum order differs)
+    assert (N * Ho * Wo + 63) // 64 * (Cout // 64) > 320
+    bias = torch.randn(Cout, generator=g).to(dev)
+    res = torch.randn(N, Ho, Wo, Cout, generator=g).to(torch.bfloat16).to(dev)
+    nparts = (N * Ho * Wo + 63) // 64
+    for kw in (dict(), dict(bias=bias, relu=True), dict(residual=res, relu=True)):
+        a = ops.conv_fwd_raw(x, wb, Cout, k, stride, pad, **kw)
+        b = ops.conv_fwd_raw(x, wb, Cout, k, stride, pad, out_f32=True, **kw)
+        assert torch.equal(a, b.to(torch.bfloat16)), kw.keys()
+    sa, sb = (torch.empty((nparts, 2, Cout), device=dev) for _ in range(2))
+    a = ops.conv_fwd_raw(x, wb, Cout, k, stride, pad, stats=sa)
+    b = ops.conv_fwd_raw(x, wb, Cout, k, stride, pad, stats=sb, out_f32=True)
+    assert torch.equal(a, b.to(torch.bfloat16))
+    # statistics rows are per 64 pixels; a 128-pixel tile puts its sums in the even row (zeros in the odd one), so compare totals
+    assert torch.allclose(sa.sum(0), sb.sum(0), rtol=1e-5, atol=1e-3)
+    # backward-data (also the DMA kernel: M = N*H*W pixels of dX)
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(torch.bfloat16).to(dev)
+    dx = ops.conv_bwd_data_raw(dy, wt, x.shape, k, stride, pad).float()
+    xr = torch.zeros(N, Cin, H, W, device=dev, requires_grad=True)
+    y = F.conv2d(xr, w4.detach().to(torch.bfloat16).float(), None, stride, pad)
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    ref = xr.grad.permute(0, 2, 3, 1)
+    assert float((dx - ref).norm() / ref.norm()) < 6e-3
