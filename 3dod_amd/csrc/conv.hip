@@ -441,27 +441,34 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
     for (int i = 0; i < NBW; ++i) wrow[i] = (unsigned)((n0 + (tid >> 2) + 64 * i) * p.Kdim) * 2u + csrc[i];
 
     const int nstage = p.Kdim / BK;
+    int cur_tap = -1;
+    unsigned tb[2] = {OOB, OOB};                     // byte offset of (pixel row i, current filter tap, this lane's chunk) or OOB
     auto issue = [&](int st, int buf) {
         const int k0 = st * BK;
         const int tap = KS == 1 ? 0 : (k0 >> p.cshift), cc = KS == 1 ? k0 : (k0 & (p.Cin - 1));
-        const int r = tap / KS, s2 = tap - r * KS;
+        if (tap != cur_tap) {                        // block-uniform: the tap decomposition and bounds test once per tap
+            const int r = tap / KS, s2 = tap - r * KS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int hi, wi;
+                bool ok = rv[i];
+                if (MODE == 0) { hi = hb[i] + r; wi = wb[i] + s2; }
+                else {
+                    const int th = hb[i] - r, tw = wb[i] - s2;
+                    if (p.stride == 2) { ok = ok && (((th | tw) & 1) == 0); hi = th >> 1; wi = tw >> 1; }
+                    else { hi = th; wi = tw; }
+                }
+                ok = ok && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
+                tb[i] = ok ? (unsigned)(((nimg[i] * p.Hin + hi) * p.Win + wi) * p.Cin) * 2u + csrc[i] : OOB;
+            }
+            cur_tap = tap;
+        }
         u16* base = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int hi, wi;
-            bool ok = rv[i];
-            if (MODE == 0) { hi = hb[i] + r; wi = wb[i] + s2; }
-            else {
-                const int th = hb[i] - r, tw = wb[i] - s2;
-                if (p.stride == 2) { ok = ok && (((th | tw) & 1) == 0); hi = th >> 1; wi = tw >> 1; }
-                else { hi = th; wi = tw; }
-            }
-            ok = ok && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
-            const unsigned off = (unsigned)(((nimg[i] * p.Hin + hi) * p.Win + wi) * p.Cin + cc) * 2u + csrc[i];
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-                dma16(rx, base + u * XS + (wave * 16 + 64 * i) * 32, ok ? off + (unsigned)u * 64u : OOB);
-        }
+                dma16(rx, base + u * XS + (wave * 16 + 64 * i) * 32, tb[i] == OOB ? OOB : tb[i] + (unsigned)(cc + u * 32) * 2u);
 #pragma unroll
         for (int i = 0; i < NBW; ++i)
 #pragma unroll
