@@ -24,7 +24,7 @@ SIGNATURES = {
     "cr_ransac_plane_batched": [P, P, P, c_int, c_int64, P, c_int64, c_float, P, P, P],
     "cr_propose_batched": [P, P, P, c_int64, P, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P, P, P, P, P],
     "cr_box_median": [P, P, c_int, c_int, c_int, P, P, c_int, P],
-    "cr_fold_bn": [P, P, P, P, P, P, c_float, P, P, c_int, c_int],
+    "cr_fold_bn": [P, P, P, P, P, P, c_float, P, P, c_int, c_int, c_int],
     "cr_hull8": [P, P, c_int, P, P, P],
     "cr_segment_counts": [P, P, c_int, P, c_int, c_int, c_int, P],
     "cr_mask_rects": [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P],
@@ -35,22 +35,22 @@ SIGNATURES = {
     "cr_scale_residual_layernorm": [P, P, P, P, P, P, P, P, c_int64, c_int, c_float],
     "cr_scale_residual": [P, P, P, P, P, c_int64, c_int],
     "cr_resize_bilinear_ac": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int],
-    "cr_conv2d_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int],
-    "cr_conv2d_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
-    "cr_conv2d_bwd_weight": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
-    "cr_conv2d_bwd_weight_bias": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "cr_conv2d_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, c_int],
+    "cr_conv2d_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "cr_conv2d_bwd_weight": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "cr_conv2d_bwd_weight_bias": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "cr_cast_f32_to_bf16": [P, P, P, c_int64],
-    "cr_weight_transpose": [P, P, P, c_int, c_int, c_int],
+    "cr_weight_transpose": [P, P, P, c_int, c_int, c_int, c_int],
     "cr_colsum_accum": [P, P, c_int, c_int64, c_int, P, P],
-    "cr_bn_fwd": [P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, P],
-    "cr_bn_bwd": [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int],
-    "cr_pool2x_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int],
-    "cr_pool2x_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int],
-    "cr_upsample2x_add": [P, P, P, P, c_int, c_int, c_int, c_int],
-    "cr_sum2x2": [P, P, P, c_int, c_int, c_int, c_int],
-    "cr_preprocess": [P, P, P, c_int, c_int, c_int, P, P],
-    "cr_roi_align_fwd": [P, P, P, P, P, c_int, c_int, P, c_int64, c_int, c_int, P],
-    "cr_roi_align_bwd": [P, P, P, P, P, c_int, c_int, P, c_int64, c_int, c_int, P],
+    "cr_bn_fwd": [P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, P, c_int],
+    "cr_bn_bwd": [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int],
+    "cr_pool2x_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int],
+    "cr_pool2x_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int],
+    "cr_upsample2x_add": [P, P, P, P, c_int, c_int, c_int, c_int, c_int],
+    "cr_sum2x2": [P, P, P, c_int, c_int, c_int, c_int, c_int],
+    "cr_preprocess": [P, P, P, c_int, c_int, c_int, P, P, c_int],
+    "cr_roi_align_fwd": [P, P, P, P, P, c_int, c_int, P, c_int64, c_int, c_int, P, c_int],
+    "cr_roi_align_bwd": [P, P, P, P, P, c_int, c_int, P, c_int64, c_int, c_int, P, c_int],
     "cr_nms_grouped": [P, P, P, c_int, c_int, c_float, P, P],
     "cr_cube_loss_fwd": [P, P, c_int64, c_int, c_int, c_int, c_int, P, P],
     "cr_cube_loss_bwd": [P, P, c_int64, c_int, c_int, c_int, c_int, P, P, P, P, P, P],
@@ -66,11 +66,11 @@ SIGNATURES = {
     "cr_cube_select_bwd": [P, P, c_int, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P],
     "cr_cube_reduce": [P, P, P, P, P, c_int, c_int, P, P, P],
     "cr_cube_reduce_bwd": [P, P, P, P, c_int, c_int, P, P, P, P],
-    "cr_weights_prepare": [P, P, P, P, P, P, c_int],
-    "cr_fc_weight_prepare": [P, P, P, c_int, c_int, c_int],
-    "cr_fc_grad_accum": [P, P, P, c_int, c_int, c_int],
-    "cr_maxpool3x3s2_fwd": [P, P, P, c_int, c_int, c_int, c_int],
-    "cr_maxpool3x3s2_bwd": [P, P, P, P, c_int, c_int, c_int, c_int],
+    "cr_weights_prepare": [P, P, P, P, P, P, c_int, c_int],
+    "cr_fc_weight_prepare": [P, P, P, c_int, c_int, c_int, c_int],
+    "cr_fc_grad_accum": [P, P, P, c_int, c_int, c_int, c_int],
+    "cr_maxpool3x3s2_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int],
+    "cr_maxpool3x3s2_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int],
     "cr_cube_decode_infer": [P, P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, P],
     "cr_box3d_overlap": [P, P, P, c_int, c_int, P, P],
     "cr_nonfinite_flag": [P, P, c_int64, P],

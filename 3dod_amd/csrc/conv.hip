@@ -17,35 +17,38 @@
 //   D: col = l&15, row = 4(l>>4)+reg.
 // We feed WEIGHTS as A (rows = output channels) and PIXELS as B (cols = pixels), so a lane
 // ends up with 4 consecutive output channels of one pixel = one 8-byte NHWC store.
+//
+// Two arithmetic modes, selected per call by the storage type of the activations (act_f32 of the C ABI):
+//   bf16  operands bf16, v_mfma_f32_16x16x32_bf16, f32 accumulate   (fast mode)
+//   f32   operands f32,  v_mfma_f32_16x16x4_f32 (exact f32 fmaf chain, 157 TFLOP/s peak) -- the reference's precision
+// Both share the kernels: an LDS row is 64 bytes = four 16-B chunks = 32 bf16 or 16 f32 of k, so the LDS image, the
+// gathers and the fragment reads are byte-identical; only the k extent of a sub-step (SUB = 32 / 16) and the MFMA differ.
+// In f32 mode lane l's 16-B fragment holds k = 4(l>>4) .. +3 of its row; MFMA e (0..3) of a sub-step multiplies element
+// e of every lane's A and B fragments, i.e. the k set {e, 4+e, 8+e, 12+e} -- the same permutation on both operands.
 #include "cr_common.h"
+#include "cr_elem.h"
 #include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16;
 
 #define CONV_T 256
 #define STAT_REPL 32        // (legacy name) -- BN statistics are now per-block partial sums, reduced in a fixed order
 
-__device__ __forceinline__ float bf2f(u16 b) { return __uint_as_float(((unsigned)b) << 16); }
-__device__ __forceinline__ u16 f2bf(float f) {
-    __bf16 b = (__bf16)f;                      // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
-    return __builtin_bit_cast(u16, b);
-}
-
 struct ConvP {
-    const u16* x;        // gather source, NHWC bf16 (fwd: input; bwd-data: dY)
-    const u16* w;        // [Cout][Kdim] bf16, k = (r*KS + s)*Cin + c
+    const void* x;       // gather source, NHWC bf16 or f32 (fwd: input; bwd-data: dY)
+    const void* w;       // [Cout][Kdim] in the activations' type, k = (r*KS + s)*Cin + c
     void* y;             // [M][Cout] bf16 or f32
-    const u16* res;      // optional residual [M][Cout] bf16 (added before ReLU)
+    const void* res;     // optional residual [M][Cout] in the activations' type (added before ReLU)
     const float* bias;   // optional [Cout]
     float* stats;        // optional [ceil(M/128)][2][Cout]: per-M-tile sum and sum of squares of the conv output
     int N, Hin, Win, Cin, Hout, Wout, Cout;
     int stride, pad, Kdim, M, cshift, relu;
     unsigned x_bytes, w_bytes;   // extents for the buffer-load descriptors (out-of-range voffset reads 0)
     int xcd;                     // 1 = XCD-aware tile order
+    int f32;                     // 1 = f32 operands / outputs (host-side dispatch only)
 };
 
 // LDS image of a [rows][32] bf16 tile (64-B rows, four 16-B chunks): chunk' = chunk ^ ((-(row>>2)) & 3)
@@ -68,9 +71,32 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 32 + ((chunk ^ ((-(row >> 2)) & 3)) << 3);
 }
 
+// one sub-step of MFMAs on 16-B fragments: T = u16 -> one 16x16x32 bf16 MFMA; T = float -> four 16x16x4 f32 MFMAs
+template <typename T, int TC, int TP>
+__device__ __forceinline__ void mfma_substep(const u32x4 (&wf)[TC], const u32x4 (&xf)[TP], f32x4 (&acc)[TC][TP]) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]),
+                                                                    __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
+    } else {
+        // e outermost: consecutive MFMAs hit different accumulators (40-cycle dependent latency vs 32-cycle issue)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i][e]), __uint_as_float(xf[j][e]),
+                                                                     acc[i][j], 0, 0, 0);
+    }
+}
+
 // Shared epilogue of the implicit-GEMM kernels: bias, BN statistics, residual, ReLU, store (4 consecutive channels per
 // lane).  sStat: >= 4*2*BN floats of LDS that nothing else uses any more (the k loop ended with a barrier).
-template <int BM, int BN, int TC, int TP, typename OutT>
+template <int BM, int BN, int TC, int TP, typename OutT, typename T = u16>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[TC][TP], float* sStat, int m0, int n0, int mt,
                                               int poff, int coff, int tid, int lane, int wave, bool lead) {
     const bool do_stats = p.stats != nullptr;
@@ -102,9 +128,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[TC][T
                 }
                 const size_t o = (size_t)m * p.Cout + ch;
                 if (p.res) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + o);
-                    v[0] += bf2f((u16)(rr.x & 0xffff)); v[1] += bf2f((u16)(rr.x >> 16));
-                    v[2] += bf2f((u16)(rr.y & 0xffff)); v[3] += bf2f((u16)(rr.y >> 16));
+                    if constexpr (sizeof(T) == 2) {
+                        const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(p.res) + o);
+                        v[0] += bf2f((u16)(rr.x & 0xffff)); v[1] += bf2f((u16)(rr.x >> 16));
+                        v[2] += bf2f((u16)(rr.y & 0xffff)); v[3] += bf2f((u16)(rr.y >> 16));
+                    } else {
+                        const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + o);
+                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    }
                 }
                 if (p.relu) {
 #pragma unroll
@@ -165,17 +196,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[TC][T
 // KG = wave groups per block (intra-block split-K): layers whose grid is <= ~1 block per CU run 4 groups of 4 waves on
 // interleaved k sub-steps of the same output tile (4 waves per SIMD to overlap the per-sub-step instruction/latency
 // chain that a single wave per SIMD exposes) and reduce the accumulators through LDS before the shared epilogue.
-template <int BM, int BN, int KS, int MODE, typename OutT, int KU, int KG>
+template <int BM, int BN, int KS, int MODE, typename OutT, int KU, int KG, typename T = u16>
 __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
+    constexpr int ES = (int)sizeof(T);               // bytes per operand element
+    constexpr int KE = 16 / ES;                      // k elements per 16-B chunk (8 bf16 / 4 f32)
+    constexpr int SUB = 4 * KE;                      // k extent of one sub-step = one 64-B LDS row (32 / 16)
     // 4 waves tile the BM x BN block: 2x2 for the square-ish tiles, 4x1 (pixels) for narrow channel tiles
-    constexpr int WAVES_M = (BN == 128 || BM == 64) ? 2 : 4;
+    constexpr int WAVES_M = (BN == 16) ? 4 : ((BN == 128 || BM == 64) ? 2 : 4);
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int TP = BM / WAVES_M / 16;            // pixel tiles (16) per wave
     constexpr int TC = BN / WAVES_N / 16;            // channel tiles per wave
     constexpr int NA = BM * 4 / CONV_T;              // pixel-row chunks per thread (2 or 1)
     constexpr int NB = (BN * 4 + CONV_T - 1) / CONV_T;   // weight chunks per thread
     static_assert(TP >= 1 && TC >= 1 && NA >= 1, "tile too small for 4 waves");
-    constexpr int XE = KU * BM * 32, WE = KU * BN * 32;          // LDS elements per group
+    constexpr int XE = KU * BM * 32, WE = KU * BN * 32;          // LDS u16 units per group (rows of 64 B)
     __shared__ __attribute__((aligned(16))) u16 smem[KG * (XE + WE)];
     u16* sXall = smem;
     u16* sWall = smem + KG * XE;
@@ -217,9 +251,9 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    // Fast gather path (KS > 1, Cin % 32 == 0): a 32-wide k sub-step never straddles a filter tap, so the tap
+    // Fast gather path (KS > 1, Cin % SUB == 0): a sub-step never straddles a filter tap, so the tap
     // decomposition, the bounds test and the pixel offset are recomputed only when the tap changes.
-    const bool fast = (KS > 1) && ((p.Cin & 31) == 0);
+    const bool fast = (KS > 1) && ((p.Cin & (SUB - 1)) == 0);
     int cur_tap = -1;
     unsigned tb[NA];                                // byte offset of (pixel, current tap, chunk cA) or OOB
 #pragma unroll
@@ -234,7 +268,7 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
             else { hi = th; wi = tw; }
         }
         ok = ok && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
-        const unsigned off = (unsigned)(((nimg[i] * p.Hin + hi) * p.Win + wi) * p.Cin) * 2u;
+        const unsigned off = (unsigned)(((nimg[i] * p.Hin + hi) * p.Win + wi) * p.Cin) * (unsigned)ES;
         return ok ? off : OOB;
     };
 
@@ -243,7 +277,7 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
       for (int u = 0; u < KU; ++u) {
         const int kt = (stage * KG + grp) * KU + u;     // groups take interleaved stages
         if (fast) {
-            const int tap = (kt * 32) >> p.cshift, cc = (kt * 32) & (p.Cin - 1);
+            const int tap = (kt * SUB) >> p.cshift, cc = (kt * SUB) & (p.Cin - 1);
             if (tap != cur_tap) {
                 const int r = tap / KS, s2 = tap - r * KS;
 #pragma unroll
@@ -254,9 +288,9 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
                 cur_tap = tap;
             }
 #pragma unroll
-            for (int i = 0; i < NA; ++i) ra[u][i] = buf_load16(rx, tb[i] + (unsigned)cc * 2u);
+            for (int i = 0; i < NA; ++i) ra[u][i] = buf_load16(rx, tb[i] + (unsigned)cc * (unsigned)ES);
         } else {
-            const int k0 = kt * 32 + cA * 8;
+            const int k0 = kt * SUB + cA * KE;
             int r = 0, s2 = 0, c0 = k0;
             if (KS > 1) {
                 const int tap = k0 >> p.cshift;
@@ -267,15 +301,15 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const unsigned o = pix_off(i, r, s2, k0 < p.Kdim);
-                ra[u][i] = buf_load16(rx, o == OOB ? OOB : o + (unsigned)c0 * 2u);
+                ra[u][i] = buf_load16(rx, o == OOB ? OOB : o + (unsigned)c0 * (unsigned)ES);
             }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + CONV_T * i;
-            const int row = idx >> 2, kb = kt * 32 + (idx & 3) * 8;
+            const int row = idx >> 2, kb = kt * SUB + (idx & 3) * KE;
             const bool ok = idx < BN * 4 && kb < p.Kdim;
-            rb[u][i] = buf_load16(rw, ok ? (unsigned)((n0 + row) * p.Kdim + kb) * 2u : OOB);
+            rb[u][i] = buf_load16(rw, ok ? (unsigned)((n0 + row) * p.Kdim + kb) * (unsigned)ES : OOB);
         }
       }
     };
@@ -302,7 +336,7 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.Kdim + 31) >> 5;
+    const int nk = (p.Kdim + SUB - 1) / SUB;
     const int nstage = (nk + KU * KG - 1) / (KU * KG);
     load_tiles(0);
     store_tiles();
@@ -313,18 +347,14 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             if (KG == 1 && KU > 1 && st * KU + u >= nk) break;  // block-uniform k tail (KG > 1: the tail multiplies zeros)
-            bf16x8 xf[TP], wf[TC];
+            u32x4 xf[TP], wf[TC];
 #pragma unroll
             for (int j = 0; j < TP; ++j)
-                xf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sX[u * BM * 32 + lds_off(poff + j * 16 + fr, fc)]));
+                xf[j] = *reinterpret_cast<const u32x4*>(&sX[u * BM * 32 + lds_off(poff + j * 16 + fr, fc)]);
 #pragma unroll
             for (int i = 0; i < TC; ++i)
-                wf[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&sW[u * BN * 32 + lds_off(coff + i * 16 + fr, fc)]));
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                wf[i] = *reinterpret_cast<const u32x4*>(&sW[u * BN * 32 + lds_off(coff + i * 16 + fr, fc)]);
+            mfma_substep<T, TC, TP>(wf, xf, acc);
         }
         __syncthreads();
         store_tiles();
@@ -361,7 +391,7 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
         __syncthreads();                 // `red` is dead from here on (sStat aliases it)
     }
     const bool lead = grp == 0;          // groups 1.. only keep the epilogue's barriers company
-    conv_epilogue<BM, BN, TC, TP, OutT>(p, acc, sStat, m0, n0, mt, poff, coff, tid, lane, wave, lead);
+    conv_epilogue<BM, BN, TC, TP, OutT, T>(p, acc, sStat, m0, n0, mt, poff, coff, tid, lane, wave, lead);
 }
 
 // ---------------------------------------------------------------------------
@@ -397,9 +427,10 @@ __device__ __forceinline__ u32x4 lds_read16_asm(unsigned byte_addr) {
     return v;
 }
 
-template <int BN, int KS, int MODE>
+template <int BN, int KS, int MODE, typename T = u16>
 __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
-    constexpr int BM = 128, BK = 64;
+    constexpr int ES = (int)sizeof(T), SUB = 64 / ES;                        // k per 64-B LDS row: 32 bf16 / 16 f32
+    constexpr int BM = 128, BK = 2 * SUB;
     constexpr int WAVES_M = BN == 128 ? 2 : 4, WAVES_N = 4 / WAVES_M;      // as k_conv_igemm: same statistics order
     constexpr int TP = BM / WAVES_M / 16, TC = BN / WAVES_N / 16;
     constexpr int NBW = BN / 64;                                            // weight rows per thread (chunks of 64 rows)
@@ -438,7 +469,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
     constexpr unsigned OOB = 0x80000000u;
     unsigned wrow[NBW];
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) wrow[i] = (unsigned)((n0 + (tid >> 2) + 64 * i) * p.Kdim) * 2u + csrc[i];
+    for (int i = 0; i < NBW; ++i) wrow[i] = (unsigned)((n0 + (tid >> 2) + 64 * i) * p.Kdim) * (unsigned)ES + csrc[i];
 
     const int nstage = p.Kdim / BK;
     int cur_tap = -1;
@@ -459,7 +490,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
                     else { hi = th; wi = tw; }
                 }
                 ok = ok && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
-                tb[i] = ok ? (unsigned)(((nimg[i] * p.Hin + hi) * p.Win + wi) * p.Cin) * 2u + csrc[i] : OOB;
+                tb[i] = ok ? (unsigned)(((nimg[i] * p.Hin + hi) * p.Win + wi) * p.Cin) * (unsigned)ES + csrc[i] : OOB;
             }
             cur_tap = tap;
         }
@@ -468,12 +499,12 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-                dma16(rx, base + u * XS + (wave * 16 + 64 * i) * 32, tb[i] == OOB ? OOB : tb[i] + (unsigned)(cc + u * 32) * 2u);
+                dma16(rx, base + u * XS + (wave * 16 + 64 * i) * 32, tb[i] == OOB ? OOB : tb[i] + (unsigned)(cc + u * SUB) * (unsigned)ES);
 #pragma unroll
         for (int i = 0; i < NBW; ++i)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-                dma16(rw, base + 2 * XS + u * WS + (wave * 16 + 64 * i) * 32, wrow[i] + (unsigned)(k0 + u * 32) * 2u);
+                dma16(rw, base + 2 * XS + u * WS + (wave * 16 + 64 * i) * 32, wrow[i] + (unsigned)(k0 + u * SUB) * (unsigned)ES);
     };
 
     const int poff = (wave / WAVES_N) * (BM / WAVES_M), coff = (wave % WAVES_N) * (BN / WAVES_N);
@@ -513,17 +544,12 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
                                       "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]));
             else         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0]), "+v"(xf[TP - 1]),
                                       "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]));
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]),
-                                                                        __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
+            mfma_substep<T, TC, TP>(wf, xf, acc);
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // everyone is done with `buf` before stage st+2 refills it
     }
-    conv_epilogue<BM, BN, TC, TP, u16>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt, poff, coff, tid, lane, wave, true);
+    conv_epilogue<BM, BN, TC, TP, T, T>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt, poff, coff, tid, lane, wave, true);
 }
 
 
@@ -534,6 +560,14 @@ static int launch_igemm_t(cr_ctx* ctx, const ConvP& p, int out_f32) {
         hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, MODE, float, KU, KG>), dim3(grid), dim3(CONV_T * KG), 0, ctx->stream, p);
     else
         hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, MODE, u16, KU, KG>), dim3(grid), dim3(CONV_T * KG), 0, ctx->stream, p);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+template <int BM, int BN, int KS, int MODE, int KU>
+static int launch_igemm_f32(cr_ctx* ctx, const ConvP& p) {
+    const int grid = (int)(cr_cdiv(p.M, BM) * (p.Cout / BN));
+    hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, MODE, float, KU, 1, float>), dim3(grid), dim3(CONV_T), 0, ctx->stream, p);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -550,7 +584,10 @@ static int xcd_enabled() {
 // literal template arguments from a plain function (the launch from inside a function template left the host stubs undefined)
 static void launch_dma_kernel(int bn, int ks, int mode, hipStream_t stream, const ConvP& p) {
     const dim3 grid((unsigned)(cr_cdiv(p.M, 128) * (p.Cout / bn))), block(CONV_T);
-#define CR_DMA_CASE(B, K, M_) if (bn == B && ks == K && mode == M_) { hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_>), grid, block, 0, stream, p); return; }
+#define CR_DMA_CASE(B, K, M_) if (bn == B && ks == K && mode == M_) { \
+        if (p.f32) hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_, float>), grid, block, 0, stream, p); \
+        else hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_, u16>), grid, block, 0, stream, p); \
+        return; }
     CR_DMA_CASE(128, 3, 0) CR_DMA_CASE(128, 3, 1) CR_DMA_CASE(128, 1, 0) CR_DMA_CASE(128, 1, 1)
     CR_DMA_CASE(64, 3, 0) CR_DMA_CASE(64, 3, 1) CR_DMA_CASE(64, 1, 0) CR_DMA_CASE(64, 1, 1)
 #undef CR_DMA_CASE
@@ -567,7 +604,8 @@ static bool try_launch_dma(cr_ctx* ctx, const ConvP& p, int out_f32, int* rc) {
     if constexpr (KS == 7) {
         return false;
     } else {
-        if (out_f32 || !dma_enabled() || (p.Cin & 63) != 0 || p.Cout % 64 != 0) return false;
+        // a k stage is two 64-B rows: 64 bf16 / 32 f32 of k, and must not straddle a filter tap
+        if ((!p.f32 && out_f32) || !dma_enabled() || (p.Cin & (p.f32 ? 31 : 63)) != 0 || p.Cout % 64 != 0) return false;
         static const int min_tiles = env_int("CR_CONV_DMA_MIN_TILES", 128), force_bn = env_int("CR_CONV_DMA_BN", 0);
         const int64_t big_tiles = cr_cdiv(p.M, 128) * (p.Cout >= 128 ? p.Cout / 128 : 1);
         if (big_tiles < min_tiles) return false;             // small grids keep the 64x64 / split-K kernels
@@ -585,6 +623,21 @@ template <int KS, int MODE>
 static int launch_igemm_ks(cr_ctx* ctx, const ConvP& p, int out_f32) {
     int rc_dma = CR_OK;
     if (try_launch_dma<KS, MODE>(ctx, p, out_f32, &rc_dma)) return rc_dma;
+    if (p.f32) {
+        // f32 MFMA runs at 1/16 of the bf16 rate: the kernels are MFMA-bound, one wave per SIMD with >= 2 independent
+        // accumulators already issues at the full rate, so the tile is chosen to put a block on every CU (intra-block
+        // split-K adds waves, not CUs, and is not used); two sub-steps (32 of k) per stage cover the global round trip
+        const int64_t b128 = p.Cout % 128 == 0 ? cr_cdiv(p.M, 128) * (p.Cout / 128) : 0;
+        const int64_t b64 = p.Cout % 64 == 0 ? cr_cdiv(p.M, 64) * (p.Cout / 64) : 0;
+        if (b128 >= 256) return launch_igemm_f32<128, 128, KS, MODE, 2>(ctx, p);
+        if (b64 >= 192) return launch_igemm_f32<64, 64, KS, MODE, 2>(ctx, p);
+        if (p.Cout % 32 == 0) {
+            if (cr_cdiv(p.M, 128) * (p.Cout / 32) >= 512) return launch_igemm_f32<128, 32, KS, MODE, 2>(ctx, p);
+            return launch_igemm_f32<64, 32, KS, MODE, 2>(ctx, p);
+        }
+        if (cr_cdiv(p.M, 128) * (p.Cout / 16) >= 512) return launch_igemm_f32<128, 16, KS, MODE, 2>(ctx, p);
+        return launch_igemm_f32<64, 16, KS, MODE, 2>(ctx, p);
+    }
     // the 32x32 ... 8x8 levels at 4 images/GPU give only 8-64 tiles of 128x128: use 64x64 tiles there so that the
     // launch covers the 256 CUs (MI355X: "a launch needs >> 256 workgroups")
     const int64_t big_tiles = cr_cdiv(p.M, 128) * (p.Cout >= 128 ? p.Cout / 128 : 1);
@@ -613,7 +666,8 @@ static int ilog2_exact(int v) {
     return ((1 << s) == v) ? s : -1;
 }
 
-static int conv_common_checks(const char* who, int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad) {
+static int conv_common_checks(const char* who, int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad,
+                              int act_f32 = 0) {
     CR_CHECK_ARG(N > 0 && H > 0 && W > 0, "%s: bad input dims", who);
     CR_CHECK_ARG(Cin % 8 == 0 && Cin >= 8, "%s: Cin=%d must be a multiple of 8 (NHWC 16-B chunks)", who, Cin);
     CR_CHECK_ARG(Cout % 16 == 0, "%s: Cout=%d must be a multiple of 16", who, Cout);
@@ -621,26 +675,28 @@ static int conv_common_checks(const char* who, int N, int H, int W, int Cin, int
     CR_CHECK_ARG(stride == 1 || stride == 2, "%s: stride %d not supported (1,2)", who, stride);
     CR_CHECK_ARG(ks == 1 || ilog2_exact(Cin) >= 0, "%s: Cin=%d must be a power of two for %dx%d kernels", who, Cin, ks, ks);
     CR_CHECK_ARG(pad >= 0 && pad <= ks / 2, "%s: pad %d", who, pad);
-    CR_CHECK_ARG((int64_t)N * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < (int64_t)0x3fffffff &&
-                 (int64_t)Cout * ks * ks * Cin < (int64_t)0x3fffffff,
+    const int64_t lim = act_f32 ? (int64_t)0x1fffffff : (int64_t)0x3fffffff;
+    CR_CHECK_ARG((int64_t)N * H * W * (int64_t)(Cin > Cout ? Cin : Cout) < lim && (int64_t)Cout * ks * ks * Cin < lim,
                  "%s: tensor too large for 31-bit byte offsets (buffer loads)", who);
     return CR_OK;
 }
 
 extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y, int N, int H, int W, int Cin,
                              int Cout, int ks, int stride, int pad, const float* bias, const void* residual,
-                             int relu, float* stats, int out_f32) {
+                             int relu, float* stats, int out_f32, int act_f32) {
     CR_CHECK_ARG(ctx && x && w && y, "cr_conv2d_fwd: NULL pointer");
-    int rc = conv_common_checks("cr_conv2d_fwd", N, H, W, Cin, Cout, ks, stride, pad);
+    int rc = conv_common_checks("cr_conv2d_fwd", N, H, W, Cin, Cout, ks, stride, pad, act_f32);
     if (rc) return rc;
+    const size_t es = act_f32 ? 4 : 2;
     ConvP p;
-    p.x = (const u16*)x; p.w = (const u16*)w; p.y = y; p.res = (const u16*)residual; p.bias = bias; p.stats = stats;
+    p.x = x; p.w = w; p.y = y; p.res = residual; p.bias = bias; p.stats = stats;
     p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Cout = Cout;
     p.Hout = (H + 2 * pad - ks) / stride + 1;
     p.Wout = (W + 2 * pad - ks) / stride + 1;
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = N * p.Hout * p.Wout;
-    p.cshift = ks == 1 ? 0 : ilog2_exact(Cin); p.relu = relu; p.xcd = xcd_enabled();
-    p.x_bytes = (unsigned)((size_t)N * H * W * Cin * 2); p.w_bytes = (unsigned)((size_t)Cout * p.Kdim * 2);
+    p.cshift = ks == 1 ? 0 : ilog2_exact(Cin); p.relu = relu; p.xcd = xcd_enabled(); p.f32 = act_f32 ? 1 : 0;
+    p.x_bytes = (unsigned)((size_t)N * H * W * Cin * es); p.w_bytes = (unsigned)((size_t)Cout * p.Kdim * es);
+    if (act_f32) out_f32 = 1;
     if (ks == 1) return launch_igemm_ks<1, 0>(ctx, p, out_f32);
     if (ks == 3) return launch_igemm_ks<3, 0>(ctx, p, out_f32);
     return launch_igemm_ks<7, 0>(ctx, p, out_f32);
@@ -649,30 +705,31 @@ extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y,
 // dX[n,h,w,c] = sum_{r,s,k} dY[n,(h+pad-r)/stride,(w+pad-s)/stride,k] * W[k,r,s,c]
 // wt = weights re-laid as [Cin][(r*KS+s)*Cout + k]  (cr_weight_transpose)
 extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int N, int H, int W,
-                                  int Cin, int Cout, int ks, int stride, int pad) {
+                                  int Cin, int Cout, int ks, int stride, int pad, int act_f32) {
     CR_CHECK_ARG(ctx && dy && wt && dx, "cr_conv2d_bwd_data: NULL pointer");
-    int rc = conv_common_checks("cr_conv2d_bwd_data", N, H, W, Cout, Cin, ks, stride, pad);
+    int rc = conv_common_checks("cr_conv2d_bwd_data", N, H, W, Cout, Cin, ks, stride, pad, act_f32);
     if (rc) return rc;
     CR_CHECK_ARG(Cin % 16 == 0, "cr_conv2d_bwd_data: Cin=%d must be a multiple of 16", Cin);
+    const size_t es = act_f32 ? 4 : 2;
     ConvP p;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
-    p.x = (const u16*)dy; p.w = (const u16*)wt; p.y = dx; p.res = nullptr; p.bias = nullptr; p.stats = nullptr;
+    p.x = dy; p.w = wt; p.y = dx; p.res = nullptr; p.bias = nullptr; p.stats = nullptr;
     p.N = N; p.Hin = Ho; p.Win = Wo; p.Cin = Cout;      // gather source = dY
     p.Hout = H; p.Wout = W; p.Cout = Cin;               // GEMM output = dX
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cout; p.M = N * H * W;
-    p.cshift = ks == 1 ? 0 : ilog2_exact(Cout); p.relu = 0; p.xcd = xcd_enabled();
-    p.x_bytes = (unsigned)((size_t)N * Ho * Wo * Cout * 2); p.w_bytes = (unsigned)((size_t)Cin * p.Kdim * 2);
-    if (ks == 1) return launch_igemm_ks<1, 1>(ctx, p, 0);
-    if (ks == 3) return launch_igemm_ks<3, 1>(ctx, p, 0);
-    return launch_igemm_ks<7, 1>(ctx, p, 0);
+    p.cshift = ks == 1 ? 0 : ilog2_exact(Cout); p.relu = 0; p.xcd = xcd_enabled(); p.f32 = act_f32 ? 1 : 0;
+    p.x_bytes = (unsigned)((size_t)N * Ho * Wo * Cout * es); p.w_bytes = (unsigned)((size_t)Cin * p.Kdim * es);
+    if (ks == 1) return launch_igemm_ks<1, 1>(ctx, p, act_f32 ? 1 : 0);
+    if (ks == 3) return launch_igemm_ks<3, 1>(ctx, p, act_f32 ? 1 : 0);
+    return launch_igemm_ks<7, 1>(ctx, p, act_f32 ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------
 // backward-weight
 // ---------------------------------------------------------------------------
 struct WgP {
-    const u16* dy;   // [M][Cout]
-    const u16* x;    // NHWC
+    const void* dy;  // [M][Cout]  bf16 or f32
+    const void* x;   // NHWC
     float* dw;       // [Cout][Kdim] f32, accumulated with atomics
     int N, Hin, Win, Cin, Hout, Wout, Cout, stride, pad, Kdim, M, cshift;
     int steps_per_split;    // 32-pixel steps handled by one split
@@ -897,6 +954,196 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_wgrad(WgP p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// backward-weight in f32 (v_mfma_f32_16x16x4_f32): dW[ch][k] += sum_pixels dY[pixel][ch] * X_gather[pixel][k].
+// Both operands arrive pixel-major ([pixel][channel] rows); the MFMA wants lane l to hold (row l&15, pixel l>>4), which
+// is a plain ds_read_b32 at [pixel 4t + (l>>4)][col0 + (l&15)]: the two 16-lane halves of a 32-lane LDS group read two
+// different pixel rows, so the row pitch is chosen = 16 (mod 32) banks and the read is conflict-free.  A sub-step is 16
+// pixels (4 MFMA k-steps); KU = 2 sub-steps per stage.  MFMA-bound (1/16 of the bf16 rate): the f32 atomics of the
+// split-over-pixels scheme are hidden behind 16x more matrix time than in the bf16 kernel.
+// ---------------------------------------------------------------------------
+template <int TM, int KS>
+__global__ __launch_bounds__(CONV_T) void k_conv_wgrad_f32(WgP p) {
+    constexpr int TN = 128, KU = 2, PS = 16;             // k tile, sub-steps per stage, pixels per sub-step
+    constexpr int WM = (TM == 128) ? 2 : 1, WN = 4 / WM;
+    constexpr int WTM = TM / WM, WTN = TN / WN;          // wave tile
+    constexpr int TI = WTM / 16, TJ = WTN / 16;
+    constexpr int PP = ((TM + 16) % 32 == 16) ? TM + 16 : TM + 32, PQ = TN + 16;     // row pitches (floats), = 16 mod 32
+    constexpr int CPR = TM / 4;                          // dy chunks (4 floats) per pixel row
+    constexpr int NP = (PS * CPR + CONV_T - 1) / CONV_T; // dy chunks per thread per sub-step
+    __shared__ __attribute__((aligned(16))) float smem[KU * PS * (PP + PQ)];
+    float* sP = smem;
+    float* sQ = smem + KU * PS * PP;
+    const float* __restrict__ xg = reinterpret_cast<const float*>(p.x);
+    (void)xg;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int bx = bid % p.tm, by = (bid / p.tm) % p.tn, bz = bid / (p.tm * p.tn);
+    const int c0 = bx * TM, q0 = by * TN;
+    const int step0 = bz * p.steps_per_split;            // steps are PS pixels here
+    const int nsteps_total = (p.M + PS - 1) / PS;
+    const int step1 = min(step0 + p.steps_per_split, nsteps_total);
+    if (step0 >= step1) return;                          // block-uniform
+
+    // Q gather: 16 pixels x 32 chunks of 4 floats = 512 chunks per sub-step, 2 per thread; the k chunk (filter tap,
+    // channel) is fixed per thread, the two pixel rows walk forward incrementally
+    const int qc = tid & 31;
+    const int qk = q0 + qc * 4;
+    int qr = 0, qs = 0, qch = qk;
+    const bool qvalid = qk < p.Kdim;
+    if (KS > 1) {
+        const int tap = qk >> p.cshift;
+        qch = qk & (p.Cin - 1);
+        qr = tap / KS;
+        qs = tap - qr * KS;
+    }
+    int pn[2], pho[2], pwo[2];
+    {
+        const int hw = p.Hout * p.Wout;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = step0 * PS + (tid >> 5) + 8 * i;
+            pn[i] = m / hw;
+            const int rem = m - pn[i] * hw;
+            pho[i] = rem / p.Wout;
+            pwo[i] = rem - pho[i] * p.Wout;
+        }
+    }
+    int mrow = step0 * PS;
+    const int mend = min(p.M, step1 * PS);
+    uint4 rq[KU][2], rp[KU][NP];
+    auto advance = [&](int pixels) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            pwo[i] += pixels;
+            while (pwo[i] >= p.Wout) { pwo[i] -= p.Wout; ++pho[i]; }
+            while (pho[i] >= p.Hout) { pho[i] -= p.Hout; ++pn[i]; }
+        }
+        mrow += pixels;
+    };
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    auto load_stage = [&]() {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hi = pho[i] * p.stride - p.pad + qr, wi = pwo[i] * p.stride - p.pad + qs;
+            const bool ok = qvalid && pn[i] < p.N && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+            const unsigned off = (unsigned)(((pn[i] * p.Hin + hi) * p.Win + wi) * p.Cin + qch) * 4u;
+            rq[u][i] = buf_load16(rx, ok ? off : OOB);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + CONV_T * i;
+            const int prow = idx / CPR, pc = idx - prow * CPR;
+            const bool ok = idx < PS * CPR && mrow + prow < mend && c0 + pc * 4 < p.Cout;
+            const unsigned off = (unsigned)((mrow + prow) * p.Cout + c0 + pc * 4) * 4u;
+            rp[u][i] = buf_load16(rdy, ok ? off : OOB);
+        }
+        advance(PS);
+      }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<uint4*>(&sQ[(u * PS + (tid >> 5) + 8 * i) * PQ + qc * 4]) = rq[u][i];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + CONV_T * i;
+            const int prow = idx / CPR, pc = idx - prow * CPR;
+            if (idx < PS * CPR) *reinterpret_cast<uint4*>(&sP[(u * PS + prow) * PP + pc * 4]) = rp[u][i];
+        }
+      }
+    };
+
+    const int wm = (WM == 2) ? (wave >> 1) : 0, wn = (WM == 2) ? (wave & 1) : wave;
+    const int moff = wm * WTM, noff = wn * WTN;
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, li = lane & 15;
+    const int nstage = (step1 - step0 + KU - 1) / KU;
+    load_stage();
+    store_stage();
+    __syncthreads();
+    const bool do_bias = p.dbias != nullptr && by == 0 && tid < TM;
+    float bsum = 0.f;
+    for (int st = 0; st < nstage; ++st) {
+        if (st + 1 < nstage) load_stage();
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = 0; r < KU * PS; ++r) bsum += sP[r * PP + tid];
+        }
+#pragma unroll
+        for (int t = 0; t < KU * PS / 4; ++t) {          // MFMA k-steps of 4 pixels
+            float af[TI], bq[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = sP[(4 * t + g) * PP + moff + i * 16 + li];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bq[j] = sQ[(4 * t + g) * PQ + noff + j * 16 + li];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (st + 1 < nstage) {
+            store_stage();
+            __syncthreads();
+        }
+    }
+    if (do_bias && c0 + tid < p.Cout) atomicAdd(&p.dbias[c0 + tid], bsum);
+    // D: col (lane&15) = k index, row 4(lane>>4)+reg = channel
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int kk = q0 + noff + j * 16 + li;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = c0 + moff + i * 16 + 4 * g + e;
+                if (kk < p.Kdim && ch < p.Cout) atomicAdd(&p.dw[(size_t)ch * p.Kdim + kk], acc[i][j][e]);
+            }
+        }
+}
+
+template <int KS>
+static int launch_wgrad_f32_ks(cr_ctx* ctx, WgP& p) {
+    constexpr int PS = 16;
+    const int nsteps = (p.M + PS - 1) / PS;
+    const int tn = (int)cr_cdiv(p.Kdim, 128);
+    const int TM = p.Cout >= 128 ? 128 : (p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16));
+    const int tm = (int)cr_cdiv(p.Cout, TM);
+    const int tiles = tm * tn;
+    // split the pixel range so that ~3 blocks per CU are resident, every block keeping >= 8 stages (256 pixels) of MFMA
+    // work to hide its atomics behind
+    static const int force_splits = env_int("CR_WG_SPLITS_F32", 0);
+    int splits = (768 + tiles - 1) / tiles;
+    if (splits > nsteps / 16) splits = nsteps / 16;
+    if (force_splits > 0) splits = force_splits;
+    if (splits > nsteps) splits = nsteps;
+    if (splits < 1) splits = 1;
+    p.steps_per_split = (nsteps + splits - 1) / splits;
+    p.steps_per_split = (p.steps_per_split + 1) & ~1;            // whole stages (KU = 2 sub-steps)
+    splits = (nsteps + p.steps_per_split - 1) / p.steps_per_split;
+    dim3 grid(tm * tn * splits);
+    p.tm = tm; p.tn = tn; p.xcd = xcd_enabled();
+    if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad_f32<128, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    else if (TM == 64) hipLaunchKernelGGL((k_conv_wgrad_f32<64, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    else if (TM == 32) hipLaunchKernelGGL((k_conv_wgrad_f32<32, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((k_conv_wgrad_f32<16, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
 template <int KS>
 static int launch_wgrad_ks(cr_ctx* ctx, WgP& p) {
     const int nsteps = (p.M + 31) >> 5;
@@ -968,22 +1215,28 @@ __global__ void k_fill_zero_f32(float* __restrict__ p, int64_t n) {
 // dW[k][r][s][c] (+)= sum dY * X ; dw is f32 [Cout][ks*ks*Cin]; `accumulate`=0 zeroes it first (with a kernel, not
 // hipMemsetAsync: memset nodes inside captured HIP graphs were observed to leave garbage on ROCm 7.2).
 static int conv2d_bwd_weight_impl(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
-                                  int Cin, int Cout, int ks, int stride, int pad, int accumulate) {
+                                  int Cin, int Cout, int ks, int stride, int pad, int accumulate, int act_f32) {
     CR_CHECK_ARG(ctx && dy && x && dw, "cr_conv2d_bwd_weight: NULL pointer");
-    int rc = conv_common_checks("cr_conv2d_bwd_weight", N, H, W, Cin, Cout, ks, stride, pad);
+    int rc = conv_common_checks("cr_conv2d_bwd_weight", N, H, W, Cin, Cout, ks, stride, pad, act_f32);
     if (rc) return rc;
+    const size_t es = act_f32 ? 4 : 2;
     WgP p;
-    p.dy = (const u16*)dy; p.x = (const u16*)x; p.dw = dw; p.dbias = dbias;
+    p.dy = dy; p.x = x; p.dw = dw; p.dbias = dbias;
     p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Cout = Cout;
     p.Hout = (H + 2 * pad - ks) / stride + 1;
     p.Wout = (W + 2 * pad - ks) / stride + 1;
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = N * p.Hout * p.Wout;
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cin);
-    p.x_bytes = (unsigned)((size_t)N * H * W * Cin * 2); p.dy_bytes = (unsigned)((size_t)p.M * Cout * 2);
+    p.x_bytes = (unsigned)((size_t)N * H * W * Cin * es); p.dy_bytes = (unsigned)((size_t)p.M * Cout * es);
     if (!accumulate) {
         const int64_t nz = (int64_t)Cout * p.Kdim;
         hipLaunchKernelGGL(k_fill_zero_f32, dim3((unsigned)cr_cdiv(nz, 256)), dim3(256), 0, ctx->stream, dw, nz);
         CR_LAUNCH_CHECK();
+    }
+    if (act_f32) {
+        if (ks == 1) return launch_wgrad_f32_ks<1>(ctx, p);
+        if (ks == 3) return launch_wgrad_f32_ks<3>(ctx, p);
+        return launch_wgrad_f32_ks<7>(ctx, p);
     }
     if (ks == 1) return launch_wgrad_ks<1>(ctx, p);
     if (ks == 3) return launch_wgrad_ks<3>(ctx, p);
@@ -991,15 +1244,15 @@ static int conv2d_bwd_weight_impl(cr_ctx* ctx, const void* dy, const void* x, fl
 }
 
 extern "C" int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W,
-                                    int Cin, int Cout, int ks, int stride, int pad, int accumulate) {
-    return conv2d_bwd_weight_impl(ctx, dy, x, dw, nullptr, N, H, W, Cin, Cout, ks, stride, pad, accumulate);
+                                    int Cin, int Cout, int ks, int stride, int pad, int accumulate, int act_f32) {
+    return conv2d_bwd_weight_impl(ctx, dy, x, dw, nullptr, N, H, W, Cin, Cout, ks, stride, pad, accumulate, act_f32);
 }
 
 // same, and dbias[Cout] += sum over pixels of dy (the bias gradient of a conv with bias: detectron2 FPN / RPN head convs)
 extern "C" int cr_conv2d_bwd_weight_bias(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int N, int H,
-                                         int W, int Cin, int Cout, int ks, int stride, int pad, int accumulate) {
+                                         int W, int Cin, int Cout, int ks, int stride, int pad, int accumulate, int act_f32) {
     CR_CHECK_ARG(dbias, "cr_conv2d_bwd_weight_bias: NULL dbias");
-    return conv2d_bwd_weight_impl(ctx, dy, x, dw, dbias, N, H, W, Cin, Cout, ks, stride, pad, accumulate);
+    return conv2d_bwd_weight_impl(ctx, dy, x, dw, dbias, N, H, W, Cin, Cout, ks, stride, pad, accumulate, act_f32);
 }
 
 // ---------------------------------------------------------------------------
@@ -1023,23 +1276,30 @@ __global__ void k_cast_f32_bf16(const float* __restrict__ src, u16* __restrict__
 // wf[co][:] = w[co][:] * s[co] (bf16) and bias[co] = beta[co] - mean[co] * s[co] with s = gamma / sqrt(var + eps) turn
 // conv + BN (+ residual, ReLU) into ONE convolution with a bias epilogue: no statistics, no second pass over the
 // activations.  One launch per layer (weights may have changed since the last call; the result is tiny).
+template <typename T>
 __global__ __launch_bounds__(256) void k_fold_bn(const float* __restrict__ w, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, const float* __restrict__ mean,
-                                                 const float* __restrict__ var, float eps, u16* __restrict__ wf,
+                                                 const float* __restrict__ var, float eps, T* __restrict__ wf,
                                                  float* __restrict__ bias, int Cout, int K) {
     const int co = blockIdx.x;
     const float s = gamma[co] * rsqrtf(var[co] + eps);
     if (threadIdx.x == 0) bias[co] = beta[co] - mean[co] * s;
     const float* wr = w + (size_t)co * K;
-    u16* o = wf + (size_t)co * K;
-    for (int i = threadIdx.x; i < K; i += 256) o[i] = f2bf(wr[i] * s);
+    T* o = wf + (size_t)co * K;
+    for (int i = threadIdx.x; i < K; i += 256) {
+        if constexpr (sizeof(T) == 2) o[i] = f2bf(wr[i] * s); else o[i] = wr[i] * s;
+    }
 }
 
 extern "C" int cr_fold_bn(cr_ctx* ctx, const float* w, const float* gamma, const float* beta, const float* mean,
-                          const float* var, float eps, void* wf, float* bias, int Cout, int K) {
+                          const float* var, float eps, void* wf, float* bias, int Cout, int K, int act_f32) {
     CR_CHECK_ARG(ctx && w && gamma && beta && mean && var && wf && bias && Cout > 0 && K > 0, "cr_fold_bn: bad args");
-    hipLaunchKernelGGL(k_fold_bn, dim3((unsigned)Cout), dim3(256), 0, ctx->stream, w, gamma, beta, mean, var, eps, (u16*)wf,
-                       bias, Cout, K);
+    if (act_f32)
+        hipLaunchKernelGGL(k_fold_bn<float>, dim3((unsigned)Cout), dim3(256), 0, ctx->stream, w, gamma, beta, mean, var, eps,
+                           (float*)wf, bias, Cout, K);
+    else
+        hipLaunchKernelGGL(k_fold_bn<u16>, dim3((unsigned)Cout), dim3(256), 0, ctx->stream, w, gamma, beta, mean, var, eps,
+                           (u16*)wf, bias, Cout, K);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -1055,7 +1315,8 @@ extern "C" int cr_cast_f32_to_bf16(cr_ctx* ctx, const float* src, void* dst, int
     return CR_OK;
 }
 
-__global__ void k_weight_transpose(const float* __restrict__ w, u16* __restrict__ wt, int Cout, int taps, int Cin) {
+template <typename T>
+__global__ void k_weight_transpose(const float* __restrict__ w, T* __restrict__ wt, int Cout, int taps, int Cin) {
     // wt[c][t][k] = w[k][t][c]
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = (int64_t)Cout * taps * Cin;
@@ -1063,14 +1324,19 @@ __global__ void k_weight_transpose(const float* __restrict__ w, u16* __restrict_
     const int k = (int)(i % Cout);
     const int t = (int)((i / Cout) % taps);
     const int c = (int)(i / ((int64_t)Cout * taps));
-    wt[i] = f2bf(w[((int64_t)k * taps + t) * Cin + c]);
+    const float v = w[((int64_t)k * taps + t) * Cin + c];
+    if constexpr (sizeof(T) == 2) wt[i] = f2bf(v); else wt[i] = v;
 }
 
-extern "C" int cr_weight_transpose(cr_ctx* ctx, const float* w, void* wt, int Cout, int ks, int Cin) {
+extern "C" int cr_weight_transpose(cr_ctx* ctx, const float* w, void* wt, int Cout, int ks, int Cin, int act_f32) {
     CR_CHECK_ARG(ctx && w && wt && Cout > 0 && Cin > 0 && ks > 0, "cr_weight_transpose: bad args");
     const int64_t n = (int64_t)Cout * ks * ks * Cin;
-    hipLaunchKernelGGL(k_weight_transpose, dim3((unsigned)cr_cdiv(n, 256)), dim3(256), 0, ctx->stream, w, (u16*)wt,
-                       Cout, ks * ks, Cin);
+    if (act_f32)
+        hipLaunchKernelGGL(k_weight_transpose<float>, dim3((unsigned)cr_cdiv(n, 256)), dim3(256), 0, ctx->stream, w, (float*)wt,
+                           Cout, ks * ks, Cin);
+    else
+        hipLaunchKernelGGL(k_weight_transpose<u16>, dim3((unsigned)cr_cdiv(n, 256)), dim3(256), 0, ctx->stream, w, (u16*)wt,
+                           Cout, ks * ks, Cin);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -1081,30 +1347,31 @@ extern "C" int cr_weight_transpose(cr_ctx* ctx, const float* w, void* wt, int Co
 // A block handles a 32 (cout) x 32 (cin) tile of one filter tap of one tensor (host-built tile table), writing the
 // bf16 copy in place order and the transposed copy through an LDS tile (both sides coalesced).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_weights_prepare(const float* __restrict__ src_base, u16* __restrict__ dst_base,
-                                                         u16* __restrict__ dstT_base, const cr_wdesc* __restrict__ descs,
+template <typename T>
+__global__ __launch_bounds__(256) void k_weights_prepare(const float* __restrict__ src_base, T* __restrict__ dst_base,
+                                                         T* __restrict__ dstT_base, const cr_wdesc* __restrict__ descs,
                                                          const int4* __restrict__ tiles) {
-    __shared__ u16 tile[32][33];
+    __shared__ T tile[32][33];
     const int4 tl = tiles[blockIdx.x];                   // (tensor, tap, cout0, cin0)
     const cr_wdesc d = descs[tl.x];
     const int r = tl.y, o0 = tl.z, c0 = tl.w;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
     const float* src = src_base + d.src_off;
-    u16* dst = dst_base + d.dst_off;
+    T* dst = dst_base ? dst_base + d.dst_off : nullptr;  // f32 mode: the master weights ARE the forward operand (no copy)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int o = o0 + ty + 8 * i, c = c0 + tx;
-        u16 v = 0;
+        T v = 0;
         if (o < d.Cout && c < d.Cin) {
             const int64_t e = ((int64_t)o * d.KK + r) * d.Cin + c;
-            v = f2bf(src[e]);
-            dst[e] = v;
+            if constexpr (sizeof(T) == 2) v = f2bf(src[e]); else v = src[e];
+            if (dst) dst[e] = v;
         }
         tile[ty + 8 * i][tx] = v;
     }
     if (!d.need_T) return;                               // block-uniform
     __syncthreads();
-    u16* dstT = dstT_base + d.dstT_off;
+    T* dstT = dstT_base + d.dstT_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, o = o0 + tx;
@@ -1113,12 +1380,16 @@ __global__ __launch_bounds__(256) void k_weights_prepare(const float* __restrict
 }
 
 extern "C" int cr_weights_prepare(cr_ctx* ctx, const float* src_base, void* dst_base, void* dstT_base,
-                                  const cr_wdesc* descs_dev, const int* tiles_dev, int ntiles) {
+                                  const cr_wdesc* descs_dev, const int* tiles_dev, int ntiles, int act_f32) {
     CR_CHECK_ARG(ctx && ntiles >= 0, "cr_weights_prepare: bad args");
     if (ntiles == 0) return CR_OK;
-    CR_CHECK_ARG(src_base && dst_base && dstT_base && descs_dev && tiles_dev, "cr_weights_prepare: NULL pointer");
-    hipLaunchKernelGGL(k_weights_prepare, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, src_base, (u16*)dst_base,
-                       (u16*)dstT_base, descs_dev, (const int4*)tiles_dev);
+    CR_CHECK_ARG(src_base && (dst_base || act_f32) && dstT_base && descs_dev && tiles_dev, "cr_weights_prepare: NULL pointer");
+    if (act_f32)
+        hipLaunchKernelGGL(k_weights_prepare<float>, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, src_base,
+                           (float*)dst_base, (float*)dstT_base, descs_dev, (const int4*)tiles_dev);
+    else
+        hipLaunchKernelGGL(k_weights_prepare<u16>, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, src_base,
+                           (u16*)dst_base, (u16*)dstT_base, descs_dev, (const int4*)tiles_dev);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -1131,32 +1402,47 @@ extern "C" int cr_weights_prepare(cr_ctx* ctx, const float* src_base, void* dst_
 // A block handles one output row and a tile of 64 input channels: both sides move whole contiguous runs.
 // ---------------------------------------------------------------------------
 #define FC_CT 64
-__global__ __launch_bounds__(256) void k_fc_weight_prepare(const float* __restrict__ src, u16* __restrict__ dst, int C, int HW) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_fc_weight_prepare(const float* __restrict__ src, T* __restrict__ dst, int C, int HW) {
     extern __shared__ float s_fc[];                       // [FC_CT][HW + 1]
     const int o = blockIdx.y, c0 = blockIdx.x * FC_CT;
     const int nc = min(FC_CT, C - c0), P1 = HW + 1;
     const float* in = src + ((size_t)o * C + c0) * HW;    // nc * HW contiguous floats
     for (int i = threadIdx.x; i < nc * HW; i += 256) s_fc[(i / HW) * P1 + (i % HW)] = in[i];
     __syncthreads();
-    u16* out = dst + (size_t)o * HW * C + c0;
+    T* out = dst + (size_t)o * HW * C + c0;
     for (int i = threadIdx.x; i < nc * HW; i += 256) {
         const int hw = i / nc, c = i - hw * nc;
-        out[(size_t)hw * C + c] = f2bf(s_fc[c * P1 + hw]);
+        if constexpr (sizeof(T) == 2) out[(size_t)hw * C + c] = f2bf(s_fc[c * P1 + hw]);
+        else out[(size_t)hw * C + c] = s_fc[c * P1 + hw];
     }
 }
 
-__global__ __launch_bounds__(256) void k_fc_grad_accum(const u16* __restrict__ g, float* __restrict__ acc, int C, int HW) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_fc_grad_accum(const T* __restrict__ g, float* __restrict__ acc, int C, int HW) {
     extern __shared__ float s_fc[];
     const int o = blockIdx.y, c0 = blockIdx.x * FC_CT;
     const int nc = min(FC_CT, C - c0), P1 = HW + 1;
-    const u16* in = g + (size_t)o * HW * C + c0;
+    const T* in = g + (size_t)o * HW * C + c0;
     for (int i = threadIdx.x; i < nc * HW; i += 256) {
         const int hw = i / nc, c = i - hw * nc;
-        s_fc[c * P1 + hw] = bf2f(in[(size_t)hw * C + c]);
+        s_fc[c * P1 + hw] = load1<T>(in, (size_t)hw * C + c);
     }
     __syncthreads();
     float* out = acc + ((size_t)o * C + c0) * HW;
     for (int i = threadIdx.x; i < nc * HW; i += 256) out[i] += s_fc[(i / HW) * P1 + (i % HW)];
+}
+
+__global__ void k_axpy_f32_f32(const float* __restrict__ g, float* __restrict__ acc, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(g + i);
+        float4 a = *reinterpret_cast<float4*>(acc + i);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        *reinterpret_cast<float4*>(acc + i) = a;
+    } else {
+        for (int64_t j = i; j < n; ++j) acc[j] += g[j];
+    }
 }
 
 __global__ void k_axpy_bf16_f32(const u16* __restrict__ g, float* __restrict__ acc, int64_t n) {
@@ -1172,25 +1458,40 @@ __global__ void k_axpy_bf16_f32(const u16* __restrict__ g, float* __restrict__ a
     }
 }
 
-extern "C" int cr_fc_weight_prepare(cr_ctx* ctx, const float* w, void* wb, int O, int C, int HW) {
+extern "C" int cr_fc_weight_prepare(cr_ctx* ctx, const float* w, void* wb, int O, int C, int HW, int act_f32) {
     CR_CHECK_ARG(ctx && w && wb && O > 0 && C > 0 && HW > 0 && HW <= 1024, "cr_fc_weight_prepare: bad args");
-    if (HW == 1) return cr_cast_f32_to_bf16(ctx, w, wb, (int64_t)O * C);
-    hipLaunchKernelGGL(k_fc_weight_prepare, dim3((unsigned)cr_cdiv(C, FC_CT), O), dim3(256), FC_CT * (HW + 1) * sizeof(float),
-                       ctx->stream, w, (u16*)wb, C, HW);
+    if (HW == 1) {
+        if (!act_f32) return cr_cast_f32_to_bf16(ctx, w, wb, (int64_t)O * C);
+        CR_HIP(hipMemcpyAsync(wb, w, (size_t)O * C * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        return CR_OK;
+    }
+    if (act_f32)
+        hipLaunchKernelGGL(k_fc_weight_prepare<float>, dim3((unsigned)cr_cdiv(C, FC_CT), O), dim3(256),
+                           FC_CT * (HW + 1) * sizeof(float), ctx->stream, w, (float*)wb, C, HW);
+    else
+        hipLaunchKernelGGL(k_fc_weight_prepare<u16>, dim3((unsigned)cr_cdiv(C, FC_CT), O), dim3(256),
+                           FC_CT * (HW + 1) * sizeof(float), ctx->stream, w, (u16*)wb, C, HW);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
 
-extern "C" int cr_fc_grad_accum(cr_ctx* ctx, const void* g, float* acc, int O, int C, int HW) {
+extern "C" int cr_fc_grad_accum(cr_ctx* ctx, const void* g, float* acc, int O, int C, int HW, int act_f32) {
     CR_CHECK_ARG(ctx && g && acc && O > 0 && C > 0 && HW > 0 && HW <= 1024, "cr_fc_grad_accum: bad args");
     if (HW == 1) {
         const int64_t n = (int64_t)O * C;
         CR_CHECK_ARG((((uintptr_t)g) & 7) == 0 && (((uintptr_t)acc) & 15) == 0, "cr_fc_grad_accum: misaligned");
-        hipLaunchKernelGGL(k_axpy_bf16_f32, dim3((unsigned)cr_cdiv(cr_cdiv(n, 4), 256)), dim3(256), 0, ctx->stream, (const u16*)g,
-                           acc, n);
+        if (act_f32)
+            hipLaunchKernelGGL(k_axpy_f32_f32, dim3((unsigned)cr_cdiv(cr_cdiv(n, 4), 256)), dim3(256), 0, ctx->stream,
+                               (const float*)g, acc, n);
+        else
+            hipLaunchKernelGGL(k_axpy_bf16_f32, dim3((unsigned)cr_cdiv(cr_cdiv(n, 4), 256)), dim3(256), 0, ctx->stream,
+                               (const u16*)g, acc, n);
+    } else if (act_f32) {
+        hipLaunchKernelGGL(k_fc_grad_accum<float>, dim3((unsigned)cr_cdiv(C, FC_CT), O), dim3(256),
+                           FC_CT * (HW + 1) * sizeof(float), ctx->stream, (const float*)g, acc, C, HW);
     } else {
-        hipLaunchKernelGGL(k_fc_grad_accum, dim3((unsigned)cr_cdiv(C, FC_CT), O), dim3(256), FC_CT * (HW + 1) * sizeof(float),
-                           ctx->stream, (const u16*)g, acc, C, HW);
+        hipLaunchKernelGGL(k_fc_grad_accum<u16>, dim3((unsigned)cr_cdiv(C, FC_CT), O), dim3(256),
+                           FC_CT * (HW + 1) * sizeof(float), ctx->stream, (const u16*)g, acc, C, HW);
     }
     CR_LAUNCH_CHECK();
     return CR_OK;
@@ -1233,39 +1534,32 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ s
 }
 
 // y = relu?( (x - mean) * invstd * gamma + beta (+ residual) ), 8 channels per thread
-__global__ __launch_bounds__(256) void k_bn_apply(const u16* __restrict__ x, const float* __restrict__ mean_invstd,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const float* __restrict__ mean_invstd,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  const u16* __restrict__ res, u16* __restrict__ y, int64_t M, int C,
+                                                  const T* __restrict__ res, T* __restrict__ y, int64_t M, int C,
                                                   int relu) {
     const int cg = C >> 3;
     const int64_t total = M * cg;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % cg) << 3;
-        const uint4 xv = *reinterpret_cast<const uint4*>(x + i * 8);
-        uint4 rv = make_uint4(0, 0, 0, 0);
-        if (res) rv = *reinterpret_cast<const uint4*>(res + i * 8);
-        const unsigned xs[4] = {xv.x, xv.y, xv.z, xv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
-        unsigned o[4];
+        float xv[8], rv[8], o[8];
+        load8<T>(x, (size_t)i * 8, xv);
+        if (res) load8<T>(res, (size_t)i * 8, rv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c = c0 + 2 * e + h;
-                const float xf = bf2f((u16)(h ? xs[e] >> 16 : xs[e] & 0xffff));
-                float t = (xf - mean_invstd[c]) * mean_invstd[C + c] * gamma[c] + beta[c];
-                if (res) t += bf2f((u16)(h ? rs[e] >> 16 : rs[e] & 0xffff));
-                v[h] = relu ? fmaxf(t, 0.f) : t;
-            }
-            o[e] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            float t = (xv[e] - mean_invstd[c]) * mean_invstd[C + c] * gamma[c] + beta[c];
+            if (res) t += rv[e];
+            o[e] = relu ? fmaxf(t, 0.f) : t;
         }
-        *reinterpret_cast<uint4*>(y + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        store8<T>(y, (size_t)i * 8, o);
     }
 }
 
 extern "C" int cr_bn_fwd(cr_ctx* ctx, const void* x, const float* stats, int nparts, const float* gamma,
                          const float* beta, const void* residual, void* y, int64_t M, int C, int relu, float eps,
-                         float momentum, float* mean_invstd, float* running_mean, float* running_var) {
+                         float momentum, float* mean_invstd, float* running_mean, float* running_var, int act_f32) {
     CR_CHECK_ARG(ctx && x && stats && gamma && beta && y && mean_invstd, "cr_bn_fwd: NULL pointer");
     CR_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && nparts > 0, "cr_bn_fwd: bad dims M=%lld C=%d", (long long)M, C);
     hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)C), dim3(256), 0, ctx->stream, stats, nparts, C, (float)M, eps,
@@ -1273,16 +1567,21 @@ extern "C" int cr_bn_fwd(cr_ctx* ctx, const void* x, const float* stats, int npa
     CR_LAUNCH_CHECK();
     const int64_t total = M * (C >> 3);
     const unsigned grid = (unsigned)(cr_cdiv(total, 256) < 4096 ? cr_cdiv(total, 256) : 4096);
-    hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(256), 0, ctx->stream, (const u16*)x, mean_invstd, gamma, beta,
-                       (const u16*)residual, (u16*)y, M, C, relu);
+    if (act_f32)
+        hipLaunchKernelGGL(k_bn_apply<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)x, mean_invstd, gamma, beta,
+                           (const float*)residual, (float*)y, M, C, relu);
+    else
+        hipLaunchKernelGGL(k_bn_apply<u16>, dim3(grid), dim3(256), 0, ctx->stream, (const u16*)x, mean_invstd, gamma, beta,
+                           (const u16*)residual, (u16*)y, M, C, relu);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
 
 // backward reduce: g = dy * (relu ? out > 0 : 1);  partial[block][0][c] = sum g ; partial[block][1][c] = sum g*xhat
 #define BNB_MAXBLOCKS 1024
-__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const u16* __restrict__ dy, const u16* __restrict__ out,
-                                                       const u16* __restrict__ x, const float* __restrict__ mean_invstd,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ dy, const T* __restrict__ out,
+                                                       const T* __restrict__ x, const float* __restrict__ mean_invstd,
                                                        float* __restrict__ partial, int64_t M, int C, int relu) {
     extern __shared__ float s_acc[];        // [rows_per_block][2][C]  (= 4096 floats for every supported C)
     const int cg = C >> 3;
@@ -1293,19 +1592,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const u16* __restrict__ d
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; mu[e] = mean_invstd[c0 + e]; is[e] = mean_invstd[C + c0 + e]; }
     for (int64_t m = (int64_t)blockIdx.x * rows_per_block + myrow; m < M; m += (int64_t)gridDim.x * rows_per_block) {
-        const int64_t i = m * cg + mycg;
-        const uint4 dv = *reinterpret_cast<const uint4*>(dy + i * 8);
-        const uint4 xv = *reinterpret_cast<const uint4*>(x + i * 8);
-        uint4 ov = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-        if (relu) ov = *reinterpret_cast<const uint4*>(out + i * 8);
-        const unsigned ds[4] = {dv.x, dv.y, dv.z, dv.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w}, os[4] = {ov.x, ov.y, ov.z, ov.w};
+        const size_t i8 = (size_t)(m * cg + mycg) * 8;
+        float dv[8], xv[8], ov[8];
+        load8<T>(dy, i8, dv);
+        load8<T>(x, i8, xv);
+        if (relu) load8<T>(out, i8, ov);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int w = e >> 1, h = e & 1;
-            const float o = bf2f((u16)(h ? os[w] >> 16 : os[w] & 0xffff));
-            float gq = bf2f((u16)(h ? ds[w] >> 16 : ds[w] & 0xffff));
-            gq = o > 0.f ? gq : 0.f;
-            const float xh = (bf2f((u16)(h ? xs[w] >> 16 : xs[w] & 0xffff)) - mu[e]) * is[e];
+            const float gq = (!relu || ov[e] > 0.f) ? dv[e] : 0.f;
+            const float xh = (xv[e] - mu[e]) * is[e];
             a[e] += gq;
             b[e] += gq * xh;
         }
@@ -1348,41 +1643,33 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
 }
 
 // dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); also writes g (the masked grad) for the residual branch
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(const u16* __restrict__ dy, const u16* __restrict__ out,
-                                                      const u16* __restrict__ x, const float* __restrict__ mean_invstd,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ out,
+                                                      const T* __restrict__ x, const float* __restrict__ mean_invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                      u16* __restrict__ dx, u16* __restrict__ dres, int64_t M, int C,
+                                                      T* __restrict__ dx, T* __restrict__ dres, int64_t M, int C,
                                                       int relu) {
     const int cg = C >> 3;
     const float invM = 1.f / (float)M;
     const int64_t total = M * cg;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % cg) << 3;
-        const uint4 dv = *reinterpret_cast<const uint4*>(dy + i * 8);
-        const uint4 xv = *reinterpret_cast<const uint4*>(x + i * 8);
-        uint4 ov = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-        if (relu) ov = *reinterpret_cast<const uint4*>(out + i * 8);
-        const unsigned ds[4] = {dv.x, dv.y, dv.z, dv.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w}, os[4] = {ov.x, ov.y, ov.z, ov.w};
-        unsigned od[4], og[4];
+        const size_t i8 = (size_t)i * 8;
+        float dv[8], xv[8], ov[8], vd[8], vg[8];
+        load8<T>(dy, i8, dv);
+        load8<T>(x, i8, xv);
+        if (relu) load8<T>(out, i8, ov);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            float vd[2], vg[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c = c0 + 2 * w + h;
-                const float o = bf2f((u16)(h ? os[w] >> 16 : os[w] & 0xffff));
-                float gq = bf2f((u16)(h ? ds[w] >> 16 : ds[w] & 0xffff));
-                gq = o > 0.f ? gq : 0.f;
-                const float is = mean_invstd[C + c];
-                const float xh = (bf2f((u16)(h ? xs[w] >> 16 : xs[w] & 0xffff)) - mean_invstd[c]) * is;
-                vd[h] = gamma[c] * is * (gq - sums[c] * invM - xh * sums[C + c] * invM);
-                vg[h] = gq;
-            }
-            od[w] = (unsigned)f2bf(vd[0]) | ((unsigned)f2bf(vd[1]) << 16);
-            og[w] = (unsigned)f2bf(vg[0]) | ((unsigned)f2bf(vg[1]) << 16);
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            const float gq = (!relu || ov[e] > 0.f) ? dv[e] : 0.f;
+            const float is = mean_invstd[C + c];
+            const float xh = (xv[e] - mean_invstd[c]) * is;
+            vd[e] = gamma[c] * is * (gq - sums[c] * invM - xh * sums[C + c] * invM);
+            vg[e] = gq;
         }
-        *reinterpret_cast<uint4*>(dx + i * 8) = make_uint4(od[0], od[1], od[2], od[3]);
-        if (dres) *reinterpret_cast<uint4*>(dres + i * 8) = make_uint4(og[0], og[1], og[2], og[3]);
+        store8<T>(dx, i8, vd);
+        if (dres) store8<T>(dres, i8, vg);
     }
 }
 
@@ -1390,7 +1677,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const u16* __restrict__ dy
 // dgamma/dbeta are ACCUMULATED (+=).  No atomics: bitwise reproducible.
 extern "C" int cr_bn_bwd(cr_ctx* ctx, const void* dy, const void* out, const void* x, const float* mean_invstd,
                          const float* gamma, float* sums, void* dx, void* dres, float* dgamma, float* dbeta,
-                         int64_t M, int C, int relu) {
+                         int64_t M, int C, int relu, int act_f32) {
     CR_CHECK_ARG(ctx && dy && x && mean_invstd && gamma && sums && dx && dgamma && dbeta, "cr_bn_bwd: NULL pointer");
     CR_CHECK_ARG(!relu || out, "cr_bn_bwd: relu needs the forward output");
     CR_CHECK_ARG(M > 0 && C % 8 == 0 && C <= 2048 && 256 % (C >> 3) == 0, "cr_bn_bwd: unsupported C=%d", C);
@@ -1399,16 +1686,25 @@ extern "C" int cr_bn_bwd(cr_ctx* ctx, const void* dy, const void* out, const voi
     if (nb > BNB_MAXBLOCKS) nb = BNB_MAXBLOCKS;
     if (nb < 1) nb = 1;
     float* reduced = sums + (size_t)BNB_MAXBLOCKS * 2 * C;
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3((unsigned)nb), dim3(256), sizeof(float) * rows_per_block * 2 * C, ctx->stream,
-                       (const u16*)dy, (const u16*)out, (const u16*)x, mean_invstd, sums, M, C, relu);
+    const size_t shm = sizeof(float) * rows_per_block * 2 * C;
+    if (act_f32)
+        hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3((unsigned)nb), dim3(256), shm, ctx->stream, (const float*)dy,
+                           (const float*)out, (const float*)x, mean_invstd, sums, M, C, relu);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_reduce<u16>, dim3((unsigned)nb), dim3(256), shm, ctx->stream, (const u16*)dy,
+                           (const u16*)out, (const u16*)x, mean_invstd, sums, M, C, relu);
     CR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)C), dim3(256), 0, ctx->stream, sums, (int)nb, C, reduced, dgamma,
                        dbeta);
     CR_LAUNCH_CHECK();
     const int64_t total = M * (C >> 3);
     const unsigned grid = (unsigned)(cr_cdiv(total, 256) < 4096 ? cr_cdiv(total, 256) : 4096);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(256), 0, ctx->stream, (const u16*)dy, (const u16*)out,
-                       (const u16*)x, mean_invstd, gamma, reduced, (u16*)dx, (u16*)dres, M, C, relu);
+    if (act_f32)
+        hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)dy, (const float*)out,
+                           (const float*)x, mean_invstd, gamma, reduced, (float*)dx, (float*)dres, M, C, relu);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_apply<u16>, dim3(grid), dim3(256), 0, ctx->stream, (const u16*)dy, (const u16*)out,
+                           (const u16*)x, mean_invstd, gamma, reduced, (u16*)dx, (u16*)dres, M, C, relu);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -1464,25 +1760,19 @@ extern "C" int cr_colsum_accum(cr_ctx* ctx, const void* x, int is_f32, int64_t M
 }
 
 // ---------------------------------------------------------------------------
-// pooling / resampling / elementwise, NHWC bf16, 8 channels (16 B) per thread
+// pooling / resampling / elementwise, NHWC (bf16 or f32 storage), 8 channels per thread
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void unpack8(const uint4 v, float* f) {
-    f[0] = bf2f((u16)(v.x & 0xffff)); f[1] = bf2f((u16)(v.x >> 16));
-    f[2] = bf2f((u16)(v.y & 0xffff)); f[3] = bf2f((u16)(v.y >> 16));
-    f[4] = bf2f((u16)(v.z & 0xffff)); f[5] = bf2f((u16)(v.z >> 16));
-    f[6] = bf2f((u16)(v.w & 0xffff)); f[7] = bf2f((u16)(v.w >> 16));
-}
-__device__ __forceinline__ uint4 pack8(const float* f) {
-    uint4 o;
-    o.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
-    o.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
-    o.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
-    o.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
-    return o;
-}
+#define CR_DISPATCH_T(act_f32, KERNEL, grid, block, shm, stream, ...)                                   \
+    do {                                                                                                \
+        if (act_f32) hipLaunchKernelGGL((KERNEL<float>), grid, block, shm, stream, __VA_ARGS__);        \
+        else hipLaunchKernelGGL((KERNEL<u16>), grid, block, shm, stream, __VA_ARGS__);                  \
+    } while (0)
 
 // window = 2: MaxPool2d(2,2) (dla.py:208); window = 1: max_pool2d(k=1,s=2) = subsample (dla.py:474)
-__global__ void k_pool_fwd(const u16* __restrict__ x, u16* __restrict__ y, int N, int H, int W, int C, int window) {
+template <typename T>
+__global__ void k_pool_fwd(const void* __restrict__ xv, void* __restrict__ yv, int N, int H, int W, int C, int window) {
+    const T* __restrict__ x = (const T*)xv;
+    T* __restrict__ y = (T*)yv;
     const int Ho = H / 2, Wo = W / 2, cg = C >> 3;
     const int64_t total = (int64_t)N * Ho * Wo * cg;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1491,26 +1781,28 @@ __global__ void k_pool_fwd(const u16* __restrict__ x, u16* __restrict__ y, int N
     const int wo = (int)((i / cg) % Wo);
     const int ho = (int)((i / ((int64_t)cg * Wo)) % Ho);
     const int n = (int)(i / ((int64_t)cg * Wo * Ho));
-    const u16* b = x + (((size_t)(n * H + 2 * ho) * W + 2 * wo) * C) + c * 8;
-    uint4 v = *reinterpret_cast<const uint4*>(b);
+    const size_t b = (((size_t)(n * H + 2 * ho) * W + 2 * wo) * C) + c * 8;
+    float m[8], t[8];
+    load8<T>(x, b, m);
     if (window == 2) {
-        float m[8], t[8];
-        unpack8(v, m);
         const size_t offs[3] = {(size_t)C, (size_t)W * C, (size_t)W * C + C};
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            unpack8(*reinterpret_cast<const uint4*>(b + offs[q]), t);
+            load8<T>(x, b + offs[q], t);
 #pragma unroll
             for (int e = 0; e < 8; ++e) m[e] = (t[e] > m[e] || t[e] != t[e]) ? t[e] : m[e];
         }
-        v = pack8(m);
     }
-    *reinterpret_cast<uint4*>(y + i * 8) = v;
+    store8<T>(y, (size_t)i * 8, m);
 }
 
 // routes dy to the FIRST maximal element of each window in scan order (PyTorch's tie rule)
-__global__ void k_pool_bwd(const u16* __restrict__ x, const u16* __restrict__ dy, u16* __restrict__ dx, int N, int H,
+template <typename T>
+__global__ void k_pool_bwd(const void* __restrict__ xv, const void* __restrict__ dyv, void* __restrict__ dxv, int N, int H,
                            int W, int C, int window) {
+    const T* __restrict__ x = (const T*)xv;
+    const T* __restrict__ dy = (const T*)dyv;
+    T* __restrict__ dx = (T*)dxv;
     const int Ho = H / 2, Wo = W / 2, cg = C >> 3;
     const int64_t total = (int64_t)N * Ho * Wo * cg;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1522,17 +1814,17 @@ __global__ void k_pool_bwd(const u16* __restrict__ x, const u16* __restrict__ dy
     const size_t base = (((size_t)(n * H + 2 * ho) * W + 2 * wo) * C) + c * 8;
     const size_t offs[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
     float g[8];
-    unpack8(*reinterpret_cast<const uint4*>(dy + i * 8), g);
-    float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    load8<T>(dy, (size_t)i * 8, g);
+    const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (window == 1) {
-        *reinterpret_cast<uint4*>(dx + base) = pack8(g);
+        store8<T>(dx, base, g);
 #pragma unroll
-        for (int q = 1; q < 4; ++q) *reinterpret_cast<uint4*>(dx + base + offs[q]) = pack8(z);
+        for (int q = 1; q < 4; ++q) store8<T>(dx, base + offs[q], z);
         return;
     }
     float v[4][8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) unpack8(*reinterpret_cast<const uint4*>(x + base + offs[q]), v[q]);
+    for (int q = 0; q < 4; ++q) load8<T>(x, base + offs[q], v[q]);
     int am[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -1548,29 +1840,28 @@ __global__ void k_pool_bwd(const u16* __restrict__ x, const u16* __restrict__ dy
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = am[e] == q ? g[e] : 0.f;
-        *reinterpret_cast<uint4*>(dx + base + offs[q]) = pack8(o);
+        store8<T>(dx, base + offs[q], o);
     }
 }
 
-extern "C" int cr_pool2x_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int window) {
+extern "C" int cr_pool2x_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int window, int act_f32) {
     CR_CHECK_ARG(ctx && x && y, "cr_pool2x_fwd: NULL pointer");
     CR_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && (window == 1 || window == 2), "cr_pool2x_fwd: bad dims");
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
     if (total == 0) return CR_OK;
-    hipLaunchKernelGGL(k_pool_fwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)x, (u16*)y,
-                       N, H, W, C, window);
+    CR_DISPATCH_T(act_f32, k_pool_fwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, x, y, N, H, W, C, window);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
 
 extern "C" int cr_pool2x_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C,
-                             int window) {
+                             int window, int act_f32) {
     CR_CHECK_ARG(ctx && x && dy && dx, "cr_pool2x_bwd: NULL pointer");
     CR_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && (window == 1 || window == 2), "cr_pool2x_bwd: bad dims");
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
     if (total == 0) return CR_OK;
-    hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)x,
-                       (const u16*)dy, (u16*)dx, N, H, W, C, window);
+    CR_DISPATCH_T(act_f32, k_pool_bwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, x, dy, dx, N, H, W, C,
+                  window);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -1579,7 +1870,8 @@ extern "C" int cr_pool2x_bwd(cr_ctx* ctx, const void* x, const void* dy, void* d
 // takes it from torchvision.models.resnet34 [third-party]).  NaN propagates, ties go to the first element in scan
 // order (PyTorch).  Backward is a gather: an input pixel belongs to at most 4 windows; it receives a window's
 // gradient when it is that window's (first) arg-max -- no atomics.
-__device__ __forceinline__ void pool3_window(const u16* __restrict__ x, int n, int ho, int wo, int H, int W, int C, int c8,
+template <typename T>
+__device__ __forceinline__ void pool3_window(const T* __restrict__ x, int n, int ho, int wo, int H, int W, int C, int c8,
                                              float* m, int* am) {
     const int h0 = max(2 * ho - 1, 0), w0 = max(2 * wo - 1, 0);
 #pragma unroll
@@ -1591,7 +1883,7 @@ __device__ __forceinline__ void pool3_window(const u16* __restrict__ x, int n, i
             const int w = 2 * wo - 1 + q;
             if ((unsigned)w >= (unsigned)W) continue;
             float t[8];
-            unpack8(*reinterpret_cast<const uint4*>(x + (((size_t)(n * H + h) * W + w) * C) + c8), t);
+            load8<T>(x, (((size_t)(n * H + h) * W + w) * C) + c8, t);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (t[e] > m[e] || t[e] != t[e]) { m[e] = t[e]; am[e] = h * W + w; }     // ATen's update rule
@@ -1599,7 +1891,8 @@ __device__ __forceinline__ void pool3_window(const u16* __restrict__ x, int n, i
     }
 }
 
-__global__ void k_pool3s2_fwd(const u16* __restrict__ x, u16* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+template <typename T>
+__global__ void k_pool3s2_fwd(const void* __restrict__ xv, void* __restrict__ yv, int N, int H, int W, int C, int Ho, int Wo) {
     const int cg = C >> 3;
     const int64_t total = (int64_t)N * Ho * Wo * cg;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1610,11 +1903,12 @@ __global__ void k_pool3s2_fwd(const u16* __restrict__ x, u16* __restrict__ y, in
     const int n = (int)(i / ((int64_t)cg * Wo * Ho));
     float m[8];
     int am[8];
-    pool3_window(x, n, ho, wo, H, W, C, c * 8, m, am);
-    *reinterpret_cast<uint4*>(y + i * 8) = pack8(m);
+    pool3_window<T>((const T*)xv, n, ho, wo, H, W, C, c * 8, m, am);
+    store8<T>((T*)yv, (size_t)i * 8, m);
 }
 
-__global__ void k_pool3s2_bwd(const u16* __restrict__ x, const u16* __restrict__ dy, u16* __restrict__ dx, int N, int H,
+template <typename T>
+__global__ void k_pool3s2_bwd(const void* __restrict__ xv, const void* __restrict__ dyv, void* __restrict__ dxv, int N, int H,
                               int W, int C, int Ho, int Wo) {
     const int cg = C >> 3;
     const int64_t total = (int64_t)N * H * W * cg;
@@ -1633,40 +1927,40 @@ __global__ void k_pool3s2_bwd(const u16* __restrict__ x, const u16* __restrict__
             if (wo >= Wo) continue;
             float m[8], d[8];
             int am[8];
-            pool3_window(x, n, ho, wo, H, W, C, c * 8, m, am);
-            unpack8(*reinterpret_cast<const uint4*>(dy + (((size_t)(n * Ho + ho) * Wo + wo) * C) + c * 8), d);
+            pool3_window<T>((const T*)xv, n, ho, wo, H, W, C, c * 8, m, am);
+            load8<T>((const T*)dyv, (((size_t)(n * Ho + ho) * Wo + wo) * C) + c * 8, d);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (am[e] == me) g[e] += d[e];
         }
     }
-    *reinterpret_cast<uint4*>(dx + i * 8) = pack8(g);
+    store8<T>((T*)dxv, (size_t)i * 8, g);
 }
 
-extern "C" int cr_maxpool3x3s2_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C) {
+extern "C" int cr_maxpool3x3s2_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int act_f32) {
     CR_CHECK_ARG(ctx && x && y, "cr_maxpool3x3s2_fwd: NULL pointer");
     CR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 8 == 0, "cr_maxpool3x3s2_fwd: bad dims");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int64_t total = (int64_t)N * Ho * Wo * (C / 8);
-    hipLaunchKernelGGL(k_pool3s2_fwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)x, (u16*)y, N,
-                       H, W, C, Ho, Wo);
+    CR_DISPATCH_T(act_f32, k_pool3s2_fwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, x, y, N, H, W, C, Ho, Wo);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
 
-extern "C" int cr_maxpool3x3s2_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C) {
+extern "C" int cr_maxpool3x3s2_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int act_f32) {
     CR_CHECK_ARG(ctx && x && dy && dx, "cr_maxpool3x3s2_bwd: NULL pointer");
     CR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C % 8 == 0, "cr_maxpool3x3s2_bwd: bad dims");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int64_t total = (int64_t)N * H * W * (C / 8);
-    hipLaunchKernelGGL(k_pool3s2_bwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)x,
-                       (const u16*)dy, (u16*)dx, N, H, W, C, Ho, Wo);
+    CR_DISPATCH_T(act_f32, k_pool3s2_bwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, x, dy, dx, N, H, W, C,
+                  Ho, Wo);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
 
 // FPN top-down: y[n,h,w,:] = lat[n,h,w,:] + top[n,h/2,w/2,:]   (nearest 2x upsample + sum)
-__global__ void k_upsample_add(const u16* __restrict__ lat, const u16* __restrict__ top, u16* __restrict__ y, int N,
+template <typename T>
+__global__ void k_upsample_add(const void* __restrict__ latv, const void* __restrict__ topv, void* __restrict__ yv, int N,
                                int H, int W, int C) {
     const int cg = C >> 3;
     const int64_t total = (int64_t)N * H * W * cg;
@@ -1677,15 +1971,17 @@ __global__ void k_upsample_add(const u16* __restrict__ lat, const u16* __restric
     const int h = (int)((i / ((int64_t)cg * W)) % H);
     const int n = (int)(i / ((int64_t)cg * W * H));
     float a[8], b[8];
-    unpack8(*reinterpret_cast<const uint4*>(lat + i * 8), a);
-    unpack8(*reinterpret_cast<const uint4*>(top + (((size_t)(n * (H / 2) + h / 2) * (W / 2) + w / 2) * C) + c * 8), b);
+    load8<T>((const T*)latv, (size_t)i * 8, a);
+    load8<T>((const T*)topv, (((size_t)(n * (H / 2) + h / 2) * (W / 2) + w / 2) * C) + c * 8, b);
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] += b[e];
-    *reinterpret_cast<uint4*>(y + i * 8) = pack8(a);
+    store8<T>((T*)yv, (size_t)i * 8, a);
 }
 
 // its backward w.r.t. `top`: dtop[n,h2,w2,:] = sum of the 2x2 block of dy
-__global__ void k_sum2x2(const u16* __restrict__ dy, u16* __restrict__ dtop, int N, int H, int W, int C) {
+template <typename T>
+__global__ void k_sum2x2(const void* __restrict__ dyv, void* __restrict__ dtopv, int N, int H, int W, int C) {
+    const T* __restrict__ dy = (const T*)dyv;
     const int Ho = H / 2, Wo = W / 2, cg = C >> 3;
     const int64_t total = (int64_t)N * Ho * Wo * cg;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1694,44 +1990,44 @@ __global__ void k_sum2x2(const u16* __restrict__ dy, u16* __restrict__ dtop, int
     const int wo = (int)((i / cg) % Wo);
     const int ho = (int)((i / ((int64_t)cg * Wo)) % Ho);
     const int n = (int)(i / ((int64_t)cg * Wo * Ho));
-    const u16* b = dy + (((size_t)(n * H + 2 * ho) * W + 2 * wo) * C) + c * 8;
+    const size_t b = (((size_t)(n * H + 2 * ho) * W + 2 * wo) * C) + c * 8;
     float s[8], t[8];
-    unpack8(*reinterpret_cast<const uint4*>(b), s);
+    load8<T>(dy, b, s);
     const size_t offs[3] = {(size_t)C, (size_t)W * C, (size_t)W * C + C};
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        unpack8(*reinterpret_cast<const uint4*>(b + offs[q]), t);
+        load8<T>(dy, b + offs[q], t);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] += t[e];
     }
-    *reinterpret_cast<uint4*>(dtop + i * 8) = pack8(s);
+    store8<T>((T*)dtopv, (size_t)i * 8, s);
 }
 
-extern "C" int cr_upsample2x_add(cr_ctx* ctx, const void* lat, const void* top, void* y, int N, int H, int W, int C) {
+extern "C" int cr_upsample2x_add(cr_ctx* ctx, const void* lat, const void* top, void* y, int N, int H, int W, int C,
+                                 int act_f32) {
     CR_CHECK_ARG(ctx && lat && top && y, "cr_upsample2x_add: NULL pointer");
     CR_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "cr_upsample2x_add: bad dims");
     const int64_t total = (int64_t)N * H * W * (C / 8);
     if (total == 0) return CR_OK;
-    hipLaunchKernelGGL(k_upsample_add, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)lat,
-                       (const u16*)top, (u16*)y, N, H, W, C);
+    CR_DISPATCH_T(act_f32, k_upsample_add, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, lat, top, y, N, H, W, C);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
 
-extern "C" int cr_sum2x2(cr_ctx* ctx, const void* dy, void* dtop, int N, int H, int W, int C) {
+extern "C" int cr_sum2x2(cr_ctx* ctx, const void* dy, void* dtop, int N, int H, int W, int C, int act_f32) {
     CR_CHECK_ARG(ctx && dy && dtop, "cr_sum2x2: NULL pointer");
     CR_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "cr_sum2x2: bad dims");
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
     if (total == 0) return CR_OK;
-    hipLaunchKernelGGL(k_sum2x2, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const u16*)dy,
-                       (u16*)dtop, N, H, W, C);
+    CR_DISPATCH_T(act_f32, k_sum2x2, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, dy, dtop, N, H, W, C);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
 
 // preprocess_image (detectron2 GeneralizedRCNN, Base.yaml:32-33): (x - mean)/std on a stacked
-// uint8 (N,3,H,W) batch -> NHWC bf16 with channels padded 3 -> 8 (zeros)
-__global__ void k_preprocess(const unsigned char* __restrict__ img, u16* __restrict__ y, int N, int H, int W, float m0,
+// uint8 (N,3,H,W) batch -> NHWC with channels padded 3 -> 8 (zeros)
+template <typename T>
+__global__ void k_preprocess(const unsigned char* __restrict__ img, void* __restrict__ yv, int N, int H, int W, float m0,
                              float m1, float m2, float s0, float s1, float s2) {
     const int64_t total = (int64_t)N * H * W;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1739,17 +2035,17 @@ __global__ void k_preprocess(const unsigned char* __restrict__ img, u16* __restr
     const int64_t hw = (int64_t)H * W;
     const int64_t n = i / hw, pix = i - n * hw;
     const unsigned char* b = img + n * 3 * hw + pix;
-    float f[8] = {((float)b[0] - m0) / s0, ((float)b[hw] - m1) / s1, ((float)b[2 * hw] - m2) / s2, 0, 0, 0, 0, 0};
-    *reinterpret_cast<uint4*>(y + i * 8) = pack8(f);
+    const float f[8] = {((float)b[0] - m0) / s0, ((float)b[hw] - m1) / s1, ((float)b[2 * hw] - m2) / s2, 0, 0, 0, 0, 0};
+    store8<T>((T*)yv, (size_t)i * 8, f);
 }
 
 extern "C" int cr_preprocess(cr_ctx* ctx, const unsigned char* img, void* y, int N, int H, int W, const float* mean3,
-                             const float* std3) {
+                             const float* std3, int act_f32) {
     CR_CHECK_ARG(ctx && img && y && mean3 && std3, "cr_preprocess: NULL pointer (mean3/std3 are HOST pointers)");
     const int64_t total = (int64_t)N * H * W;
     if (total == 0) return CR_OK;
-    hipLaunchKernelGGL(k_preprocess, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, img, (u16*)y, N, H, W,
-                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    CR_DISPATCH_T(act_f32, k_preprocess, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, img, y, N, H, W,
+                  mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

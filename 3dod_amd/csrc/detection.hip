@@ -11,13 +11,11 @@
 #include <math.h>
 #include <stdlib.h>
 
-typedef unsigned short u16;
-__device__ __forceinline__ float bf2f(u16 b) { return __uint_as_float(((unsigned)b) << 16); }
-__device__ __forceinline__ u16 f2bf(float f) { __bf16 b = (__bf16)f; return __builtin_bit_cast(u16, b); }
+#include "cr_elem.h"
 
 #define MAX_LEVELS 5
 struct Pyramid {
-    const u16* feat[MAX_LEVELS];   // NHWC bf16
+    const void* feat[MAX_LEVELS];  // NHWC bf16 or f32 (template parameter of the kernels)
     float* grad[MAX_LEVELS];       // NHWC f32 (backward)
     int H[MAX_LEVELS], W[MAX_LEVELS];
     float scale[MAX_LEVELS];
@@ -48,10 +46,10 @@ __device__ __forceinline__ Samp bilinear(float y, float x, int H, int W) {
     return s;
 }
 
-// one thread = (roi, ph, pw, 8 channels).  rois (R,5) = [batch, x1,y1,x2,y2].  out (R,PH,PW,C) bf16
-template <bool BWD>
+// one thread = (roi, ph, pw, 8 channels).  rois (R,5) = [batch, x1,y1,x2,y2].  out (R,PH,PW,C) in the storage type T
+template <bool BWD, typename T>
 __global__ __launch_bounds__(256) void k_roi_align(Pyramid py, const float* __restrict__ rois, int R, int PH, int PW,
-                                                   u16* __restrict__ out, const u16* __restrict__ dout) {
+                                                   T* __restrict__ out, const T* __restrict__ dout) {
     const int cg = py.C >> 3;
     const int64_t total = (int64_t)R * PH * PW * cg;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,10 +71,9 @@ __global__ __launch_bounds__(256) void k_roi_align(Pyramid py, const float* __re
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float g8[8];
     if (BWD) {
-        const uint4 dv = *reinterpret_cast<const uint4*>(dout + i * 8);
-        const unsigned w4[4] = {dv.x, dv.y, dv.z, dv.w};
+        load8<T>(dout, (size_t)i * 8, g8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g8[e] = bf2f((u16)((e & 1) ? w4[e >> 1] >> 16 : w4[e >> 1] & 0xffff)) / cnt;
+        for (int e = 0; e < 8; ++e) g8[e] /= cnt;
     }
     const size_t img = (size_t)n * H * W;
     for (int iy = 0; iy < gh; ++iy) {
@@ -88,17 +85,11 @@ __global__ __launch_bounds__(256) void k_roi_align(Pyramid py, const float* __re
             const size_t o1 = (img + (size_t)s.yl * W + s.xl) * py.C + c * 8, o2 = (img + (size_t)s.yl * W + s.xh) * py.C + c * 8;
             const size_t o3 = (img + (size_t)s.yh * W + s.xl) * py.C + c * 8, o4 = (img + (size_t)s.yh * W + s.xh) * py.C + c * 8;
             if (!BWD) {
-                const u16* f = py.feat[lv];
-                const uint4 v1 = *reinterpret_cast<const uint4*>(f + o1), v2 = *reinterpret_cast<const uint4*>(f + o2);
-                const uint4 v3 = *reinterpret_cast<const uint4*>(f + o3), v4 = *reinterpret_cast<const uint4*>(f + o4);
-                const unsigned a1[4] = {v1.x, v1.y, v1.z, v1.w}, a2[4] = {v2.x, v2.y, v2.z, v2.w};
-                const unsigned a3[4] = {v3.x, v3.y, v3.z, v3.w}, a4[4] = {v4.x, v4.y, v4.z, v4.w};
+                const T* f = (const T*)py.feat[lv];
+                float a1[8], a2[8], a3[8], a4[8];
+                load8<T>(f, o1, a1); load8<T>(f, o2, a2); load8<T>(f, o3, a3); load8<T>(f, o4, a4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int w = e >> 1, sh = (e & 1) * 16;
-                    acc[e] += s.w1 * bf2f((u16)(a1[w] >> sh)) + s.w2 * bf2f((u16)(a2[w] >> sh)) +
-                              s.w3 * bf2f((u16)(a3[w] >> sh)) + s.w4 * bf2f((u16)(a4[w] >> sh));
-                }
+                for (int e = 0; e < 8; ++e) acc[e] += s.w1 * a1[e] + s.w2 * a2[e] + s.w3 * a3[e] + s.w4 * a4[e];
             } else {
                 float* gq = py.grad[lv];
 #pragma unroll
@@ -112,19 +103,17 @@ __global__ __launch_bounds__(256) void k_roi_align(Pyramid py, const float* __re
         }
     }
     if (!BWD) {
-        uint4 o;
-        unsigned pk[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) pk[w] = (unsigned)f2bf(acc[2 * w] / cnt) | ((unsigned)f2bf(acc[2 * w + 1] / cnt) << 16);
-        o = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        *reinterpret_cast<uint4*>(out + i * 8) = o;
+        for (int e = 0; e < 8; ++e) acc[e] /= cnt;
+        store8<T>(out, (size_t)i * 8, acc);
     }
 }
 
 // backward: one thread = (roi, ph, pw, ONE channel), channel fastest, so every atomic wave-instruction adds
 // 64 consecutive floats (256 contiguous bytes: the full-rate shape of MI355X_MICROARCH.md "Global float atomics").
+template <typename T>
 __global__ __launch_bounds__(256) void k_roi_align_bwd(Pyramid py, const float* __restrict__ rois, int R, int PH,
-                                                       int PW, const u16* __restrict__ dout) {
+                                                       int PW, const T* __restrict__ dout) {
     const int C = py.C;
     const int64_t total = (int64_t)R * PH * PW * C;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -143,7 +132,7 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(Pyramid py, const float* 
     const float bw = rw / (float)PW, bh = rh / (float)PH;
     const int gh = (int)ceilf(rh / (float)PH), gw = (int)ceilf(rw / (float)PW);
     const float cnt = fmaxf((float)(gh * gw), 1.f);
-    const float g = bf2f(dout[i]) / cnt;
+    const float g = load1<T>(dout, (size_t)i) / cnt;
     if (g == 0.f) return;        // masked-out (padding) RoIs and dead channels add nothing: skip their 16 atomics
     float* gq = py.grad[lv] + (size_t)n * H * W * C + c;
     for (int iy = 0; iy < gh; ++iy) {
@@ -179,9 +168,9 @@ __device__ __forceinline__ Lin1 lin1(float y, int H) {
     return s;
 }
 
-template <int P>
+template <int P, typename T>
 __global__ __launch_bounds__(256) void k_roi_align_bwd_sep(Pyramid py, const float* __restrict__ rois, int R,
-                                                           const u16* __restrict__ dout, int maxH) {
+                                                           const T* __restrict__ dout, int maxH) {
     extern __shared__ float sm[];                        // Ay [maxH][P] | Ax [maxW][P]
     __shared__ int s_lo[2], s_hi[2];
     float* Ay = sm;
@@ -236,7 +225,7 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd_sep(Pyramid py, const flo
         for (int ph = 0; ph < P; ++ph)
 #pragma unroll
             for (int pw = 0; pw < P; ++pw) {
-                G[ph][pw] = bf2f(dout[(((size_t)r * P + ph) * P + pw) * C + c]);
+                G[ph][pw] = load1<T>(dout, (((size_t)r * P + ph) * P + pw) * C + c);
                 any |= G[ph][pw] != 0.f;
             }
         if (!any) continue;                              // masked (padding) RoIs carry zero gradient
@@ -270,7 +259,7 @@ static int fill_pyramid(Pyramid& py, const void* const* feats, float* const* gra
     CR_CHECK_ARG(C % 8 == 0, "roi_align: C %% 8");
     py.nlev = nlev; py.C = C;
     for (int l = 0; l < nlev; ++l) {
-        py.feat[l] = feats ? (const u16*)feats[l] : nullptr;
+        py.feat[l] = feats ? feats[l] : nullptr;
         py.grad[l] = grads ? grads[l] : nullptr;
         py.H[l] = Hs[l]; py.W[l] = Ws[l]; py.scale[l] = scales[l];
     }
@@ -281,7 +270,7 @@ static int fill_pyramid(Pyramid& py, const void* const* feats, float* const* gra
 // feats/Hs/Ws/scales are HOST arrays of length nlev (device pointers inside feats)
 extern "C" int cr_roi_align_fwd(cr_ctx* ctx, const void* const* feats, const int* Hs, const int* Ws,
                                 const float* scales, int nlev, int C, const float* rois, int64_t R, int PH, int PW,
-                                void* out) {
+                                void* out, int act_f32) {
     CR_CHECK_ARG(ctx && feats && Hs && Ws && scales, "cr_roi_align_fwd: NULL pointer");
     if (R == 0) return CR_OK;
     CR_CHECK_ARG(rois && out && PH > 0 && PW > 0, "cr_roi_align_fwd: bad args");
@@ -289,15 +278,20 @@ extern "C" int cr_roi_align_fwd(cr_ctx* ctx, const void* const* feats, const int
     int rc = fill_pyramid(py, feats, nullptr, Hs, Ws, scales, nlev, C);
     if (rc) return rc;
     const int64_t total = R * PH * PW * (C / 8);
-    hipLaunchKernelGGL((k_roi_align<false>), dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py, rois,
-                       (int)R, PH, PW, (u16*)out, (const u16*)nullptr);
+    if (act_f32)
+        hipLaunchKernelGGL((k_roi_align<false, float>), dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py,
+                           rois, (int)R, PH, PW, (float*)out, (const float*)nullptr);
+    else
+        hipLaunchKernelGGL((k_roi_align<false, u16>), dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py,
+                           rois, (int)R, PH, PW, (u16*)out, (const u16*)nullptr);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
 
 // grads: HOST array of nlev device pointers to f32 NHWC maps (accumulated with atomics; zero them first)
 extern "C" int cr_roi_align_bwd(cr_ctx* ctx, float* const* grads, const int* Hs, const int* Ws, const float* scales,
-                                int nlev, int C, const float* rois, int64_t R, int PH, int PW, const void* dout) {
+                                int nlev, int C, const float* rois, int64_t R, int PH, int PW, const void* dout,
+                                int act_f32) {
     CR_CHECK_ARG(ctx && grads && Hs && Ws && scales, "cr_roi_align_bwd: NULL pointer");
     if (R == 0) return CR_OK;
     CR_CHECK_ARG(rois && dout && PH > 0 && PW > 0, "cr_roi_align_bwd: bad args");
@@ -309,16 +303,24 @@ extern "C" int cr_roi_align_bwd(cr_ctx* ctx, float* const* grads, const int* Hs,
         for (int l = 0; l < nlev; ++l) { maxH = Hs[l] > maxH ? Hs[l] : maxH; maxW = Ws[l] > maxW ? Ws[l] : maxW; }
         const size_t lds = (size_t)(maxH + maxW) * 7 * sizeof(float);
         if (lds <= 60 * 1024) {
-            hipLaunchKernelGGL((k_roi_align_bwd_sep<7>), dim3((unsigned)R), dim3(256), lds, ctx->stream, py, rois, (int)R,
-                               (const u16*)dout, maxH);
+            if (act_f32)
+                hipLaunchKernelGGL((k_roi_align_bwd_sep<7, float>), dim3((unsigned)R), dim3(256), lds, ctx->stream, py, rois,
+                                   (int)R, (const float*)dout, maxH);
+            else
+                hipLaunchKernelGGL((k_roi_align_bwd_sep<7, u16>), dim3((unsigned)R), dim3(256), lds, ctx->stream, py, rois,
+                                   (int)R, (const u16*)dout, maxH);
             CR_LAUNCH_CHECK();
             return CR_OK;
         }
     }
     const int64_t total = R * PH * PW * (int64_t)C;
     CR_CHECK_ARG(cr_cdiv(total, 256) < 0x7fffffff, "cr_roi_align_bwd: too many RoIs");
-    hipLaunchKernelGGL(k_roi_align_bwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py, rois, (int)R,
-                       PH, PW, (const u16*)dout);
+    if (act_f32)
+        hipLaunchKernelGGL(k_roi_align_bwd<float>, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py, rois,
+                           (int)R, PH, PW, (const float*)dout);
+    else
+        hipLaunchKernelGGL(k_roi_align_bwd<u16>, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py, rois,
+                           (int)R, PH, PW, (const u16*)dout);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -1,7 +1,7 @@
 """CubeHead -- cubercnn/modeling/roi_heads/cube_head.py:24-202 (same parameter names / init).
-Input is the NHWC-flattened ROIAlign output (n, 7*7*256) bf16; the first FC's weight keeps the
-reference's (c,y,x) column order in the state dict and is permuted to (y,x,c) when cast to bf16.
-FC layers are plain library GEMMs (hipBLASLt through torch.nn.functional.linear, bf16 in / f32 acc)."""
+Input is the NHWC-flattened ROIAlign output (n, 7*7*256) in the activation dtype; the first FC's weight keeps the
+reference's (c,y,x) column order in the state dict and is permuted to (y,x,c) in its compute copy.
+FC layers run through ops.linear / ops.linear_cat (f32: the implicit-GEMM kernels on the f32 MFMA)."""
 from typing import Dict
 
 import numpy as np
@@ -74,12 +74,13 @@ class CubeHead(nn.Module):
         h = F.relu(fc_nhwc(x, fcs[0], self._in_chw))
         for fc in fcs[1:]:
             h = F.relu(ops.linear(h, fc.weight, fc.bias))
-        lin = lambda m: F.linear(h, m.weight.to(h.dtype), m.bias.to(h.dtype)).float()
-        box_2d_deltas = lin(self.bbox_3D_center_deltas)
-        box_dims = lin(self.bbox_3D_dims)
-        box_pose = lin(self.bbox_3D_pose)
-        box_z = lin(self.bbox_3D_center_depth)
-        box_uncert = lin(self.bbox_3D_uncertainty).clip(0.01) if self.use_conf else None
+        preds = [self.bbox_3D_center_deltas, self.bbox_3D_dims, self.bbox_3D_pose, self.bbox_3D_center_depth]
+        if self.use_conf:
+            preds.append(self.bbox_3D_uncertainty)
+        y, offs = ops.linear_cat(h, [m.weight for m in preds], [m.bias for m in preds])      # the predictors as one GEMM
+        outs = [y[:, offs[i]:offs[i + 1]].float().contiguous() for i in range(len(preds))]
+        box_2d_deltas, box_dims, box_pose, box_z = outs[:4]
+        box_uncert = outs[4].clip(0.01) if self.use_conf else None
         box_pose = rotation_6d_to_matrix(box_pose.view(-1, 6))
         box_2d_deltas = box_2d_deltas.view(n, self.num_classes, 2)
         box_dims = box_dims.view(n, self.num_classes, 3)
@@ -99,10 +100,10 @@ def _forward_fused(self, x):
     assert self.use_conf
     preds = [self.bbox_3D_center_deltas, self.bbox_3D_dims, self.bbox_3D_pose, self.bbox_3D_center_depth,
              self.bbox_3D_uncertainty]
-    W = torch.cat([m.weight for m in preds]).to(h.dtype)
-    b = torch.cat([m.bias for m in preds]).to(h.dtype)
     K = self.num_classes
-    return F.linear(h, W, b).float(), (0, 2 * K, 5 * K, 11 * K, 12 * K)
+    y, offs = ops.linear_cat(h, [m.weight for m in preds], [m.bias for m in preds])
+    assert tuple(offs[:5]) == (0, 2 * K, 5 * K, 11 * K, 12 * K)
+    return y, tuple(offs[:5])                            # y (n, 13K rounded up to 16) f32; consumers take its row stride
 
 
 CubeHead.forward_fused = _forward_fused

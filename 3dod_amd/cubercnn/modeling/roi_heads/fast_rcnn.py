@@ -143,9 +143,9 @@ class FastRCNNOutputLayers(nn.Module):
     def forward(self, x):
         if x.dim() > 2:
             x = torch.flatten(x, start_dim=1)
-        scores = ops.linear(x, self.cls_score.weight, self.cls_score.bias).float()
-        proposal_deltas = ops.linear(x, self.bbox_pred.weight, self.bbox_pred.bias).float()
-        return scores, proposal_deltas
+        # both predictors as one GEMM (rows padded to the MFMA tile inside ops.linear_cat)
+        y, offs = ops.linear_cat(x, [self.cls_score.weight, self.bbox_pred.weight], [self.cls_score.bias, self.bbox_pred.bias])
+        return y[:, offs[0]:offs[1]].float(), y[:, offs[1]:offs[2]].float()
 
     def predict_boxes_for_gt_classes(self, predictions, proposals):
         if not len(proposals):

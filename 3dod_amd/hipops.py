@@ -2,11 +2,21 @@
 
 PyTorch is used for device memory, streams and the autograd tape only; every
 op below is one or a few calls into libcr3dod.so.  Activations are NHWC
-bfloat16 tensors; conv weights are float32 (Cout,Cin,k,k) parameters in
-channels_last memory format (physical [Cout][k*k][Cin]).
-There is no CPU path: a non-CUDA tensor raises CrError.
+tensors in the ACTIVATION DTYPE of the process; conv weights are float32
+(Cout,Cin,k,k) parameters in channels_last memory format (physical
+[Cout][k*k][Cin]).  There is no CPU path: a non-CUDA tensor raises CrError.
+
+Precision.  The reference trains and evaluates in float32 (tools/train_net.py:184-330,
+no autocast anywhere), so float32 is the default here: activations, activation
+gradients and the operands of every contraction are f32 and the convolutions / FC
+layers run on the f32 MFMA (v_mfma_f32_16x16x4_f32).  `set_precision("bf16")` (or
+CR_PRECISION=bf16 in the environment) selects the fast mode: the same tensors are
+bfloat16 and the contractions run on the bf16 MFMA with f32 accumulation.  Every op
+takes its mode from the dtype of the tensor it is handed, so both modes can coexist
+in one process (the parity tests run them side by side).
 """
 import ctypes
+import os
 
 import torch
 
@@ -15,6 +25,34 @@ from . import _lib
 bf16 = torch.bfloat16
 f32 = torch.float32
 STAT_REPL = 32
+
+_PRECISIONS = {"fp32": f32, "f32": f32, "float32": f32, "bf16": bf16, "bfloat16": bf16}
+_ACT = [_PRECISIONS[os.environ.get("CR_PRECISION", "fp32").lower()]]
+
+
+def set_precision(name):
+    """"fp32" (reference precision, default) or "bf16" (fast mode): the dtype of the activations produced by
+    preprocess() and hence of everything downstream.  Returns the previous setting's name."""
+    prev = precision()
+    _ACT[0] = _PRECISIONS[str(name).lower()]
+    return prev
+
+
+def precision():
+    return "fp32" if _ACT[0] == f32 else "bf16"
+
+
+def act_dtype():
+    return _ACT[0]
+
+
+def _af(t):
+    """act_f32 flag of the C ABI from a tensor's dtype"""
+    if t.dtype == f32:
+        return 1
+    if t.dtype == bf16:
+        return 0
+    raise _lib.CrError(f"activations must be float32 or bfloat16, got {t.dtype}")
 
 
 def _ctx(t):
@@ -74,10 +112,11 @@ class WeightBank:
     Activated by the training step objects; anything that changes weights outside the optimizer must call
     bump_weight_epoch() (the model's load_state_dict hook does)."""
 
-    def __init__(self, params, flat_p):
+    def __init__(self, params, flat_p, dtype=None):
         import numpy as np
         dev = flat_p.device
         self.flat_p = flat_p
+        self.dtype = dtype = dtype if dtype is not None else act_dtype()
         descs, tiles, self.shapes = [], [], []
         off = 0
         for i, p in enumerate(params):
@@ -98,10 +137,15 @@ class WeightBank:
         self.descs = torch.from_numpy(np.array(descs, dtype=dt).view(np.uint8).copy()).to(dev)
         self.tiles = torch.tensor(tiles, dtype=torch.int32, device=dev)
         self.ntiles = len(tiles)
-        self.dst = torch.empty((off,), dtype=bf16, device=dev)
-        self.dstT = torch.empty((off,), dtype=bf16, device=dev)
-        self.views = [(self.dst[o:o + n].view(Cout, KK * Cin), self.dstT[o:o + n].view(Cin, KK * Cout))
-                      for (o, n, Cout, KK, Cin) in self.shapes]
+        # f32 mode: the master weights ARE the forward / weight-gradient operand; only the bwd-data layout is a copy
+        self.dst = torch.empty((off,), dtype=bf16, device=dev) if dtype == bf16 else None
+        self.dstT = torch.empty((off,), dtype=dtype, device=dev)
+        if dtype == bf16:
+            self.views = [(self.dst[o:o + n].view(Cout, KK * Cin), self.dstT[o:o + n].view(Cin, KK * Cout))
+                          for (o, n, Cout, KK, Cin) in self.shapes]
+        else:
+            self.views = [(p.detach(), self.dstT[o:o + n].view(Cin, KK * Cout))
+                          for p, (o, n, Cout, KK, Cin) in zip(params, self.shapes)]
         self.epoch = None
         for i, p in enumerate(params):
             p._cr_bank = (self, i)
@@ -110,35 +154,42 @@ class WeightBank:
         if self.epoch != _WEIGHT_EPOCH[0]:
             lib = _lib.load()
             _chk(lib.cr_weights_prepare(_ctx(self.flat_p), _p(self.flat_p), _p(self.dst), _p(self.dstT), _p(self.descs),
-                                        _p(self.tiles), self.ntiles), "cr_weights_prepare")
+                                        _p(self.tiles), self.ntiles, int(self.dtype == f32)), "cr_weights_prepare")
             self.epoch = _WEIGHT_EPOCH[0]
         return self.views[i]
 
 
-def prepared_weights(weight, need_transposed):
-    """bf16 [Cout][k*k*Cin] and (optionally) bf16 [Cin][k*k*Cout] copies of a f32 channels_last weight.
-    Weights registered in a WeightBank come from the bank (one launch per step for the whole model); others are
-    cached ON the tensor object (so a new tensor at a recycled address never hits a stale entry), keyed by
-    torch's version counter and the global weight epoch."""
+def prepared_weights(weight, need_transposed, dtype=bf16):
+    """compute copies of a f32 channels_last weight in the activation dtype: [Cout][k*k*Cin] and (optionally) the bwd-data
+    layout [Cin][k*k*Cout].  In f32 mode the first one is the weight itself.  Weights registered in a WeightBank of the
+    same dtype come from the bank (one launch per step for the whole model); others are cached ON the tensor object (so
+    a new tensor at a recycled address never hits a stale entry), keyed by torch's version counter and the global
+    weight epoch."""
     bk = getattr(weight, "_cr_bank", None)
-    if bk is not None:
+    if bk is not None and bk[0].dtype == dtype:
         return bk[0].get(bk[1])
-    ent = getattr(weight, "_cr_wcache", None)
+    attr = "_cr_wcache" if dtype == bf16 else "_cr_wcache32"
+    ent = getattr(weight, attr, None)
     tag = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr())
     lib = _lib.load()
     if ent is None or ent[0] != tag:
         Cout, Cin, k, _ = weight.shape
-        wb = torch.empty((Cout, k * k * Cin), dtype=bf16, device=weight.device)
-        _chk(lib.cr_cast_f32_to_bf16(_ctx(weight), _p(weight.detach()), _p(wb), weight.numel()), "cr_cast_f32_to_bf16")
+        if dtype == bf16:
+            wb = torch.empty((Cout, k * k * Cin), dtype=bf16, device=weight.device)
+            wd = weight.detach()
+            _chk(lib.cr_cast_f32_to_bf16(_ctx(weight), _p(wd), _p(wb), weight.numel()), "cr_cast_f32_to_bf16")
+        else:
+            wb = weight.detach()
         ent = [tag, wb, None]
         try:
-            weight._cr_wcache = ent
+            setattr(weight, attr, ent)
         except Exception:
             pass
     if need_transposed and ent[2] is None:
         Cout, Cin, k, _ = weight.shape
-        wt = torch.empty((Cin, k * k * Cout), dtype=bf16, device=weight.device)
-        _chk(lib.cr_weight_transpose(_ctx(weight), _p(weight.detach()), _p(wt), Cout, k, Cin), "cr_weight_transpose")
+        wt = torch.empty((Cin, k * k * Cout), dtype=dtype, device=weight.device)
+        wd = weight.detach()
+        _chk(lib.cr_weight_transpose(_ctx(weight), _p(wd), _p(wt), Cout, k, Cin, int(dtype == f32)), "cr_weight_transpose")
         ent[2] = wt
     return ent[1], ent[2]
 
@@ -148,22 +199,25 @@ def prepared_weights(weight, need_transposed):
 # --------------------------------------------------------------------------
 def conv_fwd_raw(x, wb, Cout, k, stride, pad, bias=None, residual=None, relu=False, stats=None, out_f32=False):
     _need_cuda(x, "conv input")
-    assert x.dtype == bf16 and x.is_contiguous() and x.dim() == 4
+    af = _af(x)
+    assert x.is_contiguous() and x.dim() == 4 and wb.dtype == x.dtype and (residual is None or residual.dtype == x.dtype)
     N, H, W, Cin = x.shape
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    y = torch.empty((N, Ho, Wo, Cout), dtype=f32 if out_f32 else bf16, device=x.device)
+    y = torch.empty((N, Ho, Wo, Cout), dtype=f32 if (out_f32 or af) else bf16, device=x.device)
     lib = _lib.load()
     _chk(lib.cr_conv2d_fwd(_ctx(x), _p(x), _p(wb), _p(y), N, H, W, Cin, Cout, k, stride, pad, _p(bias), _p(residual),
-                           int(relu), _p(stats), int(out_f32)), "cr_conv2d_fwd")
+                           int(relu), _p(stats), int(out_f32), af), "cr_conv2d_fwd")
     return y
 
 
 def conv_bwd_data_raw(dy, wt, in_shape, k, stride, pad):
     N, H, W, Cin = in_shape
     Cout = dy.shape[3]
-    dx = torch.empty((N, H, W, Cin), dtype=bf16, device=dy.device)
+    assert wt.dtype == dy.dtype
+    dx = torch.empty((N, H, W, Cin), dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
-    _chk(lib.cr_conv2d_bwd_data(_ctx(dy), _p(dy), _p(wt), _p(dx), N, H, W, Cin, Cout, k, stride, pad), "cr_conv2d_bwd_data")
+    _chk(lib.cr_conv2d_bwd_data(_ctx(dy), _p(dy), _p(wt), _p(dx), N, H, W, Cin, Cout, k, stride, pad, _af(dy)),
+         "cr_conv2d_bwd_data")
     return dx
 
 
@@ -178,18 +232,20 @@ def conv_bwd_weight_raw(dy, x, k, stride, pad, sink=None, bias_acc=None):
     N, H, W, Cin = x.shape
     Cout = dy.shape[3]
     lib = _lib.load()
+    af = _af(x)
+    assert dy.dtype == x.dtype
     if bias_acc is not None:
         dw = sink if sink is not None else torch.empty((Cout, Cin, k, k), dtype=f32, device=x.device).contiguous(
             memory_format=torch.channels_last)
         _chk(lib.cr_conv2d_bwd_weight_bias(_ctx(x), _p(dy), _p(x), _p(dw), _p(bias_acc), N, H, W, Cin, Cout, k, stride, pad,
-                                           int(sink is not None)), "cr_conv2d_bwd_weight_bias")
+                                           int(sink is not None), af), "cr_conv2d_bwd_weight_bias")
         return None if sink is not None else dw
     if sink is not None:
-        _chk(lib.cr_conv2d_bwd_weight(_ctx(x), _p(dy), _p(x), _p(sink), N, H, W, Cin, Cout, k, stride, pad, 1),
+        _chk(lib.cr_conv2d_bwd_weight(_ctx(x), _p(dy), _p(x), _p(sink), N, H, W, Cin, Cout, k, stride, pad, 1, af),
              "cr_conv2d_bwd_weight")
         return None
     dw = torch.empty((Cout, Cin, k, k), dtype=f32, device=x.device).contiguous(memory_format=torch.channels_last)
-    _chk(lib.cr_conv2d_bwd_weight(_ctx(x), _p(dy), _p(x), _p(dw), N, H, W, Cin, Cout, k, stride, pad, 0),
+    _chk(lib.cr_conv2d_bwd_weight(_ctx(x), _p(dy), _p(x), _p(dw), N, H, W, Cin, Cout, k, stride, pad, 0, af),
          "cr_conv2d_bwd_weight")
     return dw
 
@@ -203,8 +259,9 @@ class _ConvBN(torch.autograd.Function):
                 training):
         Cout, Cin, k, _ = weight.shape
         need_grad = x.requires_grad or weight.requires_grad
-        wb, wt = prepared_weights(weight, need_transposed=need_grad and x.requires_grad)
+        wb, wt = prepared_weights(weight, need_grad and x.requires_grad, x.dtype)
         dev = x.device
+        af = _af(x)
         lib = _lib.load()
         if training:
             _STATS_EPOCH[0] += 1
@@ -217,7 +274,7 @@ class _ConvBN(torch.autograd.Function):
             mi = torch.empty((2, Cout), dtype=f32, device=dev)
             _chk(lib.cr_bn_fwd(_ctx(x), _p(y_raw), _p(stats), nparts, _p(gamma.detach()), _p(beta.detach()), _p(residual),
                                _p(out), M, Cout, int(relu), float(eps), float(momentum), _p(mi), _p(running_mean),
-                               _p(running_var)), "cr_bn_fwd")
+                               _p(running_var), af), "cr_bn_fwd")
         else:
             # frozen statistics with gradients enabled (freeze_bn fine-tuning; plain inference takes conv_bn_folded): an
             # affine epilogue (scale*x + shift) done by the BN kernel with mean/invstd taken from the running buffers
@@ -228,7 +285,7 @@ class _ConvBN(torch.autograd.Function):
             # one "partial" that reproduces (mean, var): sum = mean*M, sumsq = (var+mean^2)*M
             zstats = torch.stack([running_mean * M, (running_var + running_mean * running_mean) * M]).view(1, 2, Cout).contiguous()
             _chk(lib.cr_bn_fwd(_ctx(x), _p(y_raw), _p(zstats), 1, _p(gamma.detach()), _p(beta.detach()), _p(residual),
-                               _p(out), M, Cout, int(relu), float(eps), 0.0, _p(mi), _p(None), _p(None)), "cr_bn_fwd")
+                               _p(out), M, Cout, int(relu), float(eps), 0.0, _p(mi), _p(None), _p(None), af), "cr_bn_fwd")
         ctx.cfg = (k, stride, pad, relu, training, residual is not None)
         ctx.beta_ref = beta
         ctx.save_for_backward(x, weight, gamma, y_raw, out if relu else None, mi)
@@ -242,7 +299,7 @@ class _ConvBN(torch.autograd.Function):
             raise _lib.CrError("backward through frozen BatchNorm is not implemented")
         Cout = weight.shape[0]
         dev = x.device
-        dout = dout.contiguous()
+        dout = dout.to(x.dtype).contiguous()
         M = y_raw.numel() // Cout
         lib = _lib.load()
         sums = torch.empty((1025, 2, Cout), dtype=f32, device=dev)
@@ -256,10 +313,10 @@ class _ConvBN(torch.autograd.Function):
             dbeta = torch.zeros((Cout,), dtype=f32, device=dev)
             ret_g, ret_b = dgamma, dbeta
         _chk(lib.cr_bn_bwd(_ctx(x), _p(dout), _p(out), _p(y_raw), _p(mi), _p(gamma.detach()), _p(sums), _p(dx_raw),
-                           _p(dres), _p(dgamma), _p(dbeta), M, Cout, int(relu)), "cr_bn_bwd")
+                           _p(dres), _p(dgamma), _p(dbeta), M, Cout, int(relu), _af(x)), "cr_bn_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
-            _, wt = prepared_weights(weight, need_transposed=True)
+            _, wt = prepared_weights(weight, True, x.dtype)
             dx = conv_bwd_data_raw(dx_raw, wt, x.shape, k, stride, pad)
         dw = conv_bwd_weight_raw(dx_raw, x, k, stride, pad, grad_sink(weight)) if ctx.needs_input_grad[1] else None
         return dx, dw, ret_g, ret_b, dres, None, None, None, None, None, None, None, None
@@ -281,16 +338,18 @@ def conv_bn_folded(x, weight, gamma, beta, running_mean, running_var, stride=1, 
     capturing = torch.cuda.is_current_stream_capturing()
     tag = None if capturing else (weight._version, gamma._version, beta._version, running_mean._version, running_var._version,
                                   _WEIGHT_EPOCH[0], _STATS_EPOCH[0], weight.data_ptr(), running_mean.data_ptr(), float(eps))
-    ent = None if capturing else getattr(weight, "_cr_fold", None)
+    attr = "_cr_fold" if x.dtype == bf16 else "_cr_fold32"
+    ent = None if capturing else getattr(weight, attr, None)
     if ent is None or ent[0] != tag:
-        wf = torch.empty((Cout, K_), dtype=bf16, device=x.device)
+        wf = torch.empty((Cout, K_), dtype=x.dtype, device=x.device)
         bias_f = torch.empty((Cout,), dtype=f32, device=x.device)
-        _chk(_lib.load().cr_fold_bn(_ctx(x), _p(weight.detach()), _p(gamma.detach()), _p(beta.detach()), _p(running_mean),
-                                    _p(running_var), float(eps), _p(wf), _p(bias_f), Cout, K_), "cr_fold_bn")
+        wd, gd, bd = weight.detach(), gamma.detach(), beta.detach()
+        _chk(_lib.load().cr_fold_bn(_ctx(x), _p(wd), _p(gd), _p(bd), _p(running_mean),
+                                    _p(running_var), float(eps), _p(wf), _p(bias_f), Cout, K_, _af(x)), "cr_fold_bn")
         ent = (tag, wf, bias_f)
         if not capturing:
             try:
-                weight._cr_fold = ent
+                setattr(weight, attr, ent)
             except Exception:
                 pass
     return conv_fwd_raw(x, ent[1], Cout, k, stride, pad, bias=ent[2], residual=residual, relu=relu)
@@ -312,7 +371,7 @@ class _ConvBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, relu, out_f32):
         Cout, Cin, k, _ = weight.shape
-        wb, _ = prepared_weights(weight, need_transposed=False)
+        wb, _ = prepared_weights(weight, False, x.dtype)
         y = conv_fwd_raw(x, wb, Cout, k, stride, pad, bias=None if bias is None else bias.detach(), relu=relu,
                          out_f32=out_f32)
         ctx.cfg = (k, stride, pad, relu, bias is not None)
@@ -335,17 +394,17 @@ class _ConvBias(torch.autograd.Function):
             bsink = grad_sink(ctx.bias_ref)
             acc = bsink if bsink is not None else torch.zeros((C,), dtype=f32, device=g.device)
             db = None if bsink is not None else acc
-            if not (ctx.needs_input_grad[1] and g.dtype == bf16):
+            if not (ctx.needs_input_grad[1] and g.dtype == x.dtype):
                 # no weight-gradient launch to ride on (or an f32 upstream gradient): separate column sum
                 ws = torch.empty((1024, C), dtype=f32, device=g.device)
                 lib = _lib.load()
                 _chk(lib.cr_colsum_accum(_ctx(g), _p(g), int(g.dtype == f32), g.numel() // C, C, _p(ws), _p(acc)),
                      "cr_colsum_accum")
                 acc = None
-        g = g.to(bf16).contiguous()
+        g = g.to(x.dtype).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            _, wt = prepared_weights(weight, need_transposed=True)
+            _, wt = prepared_weights(weight, True, x.dtype)
             dx = conv_bwd_data_raw(g, wt, x.shape, k, stride, pad)
         # the bias gradient (column sums of dy) is accumulated inside the weight-gradient kernel
         dw = conv_bwd_weight_raw(g, x, k, stride, pad, grad_sink(weight), bias_acc=acc) if ctx.needs_input_grad[1] else None
@@ -418,9 +477,9 @@ class _Pool2x(torch.autograd.Function):
     def forward(ctx, x, window):
         _need_cuda(x, "pool input")
         N, H, W, C = x.shape
-        y = torch.empty((N, H // 2, W // 2, C), dtype=bf16, device=x.device)
+        y = torch.empty((N, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
         lib = _lib.load()
-        _chk(lib.cr_pool2x_fwd(_ctx(x), _p(x), _p(y), N, H, W, C, window), "cr_pool2x_fwd")
+        _chk(lib.cr_pool2x_fwd(_ctx(x), _p(x), _p(y), N, H, W, C, window, _af(x)), "cr_pool2x_fwd")
         ctx.window = window
         ctx.save_for_backward(x)
         return y
@@ -431,7 +490,8 @@ class _Pool2x(torch.autograd.Function):
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
         lib = _lib.load()
-        _chk(lib.cr_pool2x_bwd(_ctx(x), _p(x), _p(dy.contiguous()), _p(dx), N, H, W, C, ctx.window), "cr_pool2x_bwd")
+        dy = dy.to(x.dtype).contiguous()
+        _chk(lib.cr_pool2x_bwd(_ctx(x), _p(x), _p(dy), _p(dx), N, H, W, C, ctx.window, _af(x)), "cr_pool2x_bwd")
         return dx, None
 
 
@@ -440,9 +500,9 @@ class _Pool3s2(torch.autograd.Function):
     def forward(ctx, x):
         _need_cuda(x, "pool input")
         N, H, W, C = x.shape
-        y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=bf16, device=x.device)
+        y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
         lib = _lib.load()
-        _chk(lib.cr_maxpool3x3s2_fwd(_ctx(x), _p(x), _p(y), N, H, W, C), "cr_maxpool3x3s2_fwd")
+        _chk(lib.cr_maxpool3x3s2_fwd(_ctx(x), _p(x), _p(y), N, H, W, C, _af(x)), "cr_maxpool3x3s2_fwd")
         ctx.save_for_backward(x)
         return y
 
@@ -452,7 +512,8 @@ class _Pool3s2(torch.autograd.Function):
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
         lib = _lib.load()
-        _chk(lib.cr_maxpool3x3s2_bwd(_ctx(x), _p(x), _p(dy.contiguous()), _p(dx), N, H, W, C), "cr_maxpool3x3s2_bwd")
+        dy = dy.to(x.dtype).contiguous()
+        _chk(lib.cr_maxpool3x3s2_bwd(_ctx(x), _p(x), _p(dy), _p(dx), N, H, W, C, _af(x)), "cr_maxpool3x3s2_bwd")
         return dx
 
 
@@ -479,7 +540,8 @@ class _UpsampleAdd(torch.autograd.Function):
         assert tuple(top.shape) == (N, H // 2, W // 2, C)
         y = torch.empty_like(lat)
         lib = _lib.load()
-        _chk(lib.cr_upsample2x_add(_ctx(lat), _p(lat), _p(top), _p(y), N, H, W, C), "cr_upsample2x_add")
+        assert lat.dtype == top.dtype
+        _chk(lib.cr_upsample2x_add(_ctx(lat), _p(lat), _p(top), _p(y), N, H, W, C, _af(lat)), "cr_upsample2x_add")
         ctx.shape = (N, H, W, C)
         return y
 
@@ -487,9 +549,9 @@ class _UpsampleAdd(torch.autograd.Function):
     def backward(ctx, dy):
         N, H, W, C = ctx.shape
         dy = dy.contiguous()
-        dtop = torch.empty((N, H // 2, W // 2, C), dtype=bf16, device=dy.device)
+        dtop = torch.empty((N, H // 2, W // 2, C), dtype=dy.dtype, device=dy.device)
         lib = _lib.load()
-        _chk(lib.cr_sum2x2(_ctx(dy), _p(dy), _p(dtop), N, H, W, C), "cr_sum2x2")
+        _chk(lib.cr_sum2x2(_ctx(dy), _p(dy), _p(dtop), N, H, W, C, _af(dy)), "cr_sum2x2")
         return dy, dtop
 
 
@@ -498,17 +560,18 @@ def upsample2x_add(lat, top):
     return _UpsampleAdd.apply(lat, top)
 
 
-def preprocess(images_u8, mean, std):
-    """(N,3,H,W) uint8 -> normalised NHWC bf16 with 8 channels (3 real + 5 zero)."""
+def preprocess(images_u8, mean, std, dtype=None):
+    """(N,3,H,W) uint8 -> normalised NHWC with 8 channels (3 real + 5 zero) in the activation dtype of the process
+    (set_precision) unless `dtype` says otherwise: this call decides the precision of everything downstream."""
     _need_cuda(images_u8, "images")
     assert images_u8.dtype == torch.uint8 and images_u8.is_contiguous()
     N, _, H, W = images_u8.shape
-    y = torch.empty((N, H, W, 8), dtype=bf16, device=images_u8.device)
+    y = torch.empty((N, H, W, 8), dtype=dtype if dtype is not None else act_dtype(), device=images_u8.device)
     m = (ctypes.c_float * 3)(*[float(v) for v in mean])
     s = (ctypes.c_float * 3)(*[float(v) for v in std])
     lib = _lib.load()
     _chk(lib.cr_preprocess(_ctx(images_u8), _p(images_u8), _p(y), N, H, W, ctypes.cast(m, ctypes.c_void_p),
-                           ctypes.cast(s, ctypes.c_void_p)), "cr_preprocess")
+                           ctypes.cast(s, ctypes.c_void_p), _af(y)), "cr_preprocess")
     return y
 
 
@@ -531,27 +594,30 @@ class _ROIAlign(torch.autograd.Function):
         _need_cuda(rois, "rois")
         C = feats[0].shape[3]
         R = rois.shape[0]
-        out = torch.empty((R, out_size, out_size, C), dtype=bf16, device=rois.device)
+        dt = feats[0].dtype
+        assert all(f.dtype == dt and f.is_contiguous() for f in feats)
+        out = torch.empty((R, out_size, out_size, C), dtype=dt, device=rois.device)
         n, ptrs, Hs, Ws, sc, cast = _pyr_args(feats, scales)
         lib = _lib.load()
         rois = rois.contiguous()
         _chk(lib.cr_roi_align_fwd(_ctx(rois), cast(ptrs), cast(Hs), cast(Ws), cast(sc), n, C, _p(rois), R, out_size,
-                                  out_size, _p(out)), "cr_roi_align_fwd")
-        ctx.cfg = (scales, out_size, [tuple(f.shape) for f in feats])
+                                  out_size, _p(out), _af(out)), "cr_roi_align_fwd")
+        ctx.cfg = (scales, out_size, [tuple(f.shape) for f in feats], dt)
         ctx.save_for_backward(rois)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (rois,) = ctx.saved_tensors
-        scales, out_size, shapes = ctx.cfg
+        scales, out_size, shapes, dt = ctx.cfg
         C = shapes[0][3]
         grads = [torch.zeros(s, dtype=f32, device=rois.device) for s in shapes]
         n, ptrs, Hs, Ws, sc, cast = _pyr_args(grads, scales)
         lib = _lib.load()
+        dout = dout.to(dt).contiguous()
         _chk(lib.cr_roi_align_bwd(_ctx(rois), cast(ptrs), cast(Hs), cast(Ws), cast(sc), n, C, _p(rois), rois.shape[0],
-                                  out_size, out_size, _p(dout.contiguous())), "cr_roi_align_bwd")
-        return (None, None, None) + tuple(g.to(bf16) for g in grads)
+                                  out_size, out_size, _p(dout), _af(dout)), "cr_roi_align_bwd")
+        return (None, None, None) + tuple(g if dt == f32 else g.to(dt) for g in grads)
 
 
 class _SharedPrefix(torch.autograd.Function):
@@ -581,7 +647,7 @@ def shared_prefix(pooled, B, S, kf):
 
 
 def roi_align_pyramid(feats, rois, scales, out_size):
-    """feats: list of NHWC bf16 maps (fine -> coarse); rois (R,5) f32 [batch,x1,y1,x2,y2]."""
+    """feats: list of NHWC maps (fine -> coarse) in the activation dtype; rois (R,5) f32 [batch,x1,y1,x2,y2]."""
     return _ROIAlign.apply(rois.to(f32), tuple(scales), out_size, *feats)
 
 
@@ -631,23 +697,30 @@ def cube_decode_loss(dxy, zr, dr, Ra, u, src_boxes, K4, v2r, prior_mean, gt2d, g
 
 
 # --------------------------------------------------------------------------
-# FC layers of the RoI heads: library GEMMs (hipBLASLt through torch.mm) around own weight-prep / gradient kernels
+# FC layers of the RoI heads.  f32 mode: the implicit-GEMM kernels themselves (a linear layer is a 1x1 convolution over
+# an (1,1,rows,K) map: cr_conv2d_fwd / _bwd_data / _bwd_weight on the f32 MFMA).  bf16 mode: library GEMMs (hipBLASLt
+# through torch.mm) around own weight-prep / gradient kernels.
 # --------------------------------------------------------------------------
-def prepared_fc_weight(weight, chw=None):
-    """bf16 copy of an nn.Linear weight (O, K) f32, cached per weight epoch on the tensor.  chw = (C,H,W): the columns are
-    re-ordered from the checkpoint's (c,h,w) flattening to (h,w,c) for NHWC-flattened RoI features."""
-    ent = getattr(weight, "_cr_fccache", None)
+def prepared_fc_weight(weight, chw=None, dtype=bf16):
+    """compute copy of an nn.Linear weight (O, K) f32 in `dtype`, cached per weight epoch on the tensor.  chw = (C,H,W):
+    the columns are re-ordered from the checkpoint's (c,h,w) flattening to (h,w,c) for NHWC-flattened RoI features.
+    f32 without a permutation: the weight itself."""
+    if dtype == f32 and chw is None:
+        return weight.detach()
+    attr = "_cr_fccache" if dtype == bf16 else "_cr_fccache32"
+    ent = getattr(weight, attr, None)
     tag = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr(), chw)
     if ent is None or ent[0] != tag:
         O, K = weight.shape
         C, HW = (chw[0], chw[1] * chw[2]) if chw is not None else (K, 1)
         assert C * HW == K
-        wb = torch.empty((O, K), dtype=bf16, device=weight.device)
+        wb = torch.empty((O, K), dtype=dtype, device=weight.device)
         lib = _lib.load()
-        _chk(lib.cr_fc_weight_prepare(_ctx(weight), _p(weight.detach().contiguous()), _p(wb), O, C, HW), "cr_fc_weight_prepare")
+        wd = weight.detach().contiguous()
+        _chk(lib.cr_fc_weight_prepare(_ctx(weight), _p(wd), _p(wb), O, C, HW, int(dtype == f32)), "cr_fc_weight_prepare")
         ent = (tag, wb)
         try:
-            weight._cr_fccache = ent
+            setattr(weight, attr, ent)
         except Exception:
             pass
     return ent[1]
@@ -666,10 +739,37 @@ def _bf16_copy(t):
     return ent[1]
 
 
+def _fc_transposed32(wp, weight, chw):
+    """(K, O) f32 copy of the prepared weight for the backward-data GEMM, cached like the prepared weight"""
+    ent = getattr(weight, "_cr_fcT32", None)
+    tag = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr(), chw)
+    if ent is None or ent[0] != tag:
+        O, K = wp.shape
+        wt = torch.empty((K, O), dtype=f32, device=wp.device)
+        _chk(_lib.load().cr_weight_transpose(_ctx(wp), _p(wp), _p(wt), O, 1, K, 1), "cr_weight_transpose")
+        ent = (tag, wt)
+        try:
+            weight._cr_fcT32 = ent
+        except Exception:
+            pass
+    return ent[1]
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, chw):
         _need_cuda(x, "linear input")
+        if x.dtype == f32:
+            O, K = weight.shape
+            if O % 16 or K % 16:
+                raise _lib.CrError(f"linear: f32 GEMM needs O and K multiples of 16 (got {O}x{K}); use linear_padded")
+            wp = prepared_fc_weight(weight, chw, f32)
+            xc = x.contiguous()
+            y = conv_fwd_raw(xc.view(1, 1, xc.shape[0], K), wp, O, 1, 1, 0,
+                             bias=None if bias is None else bias.detach()).view(xc.shape[0], O)
+            ctx.save_for_backward(xc, wp)
+            ctx.refs = (weight, bias, chw, f32)
+            return y
         wb = prepared_fc_weight(weight, chw)
         xb = x.to(bf16)
         y = torch.addmm(_bf16_copy(bias), xb, wb.t()) if bias is not None else torch.mm(xb, wb.t())
@@ -681,33 +781,104 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         xb, wb = ctx.saved_tensors
         weight, bias, chw, xdt = ctx.refs
-        dy = dy.to(bf16).contiguous()
-        dx = torch.mm(dy, wb).to(xdt) if ctx.needs_input_grad[0] else None
-        dw = db = None
         lib = _lib.load()
         O, K = weight.shape
         C, HW = (chw[0], chw[1] * chw[2]) if chw is not None else (K, 1)
+        is32 = xb.dtype == f32
+        dy = dy.to(xb.dtype).contiguous()
+        R = dy.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if is32:
+                wt = _fc_transposed32(wb, weight, chw)
+                dx = conv_bwd_data_raw(dy.view(1, 1, R, O), wt, (1, 1, R, K), 1, 1, 0).view(R, K)
+            else:
+                dx = torch.mm(dy, wb).to(xdt)
         if ctx.needs_input_grad[1]:
-            g = torch.mm(dy.t(), xb)                                   # (O, K) bf16 in the compute (h,w,c) order
             acc = grad_sink(weight)
-            if acc is None:
-                acc = torch.zeros((O, K), dtype=f32, device=dy.device)
-                dw = acc
-            _chk(lib.cr_fc_grad_accum(_ctx(dy), _p(g), _p(acc), O, C, HW), "cr_fc_grad_accum")
+            if is32 and HW == 1 and acc is not None:
+                # the weight gradient lands in the flat gradient straight from the GEMM's epilogue
+                _chk(lib.cr_conv2d_bwd_weight(_ctx(dy), _p(dy), _p(xb), _p(acc), 1, 1, R, K, O, 1, 1, 0, 1, 1),
+                     "cr_conv2d_bwd_weight")
+            else:
+                if is32:
+                    g = torch.empty((O, K), dtype=f32, device=dy.device)
+                    _chk(lib.cr_conv2d_bwd_weight(_ctx(dy), _p(dy), _p(xb), _p(g), 1, 1, R, K, O, 1, 1, 0, 0, 1),
+                         "cr_conv2d_bwd_weight")
+                else:
+                    g = torch.mm(dy.t(), xb)                           # (O, K) bf16 in the compute (h,w,c) order
+                if acc is None:
+                    acc = torch.zeros((O, K), dtype=f32, device=dy.device)
+                    dw = acc
+                _chk(lib.cr_fc_grad_accum(_ctx(dy), _p(g), _p(acc), O, C, HW, int(is32)), "cr_fc_grad_accum")
         if bias is not None and ctx.needs_input_grad[2]:
             acc = grad_sink(bias)
             if acc is None:
                 acc = torch.zeros((O,), dtype=f32, device=dy.device)
                 db = acc
             ws = torch.empty((1024, O), dtype=f32, device=dy.device)
-            _chk(lib.cr_colsum_accum(_ctx(dy), _p(dy), 0, dy.shape[0], O, _p(ws), _p(acc)), "cr_colsum_accum")
+            _chk(lib.cr_colsum_accum(_ctx(dy), _p(dy), int(is32), R, O, _p(ws), _p(acc)), "cr_colsum_accum")
         return dx, dw, db, None
 
 
 def linear(x, weight, bias=None, chw=None):
-    """F.linear in bf16 with the weight copy cached per optimizer step and the gradients accumulated straight into the
-    optimizer's flat gradient (when the parameters carry sinks).  chw: see prepared_fc_weight."""
+    """F.linear on the MFMA in x's precision with the weight copy cached per optimizer step and the gradients accumulated
+    straight into the optimizer's flat gradient (when the parameters carry sinks).  chw: see prepared_fc_weight.
+    f32 needs O % 16 == 0 (see linear_cat for predictors with odd widths)."""
     return _Linear.apply(x, weight, bias, chw)
+
+
+def linear_cat(x, weights, biases):
+    """[x @ w.T + b for w, b in zip(weights, biases)] as ONE GEMM: the predictor layers of a head share their input, so
+    their weights are stacked (rows zero-padded to a multiple of 16 for the MFMA tiles) and the output is returned as
+    the padded (R, O_pad) f32 matrix plus the column offset of each predictor.  Gradients are routed back into each
+    parameter (or its gradient sink) by cat_rows."""
+    sizes = [int(w.shape[0]) for w in weights]
+    O = sum(sizes)
+    Op = (O + 15) // 16 * 16
+    W = cat_rows(list(weights), Op)
+    b = cat_rows(list(biases), Op)
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    if x.dtype == f32:
+        y = _LinearPlain.apply(x, W, b)
+    else:
+        y = torch.nn.functional.linear(x, W.to(x.dtype), b.to(x.dtype)).float()
+    return y, offs
+
+
+class _LinearPlain(torch.autograd.Function):
+    """f32 GEMM with the weight passed as a tensor in the graph (linear_cat's stacked predictor weights)."""
+    @staticmethod
+    def forward(ctx, x, W, b):
+        O, K = W.shape
+        xc, Wc = x.contiguous(), W.contiguous()
+        y = conv_fwd_raw(xc.view(1, 1, xc.shape[0], K), Wc, O, 1, 1, 0, bias=b.contiguous()).view(xc.shape[0], O)
+        ctx.save_for_backward(xc, Wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, Wc = ctx.saved_tensors
+        O, K = Wc.shape
+        R = xc.shape[0]
+        dy = dy.contiguous()
+        lib = _lib.load()
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty((K, O), dtype=f32, device=Wc.device)
+            _chk(lib.cr_weight_transpose(_ctx(Wc), _p(Wc), _p(wt), O, 1, K, 1), "cr_weight_transpose")
+            dx = conv_bwd_data_raw(dy.view(1, 1, R, O), wt, (1, 1, R, K), 1, 1, 0).view(R, K)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty((O, K), dtype=f32, device=dy.device)
+            _chk(lib.cr_conv2d_bwd_weight(_ctx(dy), _p(dy), _p(xc), _p(dW), 1, 1, R, K, O, 1, 1, 0, 0, 1),
+                 "cr_conv2d_bwd_weight")
+        if ctx.needs_input_grad[2]:
+            db = torch.zeros((O,), dtype=f32, device=dy.device)
+            ws = torch.empty((1024, O), dtype=f32, device=dy.device)
+            _chk(lib.cr_colsum_accum(_ctx(dy), _p(dy), 1, R, O, _p(ws), _p(db)), "cr_colsum_accum")
+        return dx, dW, db
 
 
 # --------------------------------------------------------------------------

@@ -169,7 +169,8 @@ def bench_inference(args, rank, world, dev):
         dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     return {"metric": "images/sec Cube R-CNN DLA34-FPN inference (BASELINE configs[1])", "value": B * world * args.steps / dt,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": importlib.import_module("3dod_amd.hipops").precision(), "data": "synthetic",
             "config": {"workload": "Cube R-CNN DLA34+FPN inference, 8 img/GPU 512x512, random-init weights, full post-processing",
                        "global_batch": B * world, "parallelism": f"dp{world}", "detections_per_step": n_det / max(args.steps, 1)}}
 
@@ -278,7 +279,7 @@ def bench_weak(args, rank, world, dev):
                       + ("live Depth-Anything-V2 depth maps)" if live else "precomputed depth maps)"),
             "value": B * world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": importlib.import_module("3dod_amd.hipops").precision(), "data": "synthetic",
             "config": {"workload": "RCNN3D_combined_features + ROIHeads3DScore train step, 2 img/GPU 512x512, losses "
                                    + ",".join(cfg.loss_functions) + ("; depth maps from the Depth-Anything-V2 ViT-L forward "
                                    "inside the step (CR_LIVE_DEPTH=1)" if live else "; precomputed depth maps (as the reference trains)"),

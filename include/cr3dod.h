@@ -176,8 +176,16 @@ int cr_scale_residual(cr_ctx* ctx, const void* x, const void* y, const float* ga
  * (util/blocks.py:139, dpt.py:150). */
 int cr_resize_bilinear_ac(cr_ctx* ctx, const void* x, void* y, int B, int h, int w, int Ho, int Wo, int C);
 
-/* ---- convolution stack (bf16 MFMA, f32 accumulate, NHWC) ---------------- */
-/* Activations are NHWC bf16 (channels padded to a multiple of 8).  Conv weights
+/* ---- convolution stack (MFMA, f32 accumulate, NHWC) --------------------- */
+/* Two arithmetic modes, chosen per call by `act_f32` (the trailing argument of every entry point that touches
+ * activations):
+ *   act_f32 = 1  activations, compute weights and activation gradients are float32; contractions run on
+ *                v_mfma_f32_16x16x4_f32 (exact f32 fmaf chains, 157 TFLOP/s peak).  This is the REFERENCE'S precision:
+ *                tools/train_net.py:184-330 trains in float32, no autocast anywhere -- and the default of the Python host.
+ *   act_f32 = 0  the same tensors are bfloat16 (v_mfma_f32_16x16x32_bf16, f32 accumulate, 2.5 PFLOP/s peak): the fast
+ *                mode, opt-in; parameters, gradients of parameters and all statistics stay float32 in both modes.
+ * "bf16" in the comments below reads "bf16 or f32 by act_f32".
+ * Activations are NHWC (channels padded to a multiple of 8).  Conv weights
  * are [Cout][ks*ks][Cin] = the physical (channels_last) layout of a
  * (Cout,Cin,ks,ks) parameter, so state-dict shapes stay the reference's.
  * Replaces torch ATen/cuDNN conv2d + BatchNorm2d + ReLU of
@@ -190,52 +198,52 @@ int cr_resize_bilinear_ac(cr_ctx* ctx, const void* x, void* y, int B, int h, int
  * of the (pre-residual, pre-ReLU) conv output for BatchNorm (every entry is written; no atomics -> reproducible). */
 int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout,
                   int ks, int stride, int pad, const float* bias, const void* residual, int relu,
-                  float* stats, int out_f32);
+                  float* stats, int out_f32, int act_f32);
 
 /* dx (N,H,W,Cin) bf16 from dy (N,Ho,Wo,Cout) bf16; wt = cr_weight_transpose(w). */
 int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int N, int H, int W, int Cin,
-                       int Cout, int ks, int stride, int pad);
+                       int Cout, int ks, int stride, int pad, int act_f32);
 /* dw f32 (Cout, ks*ks*Cin); accumulate=0 zeroes it first (shared RPN-head weights accumulate over levels). */
 int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
-                         int Cout, int ks, int stride, int pad, int accumulate);
+                         int Cout, int ks, int stride, int pad, int accumulate, int act_f32);
 /* Fold a frozen BatchNorm2d into the preceding convolution for inference: wf (Cout, K) bf16 = w * gamma / sqrt(var + eps),
  * bias (Cout) f32 = beta - mean * gamma / sqrt(var + eps); w (Cout, K) f32 in the kernels' [Cout][kh][kw][Cin] order.
  * conv(x, wf) + bias (+ residual, ReLU in the conv epilogue) == BatchNorm(conv(x, w)) in eval mode
  * (cubercnn/modeling/backbone/dla.py:40-68: conv -> bn -> relu with BatchNorm = nn.BatchNorm2d in eval()). */
 int cr_fold_bn(cr_ctx* ctx, const float* w, const float* gamma, const float* beta, const float* mean, const float* var,
-               float eps, void* wf, float* bias, int Cout, int K);
+               float eps, void* wf, float* bias, int Cout, int K, int act_f32);
 
 /* same, plus dbias[Cout] += sum over output pixels of dy (bias gradient of the FPN / RPN-head convs), accumulated inside
  * the same kernel from the dy tiles it stages anyway (dbias must be zeroed or hold the running gradient). */
 int cr_conv2d_bwd_weight_bias(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
-                              int Cin, int Cout, int ks, int stride, int pad, int accumulate);
+                              int Cin, int Cout, int ks, int stride, int pad, int accumulate, int act_f32);
 int cr_cast_f32_to_bf16(cr_ctx* ctx, const float* src, void* dst, int64_t n);
 /* bias gradient: out[c] += sum_m x[m][c]; x (M,C) bf16 or f32; ws = 1024*C floats; deterministic. */
 int cr_colsum_accum(cr_ctx* ctx, const void* x, int is_f32, int64_t M, int C, float* ws, float* out);
 /* wt[c][tap][k] (bf16) = w[k][tap][c] (f32) */
-int cr_weight_transpose(cr_ctx* ctx, const float* w, void* wt, int Cout, int ks, int Cin);
+int cr_weight_transpose(cr_ctx* ctx, const float* w, void* wt, int Cout, int ks, int Cin, int act_f32);
 
 /* BatchNorm2d, training mode, per-GPU statistics (dla.py:17).  stats from cr_conv2d_fwd.
  * stats = [nparts][2][C] partial sums.  y = relu?((x-mean)*invstd*gamma + beta + residual?); writes
  * mean_invstd [2][C]; updates running stats (may be NULL). */
 int cr_bn_fwd(cr_ctx* ctx, const void* x, const float* stats, int nparts, const float* gamma, const float* beta,
               const void* residual, void* y, int64_t M, int C, int relu, float eps, float momentum,
-              float* mean_invstd, float* running_mean, float* running_var);
+              float* mean_invstd, float* running_mean, float* running_var, int act_f32);
 /* g = dy*(out>0 if relu); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dres = g (may be NULL);
  * dgamma/dbeta are ACCUMULATED; sums = f32 [1025][2][C] workspace (1024 block partials + the reduced row). */
 int cr_bn_bwd(cr_ctx* ctx, const void* dy, const void* out, const void* x, const float* mean_invstd,
               const float* gamma, float* sums, void* dx, void* dres, float* dgamma, float* dbeta, int64_t M,
-              int C, int relu);
+              int C, int relu, int act_f32);
 
 /* window 2: MaxPool2d(2,2) (dla.py:208); window 1: max_pool2d(k=1,s=2) (dla.py:474). */
-int cr_pool2x_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int window);
-int cr_pool2x_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int window);
+int cr_pool2x_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int window, int act_f32);
+int cr_pool2x_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int window, int act_f32);
 /* FPN top-down path (detectron2 FPN, fuse_type "sum"): y = lat + nearest_up2x(top); and d/dtop. */
-int cr_upsample2x_add(cr_ctx* ctx, const void* lat, const void* top, void* y, int N, int H, int W, int C);
-int cr_sum2x2(cr_ctx* ctx, const void* dy, void* dtop, int N, int H, int W, int C);
+int cr_upsample2x_add(cr_ctx* ctx, const void* lat, const void* top, void* y, int N, int H, int W, int C, int act_f32);
+int cr_sum2x2(cr_ctx* ctx, const void* dy, void* dtop, int N, int H, int W, int C, int act_f32);
 /* preprocess_image: uint8 (N,3,H,W) -> (x-mean)/std -> NHWC bf16, channels 3->8.  mean3/std3: HOST floats. */
 int cr_preprocess(cr_ctx* ctx, const unsigned char* img, void* y, int N, int H, int W, const float* mean3,
-                  const float* std3);
+                  const float* std3, int act_f32);
 
 /* ---- detection ops ------------------------------------------------------ */
 /* ROIPooler(ROIAlignV2): torchvision roi_align(aligned=True, sampling_ratio=0) with detectron2's FPN level
@@ -243,9 +251,9 @@ int cr_preprocess(cr_ctx* ctx, const unsigned char* img, void* y, int N, int H, 
  * [batch,x1,y1,x2,y2]; out / dout (R,PH,PW,C) bf16; grads f32 NHWC maps (atomics; zero first).
  * roi_heads.py:2075-2080,2178,2273. */
 int cr_roi_align_fwd(cr_ctx* ctx, const void* const* feats, const int* Hs, const int* Ws, const float* scales,
-                     int nlev, int C, const float* rois, int64_t R, int PH, int PW, void* out);
+                     int nlev, int C, const float* rois, int64_t R, int PH, int PW, void* out, int act_f32);
 int cr_roi_align_bwd(cr_ctx* ctx, float* const* grads, const int* Hs, const int* Ws, const float* scales,
-                     int nlev, int C, const float* rois, int64_t R, int PH, int PW, const void* dout);
+                     int nlev, int C, const float* rois, int64_t R, int PH, int PW, const void* dout, int act_f32);
 /* batched NMS over G independent groups; boxes (G,maxn,4) sorted by descending score per group, counts (G)
  * int32; keep (G,maxn) uint8; mask_ws: G*maxn*ceil(maxn/64)*8 bytes.  fast_rcnn.py:105, detectron2 RPN. */
 int cr_nms_grouped(cr_ctx* ctx, const float* boxes, const int* counts, int G, int maxn, float thresh,
@@ -269,14 +277,14 @@ int cr_cube_loss_bwd(cr_ctx* ctx, const float* const* inputs, int64_t n, int all
 
 /* nn.MaxPool2d(3, stride=2, padding=1) of the torchvision ResNet stem (cubercnn/modeling/backbone/resnet.py:33,49),
  * NHWC bf16, output ((H-1)/2+1, (W-1)/2+1); PyTorch's NaN and first-max tie rules. */
-int cr_maxpool3x3s2_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C);
-int cr_maxpool3x3s2_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C);
+int cr_maxpool3x3s2_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int act_f32);
+int cr_maxpool3x3s2_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int act_f32);
 
 /* FC weights of the RoI heads (roi_heads.py:2160-2204, cube_head.py:152-202).  w f32 (O, C, HW) in the checkpoint's
  * (c,h,w) column order -> wb bf16 (O, HW, C) for NHWC-flattened inputs (HW = 1: plain cast); and the transpose for the
  * gradient: acc f32 (O, C, HW) += g bf16 (O, HW, C). */
-int cr_fc_weight_prepare(cr_ctx* ctx, const float* w, void* wb, int O, int C, int HW);
-int cr_fc_grad_accum(cr_ctx* ctx, const void* g, float* acc, int O, int C, int HW);
+int cr_fc_weight_prepare(cr_ctx* ctx, const float* w, void* wb, int O, int C, int HW, int act_f32);
+int cr_fc_grad_accum(cr_ctx* ctx, const void* g, float* acc, int O, int C, int HW, int act_f32);
 
 /* multi-tensor form of cr_cast_f32_to_bf16 + cr_weight_transpose: every conv weight of the model in one launch.
  * descs_dev: device array of cr_wdesc (offsets in ELEMENTS from the three base pointers); tiles_dev: device array of
@@ -286,7 +294,7 @@ typedef struct cr_wdesc {
     int Cout, KK, Cin, need_T;          /* KK = k*k taps; need_T = 0 skips the transposed copy */
 } cr_wdesc;
 int cr_weights_prepare(cr_ctx* ctx, const float* src_base, void* dst_base, void* dstT_base, const cr_wdesc* descs_dev,
-                       const int* tiles_dev, int ntiles);
+                       const int* tiles_dev, int ntiles, int act_f32);
 
 /* ---- static-shape training glue of the RPN (3dod_amd/csrc/dense_train.hip) -----------------------------------
  * Batched, sync-free forms of cubercnn/modeling/proposal_generator/rpn.py:41-110 (label_and_sample_anchors with

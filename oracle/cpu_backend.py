@@ -99,7 +99,7 @@ def upsample2x_add(lat, top):
     return _q(_nhwc(_nchw(lat) + F.interpolate(_nchw(top), scale_factor=2.0, mode="nearest")))
 
 
-def preprocess(images_u8, mean, std):
+def preprocess(images_u8, mean, std, dtype=None):
     x = (images_u8.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
     x = _q(_nhwc(x))
     return torch.cat([x, x.new_zeros(x.shape[:3] + (5,))], 3)
@@ -166,6 +166,28 @@ def linear(x, weight, bias=None, chw=None):
         C, H, W = chw
         w = weight.view(weight.shape[0], C, H, W).permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
     return _q(F.linear(_q(x.float()), _q(w), None if bias is None else _q(bias)))
+
+
+def linear_cat(x, weights, biases):
+    """the predictors of a head as one GEMM: (R, O_pad) with O_pad = sum of widths rounded up to 16, + column offsets
+    (mirror of hipops.linear_cat)"""
+    sizes = [int(w.shape[0]) for w in weights]
+    O = sum(sizes)
+    Op = (O + 15) // 16 * 16
+    W = torch.cat(list(weights) + ([weights[0].new_zeros((Op - O, weights[0].shape[1]))] if Op > O else []))
+    b = torch.cat(list(biases) + ([biases[0].new_zeros((Op - O,))] if Op > O else []))
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    return F.linear(_q(x.float()), _q(W), _q(b)), offs
+
+
+def act_dtype():
+    return f32
+
+
+def precision():
+    return "fp32"
 
 
 def nms_grouped(boxes, counts, thresh):

@@ -39,11 +39,12 @@ tot = collections.Counter()
 print(f"{'N,H,W,Cin':>20s} {'Cout':>4s} k s  cnt | {'GF':>6s} | {'fwd us':>7s} {'TF':>5s} | {'bwdD us':>7s} {'TF':>5s} | {'wgrad us':>8s} {'TF':>5s}")
 for (xs, Cout, k, stride, pad), cnt in sorted(shapes.items(), key=lambda kv: -kv[0][0][1] * 1000 - kv[0][1]):
     N, H, W, Cin = xs
-    x = torch.randn(xs, device=dev).to(torch.bfloat16)
+    dt = ops.act_dtype()                # CR_PRECISION=fp32 (default) | bf16
+    x = torch.randn(xs, device=dev).to(dt)
     w = torch.randn(Cout, Cin, k, k, device=dev).contiguous(memory_format=torch.channels_last)
-    wb, wt = ops.prepared_weights(w, True)
+    wb, wt = ops.prepared_weights(w, True, dt)
     y = ops.conv_fwd_raw(x, wb, Cout, k, stride, pad)
-    dy = torch.randn_like(y.float()).to(torch.bfloat16)
+    dy = torch.randn_like(y.float()).to(dt)
     sink = torch.zeros(Cout * Cin * k * k, device=dev)
     gf = 2.0 * y.numel() * Cin * k * k / 1e9
     only_wg = "--only-wg" in sys.argv

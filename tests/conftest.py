@@ -17,3 +17,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(params=["fp32", "bf16"])
+def precision(request):
+    """runs a GPU test once per arithmetic mode of the conv path: "fp32" = the reference's precision (the default of the
+    product), "bf16" = the opt-in fast mode.  Restores the previous mode afterwards."""
+    import importlib
+    ops = importlib.import_module("3dod_amd.hipops")
+    prev = ops.set_precision(request.param)
+    yield request.param
+    ops.set_precision(prev)

@@ -250,7 +250,7 @@ def test_weight_bank_matches_per_tensor_prep():
     for p in params:
         wb, wt = ops.prepared_weights(p, True)
         ref.append((wb.clone(), wt.clone()))
-    bank = ops.WeightBank(params, flat)
+    bank = ops.WeightBank(params, flat, dtype=bf16)
     ops.bump_weight_epoch()
     for i, p in enumerate(params):
         wb, wt = ops.prepared_weights(p, True)
@@ -261,6 +261,14 @@ def test_weight_bank_matches_per_tensor_prep():
     ops.bump_weight_epoch()
     wb, _ = ops.prepared_weights(params[0], False)
     assert torch.equal(wb.float(), (ref[0][0].float() * 2.0))
+    # float32 bank (reference precision): the master weights are the forward operand, only the bwd-data layout is a copy
+    bank32 = ops.WeightBank(params, flat, dtype=torch.float32)
+    ops.bump_weight_epoch()
+    for i, p in enumerate(params):
+        wb, wt = ops.prepared_weights(p, True, torch.float32)
+        assert wb.data_ptr() == p.data_ptr() and wt.data_ptr() == bank32.views[i][1].data_ptr()
+        co, ci, k, _ = p.shape
+        assert torch.equal(wt.view(ci, k * k, co), p.detach().permute(1, 2, 3, 0).reshape(ci, k * k, co)), i
 
 
 @pytest.mark.parametrize("hw", [(12, 20), (13, 21), (2, 2)])

@@ -99,11 +99,15 @@ def test_dla_trunk_matches_reference_golden(golden_dir):
         assert l2e < tol[name], (name, l2e, mx)
 
 
-def test_modules_in_isolation(built):
+def test_modules_in_isolation(built, precision):
     """every conv module of the trunk, the FPN and the RPN head: the HIP result on the module's actual GPU inputs
-    vs the bf16-emulating float32 oracle on the same inputs.  This is the arithmetic check: relative L2 <= 2e-3,
-    max-norm <= 2e-2 (one bf16 ulp at a few elements)."""
+    vs the float32 oracle on the same inputs.  This is the arithmetic check.
+      fp32 (reference precision): relative L2 <= 2e-5, max-norm <= 2e-4 (summation order only);
+      bf16 (fast mode) against the bf16-emulating oracle: relative L2 <= 2e-3, max-norm <= 2e-2 (one bf16 ulp at a few
+      elements)."""
     from oracle import cpu_backend
+    emu = precision == "bf16"
+    t_l2, t_mx = (2e-3, 2e-2) if emu else (2e-5, 2e-4)
     cfg, model, opt, syn, solver = built
     dla = importlib.import_module("3dod_amd.cubercnn.modeling.backbone.dla")
     modeling = importlib.import_module("3dod_amd.cubercnn.modeling")
@@ -130,7 +134,7 @@ def test_modules_in_isolation(built):
     saved = {n: importlib.import_module(n).ops for n in cpu_backend.PATCHED}
     try:
         cpu_backend.install()
-        cpu_backend.EMULATE_BF16 = True
+        cpu_backend.EMULATE_BF16 = emu
         ref = modeling.build_model(syn.make_cfg(overrides=["MODEL.DEVICE", "cpu", "VIS_PERIOD", 0, "log", False]))
         ref.load_state_dict(sd)
         ref.train()
@@ -140,7 +144,7 @@ def test_modules_in_isolation(built):
             for name, (inp, out) in rec.items():
                 l2e, mx = _rel(mods[name](*inp), out)
                 worst = max(worst, l2e)
-                assert l2e < 2e-3 and mx < 2e-2, (name, l2e, mx)
+                assert l2e < t_l2 and mx < t_mx, (name, l2e, mx)
             # FPN on the GPU's bottom-up features, RPN head on the GPU's FPN features
             class _BU(torch.nn.Module):
                 def forward(self, x):
@@ -151,11 +155,11 @@ def test_modules_in_isolation(built):
             ref.backbone.bottom_up = real_bu
             for k in feats:
                 l2e, mx = _rel(feats[k], f_ref[k])
-                assert l2e < 3e-3 and mx < 3e-2, (k, l2e, mx)
+                assert l2e < 1.5 * t_l2 and mx < 1.5 * t_mx, (k, l2e, mx)
             lg, dl = ref.proposal_generator.rpn_head([feats[f].float().cpu() for f in pg.in_features])
             for a, b in zip(list(logits) + list(deltas), list(lg) + list(dl)):
                 l2e, mx = _rel(a, b)
-                assert l2e < 3e-3 and mx < 3e-2, (l2e, mx)
+                assert l2e < 1.5 * t_l2 and mx < 1.5 * t_mx, (l2e, mx)
     finally:
         cpu_backend.EMULATE_BF16 = False
         for n, o in saved.items():
