@@ -69,7 +69,7 @@ class RCNN3D(nn.Module):
         if sample_batched_inputs is not None:
             il, batch = self._stack_images(sample_batched_inputs)
             self._graphed_eval = GraphedDenseEval(self, batch)
-            self._graphed_eval_cache[self._graphed_eval.shape] = self._graphed_eval
+            self._graphed_eval_cache[(self._graphed_eval.shape, ops.precision())] = self._graphed_eval
         return self._graphed_eval
 
     def _eval_graph_for(self, batch):
@@ -77,7 +77,7 @@ class RCNN3D(nn.Module):
         cache = self._graphed_eval_cache
         if cache is None:
             return None
-        key = tuple(batch.shape)
+        key = (tuple(batch.shape), ops.precision())
         ge = cache.get(key)
         if ge is not None:
             cache.move_to_end(key)
