@@ -1,0 +1,55 @@
+"""CPU: pins the oracle (oracle/cpu_backend.py) of the static-shape training glue to the REFERENCE'S OWN outputs
+(tests/golden/dense_train_g7.npz from rpn.py:41-354, roi_heads.py:2737-2840, fast_rcnn.py:57-260, cube_head.py:24-202; see
+tests/golden/make_golden_dense.py and tests/g7_checks.py).  The GPU twin is tests/test_gpu_dense_golden.py."""
+import importlib
+
+import pytest
+import torch
+
+import g7_checks as C
+from oracle import cpu_backend as O
+
+DEV = torch.device("cpu")
+
+
+@pytest.fixture(scope="module")
+def G():
+    return C.load()
+
+
+@pytest.fixture()
+def oracle_backend():
+    """the product's host modules run on the oracle backend for the duration of one test"""
+    saved = {n: importlib.import_module(n).ops for n in O.PATCHED}
+    O.install()
+    yield O
+    for n, o in saved.items():
+        importlib.import_module(n).ops = o
+
+
+@pytest.mark.parametrize("tag", ["rpn", "rpnh"])
+def test_rpn_labels_sampling_and_losses_match_reference(G, tag):
+    C.check_rpn(O, DEV, G, tag)
+
+
+def test_roi_sampling_and_box_losses_match_reference(G):
+    C.check_roi_and_box_loss(O, DEV, G)
+
+
+def test_matched_pairwise_iou_matches_reference(G):
+    rpn = importlib.import_module("3dod_amd.cubercnn.modeling.proposal_generator.rpn")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    got = rpn.matched_pairwise_iou(d2.Boxes(G["rpn_miou_b1"]), d2.Boxes(G["rpn_miou_b2"]))
+    assert torch.allclose(got, G["rpn_miou"], rtol=0, atol=1e-7)
+
+
+def test_inference_filter_matches_reference(G, oracle_backend):
+    fr = importlib.import_module("3dod_amd.cubercnn.modeling.roi_heads.fast_rcnn")
+    C.check_inference_filter(fr, DEV, G)
+
+
+def test_cube_head_forward_matches_reference(G, oracle_backend):
+    ch = importlib.import_module("3dod_amd.cubercnn.modeling.roi_heads.cube_head")
+    syn = importlib.import_module("3dod_amd.synthetic")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    C.check_cube_head(ch, syn.make_cfg, d2, DEV, G)
