@@ -74,7 +74,7 @@ SIGNATURES = {
     "cr_cube_decode_infer": [P, P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, P],
     "cr_box3d_overlap": [P, P, P, c_int, c_int, P, P],
     "cr_nonfinite_flag": [P, P, c_int64, P],
-    "cr_sgd_step": [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P],
+    "cr_sgd_step": [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, P],
 }
 
 

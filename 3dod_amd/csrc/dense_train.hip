@@ -93,7 +93,7 @@ extern "C" int cr_rpn_decode_select(cr_ctx* ctx, const float* anchors, const flo
 //    inter / area(box).  best (B,G) u64 (optional, zero-filled by the call): per valid gt the max IoU over boxes and the
 //    lowest box index attaining it, packed (iou_bits << 32) | ~index.
 // ---------------------------------------------------------------------------------------------------------------
-#define MAXG 64
+#define MAXG 64      // ground-truth rows staged in LDS at a time: G itself is unbounded (crowded Omni3D images exceed 64)
 __global__ __launch_bounds__(256) void k_box_match(const float* __restrict__ boxes, int64_t box_bstride,
                                                    const float* __restrict__ gtb, const int64_t* __restrict__ gtc, int B,
                                                    int R, int G, float* __restrict__ max_iou, int* __restrict__ argmax,
@@ -103,45 +103,52 @@ __global__ __launch_bounds__(256) void k_box_match(const float* __restrict__ box
     __shared__ int scls[MAXG];
     __shared__ unsigned long long sbest[MAXG];
     const int b = blockIdx.y, t = threadIdx.x;
-    for (int g = t; g < G; g += 256) {
-        const float* p = gtb + ((size_t)b * G + g) * 4;
-        sg[g * 4 + 0] = p[0]; sg[g * 4 + 1] = p[1]; sg[g * 4 + 2] = p[2]; sg[g * 4 + 3] = p[3];
-        sarea[g] = (p[2] - p[0]) * (p[3] - p[1]);
-        scls[g] = (int)gtc[(size_t)b * G + g];
-        sbest[g] = 0ULL;
-    }
-    __syncthreads();
     const int r = blockIdx.x * 256 + t;
-    if (r < R) {
-        const Box bx = ldbox(boxes + (size_t)b * box_bstride + (size_t)r * 4);
-        const float ab = box_area(bx);
-        float mi = NEG_IOU, ma = 0.f;
-        int am = 0;
-        for (int g = 0; g < G; ++g) {
-            const int c = scls[g];
-            if (c < -1) continue;
-            const Box gb{sg[g * 4], sg[g * 4 + 1], sg[g * 4 + 2], sg[g * 4 + 3]};
-            if (c >= 0) {
-                const float v = iou_gt_box(gb, sarea[g], bx, ab);
-                if (v > mi) { mi = v; am = g; }
-                if (best) {
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~(unsigned)r);
-                    atomicMax(&sbest[g], key);         // v >= 0: its bit pattern orders like the float
+    Box bx{0.f, 0.f, 0.f, 0.f};
+    if (r < R) bx = ldbox(boxes + (size_t)b * box_bstride + (size_t)r * 4);
+    const float ab = box_area(bx);
+    float mi = NEG_IOU, ma = 0.f;
+    int am = 0;
+    for (int g0 = 0; g0 < G; g0 += MAXG) {                 // chunks of MAXG rows, in order (first arg-max is kept)
+        const int gn = min(MAXG, G - g0);
+        if (g0) __syncthreads();                          // the previous chunk has been consumed
+        for (int g = t; g < gn; g += 256) {
+            const float* p = gtb + ((size_t)b * G + g0 + g) * 4;
+            sg[g * 4 + 0] = p[0]; sg[g * 4 + 1] = p[1]; sg[g * 4 + 2] = p[2]; sg[g * 4 + 3] = p[3];
+            sarea[g] = (p[2] - p[0]) * (p[3] - p[1]);
+            scls[g] = (int)gtc[(size_t)b * G + g0 + g];
+            sbest[g] = 0ULL;
+        }
+        __syncthreads();
+        if (r < R) {
+            for (int g = 0; g < gn; ++g) {
+                const int c = scls[g];
+                if (c < -1) continue;
+                const Box gb{sg[g * 4], sg[g * 4 + 1], sg[g * 4 + 2], sg[g * 4 + 3]};
+                if (c >= 0) {
+                    const float v = iou_gt_box(gb, sarea[g], bx, ab);
+                    if (v > mi) { mi = v; am = g0 + g; }
+                    if (best) {
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(~(unsigned)r);
+                        atomicMax(&sbest[g], key);         // v >= 0: its bit pattern orders like the float
+                    }
+                } else {
+                    const float inter = box_inter(gb, bx);
+                    const float v = inter > 0.f ? inter / ab : 0.f;
+                    ma = fmaxf(ma, v);
                 }
-            } else {
-                const float inter = box_inter(gb, bx);
-                const float v = inter > 0.f ? inter / ab : 0.f;
-                ma = fmaxf(ma, v);
             }
         }
+        if (best) {
+            __syncthreads();
+            for (int g = t; g < gn; g += 256)
+                if (scls[g] >= 0) atomicMax(&best[(size_t)b * G + g0 + g], sbest[g]);
+        }
+    }
+    if (r < R) {
         max_iou[(size_t)b * R + r] = mi;
         argmax[(size_t)b * R + r] = am;
         max_ioa[(size_t)b * R + r] = ma;
-    }
-    if (best) {
-        __syncthreads();
-        for (int g = t; g < G; g += 256)
-            if (scls[g] >= 0) atomicMax(&best[(size_t)b * G + g], sbest[g]);
     }
 }
 
@@ -155,7 +162,7 @@ extern "C" int cr_box_match(cr_ctx* ctx, const float* boxes, int boxes_per_image
                             unsigned long long* best) {
     CR_CHECK_ARG(ctx && boxes && gt_boxes && gt_classes && max_iou && argmax && max_ioa, "cr_box_match: NULL pointer");
     if (B == 0 || R == 0) return CR_OK;
-    CR_CHECK_ARG(B > 0 && R > 0 && G > 0 && G <= MAXG, "cr_box_match: 1 <= G <= %d required (G=%d)", MAXG, G);
+    CR_CHECK_ARG(B > 0 && R > 0 && G > 0, "cr_box_match: G >= 1 required (G=%d)", G);
     if (best) {
         hipLaunchKernelGGL(k_zero_u64, dim3((unsigned)cr_cdiv((int64_t)B * G, 256)), dim3(256), 0, ctx->stream, best,
                            (int64_t)B * G);
@@ -187,28 +194,35 @@ __global__ __launch_bounds__(256) void k_rpn_label(const float* __restrict__ anc
     __shared__ float sbest[MAXG];
     __shared__ int sbidx[MAXG];      // -1 = gt not valid
     const int b = blockIdx.y, t = threadIdx.x;
-    for (int g = t; g < G; g += 256) {
-        const float* p = gtb + ((size_t)b * G + g) * 4;
-        sg[g * 4 + 0] = p[0]; sg[g * 4 + 1] = p[1]; sg[g * 4 + 2] = p[2]; sg[g * 4 + 3] = p[3];
-        sarea[g] = (p[2] - p[0]) * (p[3] - p[1]);
-        const bool v = gtc[(size_t)b * G + g] >= 0;
-        const unsigned long long k = best[(size_t)b * G + g];
-        sbest[g] = __uint_as_float((unsigned)(k >> 32));
-        sbidx[g] = v ? (int)(~(unsigned)(k & 0xffffffffULL)) : -1;
-    }
-    __syncthreads();
     const int a = blockIdx.x * 256 + t;
-    if (a >= A) return;
-    const Box bx = ldbox(anchors + (size_t)a * 4);
+    Box bx{0.f, 0.f, 0.f, 0.f};
+    if (a < A) bx = ldbox(anchors + (size_t)a * 4);
     const float ab = box_area(bx);
     bool lowq = false, is_best = false;
-    for (int g = 0; g < G; ++g) {
-        if (sbidx[g] < 0) continue;
-        const Box gb{sg[g * 4], sg[g * 4 + 1], sg[g * 4 + 2], sg[g * 4 + 3]};
-        const float v = iou_gt_box(gb, sarea[g], bx, ab);
-        lowq |= v == sbest[g];
-        is_best |= sbidx[g] == a;
+    for (int g0 = 0; g0 < G; g0 += MAXG) {                 // G is unbounded: MAXG rows staged at a time
+        const int gn = min(MAXG, G - g0);
+        if (g0) __syncthreads();
+        for (int g = t; g < gn; g += 256) {
+            const float* p = gtb + ((size_t)b * G + g0 + g) * 4;
+            sg[g * 4 + 0] = p[0]; sg[g * 4 + 1] = p[1]; sg[g * 4 + 2] = p[2]; sg[g * 4 + 3] = p[3];
+            sarea[g] = (p[2] - p[0]) * (p[3] - p[1]);
+            const bool v = gtc[(size_t)b * G + g0 + g] >= 0;
+            const unsigned long long k = best[(size_t)b * G + g0 + g];
+            sbest[g] = __uint_as_float((unsigned)(k >> 32));
+            sbidx[g] = v ? (int)(~(unsigned)(k & 0xffffffffULL)) : -1;
+        }
+        __syncthreads();
+        if (a < A) {
+            for (int g = 0; g < gn; ++g) {
+                if (sbidx[g] < 0) continue;
+                const Box gb{sg[g * 4], sg[g * 4 + 1], sg[g * 4 + 2], sg[g * 4 + 3]};
+                const float v = iou_gt_box(gb, sarea[g], bx, ab);
+                lowq |= v == sbest[g];
+                is_best |= sbidx[g] == a;
+            }
+        }
     }
+    if (a >= A) return;
     const size_t i = (size_t)b * A + a;
     const float vals = max_iou[i];
     int lab = l2;
@@ -231,7 +245,7 @@ extern "C" int cr_rpn_label(cr_ctx* ctx, const float* anchors, const float* gt_b
     CR_CHECK_ARG(ctx && anchors && gt_boxes && gt_classes && max_iou && best && expo && labels3 && labels_pre && out &&
                  matched_iou && keys, "cr_rpn_label: NULL pointer");
     if (B == 0 || A == 0) return CR_OK;
-    CR_CHECK_ARG(G > 0 && G <= MAXG, "cr_rpn_label: 1 <= G <= %d required", MAXG);
+    CR_CHECK_ARG(G > 0, "cr_rpn_label: G >= 1 required");
     hipLaunchKernelGGL(k_rpn_label, dim3((unsigned)cr_cdiv(A, 256), B), dim3(256), 0, ctx->stream, anchors, gt_boxes,
                        gt_classes, max_iou, best, expo, B, A, G, lo, hi, labels3[0], labels3[1], labels3[2], eps,
                        labels_pre, out, matched_iou, keys);

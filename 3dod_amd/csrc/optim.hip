@@ -29,10 +29,13 @@ extern "C" int cr_nonfinite_flag(cr_ctx* ctx, const float* g, int64_t n, int* fl
 }
 
 // torch.optim.SGD(momentum, dampening 0, no nesterov): g' = g*gscale + wd*p ; m = mom*m + g' ; p -= lr*m
+// lr = lr_base * (*lr_scale): the schedule's factor is read on the device, so a captured launch (HIP graph) follows the
+// warm-up / multi-step schedule without being re-captured
 __global__ __launch_bounds__(256) void k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                             int64_t n, float lr, float mom, float wd, float gscale,
-                                             const int* __restrict__ skip) {
+                                             int64_t n, float lr_base, const float* __restrict__ lr_scale, float mom, float wd,
+                                             float gscale, const int* __restrict__ skip) {
     if (skip && *skip) return;
+    const float lr = lr_scale ? lr_base * *lr_scale : lr_base;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
         if (i + 3 < n) {
             float4 pv = *reinterpret_cast<float4*>(p + i);
@@ -54,16 +57,16 @@ __global__ __launch_bounds__(256) void k_sgd(float* __restrict__ p, const float*
     }
 }
 
-extern "C" int cr_sgd_step(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, float momentum,
-                           float weight_decay, float grad_scale, const int* skip_flag) {
+extern "C" int cr_sgd_step(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, const float* lr_scale_dev,
+                           float momentum, float weight_decay, float grad_scale, const int* skip_flag) {
     CR_CHECK_ARG(ctx && n >= 0, "cr_sgd_step: bad args");
     if (n == 0) return CR_OK;
     CR_CHECK_ARG(p && g && m, "cr_sgd_step: NULL pointer");
     CR_CHECK_ARG(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m)) & 15) == 0, "cr_sgd_step: misaligned buffers");
     int64_t nb = cr_cdiv(cr_cdiv(n, 4), 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(k_sgd, dim3((unsigned)nb), dim3(256), 0, ctx->stream, p, g, m, n, lr, momentum, weight_decay,
-                       grad_scale, skip_flag);
+    hipLaunchKernelGGL(k_sgd, dim3((unsigned)nb), dim3(256), 0, ctx->stream, p, g, m, n, lr, lr_scale_dev, momentum,
+                       weight_decay, grad_scale, skip_flag);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -95,15 +95,35 @@ class FlatSGD:
                 self.segments.append(cur)
             off += pad(n)
         self.param_groups = [{"lr": s[2], "weight_decay": s[3], "range": (s[0], s[1])} for s in self.segments]
-        self.lr_scale = 1.0
+        # the schedule's current factor lives on the device too: the update kernels read it there, so an update captured
+        # in a HIP graph (GraphedTrainStep) follows warm-up / multi-step schedules driven through `lr_scale`
+        self._lr_scale = 1.0
+        self._lr_dev = torch.ones(1, dtype=torch.float32, device=dev)
+        self._lr_dev_value = 1.0
+
+    @property
+    def lr_scale(self):
+        return self._lr_scale
+
+    @lr_scale.setter
+    def lr_scale(self, v):
+        self._lr_scale = float(v)
+
+    def refresh_lr(self):
+        """push the host-side schedule factor to the device scalar (a one-float fill, only when it changed; never inside
+        a graph capture: the captured kernels read the scalar, the host refreshes it before each replay)"""
+        if self._lr_dev_value != self._lr_scale and not (self._lr_dev.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self._lr_dev.fill_(self._lr_scale)
+            self._lr_dev_value = self._lr_scale
 
     def enable_weight_bank(self):
         """one-launch-per-step bf16 recast of every conv weight (hipops.WeightBank); training-step objects call this."""
-        if getattr(self, "weight_bank", None) is None and self.flat_p.is_cuda and hasattr(ops, "WeightBank"):
+        bank = getattr(self, "weight_bank", None)
+        if self.flat_p.is_cuda and hasattr(ops, "WeightBank") and (bank is None or bank.dtype != ops.act_dtype()):
             convs = [p for p in self.params if p.dim() == 4 and p.shape[2] == p.shape[3] and
                      p.is_contiguous(memory_format=torch.channels_last)]
             if convs:
-                self.weight_bank = ops.WeightBank(convs, self.flat_p)
+                self.weight_bank = ops.WeightBank(convs, self.flat_p)     # in the precision mode of the process
                 ops.bump_weight_epoch()
         return getattr(self, "weight_bank", None)
 
@@ -126,9 +146,10 @@ class FlatSGD:
             p.grad = None
 
     def step(self, skip_flag=None, grad_scale=1.0):
+        self.refresh_lr()
         for (a, b, lr, wd) in self.segments:
-            ops.sgd_step(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], lr * self.lr_scale, self.momentum, wd,
-                         grad_scale, skip_flag)
+            ops.sgd_step(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], lr, self.momentum, wd,
+                         grad_scale, skip_flag, lr_scale_dev=self._lr_dev)
         ops.bump_weight_epoch()
 
     def state_dict(self):
@@ -137,6 +158,7 @@ class FlatSGD:
     def load_state_dict(self, sd):
         self.flat_m.copy_(sd["momentum_buffer"])
         self.lr_scale = sd.get("lr_scale", 1.0)
+        self.refresh_lr()
 
 
 def build_optimizer(cfg, model):
@@ -287,41 +309,58 @@ class GraphedTrainStep:
     Possible because the dense training path has fixed shapes and no host<->device sync.  The reference clips the
     loss to [0,1] before backward when it diverges (train_net.py:212) but then discards that step's gradients
     (:259-261), so running backward on the unclipped local loss and skipping the update gives the same parameters.
-    Per step the host only refreshes the static input buffers (image batch, padded ground truth, camera constants).
+    Per step the host only refreshes the static input buffers (image batch, padded ground truth, camera constants) and
+    the schedule's learning-rate factor (a device scalar the captured update reads).  Replays are enqueued back to back
+    (the host runs ahead of the device); CR_STEP_SYNC=1 makes the host wait for every step (debugging).
+
+    Ownership: everything whose address is baked into the graphs is either a persistent buffer of this object / the
+    optimizer (static inputs, flat parameter / gradient / momentum buffers, the weight bank, counters) or was allocated
+    during capture from the graphs' private pool.  The ground-truth buffers hold `G` rows per image; a batch with more
+    objects re-captures the graphs with a larger G (logged).
     """
     G_PAD = 32
     TOLERANCE, GAMMA = TrainStep.TOLERANCE, TrainStep.GAMMA
 
     def __init__(self, cfg, model, optimizer, sample_data, world_size=1, bucket_mb=32, warmup=2):
         from ..modeling.dense_train import GTBatch, camera_meta
-        from ..modeling.graphed import _fresh_leaves
         assert model.training and model.dense_train
         self.model, self.opt, self.world = model, optimizer, world_size
-        optimizer.enable_weight_bank()
         self.stabilize = cfg.MODEL.STABILIZE > 0
         import os
-        self.sync_each_step = os.environ.get("CR_STEP_SYNC", "1") == "1"
+        self.sync_each_step = os.environ.get("CR_STEP_SYNC", "0") == "1"
         self._GTBatch, self._camera_meta = GTBatch, camera_meta
         dev = optimizer.flat_p.device
         self.dev = dev
-        images, batch = model._stack_images(sample_data)
-        self.image_sizes = [tuple(s) for s in images.image_sizes]
-        assert all(s == tuple(batch.shape[-2:]) for s in self.image_sizes), "whole-step graph: one image size per batch"
-        self.static_img = batch.clone()
-        self.gt = GTBatch([d["instances"].to(dev) for d in sample_data], dev, G=self.G_PAD)
-        self.meta = self._meta_of(sample_data).clone()
+        self.warmup = warmup
         self.recent_loss = torch.full((), float("nan"), device=dev)
         self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self.iterations_success = torch.zeros((), device=dev)
         self.iterations_explode = torch.zeros((), device=dev)
         self.total = torch.zeros((), device=dev)
-        self.vals = None
-        self.keys = None
         n = optimizer.flat_g.numel()
         be = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets = [(i, min(i + be, n)) for i in range(0, n, be)][::-1]
         self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
         model._graphed = None
+        need = max(1, max(len(d["instances"]) for d in sample_data))
+        self._capture(sample_data, max(self.G_PAD, need))
+
+    def _capture(self, sample_data, G):
+        """(re)build the static buffers for G ground-truth rows per image and capture both graphs"""
+        from ..modeling.graphed import _fresh_leaves
+        model, optimizer, dev, world_size = self.model, self.opt, self.dev, self.world
+        optimizer.enable_weight_bank()
+        self.dtype = ops.act_dtype()
+        self.G = int(G)
+        images, batch = model._stack_images(sample_data)
+        self.image_sizes = [tuple(s) for s in images.image_sizes]
+        assert all(s == tuple(batch.shape[-2:]) for s in self.image_sizes), "whole-step graph: one image size per batch"
+        self.static_img = batch.clone()
+        self.gt = self._GTBatch([d["instances"].to(dev) for d in sample_data], dev, G=self.G)
+        self.meta = self._meta_of(sample_data).clone()
+        self.vals = None
+        self.keys = None
+        state = [t.clone() for t in (self.recent_loss, self.flag, self.iterations_success, self.iterations_explode)]
 
         def fwd_bwd():
             loss_dict = model.forward_static(self.static_img, self.image_sizes, self.gt, self.meta)
@@ -350,7 +389,7 @@ class GraphedTrainStep:
             self.flag.copy_(diverging.to(torch.int32).view(1))
             if self.stabilize:
                 ops.nonfinite_flag(optimizer.flat_g, self.flag)
-            optimizer.step(skip_flag=self.flag, grad_scale=1.0 / world_size)
+            optimizer.step(skip_flag=self.flag, grad_scale=1.0 / world_size)      # lr factor read from the device scalar
             bad = (self.flag[0] != 0).float()
             self.iterations_explode.add_(bad)
             self.iterations_success.add_(1 - bad)
@@ -361,10 +400,11 @@ class GraphedTrainStep:
         snap = [t.clone() for t in (optimizer.flat_p, optimizer.flat_m)]
         bn = [(m, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone())
               for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        optimizer.refresh_lr()
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s), _fresh_leaves([model]):
-            for _ in range(warmup):
+            for _ in range(self.warmup):
                 fwd_bwd()
                 update()
         torch.cuda.current_stream(dev).wait_stream(s)
@@ -374,8 +414,8 @@ class GraphedTrainStep:
             optimizer.flat_p.copy_(snap[0]); optimizer.flat_m.copy_(snap[1])
             for m, a, b, c in bn:
                 m.running_mean.copy_(a); m.running_var.copy_(b); m.num_batches_tracked.copy_(c)
-            self.recent_loss.fill_(float("nan")); self.flag.zero_()
-            self.iterations_success.zero_(); self.iterations_explode.zero_()
+            for t, v in zip((self.recent_loss, self.flag, self.iterations_success, self.iterations_explode), state):
+                t.copy_(v)
         restore()
         ops.bump_weight_epoch()
         with _fresh_leaves([model]):
@@ -396,13 +436,28 @@ class GraphedTrainStep:
         return self._camera_meta(self.model.roi_heads, Ks, ratios, self.image_sizes, self.dev)
 
     def load(self, data):
-        """refresh the static inputs (device-side copies only; the one host->device transfer is pinned + async)."""
+        """refresh the static inputs (device-side copies only; the one host->device transfer is pinned + async)"""
+        need = max(1, max(len(d["instances"]) for d in data))
+        if need > self.G:
+            # more objects in an image than the captured ground-truth buffers hold: re-capture with room to spare
+            # (the reference takes any number of boxes; crowded Omni3D images exceed 32)
+            import logging
+            G = 1 << (need - 1).bit_length()
+            logging.getLogger(__name__).warning("GraphedTrainStep: %d ground-truth rows in an image > %d captured; "
+                                                "re-capturing the step graphs with G = %d", need, self.G, G)
+            torch.cuda.synchronize(self.dev)
+            self._capture(data, G)
         _, batch = self.model._stack_images(data)
+        assert tuple(batch.shape) == tuple(self.static_img.shape), "whole-step graph: the batch shape is fixed at capture"
         self.static_img.copy_(batch)
-        self.gt.copy_from(self._GTBatch([d["instances"].to(self.dev) for d in data], self.dev, G=self.G_PAD))
-        self.meta.copy_(self._meta_of(data), non_blocking=True)
+        fresh = self._GTBatch([d["instances"].to(self.dev) for d in data], self.dev, G=self.G)
+        self.gt.copy_from(fresh)
+        meta = self._meta_of(data)
+        self.meta.copy_(meta, non_blocking=True)
 
     def __call__(self, data):
+        if ops.act_dtype() != self.dtype:
+            raise RuntimeError("GraphedTrainStep was captured in another precision mode (hipops.set_precision)")
         self.load(data)
         self.graph_a.replay()
         if self.world > 1:
@@ -412,7 +467,9 @@ class GraphedTrainStep:
                 for a, b in self.buckets:
                     dist.all_reduce(self.opt.flat_g[a:b])
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.opt.refresh_lr()                 # the schedule's factor for THIS update (graph B reads the device scalar)
         self.graph_b.replay()
+        ops.bump_weight_epoch()               # parameters moved through raw pointers: cached compute copies are stale
         if self.sync_each_step:
             torch.cuda.current_stream(self.dev).synchronize()
         return self.last

@@ -63,19 +63,27 @@ def _chk(rc, what):
     _lib.check(rc, what)
 
 
-_KEEP, _KEEP_POS = [None] * 128, [0]
+class _Args:
+    """Owns the temporaries of ONE kernel call.  Every wrapper below starts with `_p = _Args()` and takes its device
+    pointers through it: `_p(x.contiguous())` may create a temporary, which this object keeps referenced until the wrapper
+    returns -- i.e. until the launch has been enqueued on the stream.  After that the caching allocator's stream ordering
+    (eager) or the capture's allocation order (HIP graphs) makes reuse of the block safe.  Without an owner a temporary dies
+    as soon as its pointer has been read and the NEXT temporary of the same argument list can be handed the same block
+    before the kernel is even launched (round 1: garbage sampling indices -> out-of-bounds gathers in cr_roi_compact, the
+    memory fault of the whole-step graph mode)."""
+    __slots__ = ("keep",)
+
+    def __init__(self):
+        self.keep = []
+
+    def __call__(self, t):
+        if t is not None:
+            self.keep.append(t)
+        return _lib.ptr(t)
 
 
 def _p(t):
-    """device pointer of `t` (NULL for None).  Wrappers write `_p(x.contiguous())` inline: when that makes a temporary,
-    it would be released as soon as this returns and the NEXT temporary of the same argument list could be handed the
-    same block before the kernel is even launched (two non-contiguous inputs -> garbage).  The last 128 tensors whose
-    pointers were taken are therefore kept alive in a ring; by the time a slot is recycled its kernel has long been
-    enqueued on the stream, after which the caching allocator's stream ordering makes reuse safe."""
-    if t is not None:
-        i = _KEEP_POS[0]
-        _KEEP[i] = t
-        _KEEP_POS[0] = (i + 1) & 127
+    """device pointer of a tensor the CALLER keeps alive across the launch (NULL for None)"""
     return _lib.ptr(t)
 
 
@@ -151,6 +159,7 @@ class WeightBank:
             p._cr_bank = (self, i)
 
     def get(self, i):
+        _p = _Args()
         if self.epoch != _WEIGHT_EPOCH[0]:
             lib = _lib.load()
             _chk(lib.cr_weights_prepare(_ctx(self.flat_p), _p(self.flat_p), _p(self.dst), _p(self.dstT), _p(self.descs),
@@ -165,6 +174,7 @@ def prepared_weights(weight, need_transposed, dtype=bf16):
     same dtype come from the bank (one launch per step for the whole model); others are cached ON the tensor object (so
     a new tensor at a recycled address never hits a stale entry), keyed by torch's version counter and the global
     weight epoch."""
+    _p = _Args()
     bk = getattr(weight, "_cr_bank", None)
     if bk is not None and bk[0].dtype == dtype:
         return bk[0].get(bk[1])
@@ -198,6 +208,7 @@ def prepared_weights(weight, need_transposed, dtype=bf16):
 # raw kernels
 # --------------------------------------------------------------------------
 def conv_fwd_raw(x, wb, Cout, k, stride, pad, bias=None, residual=None, relu=False, stats=None, out_f32=False):
+    _p = _Args()
     _need_cuda(x, "conv input")
     af = _af(x)
     assert x.is_contiguous() and x.dim() == 4 and wb.dtype == x.dtype and (residual is None or residual.dtype == x.dtype)
@@ -211,6 +222,7 @@ def conv_fwd_raw(x, wb, Cout, k, stride, pad, bias=None, residual=None, relu=Fal
 
 
 def conv_bwd_data_raw(dy, wt, in_shape, k, stride, pad):
+    _p = _Args()
     N, H, W, Cin = in_shape
     Cout = dy.shape[3]
     assert wt.dtype == dy.dtype
@@ -229,6 +241,7 @@ def grad_sink(t):
 
 def conv_bwd_weight_raw(dy, x, k, stride, pad, sink=None, bias_acc=None):
     """dW (into `sink` when given).  bias_acc: f32 [Cout] buffer that additionally receives += sum_pixels dy (fused)."""
+    _p = _Args()
     N, H, W, Cin = x.shape
     Cout = dy.shape[3]
     lib = _lib.load()
@@ -257,6 +270,7 @@ class _ConvBN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, relu, eps, momentum,
                 training):
+        _p = _Args()
         Cout, Cin, k, _ = weight.shape
         need_grad = x.requires_grad or weight.requires_grad
         wb, wt = prepared_weights(weight, need_grad and x.requires_grad, x.dtype)
@@ -293,6 +307,7 @@ class _ConvBN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        _p = _Args()
         x, weight, gamma, y_raw, out, mi = ctx.saved_tensors
         k, stride, pad, relu, training, has_res = ctx.cfg
         if not training:
@@ -331,6 +346,7 @@ def conv_bn_folded(x, weight, gamma, beta, running_mean, running_var, stride=1, 
     Outside graph capture the folded copies are cached on the weight tensor (keyed by the version counters of the five
     tensors, the weight epoch and the statistics epoch); inside a capture they are recomputed, so that a replay follows
     weights that changed since."""
+    _p = _Args()
     _need_cuda(x, "conv input")
     weight = as_krsc(weight)
     Cout, _, k, _ = weight.shape
@@ -381,6 +397,7 @@ class _ConvBias(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _p = _Args()
         x, weight, y = ctx.saved_tensors
         k, stride, pad, relu, has_bias = ctx.cfg
         g = dy
@@ -475,6 +492,7 @@ def conv_bias_act(x, weight, bias, stride=1, pad=0, relu=False, out_f32=False):
 class _Pool2x(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, window):
+        _p = _Args()
         _need_cuda(x, "pool input")
         N, H, W, C = x.shape
         y = torch.empty((N, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
@@ -486,6 +504,7 @@ class _Pool2x(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _p = _Args()
         (x,) = ctx.saved_tensors
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
@@ -498,6 +517,7 @@ class _Pool2x(torch.autograd.Function):
 class _Pool3s2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
+        _p = _Args()
         _need_cuda(x, "pool input")
         N, H, W, C = x.shape
         y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
@@ -508,6 +528,7 @@ class _Pool3s2(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _p = _Args()
         (x,) = ctx.saved_tensors
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
@@ -535,6 +556,7 @@ def subsample2x(x):
 class _UpsampleAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lat, top):
+        _p = _Args()
         _need_cuda(lat, "upsample_add input")
         N, H, W, C = lat.shape
         assert tuple(top.shape) == (N, H // 2, W // 2, C)
@@ -547,6 +569,7 @@ class _UpsampleAdd(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _p = _Args()
         N, H, W, C = ctx.shape
         dy = dy.contiguous()
         dtop = torch.empty((N, H // 2, W // 2, C), dtype=dy.dtype, device=dy.device)
@@ -563,6 +586,7 @@ def upsample2x_add(lat, top):
 def preprocess(images_u8, mean, std, dtype=None):
     """(N,3,H,W) uint8 -> normalised NHWC with 8 channels (3 real + 5 zero) in the activation dtype of the process
     (set_precision) unless `dtype` says otherwise: this call decides the precision of everything downstream."""
+    _p = _Args()
     _need_cuda(images_u8, "images")
     assert images_u8.dtype == torch.uint8 and images_u8.is_contiguous()
     N, _, H, W = images_u8.shape
@@ -591,6 +615,7 @@ def _pyr_args(feats, scales):
 class _ROIAlign(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rois, scales, out_size, *feats):
+        _p = _Args()
         _need_cuda(rois, "rois")
         C = feats[0].shape[3]
         R = rois.shape[0]
@@ -608,6 +633,7 @@ class _ROIAlign(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        _p = _Args()
         (rois,) = ctx.saved_tensors
         scales, out_size, shapes, dt = ctx.cfg
         C = shapes[0][3]
@@ -657,6 +683,7 @@ def roi_align_pyramid(feats, rois, scales, out_size):
 class _CubeLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dxy, zr, dr, Ra, u, consts, flags):
+        _p = _Args()
         _need_cuda(dxy, "cube head outputs")
         n = dxy.shape[0]
         ins = [t.contiguous().to(f32) for t in (dxy, zr, dr, Ra.reshape(n, 9), u)] + \
@@ -673,6 +700,7 @@ class _CubeLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gl, _gdec):
+        _p = _Args()
         ins, flags = ctx.ins, ctx.flags
         n = ins[0].shape[0]
         dev = ins[0].device
@@ -705,6 +733,7 @@ def prepared_fc_weight(weight, chw=None, dtype=bf16):
     """compute copy of an nn.Linear weight (O, K) f32 in `dtype`, cached per weight epoch on the tensor.  chw = (C,H,W):
     the columns are re-ordered from the checkpoint's (c,h,w) flattening to (h,w,c) for NHWC-flattened RoI features.
     f32 without a permutation: the weight itself."""
+    _p = _Args()
     if dtype == f32 and chw is None:
         return weight.detach()
     attr = "_cr_fccache" if dtype == bf16 else "_cr_fccache32"
@@ -741,6 +770,7 @@ def _bf16_copy(t):
 
 def _fc_transposed32(wp, weight, chw):
     """(K, O) f32 copy of the prepared weight for the backward-data GEMM, cached like the prepared weight"""
+    _p = _Args()
     ent = getattr(weight, "_cr_fcT32", None)
     tag = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr(), chw)
     if ent is None or ent[0] != tag:
@@ -779,6 +809,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _p = _Args()
         xb, wb = ctx.saved_tensors
         weight, bias, chw, xdt = ctx.refs
         lib = _lib.load()
@@ -860,6 +891,7 @@ class _LinearPlain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _p = _Args()
         xc, Wc = ctx.saved_tensors
         O, K = Wc.shape
         R = xc.shape[0]
@@ -886,6 +918,7 @@ class _LinearPlain(torch.autograd.Function):
 # --------------------------------------------------------------------------
 def nms_grouped(boxes, counts, thresh):
     """boxes (G,maxn,4) f32 sorted by descending score per group; counts (G,) int32 -> keep (G,maxn) bool."""
+    _p = _Args()
     _need_cuda(boxes, "boxes")
     G, maxn, _ = boxes.shape
     keep = torch.zeros((G, maxn), dtype=torch.uint8, device=boxes.device)
@@ -912,6 +945,7 @@ def _f4(vals):
 def rpn_decode_select(anchors, deltas, idx, scores, weights, scale_clamp, img_hw, min_size):
     """anchors (A,4), deltas (B,A,4), idx (B,S) int64 (-1 = empty), scores (B,S), img_hw (B,2) ->
     boxes (B,S,4) clipped, nms_boxes (B,S,4) (zero where invalid), valid (B,S) bool."""
+    _p = _Args()
     _need_cuda(deltas, "deltas")
     B, A = deltas.shape[0], anchors.shape[0]
     S = idx.shape[1]
@@ -929,6 +963,7 @@ def rpn_decode_select(anchors, deltas, idx, scores, weights, scale_clamp, img_hw
 def box_match(boxes, gt_boxes, gt_classes, want_best=False):
     """boxes (R,4) or (B,R,4); gt_boxes (B,G,4); gt_classes (B,G) int64 -> max_iou (B,R), argmax (B,R) int32,
     max_ioa (B,R), best (B,G) int64 (packed, see include/cr3dod.h) or None."""
+    _p = _Args()
     _need_cuda(gt_boxes, "gt_boxes")
     B, G = gt_classes.shape
     per_image = boxes.dim() == 3
@@ -945,6 +980,7 @@ def box_match(boxes, gt_boxes, gt_classes, want_best=False):
 
 
 def rpn_label(anchors, gt_boxes, gt_classes, max_iou, best, expo, lo, hi, labels3, eps):
+    _p = _Args()
     B, A = max_iou.shape
     G = gt_classes.shape[1]
     dev = max_iou.device
@@ -962,6 +998,7 @@ def rpn_label(anchors, gt_boxes, gt_classes, max_iou, best, expo, lo, hi, labels
 
 def rpn_scatter(out, pos_idx, pos_key, neg_idx, neg_key, n_s, ioa, ignore_thresh):
     """in place on out (B,A) int32."""
+    _p = _Args()
     B, A = out.shape
     lib = _lib.load()
     _chk(lib.cr_rpn_scatter(_ctx(out), _p(pos_idx.contiguous()), _p(pos_key.contiguous()), pos_idx.shape[1],
@@ -973,6 +1010,7 @@ def rpn_scatter(out, pos_idx, pos_key, neg_idx, neg_key, n_s, ioa, ignore_thresh
 class _RPNLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, deltas, anchors, labels, midx, gt_boxes, weights):
+        _p = _Args()
         B, A = logits.shape
         G = gt_boxes.shape[1]
         dev = logits.device
@@ -1002,6 +1040,7 @@ def rpn_loss(logits, deltas, anchors, labels, midx, gt_boxes, weights):
 
 
 def roi_label(max_iou, argmax, max_ioa, valid, gt_classes, expo, K, thr, ignore_thresh, eps):
+    _p = _Args()
     B, R = max_iou.shape
     dev = max_iou.device
     cls = torch.empty((B, R), dtype=torch.int64, device=dev)
@@ -1016,6 +1055,7 @@ def roi_label(max_iou, argmax, max_ioa, valid, gt_classes, expo, K, thr, ignore_
 
 def roi_compact(fg_idx, fg_key, bg_idx, bg_key, n_s, boxes, cls, argmax):
     """-> boxes (B,n_s,4), valid (B,n_s) bool, classes (B,n_s) int64, gt_idx (B,n_s) int64, counts (B,2) int32."""
+    _p = _Args()
     B, R = cls.shape
     dev = cls.device
     ob = torch.empty((B, n_s, 4), dtype=f32, device=dev)
@@ -1033,6 +1073,7 @@ def roi_compact(fg_idx, fg_key, bg_idx, bg_key, n_s, boxes, cls, argmax):
 class _BoxLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scores, deltas, valid, cls, pboxes, gt_idx, gt_boxes, weights, scale_clamp):
+        _p = _Args()
         B, S = valid.shape
         N, C = scores.shape
         K = C - 1
@@ -1080,6 +1121,7 @@ class _CubeHeadLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, layout, K, cls, valid, gt_idx, kf, gt3d, gtpose, priors, meta, boxes, flags):
+        _p = _Args()
         _need_cuda(raw, "cube head output")
         B, S = cls.shape
         n = B * kf
@@ -1108,6 +1150,7 @@ class _CubeHeadLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gl, g_usel, _gd, _gb, _gv):
+        _p = _Args()
         raw32, buf, validf, clsc, boxes, layout, K, B, kf, flags, dt = ctx.keep
         n = B * kf
         dev = raw32.device
@@ -1138,6 +1181,7 @@ def cube_head_loss(raw, layout, K, cls, valid, gt_idx, kf, gt3d, gtpose, priors,
 
 def cube_decode_infer(raw, layout, K, cls, img, boxes, meta6, priors, allocentric=True):
     """inference decode of the 3D head (no autograd) -> (n,42), see cr_cube_decode_infer."""
+    _p = _Args()
     _need_cuda(raw, "cube head output")
     n = raw.shape[0]
     out = torch.empty((n, 42), dtype=f32, device=raw.device)
@@ -1153,6 +1197,7 @@ def cube_decode_infer(raw, layout, K, cls, img, boxes, meta6, priors, allocentri
 class _CubeReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, L, u_sel, buf, dec, validf, inverse_z):
+        _p = _Args()
         n = L.shape[0]
         dev = L.device
         out = torch.empty((16,), dtype=f32, device=dev)
@@ -1167,6 +1212,7 @@ class _CubeReduce(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gred, _gs):
+        _p = _Args()
         Lc, buf, validf, cnt, inverse_z = ctx.keep
         n = Lc.shape[0]
         gL = torch.empty_like(Lc)
@@ -1186,14 +1232,17 @@ def cube_reduce(L, u_sel, buf, dec, validf, inverse_z=False):
 # optimizer
 # --------------------------------------------------------------------------
 def nonfinite_flag(flat_grad, flag):
+    _p = _Args()
     lib = _lib.load()
     _chk(lib.cr_nonfinite_flag(_ctx(flat_grad), _p(flat_grad), flat_grad.numel(), _p(flag)), "cr_nonfinite_flag")
 
 
-def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None):
+def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None, lr_scale_dev=None):
+    """lr_scale_dev: optional device float; the step uses lr * lr_scale_dev[0] (read on the device -> graph-capturable)"""
+    _p = _Args()
     lib = _lib.load()
-    _chk(lib.cr_sgd_step(_ctx(p), _p(p), _p(g), _p(m), p.numel(), float(lr), float(momentum), float(weight_decay),
-                         float(grad_scale), _p(skip_flag)), "cr_sgd_step")
+    _chk(lib.cr_sgd_step(_ctx(p), _p(p), _p(g), _p(m), p.numel(), float(lr), _p(lr_scale_dev), float(momentum),
+                         float(weight_decay), float(grad_scale), _p(skip_flag)), "cr_sgd_step")
 
 
 # --------------------------------------------------------------------------
@@ -1201,6 +1250,7 @@ def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None
 # --------------------------------------------------------------------------
 def attention(qkv, B, N, H, D, scale):
     """qkv (B*N, 3*H*D) bf16 = output of the qkv linear -> (B*N, H*D) bf16 (cr_attention_fwd)."""
+    _p = _Args()
     _need_cuda(qkv, "attention input")
     assert qkv.dtype == bf16 and qkv.is_contiguous() and qkv.shape == (B * N, 3 * H * D)
     out = torch.empty((B * N, H * D), dtype=bf16, device=qkv.device)
@@ -1209,6 +1259,7 @@ def attention(qkv, B, N, H, D, scale):
 
 
 def layernorm(x, gamma, beta, eps):
+    _p = _Args()
     _need_cuda(x, "layernorm input")
     assert x.dtype == bf16 and x.is_contiguous() and x.dim() == 2
     y = torch.empty_like(x)
@@ -1219,6 +1270,7 @@ def layernorm(x, gamma, beta, eps):
 
 
 def gelu_(x):
+    _p = _Args()
     _need_cuda(x, "gelu input")
     assert x.dtype == bf16 and x.is_contiguous()
     _chk(_lib.load().cr_gelu_inplace(_ctx(x), _p(x), x.numel()), "cr_gelu_inplace")
@@ -1227,6 +1279,7 @@ def gelu_(x):
 
 def scale_residual(x, y, gamma=None):
     """x + gamma * y on (M,C) bf16"""
+    _p = _Args()
     _need_cuda(x, "residual input")
     assert x.dtype == bf16 and y.dtype == bf16 and x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
     out = torch.empty_like(x)
@@ -1237,6 +1290,7 @@ def scale_residual(x, y, gamma=None):
 
 def scale_residual_layernorm(x, y, ls, gamma, beta, eps):
     """(x + ls * y, LayerNorm(x + ls * y)) on (M,C) bf16 in one kernel"""
+    _p = _Args()
     _need_cuda(x, "residual input")
     assert x.dtype == bf16 and y.dtype == bf16 and x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
     xo, ho = torch.empty_like(x), torch.empty_like(x)
@@ -1249,6 +1303,7 @@ def scale_residual_layernorm(x, y, ls, gamma, beta, eps):
 
 def resize_bilinear_ac(x, size):
     """F.interpolate(..., mode='bilinear', align_corners=True) on NHWC bf16"""
+    _p = _Args()
     _need_cuda(x, "resize input")
     assert x.dtype == bf16 and x.is_contiguous() and x.dim() == 4
     B, h, w, C = x.shape

@@ -300,7 +300,8 @@ int cr_weights_prepare(cr_ctx* ctx, const float* src_base, void* dst_base, void*
  * Batched, sync-free forms of cubercnn/modeling/proposal_generator/rpn.py:41-110 (label_and_sample_anchors with
  * ignore regions), :129-273 (losses) and :275-328 (subsample_labels), and of detectron2's Matcher /
  * Box2BoxTransform / find_top_rpn_proposals [third-party] that the reference calls there.  All pointers are device
- * pointers unless marked HOST.  gt classes: >= 0 object, -1 ignore region, -2 padding (G <= 64 per image). */
+ * pointers unless marked HOST.  gt classes: >= 0 object, -1 ignore region, -2 padding; any G >= 1 (the kernels stage the
+ * ground-truth rows through LDS 64 at a time). */
 
 /* decode + clip + validity of the per-level top-k candidates.  idx (B,S) int64 = anchor index (or -1 = empty slot),
  * scores (B,S); weights4 HOST [wx,wy,ww,wh]; img_hw (B,2) = (h,w).  boxes/nms_boxes (B,S,4), valid (B,S) u8. */
@@ -386,9 +387,11 @@ int cr_box3d_overlap(cr_ctx* ctx, const float* boxes1, const float* boxes2, int 
 
 /* ---- optimizer (tools/train_net.py:233-266, cubercnn/solver/build.py:50-56) ------------- */
 int cr_nonfinite_flag(cr_ctx* ctx, const float* g, int64_t n, int* flag);
-/* SGD momentum on flat f32 buffers; skipped on device when *skip_flag != 0 (may be NULL). */
-int cr_sgd_step(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, float momentum,
-                float weight_decay, float grad_scale, const int* skip_flag);
+/* SGD momentum on flat f32 buffers; skipped on device when *skip_flag != 0 (may be NULL).  The learning rate is
+ * lr * (*lr_scale_dev) when lr_scale_dev (a device float: the schedule's current factor, WarmupMultiStepLR of
+ * tools/train_net.py:410-414) is given, so a launch captured in a HIP graph follows the schedule. */
+int cr_sgd_step(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, const float* lr_scale_dev,
+                float momentum, float weight_decay, float grad_scale, const int* skip_flag);
 
 #ifdef __cplusplus
 }

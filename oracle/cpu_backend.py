@@ -206,9 +206,11 @@ def nonfinite_flag(flat_grad, flag):
         flag.fill_(1)
 
 
-def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None):
+def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None, lr_scale_dev=None):
     if skip_flag is not None and int(skip_flag.view(-1)[0]) != 0:
         return
+    if lr_scale_dev is not None:
+        lr = lr * float(lr_scale_dev.view(-1)[0])
     gg = g * grad_scale + weight_decay * p
     m.mul_(momentum).add_(gg)
     p.sub_(lr * m)

@@ -51,6 +51,34 @@ def test_box_match(per_image):
     assert none is None and torch.equal(mi2, mi) and torch.equal(am2, am) and torch.equal(ma2, ma)
 
 
+def test_more_than_64_ground_truth_rows():
+    """crowded images (Hypersim / SUN RGB-D with ignore regions) carry more than 64 ground-truth rows: the matcher and the
+    anchor labeller stage them through LDS in chunks of 64 -- same results as the oracle for G = 150 (objects, ignore
+    regions and padding spread over all three chunks; the forced arg-max anchors of rpn.py:75 included)."""
+    anchors = _anchors()
+    B, G = 2, 150
+    g = torch.Generator().manual_seed(41)
+    ctr = torch.rand(B, G, 2, generator=g) * 256
+    wh = torch.rand(B, G, 2, generator=g) * 100 + 8
+    gtb = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).clamp(0, 256)
+    gtc = torch.randint(0, 5, (B, G), generator=g)
+    gtc[:, ::7] = -1                                 # ignore regions in every chunk
+    gtc[0, 100:] = -2                                # padding: image 0 has 100 rows, image 1 all 150
+    A = anchors.shape[0]
+    mi, am, ma, best = ops.box_match(anchors.to(DEV), gtb.to(DEV), gtc.to(DEV), want_best=True)
+    rmi, ram, rma, rbest = O.box_match(anchors, gtb, gtc, want_best=True)
+    assert torch.equal(mi.cpu(), rmi) and torch.equal(ma.cpu(), rma) and torch.equal(am.cpu(), ram)
+    assert torch.equal(best.cpu(), rbest)
+    assert int(ram.max()) >= 128, "matches land in the third chunk too"
+    expo = torch.empty(2, B, A).exponential_(1.0, generator=g)
+    lab, out, miou, keys = ops.rpn_label(anchors.to(DEV), gtb.to(DEV), gtc.to(DEV), mi, best, expo.to(DEV), 0.3, 0.7,
+                                         [0, -1, 1], 1e-4)
+    rlab, rout, rmiou, rkeys = O.rpn_label(anchors, gtb, gtc, rmi, rbest, expo, 0.3, 0.7, [0, -1, 1], 1e-4)
+    assert torch.equal(lab.cpu(), rlab) and torch.equal(out.cpu(), rout) and torch.equal(miou.cpu(), rmiou)
+    assert torch.allclose(keys.cpu(), rkeys, rtol=1e-6, atol=0)
+    assert int((rout == 1).sum()) > 64, "more forced anchors than one LDS chunk holds"
+
+
 def test_rpn_decode_select():
     anchors = _anchors()
     A, B, S = anchors.shape[0], 2, 700

@@ -327,6 +327,52 @@ def test_whole_step_graph_trains_like_eager():
     assert tg[-1]["total_loss"] < tg[0]["total_loss"]
 
 
+def test_whole_step_graph_run_ahead_lr_schedule_and_gt_overflow():
+    """GraphedTrainStep with the host running ahead of the device (the default: no per-step sync) at the bench's batch
+    size -- the mode that faulted in round 1 (garbage sampling indices from aliased `.contiguous()` temporaries whose
+    pointers were read inline; every wrapper now owns its temporaries until the launch, hipops._Args).  Also: the
+    learning-rate schedule reaches the captured update through a device scalar (lr_scale = 0 freezes the parameters),
+    cached compute copies of the weights follow the graph's updates, and a batch with more ground-truth rows than the
+    captured buffers hold re-captures instead of failing."""
+    bt = importlib.import_module("bench_train")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    ops = importlib.import_module("3dod_amd.hipops")
+    cfg, model, opt, syn, solver = bt.build(DEV, seed=0, lr=0.0025)
+    batches = [syn.make_batch(4, 1234 + i) for i in range(4)]
+    for b in batches:
+        for d in b:
+            d["image"] = d["image"].to(DEV); d["instances"] = d["instances"].to(DEV)
+    with d2.EventStorage(0):
+        step = solver.GraphedTrainStep(cfg, model, opt, batches[0])
+        assert not step.sync_each_step and step.G >= 32
+        for i in range(40):                                   # enqueued back to back: nothing here waits for the device
+            step(batches[i % 4])
+        rep = step.report()                                   # the one sync
+        assert rep["iterations_explode"] == 0 and rep["iterations_success"] == 40
+        assert rep["total_loss"] == rep["total_loss"] and rep["total_loss"] < 50
+        # --- schedule: factor 0 -> the captured update leaves the parameters alone; factor 1 moves them again
+        p0 = opt.flat_p.clone()
+        opt.lr_scale = 0.0
+        step(batches[0]); step(batches[1])
+        # (weight decay and momentum are scaled by the learning rate too: p -= lr * m)
+        assert torch.equal(opt.flat_p, p0), "lr_scale = 0 must freeze the parameters of the captured update"
+        opt.lr_scale = 1.0
+        step(batches[2])
+        assert not torch.equal(opt.flat_p, p0)
+        # --- compute copies of the weights used by eager code after graph steps are current (weight epoch bumped)
+        w = next(p for p in model.backbone.parameters() if p.dim() == 4 and p.shape[1] >= 16)
+        wb, _ = ops.prepared_weights(w, False, torch.bfloat16)
+        assert torch.equal(wb.float().view(-1), w.detach().permute(0, 2, 3, 1).reshape(-1).to(torch.bfloat16).float())
+        # --- more ground-truth rows than the captured buffers hold
+        big = syn.make_batch(4, 99, min_obj=40, max_obj=40)
+        for d in big:
+            d["image"] = d["image"].to(DEV); d["instances"] = d["instances"].to(DEV)
+        step(big)
+        assert step.G >= 40
+        rep = step.report()
+        assert rep["total_loss"] == rep["total_loss"] and rep["iterations_explode"] == 0
+
+
 def test_train_step_comm_protocol_single_rank_group(built):
     """the multi-rank protocol (side stream, RoI-head FC gradients all-reduced while the captured trunk backward runs,
     the rest after backward) exercised on a 1-rank RCCL group: same code path as N > 1, all-reduce = identity."""
@@ -455,7 +501,7 @@ def test_eval_graph_matches_eager_inference(built):
             model.enable_graphs_eval(max_shapes=2)
             small = syn.make_batch(1, 25, size=256, with_gt=False)
             out_small = model(small)
-            assert set(model._graphed_eval_cache) == {(2, 3, 512, 512), (1, 3, 256, 256)}
+            assert {k[0] for k in model._graphed_eval_cache} == {(2, 3, 512, 512), (1, 3, 256, 256)}      # keys: (shape, precision)
             model._graphed_eval_cache.clear()
             eager_small = model(small)                                     # cache empty again -> re-captured; compare with eager
             model._graphed_eval_max = 0
@@ -465,7 +511,7 @@ def test_eval_graph_matches_eager_inference(built):
             assert torch.allclose(out_small[0]["instances"].scores, eager_small[0]["instances"].scores, atol=1e-4)
             model.enable_graphs_eval(max_shapes=2)
             model(small); model(syn.make_batch(1, 26, size=384, with_gt=False)); model(syn.make_batch(1, 27, size=320, with_gt=False))
-            assert list(model._graphed_eval_cache) == [(1, 3, 384, 384), (1, 3, 320, 320)]
+            assert [k[0] for k in model._graphed_eval_cache] == [(1, 3, 384, 384), (1, 3, 320, 320)]
     finally:
         model._graphed_eval = None
         model._graphed_eval_cache, model._graphed_eval_max = None, 0
