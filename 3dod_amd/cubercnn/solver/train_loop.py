@@ -95,7 +95,21 @@ class Checkpointer:
         self.model, self.save_dir, self.optimizer, self.scheduler, self.step_obj = model, save_dir, optimizer, scheduler, step
         self.save_to_disk = save_to_disk
 
+    @staticmethod
+    def _dist():
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
     def save(self, name, **extra):
+        """called by EVERY rank (rank 0 writes): the random-generator states of all ranks are gathered into the file so
+        that a resumed run continues each rank's own sampling stream instead of cloning rank 0's"""
+        rank, world = self._dist()
+        rng = {"cpu": torch.get_rng_state(), "cuda": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else None}
+        rng_by_rank = None
+        if world > 1:
+            rng_by_rank = [None] * world if rank == 0 else None
+            dist.gather_object(rng, rng_by_rank, dst=0)
         if not self.save_dir or not self.save_to_disk:
             return None
         os.makedirs(self.save_dir, exist_ok=True)
@@ -109,8 +123,9 @@ class Checkpointer:
             s = self.step_obj
             data["train_step"] = {"recent_loss": s.recent_loss.cpu(), "iterations_success": s.iterations_success.cpu(),
                                   "iterations_explode": s.iterations_explode.cpu()}
-        data["rng"] = {"cpu": torch.get_rng_state(),
-                       "cuda": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else None}
+        data["rng"] = rng
+        if rng_by_rank is not None:
+            data["rng_by_rank"] = rng_by_rank
         data.update(extra)
         path = os.path.join(self.save_dir, name + ".pth")
         tmp = path + ".tmp"
@@ -128,12 +143,31 @@ class Checkpointer:
             return os.path.join(self.save_dir, f.read().strip())
 
     def load(self, path, checkpointables=None):
-        """checkpointables=[]: the model only (MODEL.WEIGHTS_PRETRAIN, train_net.py:151-154)"""
+        """checkpointables=[]: the model only (MODEL.WEIGHTS_PRETRAIN, train_net.py:151-154).  Keys of the checkpoint that
+        the model does not have and parameters the checkpoint does not cover are LOGGED (as detectron2's checkpointer does,
+        [third-party]); a checkpoint that matches no parameter at all is an error, not a silent random initialisation."""
         if not path:
             return {}
         data = torch.load(path, map_location="cpu", weights_only=True)
         sd = data.pop("model") if "model" in data else data
-        self.model.load_state_dict(sd, strict=False)
+        own = self.model.state_dict()
+        shape_bad = [k for k, v in sd.items() if k in own and hasattr(v, "shape") and tuple(v.shape) != tuple(own[k].shape)]
+        if shape_bad:
+            for k in shape_bad:
+                logger.warning("checkpoint %s: shape of '%s' is %s, the model has %s -- skipped", path, k,
+                               tuple(sd[k].shape), tuple(own[k].shape))
+            sd = {k: v for k, v in sd.items() if k not in shape_bad}
+        res = self.model.load_state_dict(sd, strict=False)
+        self.incompatible = {"missing": list(res.missing_keys), "unexpected": list(res.unexpected_keys)}     # (mis-shaped keys count as missing)
+        if res.missing_keys:
+            logger.warning("checkpoint %s: %d model keys not in the checkpoint (left at their initial values): %s", path,
+                           len(res.missing_keys), ", ".join(res.missing_keys[:20]) + (" ..." if len(res.missing_keys) > 20 else ""))
+        if res.unexpected_keys:
+            logger.warning("checkpoint %s: %d checkpoint keys the model does not have (ignored): %s", path,
+                           len(res.unexpected_keys), ", ".join(res.unexpected_keys[:20]) + (" ..." if len(res.unexpected_keys) > 20 else ""))
+        if len(own) and len(res.missing_keys) >= len(own):
+            raise RuntimeError(f"checkpoint {path} matches none of the model's {len(own)} state-dict keys "
+                               f"(first checkpoint keys: {list(sd)[:5]})")
         want = lambda k: checkpointables is None or k in checkpointables
         dev = next(self.model.parameters()).device
         if want("optimizer") and self.optimizer is not None and "optimizer" in data:
@@ -146,9 +180,20 @@ class Checkpointer:
             s.iterations_success.copy_(t["iterations_success"])
             s.iterations_explode.copy_(t["iterations_explode"])
         if want("rng") and "rng" in data:
-            torch.set_rng_state(data["rng"]["cpu"])
-            if data["rng"]["cuda"] is not None and torch.cuda.is_available():
-                torch.cuda.set_rng_state_all(data["rng"]["cuda"])
+            rank, world = self._dist()
+            by_rank = data.get("rng_by_rank")
+            if by_rank is not None and len(by_rank) == world:
+                mine = by_rank[rank]                   # every rank continues ITS OWN stream
+            else:
+                mine = data["rng"]
+            torch.set_rng_state(mine["cpu"])
+            if mine["cuda"] is not None and torch.cuda.is_available():
+                torch.cuda.set_rng_state_all(mine["cuda"])
+            if (by_rank is None or len(by_rank) != world) and rank > 0:
+                # only rank 0's state is on file (single-rank checkpoint, or another world size): ranks must not share a
+                # stream -- re-seed the others from it, deterministically per rank
+                base = int(torch.initial_seed())
+                torch.manual_seed(base + 7919 * rank)
         return data
 
     def resume_or_load(self, path, resume=True):

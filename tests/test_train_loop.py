@@ -65,3 +65,23 @@ def test_checkpointer_files(tmp_path):
     # rank != 0 writes nothing
     other = solver.Checkpointer(model, str(tmp_path / "r1"), save_to_disk=False)
     assert other.save("x") is None and not (tmp_path / "r1").exists()
+
+
+def test_checkpointer_reports_incompatible_keys(tmp_path, caplog):
+    """a pretrained checkpoint whose keys do not match must not load silently as a random initialisation: missing /
+    unexpected / wrongly shaped keys are logged and recorded, a checkpoint that matches nothing is an error"""
+    import logging
+    model = torch.nn.Sequential(torch.nn.Linear(3, 2), torch.nn.Linear(2, 2))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    part = {"0.weight": sd["0.weight"] + 1.0, "0.bias": torch.zeros(5), "renamed.weight": sd["1.weight"]}
+    torch.save({"model": part}, str(tmp_path / "part.pth"))
+    ck = solver.Checkpointer(model, str(tmp_path))
+    with caplog.at_level(logging.WARNING):
+        ck.load(str(tmp_path / "part.pth"), checkpointables=[])
+    assert torch.equal(model.state_dict()["0.weight"], sd["0.weight"] + 1.0)
+    assert set(ck.incompatible["missing"]) == {"0.bias", "1.weight", "1.bias"} and ck.incompatible["unexpected"] == ["renamed.weight"]
+    text = caplog.text
+    assert "not in the checkpoint" in text and "1.weight" in text and "renamed.weight" in text and "shape of '0.bias'" in text
+    torch.save({"model": {"module." + k: v for k, v in sd.items()}}, str(tmp_path / "none.pth"))
+    with pytest.raises(RuntimeError, match="matches none"):
+        ck.load(str(tmp_path / "none.pth"), checkpointables=[])
