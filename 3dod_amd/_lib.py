@@ -69,6 +69,10 @@ SIGNATURES = {
     "cr_weights_prepare": [P, P, P, P, P, P, c_int, c_int],
     "cr_fc_weight_prepare": [P, P, P, c_int, c_int, c_int, c_int],
     "cr_fc_grad_accum": [P, P, P, c_int, c_int, c_int, c_int],
+    "cr_linear_fwd": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int],
+    "cr_linear_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int],
+    "cr_linear_bwd_weight": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int],
+    "cr_transpose2d": [P, P, P, c_int, c_int, c_int],
     "cr_maxpool3x3s2_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int],
     "cr_maxpool3x3s2_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int],
     "cr_cube_decode_infer": [P, P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, P],

@@ -2049,3 +2049,59 @@ extern "C" int cr_preprocess(cr_ctx* ctx, const unsigned char* img, void* y, int
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Linear layers of the RoI heads (FastRCNNConvFCHead 12544 -> 1024 -> 1024, the box predictors, CubeHead's shared FCs and
+// its fused 13K predictor: cubercnn/modeling/roi_heads/cube_head.py:75,113-149,161-168; roi_heads.py:2160-2204) on the
+// SAME hand-written implicit-GEMM kernels: a linear layer over R rows is a 1x1 convolution over a (1,1,R,K) map, so
+// forward / backward-data run k_conv_igemm(_dma) and the weight gradient k_conv_wgrad(_f32) -- no library GEMM.
+//   x (R,K), w (O,K), wt (K,O) in the activations' type (bf16 or f32 by act_f32); bias / dw / dbias f32.
+// ---------------------------------------------------------------------------
+extern "C" int cr_linear_fwd(cr_ctx* ctx, const void* x, const void* w, const float* bias, void* y, int R, int K, int O,
+                             int relu, int out_f32, int act_f32) {
+    CR_CHECK_ARG(R >= 0, "cr_linear_fwd: bad row count");
+    if (R == 0) return CR_OK;
+    return cr_conv2d_fwd(ctx, x, w, y, 1, 1, R, K, O, 1, 1, 0, bias, nullptr, relu, nullptr, out_f32, act_f32);
+}
+
+extern "C" int cr_linear_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int R, int K, int O, int act_f32) {
+    CR_CHECK_ARG(R >= 0, "cr_linear_bwd_data: bad row count");
+    if (R == 0) return CR_OK;
+    return cr_conv2d_bwd_data(ctx, dy, wt, dx, 1, 1, R, K, O, 1, 1, 0, act_f32);
+}
+
+// dw (O,K) f32 (+)= dy^T x ; dbias (O) += column sums of dy when given (from the dy tiles the kernel stages anyway)
+extern "C" int cr_linear_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int R, int K, int O,
+                                    int accumulate, int act_f32) {
+    CR_CHECK_ARG(R > 0, "cr_linear_bwd_weight: bad row count");
+    return conv2d_bwd_weight_impl(ctx, dy, x, dw, dbias, 1, 1, R, K, O, 1, 1, 0, accumulate, act_f32);
+}
+
+// dst (cols, rows) = src (rows, cols)^T, 2- or 4-byte elements: the (K,O) operand of cr_linear_bwd_data from a prepared
+// (O,K) weight.  32x32 tiles through LDS, both sides coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void k_transpose2d(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols) {
+    __shared__ T tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * i][tx] = src[(size_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+extern "C" int cr_transpose2d(cr_ctx* ctx, const void* src, void* dst, int rows, int cols, int act_f32) {
+    CR_CHECK_ARG(ctx && src && dst && rows > 0 && cols > 0, "cr_transpose2d: bad args");
+    const dim3 grid((unsigned)cr_cdiv(cols, 32), (unsigned)cr_cdiv(rows, 32));
+    if (act_f32) hipLaunchKernelGGL(k_transpose2d<float>, grid, dim3(256), 0, ctx->stream, (const float*)src, (float*)dst, rows, cols);
+    else hipLaunchKernelGGL(k_transpose2d<u16>, grid, dim3(256), 0, ctx->stream, (const u16*)src, (u16*)dst, rows, cols);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

@@ -725,137 +725,143 @@ def cube_decode_loss(dxy, zr, dr, Ra, u, src_boxes, K4, v2r, prior_mean, gt2d, g
 
 
 # --------------------------------------------------------------------------
-# FC layers of the RoI heads.  f32 mode: the implicit-GEMM kernels themselves (a linear layer is a 1x1 convolution over
-# an (1,1,rows,K) map: cr_conv2d_fwd / _bwd_data / _bwd_weight on the f32 MFMA).  bf16 mode: library GEMMs (hipBLASLt
-# through torch.mm) around own weight-prep / gradient kernels.
+# FC layers of the RoI heads on the hand-written implicit-GEMM kernels (cr_linear_*: a linear layer over R rows is a 1x1
+# convolution over a (1,1,R,K) map), in both precision modes -- no library GEMM on the path.
 # --------------------------------------------------------------------------
-def prepared_fc_weight(weight, chw=None, dtype=bf16):
-    """compute copy of an nn.Linear weight (O, K) f32 in `dtype`, cached per weight epoch on the tensor.  chw = (C,H,W):
-    the columns are re-ordered from the checkpoint's (c,h,w) flattening to (h,w,c) for NHWC-flattened RoI features.
-    f32 without a permutation: the weight itself."""
+def prepared_fc_weight(weight, chw=None, dtype=bf16, need_transposed=False):
+    """compute copies of an nn.Linear weight (O, K) f32 in `dtype`, cached per weight epoch on the tensor:
+    wp (O,K) and, when asked, wt (K,O) for the backward-data GEMM.  chw = (C,H,W): the columns are re-ordered from the
+    checkpoint's (c,h,w) flattening to (h,w,c) for NHWC-flattened RoI features.  f32 without a permutation: wp is the
+    weight itself."""
     _p = _Args()
-    if dtype == f32 and chw is None:
-        return weight.detach()
     attr = "_cr_fccache" if dtype == bf16 else "_cr_fccache32"
     ent = getattr(weight, attr, None)
     tag = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr(), chw)
+    lib = _lib.load()
+    O, K = weight.shape
     if ent is None or ent[0] != tag:
-        O, K = weight.shape
-        C, HW = (chw[0], chw[1] * chw[2]) if chw is not None else (K, 1)
-        assert C * HW == K
-        wb = torch.empty((O, K), dtype=dtype, device=weight.device)
-        lib = _lib.load()
-        wd = weight.detach().contiguous()
-        _chk(lib.cr_fc_weight_prepare(_ctx(weight), _p(wd), _p(wb), O, C, HW, int(dtype == f32)), "cr_fc_weight_prepare")
-        ent = (tag, wb)
+        if dtype == f32 and chw is None:
+            wp = weight.detach()
+        else:
+            C, HW = (chw[0], chw[1] * chw[2]) if chw is not None else (K, 1)
+            assert C * HW == K
+            wp = torch.empty((O, K), dtype=dtype, device=weight.device)
+            _chk(lib.cr_fc_weight_prepare(_ctx(weight), _p(weight.detach().contiguous()), _p(wp), O, C, HW, int(dtype == f32)),
+                 "cr_fc_weight_prepare")
+        ent = [tag, wp, None]
         try:
             setattr(weight, attr, ent)
         except Exception:
             pass
-    return ent[1]
+    if need_transposed and ent[2] is None:
+        wt = torch.empty((K, O), dtype=dtype, device=weight.device)
+        _chk(lib.cr_transpose2d(_ctx(weight), _p(ent[1].contiguous()), _p(wt), O, K, int(dtype == f32)), "cr_transpose2d")
+        ent[2] = wt
+    return (ent[1], ent[2]) if need_transposed else ent[1]
 
 
-def _bf16_copy(t):
-    """bf16 copy of a small f32 parameter (bias), cached on the tensor per version / weight epoch like the weights"""
-    ent = getattr(t, "_cr_b16", None)
-    tag = (t._version, _WEIGHT_EPOCH[0], t.data_ptr())
-    if ent is None or ent[0] != tag:
-        ent = (tag, t.detach().to(bf16))
-        try:
-            t._cr_b16 = ent
-        except Exception:
-            pass
-    return ent[1]
+def _act_cast(t, dtype):
+    """f32 tensor -> the activation dtype (own cast kernel for bf16; no copy for f32)"""
+    if t.dtype == dtype:
+        return t.contiguous()
+    if dtype == bf16 and t.dtype == f32:
+        _p = _Args()
+        tc = t.contiguous()
+        out = torch.empty(tc.shape, dtype=bf16, device=t.device)
+        _chk(_lib.load().cr_cast_f32_to_bf16(_ctx(t), _p(tc), _p(out), tc.numel()), "cr_cast_f32_to_bf16")
+        return out
+    return t.to(dtype).contiguous()
 
 
-def _fc_transposed32(wp, weight, chw):
-    """(K, O) f32 copy of the prepared weight for the backward-data GEMM, cached like the prepared weight"""
+def linear_fwd_raw(x, w, bias, out_f32=False, relu=False):
+    """y (R,O) = x (R,K) @ w (O,K)^T + bias on the MFMA; x / w in the same activation dtype, bias f32 or None"""
     _p = _Args()
-    ent = getattr(weight, "_cr_fcT32", None)
-    tag = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr(), chw)
-    if ent is None or ent[0] != tag:
-        O, K = wp.shape
-        wt = torch.empty((K, O), dtype=f32, device=wp.device)
-        _chk(_lib.load().cr_weight_transpose(_ctx(wp), _p(wp), _p(wt), O, 1, K, 1), "cr_weight_transpose")
-        ent = (tag, wt)
-        try:
-            weight._cr_fcT32 = ent
-        except Exception:
-            pass
-    return ent[1]
+    af = _af(x)
+    R, K = x.shape
+    O = w.shape[0]
+    if O % 16 or K % 16:
+        raise _lib.CrError(f"linear: the GEMM kernels need O and K multiples of 16 (got {O}x{K}); use linear_cat for predictors")
+    assert w.dtype == x.dtype and x.is_contiguous() and w.is_contiguous()
+    y = torch.empty((R, O), dtype=f32 if (out_f32 or af) else bf16, device=x.device)
+    _chk(_lib.load().cr_linear_fwd(_ctx(x), _p(x), _p(w), _p(bias), _p(y), R, K, O, int(relu), int(out_f32), af), "cr_linear_fwd")
+    return y
+
+
+def linear_bwd_data_raw(dy, wt):
+    _p = _Args()
+    R, O = dy.shape
+    K = wt.shape[0]
+    assert wt.dtype == dy.dtype and dy.is_contiguous() and wt.is_contiguous()
+    dx = torch.empty((R, K), dtype=dy.dtype, device=dy.device)
+    _chk(_lib.load().cr_linear_bwd_data(_ctx(dy), _p(dy), _p(wt), _p(dx), R, K, O, _af(dy)), "cr_linear_bwd_data")
+    return dx
+
+
+def linear_bwd_weight_raw(dy, x, dw, dbias, accumulate):
+    """dw (O,K) f32 (+)= dy^T x; dbias (O) f32 += column sums of dy (None: not wanted)"""
+    _p = _Args()
+    R, O = dy.shape
+    K = x.shape[1]
+    assert dy.dtype == x.dtype and dy.is_contiguous() and x.is_contiguous() and dw.dtype == f32
+    _chk(_lib.load().cr_linear_bwd_weight(_ctx(dy), _p(dy), _p(x), _p(dw), _p(dbias), R, K, O, int(accumulate), _af(x)),
+         "cr_linear_bwd_weight")
 
 
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, chw):
         _need_cuda(x, "linear input")
-        if x.dtype == f32:
-            O, K = weight.shape
-            if O % 16 or K % 16:
-                raise _lib.CrError(f"linear: f32 GEMM needs O and K multiples of 16 (got {O}x{K}); use linear_padded")
-            wp = prepared_fc_weight(weight, chw, f32)
-            xc = x.contiguous()
-            y = conv_fwd_raw(xc.view(1, 1, xc.shape[0], K), wp, O, 1, 1, 0,
-                             bias=None if bias is None else bias.detach()).view(xc.shape[0], O)
-            ctx.save_for_backward(xc, wp)
-            ctx.refs = (weight, bias, chw, f32)
-            return y
-        wb = prepared_fc_weight(weight, chw)
-        xb = x.to(bf16)
-        y = torch.addmm(_bf16_copy(bias), xb, wb.t()) if bias is not None else torch.mm(xb, wb.t())
-        ctx.save_for_backward(xb, wb)
-        ctx.refs = (weight, bias, chw, x.dtype)
+        dt = x.dtype
+        wp = prepared_fc_weight(weight, chw, dt)
+        xc = x.contiguous()
+        y = linear_fwd_raw(xc, wp, None if bias is None else bias.detach())
+        ctx.save_for_backward(xc)
+        ctx.refs = (weight, bias, chw)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         _p = _Args()
-        xb, wb = ctx.saved_tensors
-        weight, bias, chw, xdt = ctx.refs
+        (xc,) = ctx.saved_tensors
+        weight, bias, chw = ctx.refs
+        dt = xc.dtype
         lib = _lib.load()
         O, K = weight.shape
         C, HW = (chw[0], chw[1] * chw[2]) if chw is not None else (K, 1)
-        is32 = xb.dtype == f32
-        dy = dy.to(xb.dtype).contiguous()
-        R = dy.shape[0]
+        dy = _act_cast(dy, dt)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if is32:
-                wt = _fc_transposed32(wb, weight, chw)
-                dx = conv_bwd_data_raw(dy.view(1, 1, R, O), wt, (1, 1, R, K), 1, 1, 0).view(R, K)
-            else:
-                dx = torch.mm(dy, wb).to(xdt)
+            _, wt = prepared_fc_weight(weight, chw, dt, need_transposed=True)
+            dx = linear_bwd_data_raw(dy, wt)
+        want_db = bias is not None and ctx.needs_input_grad[2]
+        bacc = None
+        if want_db:
+            bacc = grad_sink(bias)
+            if bacc is None:
+                bacc = torch.zeros((O,), dtype=f32, device=dy.device)
+                db = bacc
         if ctx.needs_input_grad[1]:
             acc = grad_sink(weight)
-            if is32 and HW == 1 and acc is not None:
-                # the weight gradient lands in the flat gradient straight from the GEMM's epilogue
-                _chk(lib.cr_conv2d_bwd_weight(_ctx(dy), _p(dy), _p(xb), _p(acc), 1, 1, R, K, O, 1, 1, 0, 1, 1),
-                     "cr_conv2d_bwd_weight")
+            if HW == 1 and acc is not None:
+                # weight AND bias gradients land in the flat gradient straight from the GEMM
+                linear_bwd_weight_raw(dy, xc, acc, bacc, accumulate=True)
             else:
-                if is32:
-                    g = torch.empty((O, K), dtype=f32, device=dy.device)
-                    _chk(lib.cr_conv2d_bwd_weight(_ctx(dy), _p(dy), _p(xb), _p(g), 1, 1, R, K, O, 1, 1, 0, 0, 1),
-                         "cr_conv2d_bwd_weight")
-                else:
-                    g = torch.mm(dy.t(), xb)                           # (O, K) bf16 in the compute (h,w,c) order
+                g = torch.empty((O, K), dtype=f32, device=dy.device)     # in the compute (h,w,c) column order
+                linear_bwd_weight_raw(dy, xc, g, bacc, accumulate=False)
                 if acc is None:
                     acc = torch.zeros((O, K), dtype=f32, device=dy.device)
                     dw = acc
-                _chk(lib.cr_fc_grad_accum(_ctx(dy), _p(g), _p(acc), O, C, HW, int(is32)), "cr_fc_grad_accum")
-        if bias is not None and ctx.needs_input_grad[2]:
-            acc = grad_sink(bias)
-            if acc is None:
-                acc = torch.zeros((O,), dtype=f32, device=dy.device)
-                db = acc
+                _chk(lib.cr_fc_grad_accum(_ctx(dy), _p(g), _p(acc), O, C, HW, 1), "cr_fc_grad_accum")
+        elif want_db:
             ws = torch.empty((1024, O), dtype=f32, device=dy.device)
-            _chk(lib.cr_colsum_accum(_ctx(dy), _p(dy), int(is32), R, O, _p(ws), _p(acc)), "cr_colsum_accum")
+            _chk(lib.cr_colsum_accum(_ctx(dy), _p(dy), int(dt == f32), dy.shape[0], O, _p(ws), _p(bacc)), "cr_colsum_accum")
         return dx, dw, db, None
 
 
 def linear(x, weight, bias=None, chw=None):
-    """F.linear on the MFMA in x's precision with the weight copy cached per optimizer step and the gradients accumulated
-    straight into the optimizer's flat gradient (when the parameters carry sinks).  chw: see prepared_fc_weight.
-    f32 needs O % 16 == 0 (see linear_cat for predictors with odd widths)."""
+    """F.linear on the MFMA in x's precision (own implicit-GEMM kernels) with the weight copies cached per optimizer step
+    and the gradients accumulated straight into the optimizer's flat gradient (when the parameters carry sinks).
+    chw: see prepared_fc_weight.  Needs O % 16 == 0 (see linear_cat for predictors with odd widths)."""
     return _Linear.apply(x, weight, bias, chw)
 
 
@@ -872,20 +878,17 @@ def linear_cat(x, weights, biases):
     offs = [0]
     for n in sizes:
         offs.append(offs[-1] + n)
-    if x.dtype == f32:
-        y = _LinearPlain.apply(x, W, b)
-    else:
-        y = torch.nn.functional.linear(x, W.to(x.dtype), b.to(x.dtype)).float()
-    return y, offs
+    return _LinearPlain.apply(x, W, b), offs
 
 
 class _LinearPlain(torch.autograd.Function):
-    """f32 GEMM with the weight passed as a tensor in the graph (linear_cat's stacked predictor weights)."""
+    """GEMM with the (f32) weight passed as a tensor in the graph (linear_cat's stacked predictor weights); f32 output"""
     @staticmethod
     def forward(ctx, x, W, b):
-        O, K = W.shape
-        xc, Wc = x.contiguous(), W.contiguous()
-        y = conv_fwd_raw(xc.view(1, 1, xc.shape[0], K), Wc, O, 1, 1, 0, bias=b.contiguous()).view(xc.shape[0], O)
+        dt = x.dtype
+        xc = x.contiguous()
+        Wc = _act_cast(W.detach(), dt)
+        y = linear_fwd_raw(xc, Wc, b.detach().contiguous(), out_f32=True)
         ctx.save_for_backward(xc, Wc)
         return y
 
@@ -893,23 +896,22 @@ class _LinearPlain(torch.autograd.Function):
     def backward(ctx, dy):
         _p = _Args()
         xc, Wc = ctx.saved_tensors
+        dt = xc.dtype
         O, K = Wc.shape
-        R = xc.shape[0]
-        dy = dy.contiguous()
-        lib = _lib.load()
+        dy = _act_cast(dy, dt)
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            wt = torch.empty((K, O), dtype=f32, device=Wc.device)
-            _chk(lib.cr_weight_transpose(_ctx(Wc), _p(Wc), _p(wt), O, 1, K, 1), "cr_weight_transpose")
-            dx = conv_bwd_data_raw(dy.view(1, 1, R, O), wt, (1, 1, R, K), 1, 1, 0).view(R, K)
-        if ctx.needs_input_grad[1]:
-            dW = torch.empty((O, K), dtype=f32, device=dy.device)
-            _chk(lib.cr_conv2d_bwd_weight(_ctx(dy), _p(dy), _p(xc), _p(dW), 1, 1, R, K, O, 1, 1, 0, 0, 1),
-                 "cr_conv2d_bwd_weight")
+            wt = torch.empty((K, O), dtype=dt, device=Wc.device)
+            _chk(_lib.load().cr_transpose2d(_ctx(Wc), _p(Wc), _p(wt), O, K, int(dt == f32)), "cr_transpose2d")
+            dx = linear_bwd_data_raw(dy, wt)
         if ctx.needs_input_grad[2]:
             db = torch.zeros((O,), dtype=f32, device=dy.device)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty((O, K), dtype=f32, device=dy.device)
+            linear_bwd_weight_raw(dy, xc, dW, db, accumulate=False)
+        elif db is not None:
             ws = torch.empty((1024, O), dtype=f32, device=dy.device)
-            _chk(lib.cr_colsum_accum(_ctx(dy), _p(dy), 1, R, O, _p(ws), _p(db)), "cr_colsum_accum")
+            _chk(_lib.load().cr_colsum_accum(_ctx(dy), _p(dy), int(dt == f32), dy.shape[0], O, _p(ws), _p(db)), "cr_colsum_accum")
         return dx, dW, db
 
 

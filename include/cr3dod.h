@@ -286,6 +286,20 @@ int cr_maxpool3x3s2_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, in
 int cr_fc_weight_prepare(cr_ctx* ctx, const float* w, void* wb, int O, int C, int HW, int act_f32);
 int cr_fc_grad_accum(cr_ctx* ctx, const void* g, float* acc, int O, int C, int HW, int act_f32);
 
+/* Linear layers of the RoI heads on the hand-written implicit-GEMM kernels (a linear layer over R rows = a 1x1 convolution
+ * over a (1,1,R,K) map): replaces nn.Linear / F.linear of FastRCNNConvFCHead + FastRCNNOutputLayers [detectron2, wired at
+ * cubercnn/modeling/roi_heads/roi_heads.py:2160-2204] and of CubeHead (cubercnn/modeling/roi_heads/cube_head.py:75,113-149,
+ * 161-168; the five predictors run as ONE GEMM over stacked weights).  x (R,K), w (O,K), wt (K,O), y / dy (R,O), dx (R,K) in
+ * the activations' type (act_f32); bias, dw (O,K), dbias (O) float32.  K and O multiples of 16; K a multiple of 8.
+ * cr_linear_bwd_weight: dw (+)= dy^T x (accumulate = 0 zeroes dw first), dbias += column sums of dy when non-NULL.
+ * cr_transpose2d: dst (cols,rows) = src (rows,cols)^T for 2-byte (act_f32 = 0) or 4-byte elements: makes wt from w. */
+int cr_linear_fwd(cr_ctx* ctx, const void* x, const void* w, const float* bias, void* y, int R, int K, int O, int relu,
+                  int out_f32, int act_f32);
+int cr_linear_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int R, int K, int O, int act_f32);
+int cr_linear_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int R, int K, int O,
+                         int accumulate, int act_f32);
+int cr_transpose2d(cr_ctx* ctx, const void* src, void* dst, int rows, int cols, int act_f32);
+
 /* multi-tensor form of cr_cast_f32_to_bf16 + cr_weight_transpose: every conv weight of the model in one launch.
  * descs_dev: device array of cr_wdesc (offsets in ELEMENTS from the three base pointers); tiles_dev: device array of
  * ntiles int4 = (tensor index, filter tap, first cout, first cin) covering each tensor in 32x32 (cout x cin) tiles. */

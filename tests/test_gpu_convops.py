@@ -287,14 +287,15 @@ def test_maxpool3x3s2(hw):
     assert torch.equal(nchw(xd.grad).float().cpu() != 0, xo.grad != 0)       # same routing
 
 
-@pytest.mark.parametrize("chw", [None, (24, 7, 7), (70, 3, 5)])
+@pytest.mark.parametrize("chw", [None, (32, 7, 7), (80, 3, 5)])
 def test_linear_fc(chw):
-    """ops.linear: cached bf16 weight copy (with the (c,h,w)->(h,w,c) column re-ordering of the first RoI-head FC), library
-    GEMMs, gradients through cr_fc_grad_accum / cr_colsum_accum -- against F.linear on the re-ordered weight."""
+    """ops.linear in the bf16 mode: cached bf16 weight copy (with the (c,h,w)->(h,w,c) column re-ordering of the first
+    RoI-head FC), the implicit-GEMM kernels as a plain GEMM (cr_linear_*), weight / bias gradients from the GEMM's own
+    epilogue -- against F.linear on the re-ordered weight."""
     from oracle import cpu_backend as O
     g = torch.Generator().manual_seed(17)
     K = 96 if chw is None else chw[0] * chw[1] * chw[2]
-    n, Odim = 50, 40
+    n, Odim = 50, 48
     x, w, b = q(torch.randn(n, K, generator=g)), q(torch.randn(Odim, K, generator=g) * 0.1), q(torch.randn(Odim, generator=g))
     dy = q(torch.randn(n, Odim, generator=g))
     xo, wo, bo = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
