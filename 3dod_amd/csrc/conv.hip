@@ -49,6 +49,11 @@ struct ConvP {
     unsigned x_bytes, w_bytes;   // extents for the buffer-load descriptors (out-of-range voffset reads 0)
     int xcd;                     // 1 = XCD-aware tile order
     int f32;                     // 1 = f32 operands / outputs (host-side dispatch only)
+    // split-K over workgroups (k_conv_igemm_dma): ksplit > 1 -> block (tile, s) accumulates k stages [s*kstages, ...) and
+    // stores its raw f32 accumulators to part[s][M][Cout]; k_splitk_epilogue sums them in a fixed order and applies the
+    // epilogue (bias, BN statistics, residual, ReLU)
+    float* part;
+    int ksplit, kstages;
 };
 
 // LDS image of a [rows][32] bf16 tile (64-B rows, four 16-B chunks): chunk' = chunk ^ ((-(row>>2)) & 3)
@@ -441,7 +446,9 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
     static_assert(4 * 2 * BN * sizeof(float) <= 2 * STAGE * sizeof(u16), "sStat must fit");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = p.Cout / BN;
-    const int bid = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int tiles_total = (int)gridDim.x / p.ksplit;                      // ksplit == 1: the whole grid
+    const int ks = (int)blockIdx.x / tiles_total, bt = (int)blockIdx.x - ks * tiles_total;
+    const int bid = (p.xcd && (p.ksplit == 1 || (tiles_total & 7) == 0)) ? xcd_swizzle(bt, tiles_total) : bt;
     const int nt = bid % n_tiles, mt = bid / n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -471,7 +478,8 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
 #pragma unroll
     for (int i = 0; i < NBW; ++i) wrow[i] = (unsigned)((n0 + (tid >> 2) + 64 * i) * p.Kdim) * (unsigned)ES + csrc[i];
 
-    const int nstage = p.Kdim / BK;
+    const int nstage_all = p.Kdim / BK;
+    const int st0 = ks * p.kstages, st1 = min(st0 + p.kstages, nstage_all);  // this block's k stages (all of them when ksplit == 1)
     int cur_tap = -1;
     unsigned tb[2] = {OOB, OOB};                     // byte offset of (pixel row i, current filter tap, this lane's chunk) or OOB
     auto issue = [&](int st, int buf) {
@@ -521,10 +529,10 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
 #pragma unroll
     for (int i = 0; i < TC; ++i) wa[i] = (unsigned)lds_off(coff + i * 16 + fr, fc) * 2u;
 
-    issue(0, 0);
-    for (int st = 0; st < nstage; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nstage) {
+    issue(st0, 0);
+    for (int st = st0; st < st1; ++st) {
+        const int buf = (st - st0) & 1;
+        if (st + 1 < st1) {
             issue(st + 1, buf ^ 1);
             if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage st has landed (this wave's DMAs)
             else           asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -549,7 +557,86 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // everyone is done with `buf` before stage st+2 refills it
     }
+    if (p.ksplit > 1) {
+        // raw partial sums of this k range: part[ks][m][ch], 4 consecutive channels per lane (16-B stores)
+        const int g = lane >> 4, pl = lane & 15;
+        float* dst = p.part + (size_t)ks * p.M * p.Cout;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int m = m0 + poff + j * 16 + pl;
+                if (m < p.M)
+                    *reinterpret_cast<float4*>(dst + (size_t)m * p.Cout + n0 + coff + i * 16 + 4 * g) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        return;
+    }
     conv_epilogue<BM, BN, TC, TP, T, T>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt, poff, coff, tid, lane, wave, true);
+}
+
+// second phase of the split-K launches: out[m][c] = epilogue( sum_s part[s][m][c] ), the sum in a fixed order (bitwise
+// reproducible), the epilogue as conv_epilogue's: bias, BatchNorm statistics of the pre-residual value (one row of partial
+// sums per 64 pixels), residual, ReLU.  A block = 64 pixels x 64 channels; a thread = 4 pixels x 4 channels.
+template <typename T>
+__global__ __launch_bounds__(256) void k_splitk_epilogue(ConvP p) {
+    __shared__ float sS[16][2][64];
+    const int tid = threadIdx.x, cg4 = tid & 15, pr = tid >> 4;
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64 + cg4 * 4;
+    const size_t MC = (size_t)p.M * p.Cout;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b4[e] = p.bias[c0 + e];
+    }
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + pr + 16 * q;
+        if (m >= p.M) continue;
+        const size_t o = (size_t)m * p.Cout + c0;
+        float4 a = *reinterpret_cast<const float4*>(p.part + o);
+        for (int s2 = 1; s2 < p.ksplit; ++s2) {
+            const float4 t = *reinterpret_cast<const float4*>(p.part + (size_t)s2 * MC + o);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        float v[4] = {a.x + b4[0], a.y + b4[1], a.z + b4[2], a.w + b4[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+        if (p.res) {
+            if constexpr (sizeof(T) == 2) {
+                const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(p.res) + o);
+                v[0] += bf2f((u16)(rr.x & 0xffff)); v[1] += bf2f((u16)(rr.x >> 16));
+                v[2] += bf2f((u16)(rr.y & 0xffff)); v[3] += bf2f((u16)(rr.y >> 16));
+            } else {
+                const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + o);
+                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint2 pk;
+            pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(p.y) + o) = pk;
+        }
+    }
+    if (p.stats == nullptr) return;                      // block-uniform
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sS[pr][0][cg4 * 4 + e] = ssum[e]; sS[pr][1][cg4 * 4 + e] = ssq[e]; }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += sS[r][which][c];      // fixed order
+        p.stats[((size_t)blockIdx.x * 2 + which) * p.Cout + blockIdx.y * 64 + c] = a;
+    }
 }
 
 
@@ -583,7 +670,7 @@ static int xcd_enabled() {
 
 // literal template arguments from a plain function (the launch from inside a function template left the host stubs undefined)
 static void launch_dma_kernel(int bn, int ks, int mode, hipStream_t stream, const ConvP& p) {
-    const dim3 grid((unsigned)(cr_cdiv(p.M, 128) * (p.Cout / bn))), block(CONV_T);
+    const dim3 grid((unsigned)(cr_cdiv(p.M, 128) * (p.Cout / bn) * p.ksplit)), block(CONV_T);
 #define CR_DMA_CASE(B, K, M_) if (bn == B && ks == K && mode == M_) { \
         if (p.f32) hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_, float>), grid, block, 0, stream, p); \
         else hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_, u16>), grid, block, 0, stream, p); \
@@ -608,6 +695,33 @@ static bool try_launch_dma(cr_ctx* ctx, const ConvP& p, int out_f32, int* rc) {
         if ((!p.f32 && out_f32) || !dma_enabled() || (p.Cin & (p.f32 ? 31 : 63)) != 0 || p.Cout % 64 != 0) return false;
         static const int min_tiles = env_int("CR_CONV_DMA_MIN_TILES", 128), force_bn = env_int("CR_CONV_DMA_BN", 0);
         const int64_t big_tiles = cr_cdiv(p.M, 128) * (p.Cout >= 128 ? p.Cout / 128 : 1);
+        static const int splitk_on = env_int("CR_CONV_SPLITK", 1);
+        if (p.f32 && splitk_on && big_tiles < 192 && ctx->ws && (p.Kdim >= 2048 || (KS == 3 && p.Kdim >= 1152))) {
+            // f32 mode, few big tiles: the small-tile kernels are L2-bandwidth bound there (a 64 x 32 tile moves 0.094 B
+            // per flop = 14.7 TB/s at the f32 MFMA peak, a 128 x 128 tile 0.031), so keep 128-wide tiles and split K over
+            // workgroups until every CU has one; partial sums go to the ctx workspace, k_splitk_epilogue finishes
+            const int bn2 = p.Cout % 128 == 0 ? 128 : 64;
+            const int64_t tiles = cr_cdiv(p.M, 128) * (p.Cout / bn2);
+            const int nstage_all = p.Kdim / 32;
+            int S = (int)cr_cdiv(256, tiles);
+            if (S > nstage_all / 4) S = nstage_all / 4;                      // >= 4 stages (128 of k) per block
+            if (S > 16) S = 16;
+            const int64_t cap = (int64_t)(ctx->ws_bytes / ((size_t)p.M * p.Cout * sizeof(float)));
+            if (S > cap) S = (int)cap;
+            if (S >= 2) {
+                ConvP q = p;
+                q.kstages = (int)cr_cdiv(nstage_all, S);
+                q.ksplit = (int)cr_cdiv(nstage_all, q.kstages);
+                q.part = (float*)ctx->ws;
+                launch_dma_kernel(bn2, KS, MODE, ctx->stream, q);
+                const dim3 g2((unsigned)cr_cdiv(p.M, 64), (unsigned)(p.Cout / 64));
+                hipLaunchKernelGGL(k_splitk_epilogue<float>, g2, dim3(256), 0, ctx->stream, q);
+                hipError_t e2 = hipGetLastError();
+                if (e2 != hipSuccess) { cr_set_error("split-K conv launch failed: %s", hipGetErrorString(e2)); *rc = CR_EHIP; }
+                else *rc = CR_OK;
+                return true;
+            }
+        }
         if (big_tiles < min_tiles) return false;             // small grids keep the 64x64 / split-K kernels
         int bn = p.Cout % 128 == 0 ? 128 : 64;
         if (force_bn == 64 || (force_bn == 0 && bn == 128 && big_tiles < 512)) bn = 64;   // more workgroups on mid-size maps
@@ -695,6 +809,7 @@ extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y,
     p.Wout = (W + 2 * pad - ks) / stride + 1;
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = N * p.Hout * p.Wout;
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cin); p.relu = relu; p.xcd = xcd_enabled(); p.f32 = act_f32 ? 1 : 0;
+    p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim;
     p.x_bytes = (unsigned)((size_t)N * H * W * Cin * es); p.w_bytes = (unsigned)((size_t)Cout * p.Kdim * es);
     if (act_f32) out_f32 = 1;
     if (ks == 1) return launch_igemm_ks<1, 0>(ctx, p, out_f32);
@@ -718,6 +833,7 @@ extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, v
     p.Hout = H; p.Wout = W; p.Cout = Cin;               // GEMM output = dX
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cout; p.M = N * H * W;
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cout); p.relu = 0; p.xcd = xcd_enabled(); p.f32 = act_f32 ? 1 : 0;
+    p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim;
     p.x_bytes = (unsigned)((size_t)N * Ho * Wo * Cout * es); p.w_bytes = (unsigned)((size_t)Cin * p.Kdim * es);
     if (ks == 1) return launch_igemm_ks<1, 1>(ctx, p, act_f32 ? 1 : 0);
     if (ks == 3) return launch_igemm_ks<3, 1>(ctx, p, act_f32 ? 1 : 0);
@@ -1123,11 +1239,14 @@ static int launch_wgrad_f32_ks(cr_ctx* ctx, WgP& p) {
     const int TM = p.Cout >= 128 ? 128 : (p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16));
     const int tm = (int)cr_cdiv(p.Cout, TM);
     const int tiles = tm * tn;
-    // split the pixel range so that ~3 blocks per CU are resident, every block keeping >= 8 stages (256 pixels) of MFMA
-    // work to hide its atomics behind
+    // Split the pixel range over blocks.  Measured on the 3x3 256->256 layers (scripts/wgrad_f32_tune.py): one block per CU
+    // (one wave per SIMD) exposes the LDS / barrier latencies (92 TFLOP/s), two reach 110, three 114; a block count just
+    // ABOVE a multiple of the 256 CUs runs at the speed of the next multiple (792 blocks: 92).  So: the largest split count
+    // that keeps the grid <= 3 x 256 blocks, every block keeping >= 8 sub-steps (128 pixels) to hide its atomics behind.
     static const int force_splits = env_int("CR_WG_SPLITS_F32", 0);
-    int splits = (768 + tiles - 1) / tiles;
-    if (splits > nsteps / 16) splits = nsteps / 16;
+    const int max_splits = nsteps / 8 > 1 ? nsteps / 8 : 1;
+    int splits = 768 / tiles;
+    if (splits > max_splits) splits = max_splits;
     if (force_splits > 0) splits = force_splits;
     if (splits > nsteps) splits = nsteps;
     if (splits < 1) splits = 1;
@@ -1136,7 +1255,8 @@ static int launch_wgrad_f32_ks(cr_ctx* ctx, WgP& p) {
     splits = (nsteps + p.steps_per_split - 1) / p.steps_per_split;
     dim3 grid(tm * tn * splits);
     p.tm = tm; p.tn = tn; p.xcd = xcd_enabled();
-    if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad_f32<128, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    static const int lds_pad = env_int("CR_WG_F32_LDS_PAD", 0);     // extra dynamic LDS per block: caps the blocks per CU (tuning)
+    if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad_f32<128, KS>), grid, dim3(CONV_T), lds_pad, ctx->stream, p);
     else if (TM == 64) hipLaunchKernelGGL((k_conv_wgrad_f32<64, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
     else if (TM == 32) hipLaunchKernelGGL((k_conv_wgrad_f32<32, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
     else hipLaunchKernelGGL((k_conv_wgrad_f32<16, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
