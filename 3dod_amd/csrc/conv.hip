@@ -54,7 +54,22 @@ struct ConvP {
     // epilogue (bias, BN statistics, residual, ReLU)
     float* part;
     int ksplit, kstages;
+    // backward-data of a stride-2 convolution by output-pixel parity class (k_conv_igemm, MODE 1, cls = 1): the output pixels
+    // (2h'+ph, 2w'+pw) of one class only receive the filter taps r = ph+pad (mod 2), s = pw+pad (mod 2) -- 4 + 2 + 2 + 1 of
+    // the 9 taps of a 3x3 filter -- so each class is a stride-1 gather over its own taps and no MFMA multiplies the zeros
+    // that the plain transposed gather inserts for the other 3/4 (tap, pixel) pairs.  Hout/Wout/M then describe ONE class
+    // (H/2 x W/2 pixels); the grid holds the four classes back to back; Hfull/Wfull address the output.
+    int cls, Hfull, Wfull, wstride;      // wstride = k extent of a weight row (= Kdim except in class mode)
 };
+
+// offset (in elements) of output pixel m's channel row
+__device__ __forceinline__ size_t conv_out_row(const ConvP& p, int m, int ph, int pw) {
+    if (!p.cls) return (size_t)m * p.Cout;
+    const int hw = p.Hout * p.Wout;
+    const int n = m / hw, rem = m - n * hw;
+    const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+    return ((size_t)(n * p.Hfull + 2 * ho + ph) * p.Wfull + 2 * wo + pw) * p.Cout;
+}
 
 // LDS image of a [rows][32] bf16 tile (64-B rows, four 16-B chunks): chunk' = chunk ^ ((-(row>>2)) & 3)
 // makes the 16x16x32 fragment read (lane -> row l&15, chunk l>>4) conflict-free per ds_read_b128 lane group.
@@ -103,7 +118,7 @@ __device__ __forceinline__ void mfma_substep(const u32x4 (&wf)[TC], const u32x4 
 // lane).  sStat: >= 4*2*BN floats of LDS that nothing else uses any more (the k loop ended with a barrier).
 template <int BM, int BN, int TC, int TP, typename OutT, typename T = u16>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[TC][TP], float* sStat, int m0, int n0, int mt,
-                                              int poff, int coff, int tid, int lane, int wave, bool lead) {
+                                              int poff, int coff, int tid, int lane, int wave, bool lead, int ph = 0, int pw = 0) {
     const bool do_stats = p.stats != nullptr;
     if (do_stats) {
         if (lead) for (int i = tid; i < 4 * 2 * BN; i += CONV_T) sStat[i] = 0.f;
@@ -131,7 +146,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x4 (&acc)[TC][T
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
                 }
-                const size_t o = (size_t)m * p.Cout + ch;
+                const size_t o = conv_out_row(p, m, ph, pw) + ch;
                 if (p.res) {
                     if constexpr (sizeof(T) == 2) {
                         const uint2 rr = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(p.res) + o);
@@ -227,9 +242,32 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
     u16* sX = sXall + grp * XE;
     u16* sW = sWall + grp * WE;
     const int n_tiles = p.Cout / BN;
-    const int bid = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    int bid = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    // parity-class mode (stride-2 backward-data): the grid is 4 classes x tiles; this block's class, its taps and k extent
+    int ph = 0, pw = 0, nsr = KS, kdim = p.Kdim;
+    unsigned tapr = 0, taps_ = 0;                 // packed lists (2 bits each) of the filter rows / columns of the class
+    if (MODE == 1 && p.cls) {
+        const int per = (int)gridDim.x >> 2;
+        const int c = bid / per;
+        bid -= c * per;
+        ph = c >> 1; pw = c & 1;
+        int nr = 0, ns = 0;
+        for (int r = 0; r < KS; ++r) {
+            if (((ph + p.pad - r) & 1) == 0) tapr |= (unsigned)r << (2 * nr++);
+            if (((pw + p.pad - r) & 1) == 0) taps_ |= (unsigned)r << (2 * ns++);
+        }
+        nsr = ns;
+        kdim = nr * ns * p.Cin;
+    }
     const int nt = bid % n_tiles, mt = bid / n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
+    // filter tap (row r, column s2) of tap index j: all KS*KS taps, or the class's own
+    auto tap_rs = [&](int j, int& r, int& s2) {
+        if (MODE == 1 && p.cls) {
+            const int jr = j / nsr, js = j - jr * nsr;
+            r = (int)((tapr >> (2 * jr)) & 3u); s2 = (int)((taps_ >> (2 * js)) & 3u);
+        } else { r = j / KS; s2 = j - r * KS; }
+    };
 
     // ---- per-thread gather bookkeeping (2 pixel rows, one 16-B k-chunk each)
     const int cA = tid & 3;
@@ -246,6 +284,7 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
         const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
         nimg[i] = n;
         if (MODE == 0) { hb[i] = ho * p.stride - p.pad; wb[i] = wo * p.stride - p.pad; }
+        else if (p.cls) { hb[i] = 2 * ho + ph + p.pad;  wb[i] = 2 * wo + pw + p.pad; }
         else           { hb[i] = ho + p.pad;            wb[i] = wo + p.pad; }
     }
     uint4 ra[KU][NA], rb[KU][NB];
@@ -284,10 +323,11 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
         if (fast) {
             const int tap = (kt * SUB) >> p.cshift, cc = (kt * SUB) & (p.Cin - 1);
             if (tap != cur_tap) {
-                const int r = tap / KS, s2 = tap - r * KS;
+                int r, s2;
+                tap_rs(tap, r, s2);
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    const unsigned o = pix_off(i, r, s2, tap < KS * KS);
+                    const unsigned o = pix_off(i, r, s2, kt * SUB < kdim);
                     tb[i] = o == OOB ? OOB : o + cA * 16;
                 }
                 cur_tap = tap;
@@ -300,12 +340,11 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
             if (KS > 1) {
                 const int tap = k0 >> p.cshift;
                 c0 = k0 & (p.Cin - 1);
-                r = tap / KS;
-                s2 = tap - r * KS;
+                tap_rs(tap, r, s2);
             }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const unsigned o = pix_off(i, r, s2, k0 < p.Kdim);
+                const unsigned o = pix_off(i, r, s2, k0 < kdim);
                 ra[u][i] = buf_load16(rx, o == OOB ? OOB : o + (unsigned)c0 * (unsigned)ES);
             }
         }
@@ -313,8 +352,14 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + CONV_T * i;
             const int row = idx >> 2, kb = kt * SUB + (idx & 3) * KE;
-            const bool ok = idx < BN * 4 && kb < p.Kdim;
-            rb[u][i] = buf_load16(rw, ok ? (unsigned)((n0 + row) * p.Kdim + kb) * (unsigned)ES : OOB);
+            const bool ok = idx < BN * 4 && kb < kdim;
+            int wcol = kb;                               // column of k index kb in the weight row
+            if (MODE == 1 && p.cls) {
+                int r, s2;
+                tap_rs(kb >> p.cshift, r, s2);
+                wcol = (r * KS + s2) * p.Cin + (kb & (p.Cin - 1));
+            }
+            rb[u][i] = buf_load16(rw, ok ? (unsigned)((n0 + row) * p.wstride + wcol) * (unsigned)ES : OOB);
         }
       }
     };
@@ -341,7 +386,7 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.Kdim + SUB - 1) / SUB;
+    const int nk = (kdim + SUB - 1) / SUB;
     const int nstage = (nk + KU * KG - 1) / (KU * KG);
     load_tiles(0);
     store_tiles();
@@ -396,7 +441,7 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm(ConvP p) {
         __syncthreads();                 // `red` is dead from here on (sStat aliases it)
     }
     const bool lead = grp == 0;          // groups 1.. only keep the epilogue's barriers company
-    conv_epilogue<BM, BN, TC, TP, OutT, T>(p, acc, sStat, m0, n0, mt, poff, coff, tid, lane, wave, lead);
+    conv_epilogue<BM, BN, TC, TP, OutT, T>(p, acc, sStat, m0, n0, mt, poff, coff, tid, lane, wave, lead, ph, pw);
 }
 
 // ---------------------------------------------------------------------------
@@ -642,7 +687,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(ConvP p) {
 
 template <int BM, int BN, int KS, int MODE, int KU = 1, int KG = 1>
 static int launch_igemm_t(cr_ctx* ctx, const ConvP& p, int out_f32) {
-    const int grid = (int)(cr_cdiv(p.M, BM) * (p.Cout / BN));
+    const int grid = (int)(cr_cdiv(p.M, BM) * (p.Cout / BN)) * (p.cls ? 4 : 1);
     if (out_f32)
         hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, MODE, float, KU, KG>), dim3(grid), dim3(CONV_T * KG), 0, ctx->stream, p);
     else
@@ -653,7 +698,7 @@ static int launch_igemm_t(cr_ctx* ctx, const ConvP& p, int out_f32) {
 
 template <int BM, int BN, int KS, int MODE, int KU>
 static int launch_igemm_f32(cr_ctx* ctx, const ConvP& p) {
-    const int grid = (int)(cr_cdiv(p.M, BM) * (p.Cout / BN));
+    const int grid = (int)(cr_cdiv(p.M, BM) * (p.Cout / BN)) * (p.cls ? 4 : 1);
     hipLaunchKernelGGL((k_conv_igemm<BM, BN, KS, MODE, float, KU, 1, float>), dim3(grid), dim3(CONV_T), 0, ctx->stream, p);
     CR_LAUNCH_CHECK();
     return CR_OK;
@@ -692,7 +737,7 @@ static bool try_launch_dma(cr_ctx* ctx, const ConvP& p, int out_f32, int* rc) {
         return false;
     } else {
         // a k stage is two 64-B rows: 64 bf16 / 32 f32 of k, and must not straddle a filter tap
-        if ((!p.f32 && out_f32) || !dma_enabled() || (p.Cin & (p.f32 ? 31 : 63)) != 0 || p.Cout % 64 != 0) return false;
+        if (p.cls || (!p.f32 && out_f32) || !dma_enabled() || (p.Cin & (p.f32 ? 31 : 63)) != 0 || p.Cout % 64 != 0) return false;
         static const int min_tiles = env_int("CR_CONV_DMA_MIN_TILES", 128), force_bn = env_int("CR_CONV_DMA_BN", 0);
         const int64_t big_tiles = cr_cdiv(p.M, 128) * (p.Cout >= 128 ? p.Cout / 128 : 1);
         static const int splitk_on = env_int("CR_CONV_SPLITK", 1);
@@ -783,7 +828,9 @@ static int ilog2_exact(int v) {
 static int conv_common_checks(const char* who, int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad,
                               int act_f32 = 0) {
     CR_CHECK_ARG(N > 0 && H > 0 && W > 0, "%s: bad input dims", who);
-    CR_CHECK_ARG(Cin % 8 == 0 && Cin >= 8, "%s: Cin=%d must be a multiple of 8 (NHWC 16-B chunks)", who, Cin);
+    // a 16-B chunk holds 8 bf16 or 4 f32 channels of one pixel
+    CR_CHECK_ARG(act_f32 ? (Cin % 4 == 0 && Cin >= 4) : (Cin % 8 == 0 && Cin >= 8),
+                 "%s: Cin=%d must be a multiple of %d (NHWC 16-B chunks)", who, Cin, act_f32 ? 4 : 8);
     CR_CHECK_ARG(Cout % 16 == 0, "%s: Cout=%d must be a multiple of 16", who, Cout);
     CR_CHECK_ARG(ks == 1 || ks == 3 || ks == 7, "%s: kernel size %d not supported (1,3,7)", who, ks);
     CR_CHECK_ARG(stride == 1 || stride == 2, "%s: stride %d not supported (1,2)", who, stride);
@@ -809,7 +856,7 @@ extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y,
     p.Wout = (W + 2 * pad - ks) / stride + 1;
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = N * p.Hout * p.Wout;
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cin); p.relu = relu; p.xcd = xcd_enabled(); p.f32 = act_f32 ? 1 : 0;
-    p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim;
+    p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim; p.cls = 0; p.Hfull = p.Hout; p.Wfull = p.Wout; p.wstride = p.Kdim;
     p.x_bytes = (unsigned)((size_t)N * H * W * Cin * es); p.w_bytes = (unsigned)((size_t)Cout * p.Kdim * es);
     if (act_f32) out_f32 = 1;
     if (ks == 1) return launch_igemm_ks<1, 0>(ctx, p, out_f32);
@@ -833,8 +880,14 @@ extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, v
     p.Hout = H; p.Wout = W; p.Cout = Cin;               // GEMM output = dX
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cout; p.M = N * H * W;
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cout); p.relu = 0; p.xcd = xcd_enabled(); p.f32 = act_f32 ? 1 : 0;
-    p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim;
+    p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim; p.cls = 0; p.Hfull = p.Hout; p.Wfull = p.Wout; p.wstride = p.Kdim;
     p.x_bytes = (unsigned)((size_t)N * Ho * Wo * Cout * es); p.w_bytes = (unsigned)((size_t)Cin * p.Kdim * es);
+    static const int cls_on = env_int("CR_BWD_S2_CLASSES", 1);
+    if (cls_on && stride == 2 && ks == 3 && (H & 1) == 0 && (W & 1) == 0 && (Cout & (act_f32 ? 15 : 31)) == 0) {
+        // by output-pixel parity class (see ConvP): H/2 x W/2 pixels per class, 4 classes in one grid
+        p.cls = 1; p.Hfull = H; p.Wfull = W;
+        p.Hout = H / 2; p.Wout = W / 2; p.M = N * p.Hout * p.Wout;
+    }
     if (ks == 1) return launch_igemm_ks<1, 1>(ctx, p, act_f32 ? 1 : 0);
     if (ks == 3) return launch_igemm_ks<3, 1>(ctx, p, act_f32 ? 1 : 0);
     return launch_igemm_ks<7, 1>(ctx, p, act_f32 ? 1 : 0);
@@ -2145,7 +2198,8 @@ extern "C" int cr_sum2x2(cr_ctx* ctx, const void* dy, void* dtop, int N, int H, 
 }
 
 // preprocess_image (detectron2 GeneralizedRCNN, Base.yaml:32-33): (x - mean)/std on a stacked
-// uint8 (N,3,H,W) batch -> NHWC with channels padded 3 -> 8 (zeros)
+// uint8 (N,3,H,W) batch -> NHWC with channels padded with zeros to one 16-B chunk per pixel: 3 -> 8 (bf16) or 3 -> 4 (f32:
+// the stem convolution then multiplies 7*7*4 instead of 7*7*8 of k, half the f32 MFMA work of the padded form)
 template <typename T>
 __global__ void k_preprocess(const unsigned char* __restrict__ img, void* __restrict__ yv, int N, int H, int W, float m0,
                              float m1, float m2, float s0, float s1, float s2) {
@@ -2156,7 +2210,8 @@ __global__ void k_preprocess(const unsigned char* __restrict__ img, void* __rest
     const int64_t n = i / hw, pix = i - n * hw;
     const unsigned char* b = img + n * 3 * hw + pix;
     const float f[8] = {((float)b[0] - m0) / s0, ((float)b[hw] - m1) / s1, ((float)b[2 * hw] - m2) / s2, 0, 0, 0, 0, 0};
-    store8<T>((T*)yv, (size_t)i * 8, f);
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>((float*)yv + (size_t)i * 4) = make_float4(f[0], f[1], f[2], 0.f);
+    else store8<T>((T*)yv, (size_t)i * 8, f);
 }
 
 extern "C" int cr_preprocess(cr_ctx* ctx, const unsigned char* img, void* y, int N, int H, int W, const float* mean3,

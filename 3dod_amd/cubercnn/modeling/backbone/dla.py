@@ -17,8 +17,8 @@ BatchNorm = nn.BatchNorm2d
 
 def _conv_bn(x, conv, bn, relu, residual=None):
     w = conv.weight
-    if w.shape[1] < 8:      # RGB stem: activations carry 8 channels (3 real + 5 zero)
-        w = ops.pad_input_channels(w, 8)
+    if w.shape[1] < x.shape[-1]:      # RGB stem: activations carry 8 (bf16) or 4 (f32) channels, 3 real + zeros
+        w = ops.pad_input_channels(w, x.shape[-1])
     return ops.conv_bn_act(x, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, stride=conv.stride[0],
                            pad=conv.padding[0], relu=relu, residual=residual, eps=bn.eps, momentum=bn.momentum,
                            training=bn.training)

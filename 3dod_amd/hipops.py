@@ -584,13 +584,14 @@ def upsample2x_add(lat, top):
 
 
 def preprocess(images_u8, mean, std, dtype=None):
-    """(N,3,H,W) uint8 -> normalised NHWC with 8 channels (3 real + 5 zero) in the activation dtype of the process
+    """(N,3,H,W) uint8 -> normalised NHWC with 8 (bf16) or 4 (f32) channels (3 real + zeros) in the activation dtype of the process
     (set_precision) unless `dtype` says otherwise: this call decides the precision of everything downstream."""
     _p = _Args()
     _need_cuda(images_u8, "images")
     assert images_u8.dtype == torch.uint8 and images_u8.is_contiguous()
     N, _, H, W = images_u8.shape
-    y = torch.empty((N, H, W, 8), dtype=dtype if dtype is not None else act_dtype(), device=images_u8.device)
+    dt = dtype if dtype is not None else act_dtype()
+    y = torch.empty((N, H, W, 8 if dt == bf16 else 4), dtype=dt, device=images_u8.device)     # one 16-B chunk per pixel
     m = (ctypes.c_float * 3)(*[float(v) for v in mean])
     s = (ctypes.c_float * 3)(*[float(v) for v in std])
     lib = _lib.load()

@@ -241,7 +241,8 @@ int cr_pool2x_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, i
 /* FPN top-down path (detectron2 FPN, fuse_type "sum"): y = lat + nearest_up2x(top); and d/dtop. */
 int cr_upsample2x_add(cr_ctx* ctx, const void* lat, const void* top, void* y, int N, int H, int W, int C, int act_f32);
 int cr_sum2x2(cr_ctx* ctx, const void* dy, void* dtop, int N, int H, int W, int C, int act_f32);
-/* preprocess_image: uint8 (N,3,H,W) -> (x-mean)/std -> NHWC bf16, channels 3->8.  mean3/std3: HOST floats. */
+/* preprocess_image: uint8 (N,3,H,W) -> (x-mean)/std -> NHWC, channels zero-padded to one 16-B chunk per pixel:
+ * 3->8 (bf16) or 3->4 (f32).  mean3/std3: HOST floats. */
 int cr_preprocess(cr_ctx* ctx, const unsigned char* img, void* y, int N, int H, int W, const float* mean3,
                   const float* std3, int act_f32);
 

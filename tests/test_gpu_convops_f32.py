@@ -45,6 +45,8 @@ def mk_weight(co, ci, k, g):
 
 CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (2, 16, 16, 8, 16, 7, 1, 3),        # stem shape class (Kdim = 392: k tail inside a 16-wide sub-step)
+    (2, 16, 16, 4, 16, 7, 1, 3),        # the f32 stem as the model runs it: RGB padded to ONE 16-B chunk = 4 channels
+    (2, 64, 64, 64, 128, 3, 2, 1),      # stride 2, backward-data by output-pixel parity class (4 + 2 + 2 + 1 taps)
     (2, 32, 32, 16, 16, 3, 1, 1),
     (2, 32, 32, 16, 32, 3, 2, 1),
     (1, 24, 40, 32, 64, 3, 2, 1),       # non-square, M tail
