@@ -52,8 +52,8 @@ def cubes_project_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_
     shapes = {"corners": (N, Pn, 8, 2), "boxes": (N, Pn, 4), "iou": (N, Pn), "dim": (N, Pn),
               "corner": (N, Pn), "combined": (N, Pn)}
     out = {k: (torch.empty(shapes[k], dtype=f32, device=dev) if k in want else None) for k in shapes}
-    out["argmax"] = torch.zeros((N,), dtype=torch.int64, device=dev)
-    out["best"] = torch.zeros((N,), dtype=f32, device=dev)
+    out["argmax"] = torch.empty((N,), dtype=torch.int64, device=dev)        # the kernel writes every object's entry
+    out["best"] = torch.empty((N,), dtype=f32, device=dev)
     if N == 0:
         return out
     lib = _lib.load()

@@ -85,6 +85,16 @@ def geometry_inputs(n_obj, P, seed, dev):
     return dict(cubes=to(cubes), K=to(K), im_wh=(512, 512), ref=to(ref), mu=to(mu), sg=to(sg), rect=to(rect))
 
 
+def pmc_traffic(fname, kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 correction applied by scripts/pmc_summarize.py); None when the file is absent"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        return [v["traffic_bytes"] for k, v in d["kernels"].items() if k.startswith(kernel_prefix)][0]
+    except Exception:
+        return None
+
+
 def bench_geometry(args, rank, world, dev):
     geo = importlib.import_module("3dod_amd.geometry")
     n_img, n_obj_img, P = 64, 16, 1000
@@ -119,7 +129,7 @@ def bench_geometry(args, rank, world, dev):
         "config": {"workload": "geometry: 64 images x 16 objects x 1000 cubes per GPU, full outputs (156 B/cube), one launch",
                    "objects_per_gpu": n_obj, "proposals": P, "parallelism": f"objects sharded x{world}, no collective"},
         "roofline": {"bound": "hbm", "kernel": "k_project_score<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("r02_pmc_geometry_traffic.json", "k_project_score"),
                      "algorithmic_bytes_per_launch": bytes_per_cube * n_obj * P, "kernel_ms": kern_ms},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -107,7 +107,30 @@ def _bench_train_mode(args, rank, world, dev, prec):
         rep = step.report()
     ims = IMS_PER_GPU * world * args.steps / dt
     achieved_tf = TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU / (dt / args.steps) / 1e3
+    ins, ins_err = None, None
+    try:                             # (before the micro-benchmark: the profile's last three optimizer updates are these steps)
+        with d2.EventStorage(0):
+            ins = dominant_kernel_in_step(model, step, batches, dev)
+    except Exception as e:           # never lose the headline to the instrumentation
+        ins_err = f"{type(e).__name__}: {e}"
     kern = dominant_kernel_roofline(dev, prec)
+    try:
+        if ins_err:
+            raise RuntimeError(ins_err)
+        # the roofline figure is the IN-STEP duration (HIP events around the launches of the dominant layer inside real
+        # train steps, caches in the state the step leaves them in); the back-to-back micro-benchmark stays beside it
+        worst = min(ins, key=lambda k: ins[k]["tflops"]) if ins else None
+        if worst is not None:
+            name = {"wgrad": [k for k in kern["all_directions"] if "wgrad" in k][0],
+                    "fwd": [k for k in kern["all_directions"] if "(fwd)" in k][0],
+                    "bwd-data": [k for k in kern["all_directions"] if "(bwd-data)" in k][0]}
+            kern["microbench"] = {"kernel": kern["kernel"], "achieved": kern["achieved"], "kernel_ms": kern["kernel_ms"]}
+            kern.update(kernel=name[worst], achieved=ins[worst]["tflops"], frac=ins[worst]["tflops"] / peak,
+                        kernel_ms=ins[worst]["ms"], measured="HIP events around the kernel's launches inside train steps "
+                        "(dense region run eagerly for this measurement), mean over %d launches" % ins[worst]["launches"])
+            kern["in_step"] = {name[k]: v for k, v in ins.items()}
+    except Exception as e:           # never lose the headline to the instrumentation
+        kern["in_step_error"] = f"{type(e).__name__}: {e}"
     note("roofline done")
     import sys
     print(f"[bench] rank {rank} [{prec}]: {ims:.1f} images/s, {dt / args.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
@@ -130,6 +153,55 @@ def _bench_train_mode(args, rank, world, dev, prec):
     del step, model, opt
     torch.cuda.empty_cache()
     return res
+
+
+def dominant_kernel_in_step(model, step, batches, dev, n_steps=3):
+    """durations of the dominant layer's three kernels (3x3 256->256 on IMS_PER_GPU x 128 x 128: the FPN p2 output conv and
+    the RPN head conv on p2) INSIDE train steps: the raw launch wrappers are bracketed with HIP events on the stream they
+    launch on.  The captured dense region is switched off for these steps (a graph replay cannot be bracketed per kernel);
+    the kernels, their inputs and the cache state they find are those of the real step."""
+    ops = importlib.import_module("3dod_amd.hipops")
+    shape = (IMS_PER_GPU, 128, 128, 256)
+    recs = {"fwd": [], "bwd-data": [], "wgrad": []}
+    orig = (ops.conv_fwd_raw, ops.conv_bwd_data_raw, ops.conv_bwd_weight_raw)
+
+    def timed(kind, fn, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        recs[kind].append((e0, e1))
+        return r
+
+    def fwd(x, wb, Cout, k, stride, pad, **kw):
+        hit = tuple(x.shape) == shape and Cout == 256 and k == 3 and stride == 1
+        return timed("fwd", orig[0], x, wb, Cout, k, stride, pad, **kw) if hit else orig[0](x, wb, Cout, k, stride, pad, **kw)
+
+    def bwd(dy, wt, in_shape, k, stride, pad):
+        hit = tuple(in_shape) == shape and dy.shape[3] == 256 and k == 3 and stride == 1
+        return timed("bwd-data", orig[1], dy, wt, in_shape, k, stride, pad) if hit else orig[1](dy, wt, in_shape, k, stride, pad)
+
+    def wg(dy, x, k, stride, pad, sink=None, bias_acc=None):
+        hit = tuple(x.shape) == shape and dy.shape[3] == 256 and k == 3 and stride == 1
+        f = lambda: orig[2](dy, x, k, stride, pad, sink, bias_acc)
+        return timed("wgrad", lambda: f()) if hit else f()
+    graphed = getattr(model, "_graphed", None)
+    model._graphed = None
+    ops.conv_fwd_raw, ops.conv_bwd_data_raw, ops.conv_bwd_weight_raw = fwd, bwd, wg
+    try:
+        for i in range(n_steps):
+            step(batches[i % len(batches)])
+        torch.cuda.synchronize(dev)
+    finally:
+        ops.conv_fwd_raw, ops.conv_bwd_data_raw, ops.conv_bwd_weight_raw = orig
+        model._graphed = graphed
+    flop = 2.0 * IMS_PER_GPU * 128 * 128 * 256 * 9 * 256
+    out = {}
+    for kind, ev in recs.items():
+        if ev:
+            ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            out[kind] = {"ms": ms, "tflops": flop / ms / 1e9, "launches": len(ev)}
+    return out
 
 
 def cpu_baseline_train():
