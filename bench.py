@@ -177,12 +177,25 @@ def bench_inference(args, rank, world, dev):
             n_det += sum(len(o["instances"]) for o in out)
         barrier(world)
         dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    prec = importlib.import_module("3dod_amd.hipops").precision()
+    gflop_img = 116.8                    # 58.4 GMAC per 512x512 image with 1000 RoIs
+    ach = gflop_img * B / (dt / args.steps) / 1e3
+    res = _inference_result(args, world, B, dt, n_det, prec, ach, bt.MFMA_PEAK[prec], gflop_img)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = bt.cpu_baseline_train(inference=True)
+    return res
+
+
+def _inference_result(args, world, B, dt, n_det, prec, ach, peak, gflop_img):
     return {"metric": "images/sec Cube R-CNN DLA34-FPN inference (BASELINE configs[1])", "value": B * world * args.steps / dt,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": importlib.import_module("3dod_amd.hipops").precision(), "data": "synthetic",
+            "dtype": prec, "data": "synthetic",
             "config": {"workload": "Cube R-CNN DLA34+FPN inference, 8 img/GPU 512x512, random-init weights, full post-processing",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "detections_per_step": n_det / max(args.steps, 1)}}
+                       "global_batch": B * world, "parallelism": f"dp{world}", "detections_per_step": n_det / max(args.steps, 1)},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "scope": "whole forward incl. post-processing (algorithmic flops / wall time); per-kernel figures: "
+                                  "the train line's roofline (same conv kernels)", "algorithmic_gflop_per_image": gflop_img}}
 
 
 def bench_boxnet(args, rank, world, dev):

@@ -204,9 +204,9 @@ def dominant_kernel_in_step(model, step, batches, dev, n_steps=3):
     return out
 
 
-def cpu_baseline_train():
+def cpu_baseline_train(inference=False):
     """the oracle's float32 torch-CPU train step (oracle/cpu_train_step.py) on the box's host cores, in a separate
-    process, on a bounded sample (1 warm-up + 4 timed steps of 4 images)."""
+    process, on a bounded sample (1 warm-up + 4 timed steps of 4 images; inference: 1 + 3 batches of 8 images)."""
     import json
     import subprocess
     import sys
@@ -218,6 +218,8 @@ def cpu_baseline_train():
     threads = max(1, min(16, ncpu))          # a 1-GPU box gives this job a 16-core share
     cmd = [sys.executable, os.path.join(here, "oracle", "cpu_train_step.py"), "--images", "4", "--steps", "4",
            "--warmup", "1", "--threads", str(threads)]
+    if inference:
+        cmd = cmd[:2] + ["--inference", "--images", "8", "--steps", "3", "--warmup", "1", "--threads", str(threads)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads),
                MKL_NUM_THREADS=str(threads))
     print(f"[bench] cpu baseline: {' '.join(cmd[1:])}", file=sys.stderr, flush=True)

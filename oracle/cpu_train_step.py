@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--threads", type=int, default=os.cpu_count())
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--inference", action="store_true", help="time model.inference (eval mode) instead of the train step")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     from oracle import cpu_backend
@@ -34,6 +35,20 @@ def main():
     cfg = syn.make_cfg(overrides=["MODEL.DEVICE", "cpu", "VIS_PERIOD", 0, "log", False, "SOLVER.BASE_LR", 0.02])
     torch.manual_seed(0)
     model = modeling.build_model(cfg)
+    if args.inference:
+        model.eval()
+        batches = [syn.make_batch(args.images, 4321 + i, size=args.size, with_gt=False) for i in range(2)]
+        with torch.no_grad(), d2.EventStorage(0):
+            for i in range(args.warmup):
+                model(batches[i % 2])
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                model(batches[i % 2])
+            dt = time.perf_counter() - t0
+        print(json.dumps({"value": args.images * args.steps / dt, "unit": "images/s", "cores": args.threads, "kind": "port",
+                          "sample": f"{args.steps} inference batches of {args.images} images {args.size}x{args.size}, torch "
+                                    f"float32 eager on the host, {dt:.1f} s"}))
+        return
     model.train()
     opt = solver.build_optimizer(cfg, model)
     step = solver.TrainStep(cfg, model, opt, world_size=1)
