@@ -4,6 +4,69 @@ import torch
 from ...d2lite import pairwise_iou
 
 
+class Draws:
+    """Source of the random variates of the proposal samplers.  The reference calls torch.rand / torch.randn /
+    torch.normal / torch.randperm inline; routing them through one object keeps the call ORDER and SHAPES of the reference
+    (the recorded-draws goldens replay them, tests/golden/make_golden_proposals.py) and lets callers pass a generator."""
+
+    def __init__(self, generator=None):
+        self.generator = generator
+
+    def _g(self, device):
+        g = self.generator
+        return g if (g is not None and torch.device(g.device).type == torch.device(device).type) else None
+
+    def rand(self, shape, device):
+        return torch.rand(tuple(shape), device=device, generator=self._g(device))
+
+    def randn(self, shape, device="cpu"):
+        return torch.randn(tuple(shape), device=device, generator=self._g(device))
+
+    def normal(self, means, stds):
+        return torch.normal(means, stds, generator=self._g(means.device))
+
+    def randperm(self, n):
+        return torch.randperm(n, generator=self._g("cpu"))
+
+
+def sample_normal_in_range(means, stds, count, threshold_low=None, threshold_high=None, rng=None):
+    """utils.py:42-60: (N,) means / stds -> (N,count) normal samples; with thresholds, samples outside [low, high] are
+    redrawn (a full (N,count) draw per round, only the invalid entries replaced) for up to 10 000 rounds."""
+    rng = rng or Draws()
+    m, s = means.unsqueeze(1).expand(-1, count), stds.unsqueeze(1).expand(-1, count)
+    samples = rng.normal(m, s)
+    if threshold_high is not None and threshold_low is not None:
+        hi = threshold_high.unsqueeze(1).expand_as(samples)
+        tries = 0
+        while True:
+            invalid = (samples < threshold_low) | (samples > hi)
+            if not bool(invalid.any()):
+                break
+            samples[invalid] = rng.normal(m, s)[invalid]
+            tries += 1
+            if tries == 10000:
+                break
+    return samples
+
+
+def randn_orthobasis_torch(num_samples=1, num_instances=1, rng=None):
+    """utils.py:62-69: (num_instances, num_samples, 3, 3) random rotations-up-to-sign: Gaussian rows normalised, row 0 =
+    normalize(row1 x row2), row 1 = normalize(row2 x row0) (drawn on the host like the reference)"""
+    rng = rng or Draws()
+    z = rng.randn((num_instances, num_samples, 3, 3), "cpu")
+    z = z / torch.norm(z, p=2, dim=-1, keepdim=True)
+    z[:, :, 0] = torch.linalg.cross(z[:, :, 1], z[:, :, 2], dim=-1)
+    z[:, :, 0] = z[:, :, 0] / torch.norm(z[:, :, 0], dim=-1, keepdim=True)
+    z[:, :, 1] = torch.linalg.cross(z[:, :, 2], z[:, :, 0], dim=-1)
+    z[:, :, 1] = z[:, :, 1] / torch.norm(z[:, :, 1], dim=-1, keepdim=True)
+    return z
+
+
+def gt_in_norm_range(range_, gt):
+    """utils.py:149-153: position of gt inside [range_[0], range_[1]] in units of the range's length"""
+    return (gt - range_[0]) / abs(range_[1] - range_[0])
+
+
 def normalize_vector(v):
     v_mag = torch.sqrt(v.pow(2).sum())
     v_mag = torch.max(v_mag, torch.tensor([1e-8], device=v.device))

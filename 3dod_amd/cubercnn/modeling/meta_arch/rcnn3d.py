@@ -278,9 +278,9 @@ class BoxNet(RCNN3D):
     def forward(self, batched_inputs, experiment_type=None, proposal_function='propose'):
         assert not self.training, "BoxNet training (pseudo-GT generation) is driven by tools/eval_boxes.py: out of scope"
         experiment_type = experiment_type or {'use_pred_boxes': True}
-        return self.inference(batched_inputs, experiment_type=experiment_type)
+        return self.inference(batched_inputs, experiment_type=experiment_type, proposal_function=proposal_function)
 
-    def inference(self, batched_inputs, experiment_type=None, do_postprocess=True, generator=None):
+    def inference(self, batched_inputs, experiment_type=None, do_postprocess=True, generator=None, proposal_function='propose'):
         use_pred = (experiment_type or {}).get('use_pred_boxes', True)
         if use_pred:
             images, x = self.preprocess_image(batched_inputs)
@@ -302,7 +302,7 @@ class BoxNet(RCNN3D):
             proposals = [b["instances"] if b["instances"].gt_boxes.device == self.device else b["instances"].to(self.device)
                          for b in batched_inputs]
         results, _ = self.roi_heads(images, features, proposals, depth, ground, Ks, im_scales_ratio, masks=masks,
-                                    use_pred_boxes=use_pred, generator=generator)
+                                    use_pred_boxes=use_pred, generator=generator, proposal_function=proposal_function)
         if do_postprocess:
             return RCNN3D._postprocess(results, batched_inputs, images.image_sizes)
         return results

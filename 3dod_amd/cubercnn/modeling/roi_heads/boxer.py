@@ -60,8 +60,28 @@ class ROIHeads_Boxer(StandardROIHeads):
         else:
             self.priors_dims_per_cat = nn.Parameter(torch.ones(1, self.num_classes, 2, 3))
 
+    def predict_cubes(self, gt_boxes, priors, depth_maps_tensor, im_shape, K, proposal_function, normal_vec, gt_3d=None,
+                      generator=None):
+        """roi_heads.py:283-302: the proposals of ONE image by the sampler named `proposal_function` ('propose' = the
+        method's own sampler on the fused kernel; 'random', 'xy', 'z', 'dim', 'rotation', 'aspect' = the ablation
+        samplers of ProposalNetwork/proposals/proposals.py:20-336) -> (Cubes, list of Boxes, stats, ranges)"""
+        from ....ProposalNetwork.utils.conversions import cubes_to_box
+        from ....ProposalNetwork.utils.utils import Draws
+        if proposal_function not in PN.PROPOSAL_FUNCTIONS:
+            raise ValueError(f"unknown proposal function '{proposal_function}' (one of {sorted(PN.PROPOSAL_FUNCTIONS)})")
+        ref = Boxes(gt_boxes) if torch.is_tensor(gt_boxes) else gt_boxes
+        depth = depth_maps_tensor.squeeze()
+        if proposal_function == 'propose':
+            cubes, stats, ranges = PN.propose(ref, depth, priors, im_shape, K, number_of_proposals=self.number_of_proposals,
+                                              gt_cubes=gt_3d, ground_normal=normal_vec, generator=generator)
+        else:
+            cubes, stats, ranges = PN.PROPOSAL_FUNCTIONS[proposal_function](
+                ref, depth, priors, im_shape, K, number_of_proposals=self.number_of_proposals, gt_cubes=gt_3d,
+                rng=Draws(generator))
+        return cubes, cubes_to_box(cubes, K, im_shape), stats, ranges
+
     def forward(self, images, features, proposals, depth_maps, ground_maps, Ks, im_scales_ratio, masks=None,
-                use_pred_boxes=True, generator=None):
+                use_pred_boxes=True, generator=None, proposal_function='propose'):
         """eval-mode AP path (roi_heads.py:130-206)."""
         assert not self.training, "the pseudo-GT training modes of ROIHeads_Boxer are not built"
         if use_pred_boxes:
@@ -77,7 +97,7 @@ class ROIHeads_Boxer(StandardROIHeads):
             boxes = [i.gt_boxes for i in instances]
             classes = [i.gt_classes for i in instances]
         return self._forward_cube(images.image_sizes, boxes, classes, depth_maps, ground_maps, Ks, im_scales_ratio,
-                                  masks, generator), {}
+                                  masks, generator, proposal_function), {}
 
     def _forward_box(self, features, proposals):
         feats = [features[f] for f in self.box_in_features]
@@ -87,7 +107,7 @@ class ROIHeads_Boxer(StandardROIHeads):
 
     @torch.no_grad()
     def _forward_cube(self, image_sizes, boxes: List[Boxes], classes, depth_maps, ground_maps, Ks, im_scales_ratio,
-                      masks=None, generator=None):
+                      masks=None, generator=None, proposal_function='propose'):
         """roi_heads.py:304-660 (use_pred_boxes branch :492-505 and the Instances packing :647-660).  The reference
         walks the images one by one; here every stage (ground-plane fit, proposals, mask rectangles, scoring) is one
         launch for the whole batch, with a single host sync (the rejection sampler's exhausted flag)."""
@@ -134,8 +154,20 @@ class ROIHeads_Boxer(StandardROIHeads):
             # proposals -> scores -> best cube -> Instances are all issued before the rejection sampler's flag is read, so
             # the host never waits in the middle of the batch and its packing overlaps the kernels; a non-zero flag (rare
             # once the round count has adapted) redoes them
-            cubes_t, exhausted = PN.propose_batched(ref, img_idx, depth_maps, (mu, sg), K_img, P, normals,
-                                                    generator=generator, defer_check=True)
+            if proposal_function == 'propose':
+                cubes_t, exhausted = PN.propose_batched(ref, img_idx, depth_maps, (mu, sg), K_img, P, normals,
+                                                        generator=generator, defer_check=True)
+            else:
+                # an ablation sampler (roi_heads.py:286-297): image by image, as the reference does
+                parts, o = [], 0
+                for i, n in enumerate(counts):
+                    if n:
+                        c, _, _, _ = self.predict_cubes(boxes[i], (mu[o:o + n], sg[o:o + n]), depth_maps[i], (W, H), K_img[i],
+                                                        proposal_function, normals[i], generator=generator)
+                        parts.append(c.tensor.to(dev))
+                    o += n
+                cubes_t = torch.cat(parts).contiguous()
+                exhausted = torch.zeros((1,), dtype=torch.int32, device=dev)
             res = geo.cubes_project_score(cubes_t, K_obj, (W, H), ref, mu, sg, rects, want=())
             idx = res["argmax"]
             best = cubes_t[torch.arange(cubes_t.shape[0], device=dev), idx]    # (Ntot,15)

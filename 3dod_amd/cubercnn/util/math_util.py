@@ -61,6 +61,14 @@ def get_cuboid_verts_faces(box3d=None, R=None):
     return verts, faces
 
 
+def mat2euler(R):
+    """math_util.py:71-81: XYZ Euler angles of a rotation matrix (numpy array of 3)"""
+    import math
+    import numpy as np
+    sy = math.sqrt(R[0, 0] * R[0, 0] + R[1, 0] * R[1, 0])
+    return np.array([math.atan2(R[2, 1], R[2, 2]), math.atan2(-R[2, 0], sy), math.atan2(R[1, 0], R[0, 0])])
+
+
 def compute_virtual_scale_from_focal_spaces(f, H, f0, H0):
     """math_util.py:732-743."""
     return (H0 * f) / (f0 * H)

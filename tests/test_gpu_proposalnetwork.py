@@ -113,6 +113,32 @@ def test_boxnet_gt_boxes_path_runs_batched():
         assert ((inst.scores >= 0) | torch.isnan(inst.scores)).all()
 
 
+@pytest.mark.parametrize("fn", ["random", "xy", "z", "dim", "rotation", "aspect"])
+def test_boxnet_with_the_ablation_samplers(fn):
+    """BoxNet.forward(proposal_function=...) (rcnn3d.py:678, roi_heads.py:283-302): each of the six ablation samplers feeds
+    the same scoring kernel; one cube per object comes back (values of the samplers themselves are pinned on the CPU by
+    tests/test_proposal_variants.py against the reference's recorded draws)."""
+    syn = importlib.import_module("3dod_amd.synthetic")
+    modeling = importlib.import_module("3dod_amd.cubercnn.modeling")
+    cfg_file = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "BoxNet.yaml")
+    cfg = syn.make_cfg(cfg_file, ["MODEL.DEVICE", "cuda:0", "VIS_PERIOD", 0, "log", False,
+                                  "MODEL.ROI_CUBE_HEAD.NUMBER_OF_PROPOSALS", 200])
+    torch.manual_seed(0)
+    model = modeling.build_model(cfg).eval()
+    batch = syn.make_batch(2, 5)
+    g = torch.Generator().manual_seed(2)
+    for b in batch:
+        b["depth_map"] = torch.rand(512, 512, generator=g) * 3 + 1
+        b["ground_map"] = (torch.arange(512)[:, None] > 300).expand(512, 512).to(torch.uint8)
+    out = model(batch, experiment_type={"use_pred_boxes": False}, proposal_function=fn)
+    for o, b in zip(out, batch):
+        inst, n = o["instances"], len(b["instances"])
+        assert len(inst) == n and inst.pred_bbox3D.shape == (n, 8, 3) and inst.pred_dimensions.shape == (n, 3)
+        assert torch.isfinite(inst.pred_dimensions).all()
+    with pytest.raises(ValueError, match="unknown proposal function"):
+        model(batch, experiment_type={"use_pred_boxes": False}, proposal_function="nope")
+
+
 def test_iou_3d_and_score_point_cloud():
     """utils.iou_3d (exact IoU3D of a GT cube vs an object's proposals) and scorefunction.score_point_cloud (MABO)."""
     import importlib
