@@ -246,20 +246,19 @@ class TrainStep:
         keys = sorted(loss_dict.keys())
         vals = torch.stack([loss_dict[k].float() for k in keys])
         losses = vals.sum()
-        # ---- fused small all-reduce: loss terms (train_net.py:196 allreduce_dict)
+        # ---- fused small all-reduce: loss terms (train_net.py:196 allreduce_dict).  It runs on the communication stream
+        # UNDER the backward pass: backward is taken on the unclipped local loss -- the reference clips the loss to [0,1]
+        # when it diverges (train_net.py:212) but then discards that step's gradients (:259-261), so the clipped backward
+        # and the skipped update give the same parameters -- and the divergence decision is made after backward.
         red = vals.detach().clone()
         if world > 1:
-            dist.all_reduce(red)
-            red /= world
-        losses_reduced = red.sum()
-        first = torch.isnan(self.recent_loss)
-        recent = torch.where(first, losses_reduced * 2.0, self.recent_loss)
-        diverging = (losses_reduced > recent * self.TOLERANCE) | ~torch.isfinite(losses_reduced)
-        if not self.stabilize:
-            diverging = torch.zeros_like(diverging)
-        # loss clip when diverging (train_net.py:212), rolling mean otherwise (:218)
-        losses = torch.where(diverging, losses.clip(0, 1), losses)
-        self.recent_loss = torch.where(diverging, recent, recent * (1 - self.GAMMA) + losses_reduced * self.GAMMA)
+            if self.comm_stream is not None:
+                self.comm_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.comm_stream):
+                    dist.all_reduce(red)
+                red.record_stream(self.comm_stream)
+            else:
+                dist.all_reduce(red)
         opt.zero_grad()
         g = getattr(self.model, "_graphed", None)
         if g is not None and self.comm_stream is not None and g.pre_bwd is None:
@@ -278,6 +277,16 @@ class TrainStep:
         elif world > 1:                      # gloo / CPU rehearsal of the same protocol
             for a, b in self.buckets:
                 dist.all_reduce(opt.flat_g[a:b])
+        # ---- divergence guard (rolling mean x4, train_net.py:202-220) on the reduced loss, on the device
+        if world > 1:
+            red = red / world
+        losses_reduced = red.sum()
+        first = torch.isnan(self.recent_loss)
+        recent = torch.where(first, losses_reduced * 2.0, self.recent_loss)
+        diverging = (losses_reduced > recent * self.TOLERANCE) | ~torch.isfinite(losses_reduced)
+        if not self.stabilize:
+            diverging = torch.zeros_like(diverging)
+        self.recent_loss = torch.where(diverging, recent, recent * (1 - self.GAMMA) + losses_reduced * self.GAMMA)
         # ---- non-finite scan of the (averaged) gradient + skip flag, all on device
         self.flag.copy_(diverging.to(torch.int32).view(1))
         if self.stabilize:

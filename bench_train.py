@@ -107,6 +107,26 @@ def _bench_train_mode(args, rank, world, dev, prec):
         rep = step.report()
     ims = IMS_PER_GPU * world * args.steps / dt
     achieved_tf = TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU / (dt / args.steps) / 1e3
+    comm = {"world_size": world, "backend": "none (single process)"}
+    if world > 1:
+        # the step's one real exchange on its own: all-reduce of the flat float32 gradient over RCCL, so that a scaling
+        # run explains itself (bus bandwidth = 2 (n-1)/n x bytes / time, the ring's per-link figure)
+        import torch.distributed as dist
+        buf = torch.empty_like(opt.flat_g)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize(dev)
+        ar = B.max_over_ranks((time.perf_counter() - t1) / 5, world, dev)
+        nbytes = buf.numel() * 4
+        comm = {"world_size": world, "backend": "nccl (RCCL over xGMI), one process per GPU", "allreduce_bytes": nbytes,
+                "allreduce_ms_alone": ar * 1e3, "bus_GBps": 2.0 * (world - 1) / world * nbytes / ar / 1e9,
+                "overlap": "RoI-head FC gradients (58 %) all-reduced under the trunk backward graph, loss vector under "
+                           "backward, the rest after backward"}
+        del buf
     ins, ins_err = None, None
     try:                             # (before the micro-benchmark: the profile's last three optimizer updates are these steps)
         with d2.EventStorage(0):
@@ -145,7 +165,8 @@ def _bench_train_mode(args, rank, world, dev, prec):
                                  if prec == "fp32" else "bf16 activations / operands, f32 accumulate and parameters"),
                    "launch_mode": {"step": "whole-step HIP graphs", "dense": "dense-region HIP graphs", "none": "eager"}[mode],
                    "final_loss": rep.get("total_loss"), "skipped_steps": rep.get("iterations_explode"),
-                   "valid": bool(rep.get("iterations_explode") == 0 and rep.get("total_loss") == rep.get("total_loss"))},
+                   "valid": bool(rep.get("iterations_explode") == 0 and rep.get("total_loss") == rep.get("total_loss")),
+                   "comm": comm},
         "roofline": dict(kern, whole_step={"achieved": achieved_tf, "unit": "TFLOP/s",
                                            "frac": achieved_tf / peak,
                                            "algorithmic_gflop_per_step": TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU}),
