@@ -35,8 +35,10 @@ SIGNATURES = {
     "cr_scale_residual_layernorm": [P, P, P, P, P, P, P, P, c_int64, c_int, c_float],
     "cr_scale_residual": [P, P, P, P, P, c_int64, c_int],
     "cr_resize_bilinear_ac": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int],
-    "cr_conv2d_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, c_int],
-    "cr_conv2d_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "cr_conv2d_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, c_int, P],
+    "cr_conv2d_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "cr_weight_split3": [P, P, P, c_int64, c_int],
+    "cr_weights_split3": [P, P, P, P, c_int, c_int64],
     "cr_conv2d_bwd_weight": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "cr_conv2d_bwd_weight_bias": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "cr_cast_f32_to_bf16": [P, P, P, c_int64],
@@ -69,8 +71,8 @@ SIGNATURES = {
     "cr_weights_prepare": [P, P, P, P, P, P, c_int, c_int],
     "cr_fc_weight_prepare": [P, P, P, c_int, c_int, c_int, c_int],
     "cr_fc_grad_accum": [P, P, P, c_int, c_int, c_int, c_int],
-    "cr_linear_fwd": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int],
-    "cr_linear_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int],
+    "cr_linear_fwd": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "cr_linear_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, P],
     "cr_linear_bwd_weight": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int],
     "cr_transpose2d": [P, P, P, c_int, c_int, c_int],
     "cr_maxpool3x3s2_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int],

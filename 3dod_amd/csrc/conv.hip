@@ -28,6 +28,7 @@
 #include "cr_common.h"
 #include "cr_elem.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -60,6 +61,9 @@ struct ConvP {
     // that the plain transposed gather inserts for the other 3/4 (tap, pixel) pairs.  Hout/Wout/M then describe ONE class
     // (H/2 x W/2 pixels); the grid holds the four classes back to back; Hfull/Wfull address the output.
     int cls, Hfull, Wfull, wstride;      // wstride = k extent of a weight row (= Kdim except in class mode)
+    // split mode (k_conv_igemm_dma_s3): the weights as three bf16 planes, [row][Kdim/32][plane][32] (cr_weight_split3)
+    const void* w3;
+    unsigned w3_bytes;
 };
 
 // offset (in elements) of output pixel m's channel row
@@ -111,6 +115,33 @@ __device__ __forceinline__ void mfma_substep(const u32x4 (&wf)[TC], const u32x4 
                 for (int j = 0; j < TP; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[i][e]), __uint_as_float(xf[j][e]),
                                                                      acc[i][j], 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// f32 arithmetic on the bf16 matrix cores ("split" mode, act_f32 = 2).  An f32 value x is EXACTLY the sum of three bf16
+// values: h = the top 8 significant bits (x truncated to bf16), m = the next 8 (x - h truncated), l = the last 8
+// (x - h - m, exact).  A product w * x is then the sum of nine bf16 x bf16 products, each exact in the MFMA's f32
+// datapath; the three smallest (wm*xl, wl*xm, wl*xl <= 2^-23 |w x|) are below the rounding of an f32 product and are
+// dropped, the other six are accumulated in f32 by v_mfma_f32_16x16x32_bf16.  Six bf16 MFMAs per 32 of k cost 96 cycles
+// where the f32 MFMA needs 8 x 32 = 256: 2.7x the f32 matrix peak at f32 accuracy (measured against f64 in
+// tests/test_gpu_convops_f32.py: same error as the f32 MFMA path).  The split costs VALU work (2 and + 2 sub per element
+// + v_perm packing), done once per staged element.
+// ---------------------------------------------------------------------------
+// 8 f32 (two 16-B chunks) -> the three bf16x8 planes; element order kept (element 2q, 2q+1 -> dword q)
+__device__ __forceinline__ void split3(const u32x4& c0, const u32x4& c1, u32x4& H, u32x4& M, u32x4& L) {
+    const unsigned xs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned a = xs[2 * q], b = xs[2 * q + 1];
+        H[q] = __builtin_amdgcn_perm(b, a, 0x07060302u);                 // [b.hi16 : a.hi16]
+        const float ra = __uint_as_float(a) - __uint_as_float(a & 0xffff0000u);
+        const float rb = __uint_as_float(b) - __uint_as_float(b & 0xffff0000u);
+        const unsigned ua = __float_as_uint(ra), ub = __float_as_uint(rb);
+        M[q] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+        const float la = ra - __uint_as_float(ua & 0xffff0000u);
+        const float lb = rb - __uint_as_float(ub & 0xffff0000u);
+        L[q] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
     }
 }
 
@@ -620,6 +651,243 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
     conv_epilogue<BM, BN, TC, TP, T, T>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt, poff, coff, tid, lane, wave, true);
 }
 
+// k_conv_igemm_dma_s3: k_conv_igemm_dma in split mode (f32 activations and results, six bf16 MFMAs per tile pair and 32
+// of k; see split3).  The pixels arrive as f32 by LDS-DMA exactly as in the f32 kernel (two 64-B sub-rows = 32 of k per
+// stage); a lane's two 16-B fragments (k = 4g..4g+3 and 16+4g..16+4g+3 of the stage) are split in registers.  The
+// weights arrive PRE-SPLIT (cr_weight_split3, once per optimizer step for the whole model): per (row, 32 of k) three
+// 64-B rows, one per plane, whose element order is the pixels' fragment order (chunk c = k {4c..4c+3, 16+4c..16+4c+3}),
+// so one ds_read_b128 per plane is a lane's MFMA operand.  LDS: 2 x (16 KB pixels + 3 x BN x 64 B weights) = 80 / 56 KB.
+template <int BN, int KS, int MODE>
+__global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma_s3(ConvP p) {
+    constexpr int BM = 128, BK = 32;
+    // every wave takes ALL BN channels of 32 pixels: the split is per pixel fragment, so TP = 2 halves its VALU work per MFMA
+    // against the 64 x 64 wave tile (the two waves of a SIMD share its vector issue: 2 x 176 VALU + 192 MFMA issue slots per
+    // stage pair did not fit under the 192 x 16 MFMA cycles)
+    constexpr int WAVES_M = 4, WAVES_N = 1;
+    constexpr int TP = BM / WAVES_M / 16, TC = BN / WAVES_N / 16;
+    constexpr int NBW = BN / 64;
+    constexpr int XS = BM * 32, WS = BN * 32;                               // u16 units of one 64-B-row sub-block
+    constexpr int STAGE = 2 * XS + 3 * WS;                                  // X(k 0..15), X(k 16..31), W planes h, m, l
+    constexpr int NDMA = 4 + 3 * NBW;
+    __shared__ __attribute__((aligned(1024))) u16 smem[2 * STAGE];
+    static_assert(4 * 2 * BN * sizeof(float) <= 2 * STAGE * sizeof(u16), "sStat must fit");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = p.Cout / BN;
+    const int tiles_total = (int)gridDim.x / p.ksplit;
+    const int ks = (int)blockIdx.x / tiles_total, bt = (int)blockIdx.x - ks * tiles_total;
+    const int bid = (p.xcd && (p.ksplit == 1 || (tiles_total & 7) == 0)) ? xcd_swizzle(bt, tiles_total) : bt;
+    const int nt = bid % n_tiles, mt = bid / n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    int nimg[2], hb[2], wb[2];
+    bool rv[2];
+    unsigned csrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 2) + 64 * i;
+        const int m = m0 + row;
+        rv[i] = m < p.M;
+        const int mm = rv[i] ? m : 0;
+        const int hw = p.Hout * p.Wout;
+        const int n = mm / hw;
+        const int rem = mm - n * hw;
+        const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+        nimg[i] = n;
+        if (MODE == 0) { hb[i] = ho * p.stride - p.pad; wb[i] = wo * p.stride - p.pad; }
+        else           { hb[i] = ho + p.pad;            wb[i] = wo + p.pad; }
+        csrc[i] = (unsigned)(((tid & 3) ^ ((-(row >> 2)) & 3)) * 16);
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w3_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int nstage_all = p.Kdim / BK;
+    unsigned wrow[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) wrow[i] = (unsigned)((n0 + (tid >> 2) + 64 * i) * nstage_all) * 192u + csrc[i];
+
+    const int st0 = ks * p.kstages, st1 = min(st0 + p.kstages, nstage_all);
+    int cur_tap = -1;
+    unsigned tb[2] = {OOB, OOB};
+    auto issue = [&](int st, int buf) {
+        const int k0 = st * BK;
+        const int tap = KS == 1 ? 0 : (k0 >> p.cshift), cc = KS == 1 ? k0 : (k0 & (p.Cin - 1));
+        if (tap != cur_tap) {
+            const int r = tap / KS, s2 = tap - r * KS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int hi, wi;
+                bool ok = rv[i];
+                if (MODE == 0) { hi = hb[i] + r; wi = wb[i] + s2; }
+                else {
+                    const int th = hb[i] - r, tw = wb[i] - s2;
+                    if (p.stride == 2) { ok = ok && (((th | tw) & 1) == 0); hi = th >> 1; wi = tw >> 1; }
+                    else { hi = th; wi = tw; }
+                }
+                ok = ok && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
+                tb[i] = ok ? (unsigned)(((nimg[i] * p.Hin + hi) * p.Win + wi) * p.Cin) * 4u + csrc[i] : OOB;
+            }
+            cur_tap = tap;
+        }
+        u16* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                dma16(rx, base + u * XS + (wave * 16 + 64 * i) * 32, tb[i] == OOB ? OOB : tb[i] + (unsigned)(cc + u * 16) * 4u);
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                dma16(rw, base + 2 * XS + pl * WS + (wave * 16 + 64 * i) * 32, wrow[i] + (unsigned)st * 192u + (unsigned)pl * 64u);
+    };
+
+    const int poff = (wave / WAVES_N) * (BM / WAVES_M), coff = (wave % WAVES_N) * (BN / WAVES_N);
+    const int fr = lane & 15, fc = lane >> 4;
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned lds0 = lds_addr(smem);
+    unsigned xa[TP], wa[TC];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) xa[j] = (unsigned)lds_off(poff + j * 16 + fr, fc) * 2u;
+#pragma unroll
+    for (int i = 0; i < TC; ++i) wa[i] = (unsigned)lds_off(coff + i * 16 + fr, fc) * 2u;
+
+    issue(st0, 0);
+    for (int st = st0; st < st1; ++st) {
+        const int buf = (st - st0) & 1;
+        if (st + 1 < st1) {
+            issue(st + 1, buf ^ 1);
+            if (NDMA == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const unsigned sb = lds0 + (unsigned)(buf * STAGE) * 2u;
+        u32x4 wf[3][TC], x0[TP], x1[TP];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wf[pl][i] = lds_read16_asm(sb + (unsigned)(2 * XS + pl * WS) * 2u + wa[i]);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            x0[j] = lds_read16_asm(sb + xa[j]);
+            x1[j] = lds_read16_asm(sb + (unsigned)XS * 2u + xa[j]);
+        }
+        // all fragment reads have returned (the asm ties the wait to the registers the MFMAs / the split consume)
+        static_assert(TP == 2, "wait below names two pixel fragments");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0[0]), "+v"(x0[1]), "+v"(x1[0]), "+v"(x1[1]));
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < TC; i += 4)
+                asm volatile("" : "+v"(wf[pl][i]), "+v"(wf[pl][i + 1]), "+v"(wf[pl][i + 2]), "+v"(wf[pl][i + 3]));
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            u32x4 xs[3];
+            split3(x0[j], x1[j], xs[0], xs[1], xs[2]);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                constexpr int PW[6] = {2, 1, 0, 1, 0, 0}, PX[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[PW[t]][i]),
+                                                                        __builtin_bit_cast(bf16x8, xs[PX[t]]), acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (p.ksplit > 1) {
+        const int g = lane >> 4, pl = lane & 15;
+        float* dst = p.part + (size_t)ks * p.M * p.Cout;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int m = m0 + poff + j * 16 + pl;
+                if (m < p.M)
+                    *reinterpret_cast<float4*>(dst + (size_t)m * p.Cout + n0 + coff + i * 16 + 4 * g) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        return;
+    }
+    conv_epilogue<BM, BN, TC, TP, float, float>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt, poff, coff, tid, lane, wave, true);
+}
+
+// f32 [rows][K] (K % 32 == 0) -> split-mode weight planes [rows][K/32][3][32 bf16]; within a 64-B plane row, 16-B chunk c
+// holds k = 32 kb + {4c..4c+3, 16+4c..16+4c+3}.  One thread per (row, kb, chunk).
+__global__ __launch_bounds__(256) void k_weight_split3(const float* __restrict__ src, u16* __restrict__ dst, int64_t rows, int K) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KB = K >> 5;
+    if (i >= rows * KB * 4) return;
+    const int c = (int)(i & 3);
+    const int64_t rk = i >> 2;                            // row * KB + kb
+    const int64_t row = rk / KB;
+    const int kb = (int)(rk - row * KB);
+    const float* s0 = src + row * K + kb * 32 + 4 * c;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(s0), b = *reinterpret_cast<const u32x4*>(s0 + 16);
+    u32x4 H, M, L;
+    split3(a, b, H, M, L);
+    u16* d = dst + rk * 96 + c * 8;
+    *reinterpret_cast<u32x4*>(d) = H;
+    *reinterpret_cast<u32x4*>(d + 32) = M;
+    *reinterpret_cast<u32x4*>(d + 64) = L;
+}
+
+extern "C" int cr_weight_split3(cr_ctx* ctx, const float* src, void* dst, int64_t rows, int K) {
+    CR_CHECK_ARG(ctx && rows >= 0 && K > 0 && (K & 31) == 0, "cr_weight_split3: K=%d must be a positive multiple of 32", K);
+    if (rows == 0) return CR_OK;
+    CR_CHECK_ARG(src && dst && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "cr_weight_split3: NULL or misaligned pointer");
+    const int64_t n = rows * (K >> 5) * 4;
+    hipLaunchKernelGGL(k_weight_split3, dim3((unsigned)cr_cdiv(n, 256)), dim3(256), 0, ctx->stream, src, (u16*)dst, rows, K);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// the same for many matrices in one launch (all conv weights of the model, views into one flat buffer): desc d covers the
+// items [item0, item0 + rows * K/32 * 4) -- an item is one 16-B chunk of one plane row
+struct cr_s3desc { int64_t src_off, dst_off, item0; int rows, K; };
+__global__ __launch_bounds__(256) void k_weights_split3(const float* __restrict__ src_base, u16* __restrict__ dst_base,
+                                                        const cr_s3desc* __restrict__ descs, int ndesc, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = ndesc - 1;                           // last desc with item0 <= i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].item0 <= i) lo = mid; else hi = mid - 1;
+    }
+    const cr_s3desc d = descs[lo];
+    const int64_t li = i - d.item0;
+    const int KB = d.K >> 5;
+    const int c = (int)(li & 3);
+    const int64_t rk = li >> 2;
+    const int64_t row = rk / KB;
+    const int kb = (int)(rk - row * KB);
+    const float* s0 = src_base + d.src_off + row * d.K + kb * 32 + 4 * c;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(s0), b = *reinterpret_cast<const u32x4*>(s0 + 16);
+    u32x4 H, M, L;
+    split3(a, b, H, M, L);
+    u16* o = dst_base + d.dst_off + rk * 96 + c * 8;
+    *reinterpret_cast<u32x4*>(o) = H;
+    *reinterpret_cast<u32x4*>(o + 32) = M;
+    *reinterpret_cast<u32x4*>(o + 64) = L;
+}
+
+extern "C" int cr_weights_split3(cr_ctx* ctx, const float* src_base, void* dst_base, const void* descs_dev, int ndesc,
+                                 int64_t total_items) {
+    CR_CHECK_ARG(ctx && ndesc >= 0 && total_items >= 0, "cr_weights_split3: bad args");
+    if (ndesc == 0 || total_items == 0) return CR_OK;
+    CR_CHECK_ARG(src_base && dst_base && descs_dev, "cr_weights_split3: NULL pointer");
+    hipLaunchKernelGGL(k_weights_split3, dim3((unsigned)cr_cdiv(total_items, 256)), dim3(256), 0, ctx->stream, src_base,
+                       (u16*)dst_base, (const cr_s3desc*)descs_dev, ndesc, total_items);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
 // second phase of the split-K launches: out[m][c] = epilogue( sum_s part[s][m][c] ), the sum in a fixed order (bitwise
 // reproducible), the epilogue as conv_epilogue's: bias, BatchNorm statistics of the pre-residual value (one row of partial
 // sums per 64 pixels), residual, ReLU.  A block = 64 pixels x 64 channels; a thread = 4 pixels x 4 channels.
@@ -716,6 +984,13 @@ static int xcd_enabled() {
 // literal template arguments from a plain function (the launch from inside a function template left the host stubs undefined)
 static void launch_dma_kernel(int bn, int ks, int mode, hipStream_t stream, const ConvP& p) {
     const dim3 grid((unsigned)(cr_cdiv(p.M, 128) * (p.Cout / bn) * p.ksplit)), block(CONV_T);
+    if (p.w3) {
+#define CR_S3_CASE(B, K, M_) if (bn == B && ks == K && mode == M_) { \
+        hipLaunchKernelGGL((k_conv_igemm_dma_s3<B, K, M_>), grid, block, 0, stream, p); return; }
+        CR_S3_CASE(128, 3, 0) CR_S3_CASE(128, 3, 1) CR_S3_CASE(128, 1, 0) CR_S3_CASE(128, 1, 1)
+        CR_S3_CASE(64, 3, 0) CR_S3_CASE(64, 3, 1) CR_S3_CASE(64, 1, 0) CR_S3_CASE(64, 1, 1)
+#undef CR_S3_CASE
+    }
 #define CR_DMA_CASE(B, K, M_) if (bn == B && ks == K && mode == M_) { \
         if (p.f32) hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_, float>), grid, block, 0, stream, p); \
         else hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_, u16>), grid, block, 0, stream, p); \
@@ -844,7 +1119,7 @@ static int conv_common_checks(const char* who, int N, int H, int W, int Cin, int
 
 extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y, int N, int H, int W, int Cin,
                              int Cout, int ks, int stride, int pad, const float* bias, const void* residual,
-                             int relu, float* stats, int out_f32, int act_f32) {
+                             int relu, float* stats, int out_f32, int act_f32, const void* w_split) {
     CR_CHECK_ARG(ctx && x && w && y, "cr_conv2d_fwd: NULL pointer");
     int rc = conv_common_checks("cr_conv2d_fwd", N, H, W, Cin, Cout, ks, stride, pad, act_f32);
     if (rc) return rc;
@@ -858,6 +1133,7 @@ extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y,
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cin); p.relu = relu; p.xcd = xcd_enabled(); p.f32 = act_f32 ? 1 : 0;
     p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim; p.cls = 0; p.Hfull = p.Hout; p.Wfull = p.Wout; p.wstride = p.Kdim;
     p.x_bytes = (unsigned)((size_t)N * H * W * Cin * es); p.w_bytes = (unsigned)((size_t)Cout * p.Kdim * es);
+    p.w3 = (act_f32 == 2 && (p.Kdim & 31) == 0) ? w_split : nullptr; p.w3_bytes = (unsigned)((size_t)Cout * p.Kdim * 6);
     if (act_f32) out_f32 = 1;
     if (ks == 1) return launch_igemm_ks<1, 0>(ctx, p, out_f32);
     if (ks == 3) return launch_igemm_ks<3, 0>(ctx, p, out_f32);
@@ -867,7 +1143,7 @@ extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y,
 // dX[n,h,w,c] = sum_{r,s,k} dY[n,(h+pad-r)/stride,(w+pad-s)/stride,k] * W[k,r,s,c]
 // wt = weights re-laid as [Cin][(r*KS+s)*Cout + k]  (cr_weight_transpose)
 extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int N, int H, int W,
-                                  int Cin, int Cout, int ks, int stride, int pad, int act_f32) {
+                                  int Cin, int Cout, int ks, int stride, int pad, int act_f32, const void* wt_split) {
     CR_CHECK_ARG(ctx && dy && wt && dx, "cr_conv2d_bwd_data: NULL pointer");
     int rc = conv_common_checks("cr_conv2d_bwd_data", N, H, W, Cout, Cin, ks, stride, pad, act_f32);
     if (rc) return rc;
@@ -882,6 +1158,7 @@ extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, v
     p.cshift = ks == 1 ? 0 : ilog2_exact(Cout); p.relu = 0; p.xcd = xcd_enabled(); p.f32 = act_f32 ? 1 : 0;
     p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim; p.cls = 0; p.Hfull = p.Hout; p.Wfull = p.Wout; p.wstride = p.Kdim;
     p.x_bytes = (unsigned)((size_t)N * Ho * Wo * Cout * es); p.w_bytes = (unsigned)((size_t)Cin * p.Kdim * es);
+    p.w3 = (act_f32 == 2 && (p.Kdim & 31) == 0) ? wt_split : nullptr; p.w3_bytes = (unsigned)((size_t)Cin * p.Kdim * 6);
     static const int cls_on = env_int("CR_BWD_S2_CLASSES", 1);
     if (cls_on && stride == 2 && ks == 3 && (H & 1) == 0 && (W & 1) == 0 && (Cout & (act_f32 ? 15 : 31)) == 0) {
         // by output-pixel parity class (see ConvP): H/2 x W/2 pixels per class, 4 classes in one grid
@@ -905,6 +1182,7 @@ struct WgP {
     int tm, tn, xcd;        // tile counts (the grid is 1-D: tm * tn * splits blocks)
     unsigned x_bytes, dy_bytes;   // extents for the buffer-load descriptors
     float* dbias;           // optional [Cout]: += column sums of dy (bias gradient), accumulated by the first k-tile's blocks
+    int dbg;                // tuning only (CR_S3_DBG): 1 = no MFMAs, 2 = no LDS fragment reads either, 4 = no atomics
 };
 
 // transposing LDS read: 16-lane group reads a 4(row) x 16(col) block of 16-bit elements and
@@ -1317,6 +1595,263 @@ static int launch_wgrad_f32_ks(cr_ctx* ctx, WgP& p) {
     return CR_OK;
 }
 
+// backward-weight in split mode: k_conv_wgrad's operand scheme (pixel-major operands, transposing LDS reads, split over pixel
+// ranges with f32 atomics) on f32 inputs: a step's chunks (32 pixels) are loaded as f32, split on their way into LDS (three
+// bf16 images per operand) and every 16x16 tile pair takes six MFMAs per step.
+// Schedule: the split makes the staging phase VALU-heavy (176 VALU + 12 ds_write_b128 per lane and step) next to an MFMA
+// phase of 96 MFMAs, and two co-resident blocks run in lockstep, so phases of the same kind collide instead of overlapping
+// (measured: staging 204 us + fragment reads 83 us + MFMAs 185 us = the kernel's 472 us).  So a block is TWO wave groups
+// (8 waves, one of each group per SIMD) on interleaved steps of the block's pixel range, each with its own LDS images,
+// running half a step apart: while group A issues MFMAs group B splits and stores its next step, then they swap -- one
+// block-wide barrier per phase.  The groups' accumulators are summed in LDS before the atomics.
+template <int TM, int KS>
+__global__ __launch_bounds__(CONV_T * 2) void k_conv_wgrad_s3(WgP p) {
+    constexpr int TN = 128;
+    constexpr int WM = (TM == 128) ? 2 : 1, WN = 4 / WM;
+    constexpr int WTM = TM / WM, WTN = TN / WN;          // wave tile
+    constexpr int TI = WTM / 16, TJ = WTN / 16;
+    constexpr int PP = TM == 128 ? 144 : TM + 8, PQ = TN + 16;        // as k_conv_wgrad (bank-conflict-free tr reads)
+    auto rotQ = [](int row, int col) { return (col + (((row >> 3) & 1) << 6)) & 127; };
+    auto rotP = [&](int row, int col) { return TM == 128 ? rotQ(row, col) : col; };
+    constexpr int CPR = TM / 8;                          // dy chunks (8 channels) per pixel row
+    constexpr int NP = (32 * CPR + CONV_T - 1) / CONV_T; // dy chunks per thread per 32-pixel step
+    constexpr int PE = 32 * PP, QE = 32 * PQ;            // elements of one plane of one operand
+    constexpr int GE = 3 * (PE + QE);                    // elements of one group's images
+    constexpr int TNP = TN + 4;                          // reduction tile pitch (floats)
+    static_assert(TM * TNP * 4 <= 2 * GE * 2, "reduction tile must fit in the operand images");
+    __shared__ __attribute__((aligned(16))) u16 smem[2 * GE];
+    const int grp = (int)(threadIdx.x >> 8);
+    u16* sP = smem + grp * GE;                           // planes at sP + pl * PE
+    u16* sQ = sP + 3 * PE;                               // planes at sQ + pl * QE
+
+    const int tid = threadIdx.x & (CONV_T - 1), lane = tid & 63, wave = tid >> 6;
+    const int bid = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int bx = bid % p.tm, by = (bid / p.tm) % p.tn, bz = bid / (p.tm * p.tn);
+    const int c0 = bx * TM, q0 = by * TN;
+    const int step0 = bz * p.steps_per_split;
+    const int nsteps_total = (p.M + 31) >> 5;
+    const int step1 = min(step0 + p.steps_per_split, nsteps_total);
+    if (step0 >= step1) return;            // block-uniform
+
+    const int qc = tid & 15;
+    const int qk = q0 + qc * 8;
+    int qr = 0, qs = 0, qch = qk;
+    const bool qvalid = qk < p.Kdim;
+    if (KS > 1) {
+        const int tap = qk >> p.cshift;
+        qch = qk & (p.Cin - 1);
+        qr = tap / KS;
+        qs = tap - qr * KS;
+    }
+    const int first = step0 + grp;             // this group's first step; it then takes every second one
+    int pn[2], pho[2], pwo[2];
+    {
+        const int hw = p.Hout * p.Wout;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = first * 32 + (tid >> 4) + 16 * i;
+            pn[i] = m / hw;
+            const int rem = m - pn[i] * hw;
+            pho[i] = rem / p.Wout;
+            pwo[i] = rem - pho[i] * p.Wout;
+        }
+    }
+    int mrow = first * 32;
+    const int mend = min(p.M, step1 * 32);     // rows of later splits / past M contribute zeros
+    u32x4 rq[2][2][2], rp[2][NP][2];               // two register sets: loads run two steps ahead of their split
+    auto advance = [&](int pixels) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            pwo[i] += pixels;
+            while (pwo[i] >= p.Wout) { pwo[i] -= p.Wout; ++pho[i]; }
+            while (pho[i] >= p.Hout) { pho[i] -= p.Hout; ++pn[i]; }
+        }
+        mrow += pixels;
+    };
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    auto load_stage = [&](auto SET) {
+        constexpr int rs = decltype(SET)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hi = pho[i] * p.stride - p.pad + qr, wi = pwo[i] * p.stride - p.pad + qs;
+            const bool ok = qvalid && mrow < mend && pn[i] < p.N && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+            const unsigned off = (unsigned)(((pn[i] * p.Hin + hi) * p.Win + wi) * p.Cin + qch) * 4u;
+            rq[rs][i][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : OOB, 0, 0);
+            rq[rs][i][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off + 16u : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + CONV_T * i;
+            const int prow = idx / CPR, pc = idx - prow * CPR;
+            const bool ok = idx < 32 * CPR && mrow + prow < mend && c0 + pc * 8 < p.Cout;
+            const unsigned off = (unsigned)((mrow + prow) * p.Cout + c0 + pc * 8) * 4u;
+            rp[rs][i][0] = __builtin_amdgcn_raw_buffer_load_b128(rdy, ok ? off : OOB, 0, 0);
+            rp[rs][i][1] = __builtin_amdgcn_raw_buffer_load_b128(rdy, ok ? off + 16u : OOB, 0, 0);
+        }
+        advance(64);                            // the other group takes the step in between
+    };
+    auto store_stage = [&](auto SET) {
+        constexpr int rs = decltype(SET)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x4 H, M, L;
+            split3(rq[rs][i][0], rq[rs][i][1], H, M, L);
+            const int row = (tid >> 4) + 16 * i;
+            u16* d = &sQ[row * PQ + rotQ(row, qc * 8)];
+            *reinterpret_cast<u32x4*>(d) = H;
+            *reinterpret_cast<u32x4*>(d + QE) = M;
+            *reinterpret_cast<u32x4*>(d + 2 * QE) = L;
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + CONV_T * i;
+            const int prow = idx / CPR, pc = idx - prow * CPR;
+            if (idx < 32 * CPR) {
+                u32x4 H, M, L;
+                split3(rp[rs][i][0], rp[rs][i][1], H, M, L);
+                u16* d = &sP[prow * PP + rotP(prow, pc * 8)];
+                *reinterpret_cast<u32x4*>(d) = H;
+                *reinterpret_cast<u32x4*>(d + PE) = M;
+                *reinterpret_cast<u32x4*>(d + 2 * PE) = L;
+            }
+        }
+    };
+
+    const int wm = (WM == 2) ? (wave >> 1) : 0, wn = (WM == 2) ? (wave & 1) : wave;
+    const int moff = wm * WTM, noff = wn * WTN;
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    const bool do_bias = p.dbias != nullptr && by == 0 && tid < TM;
+    float bsum = 0.f;
+    auto compute = [&]() {
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                const u16* s0 = &sP[r * PP + rotP(r, tid)];
+                bsum += (bf2f(s0[0]) + bf2f(s0[PE])) + bf2f(s0[2 * PE]);
+            }
+        }
+        // dy planes stay in registers; the x planes come one at a time: x_h meets dy_l, dy_m, dy_h; x_m meets dy_m, dy_h;
+        // x_l meets dy_h (smallest terms first within each accumulator)
+        bf16x8 af[3][TI];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const u16* b0 = &sP[pl * PE + (8 * g + tq) * PP + rotP(8 * g + tq, moff + i * 16 + 4 * tp)];
+                const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b0 + 4 * PP);
+                af[pl][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+        for (int pb = 0; pb < 3; ++pb) {
+            bf16x8 bfr[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const u16* b0 = &sQ[pb * QE + (8 * g + tq) * PQ + rotQ(8 * g + tq, noff + j * 16 + 4 * tp)];
+                const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b0 + 4 * PQ);
+                bfr[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            if (!(p.dbg & 1)) {
+#pragma unroll
+                for (int pa = 2 - pb; pa >= 0; --pa)
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pa][i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // steps of this group: first, first + 2, ...; both groups run the same number of phases (a group without a step left
+    // stages and multiplies zeros: its loads are masked by mrow >= mend).  Loads run TWO steps ahead (alternating register
+    // sets): one MFMA phase (~0.8 us) does not cover a global round trip under load.
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int nst = (step1 - step0 + 1) >> 1;
+    load_stage(S0{});
+    load_stage(S1{});
+    store_stage(S0{});
+    __syncthreads();
+    // one iteration = steps i (register set 0 holds step i + 2 afterwards) and i + 1 (set 1 -> step i + 3)
+    auto phase_pair = [&](int i, auto CUR, auto NXT) {
+        // even phase: A multiplies step i, B splits and stores step i;  odd phase: A stores step i + 1, B multiplies step i
+        if (grp == 0) { if (i + 2 < nst) load_stage(CUR); compute(); }
+        else if (i > 0) store_stage(CUR);
+        __syncthreads();
+        if (grp == 0) { if (i + 1 < nst) store_stage(NXT); }
+        else { if (i + 2 < nst) load_stage(CUR); compute(); }
+        __syncthreads();
+    };
+    for (int i = 0; i < nst; i += 2) {
+        phase_pair(i, S0{}, S1{});
+        if (i + 1 < nst) phase_pair(i + 1, S1{}, S0{});
+    }
+    if (do_bias && c0 + tid < p.Cout) atomicAdd(&p.dbias[c0 + tid], bsum);
+    if (p.dbg & 4) { if (acc[0][0][0] == 123.456f) p.dw[0] = 1.f; return; }
+    // sum the two groups' accumulators in LDS (the operand images are dead: the loop ended with a barrier), then one set
+    // of atomics per block, full 512-B rows per wave-instruction.  D: col (lane&15) = k index, row 4(lane>>4)+reg = channel
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+        if (grp == gg) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float* d = &tile[(moff + i * 16 + 4 * g + e) * TNP + noff + j * 16 + li];
+                        if (gg == 0) *d = acc[i][j][e]; else *d += acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < TM * TN; idx += CONV_T * 2) {
+        const int chl = idx / TN, kl = idx - chl * TN;
+        const int ch = c0 + chl, kk = q0 + kl;
+        if (kk < p.Kdim && ch < p.Cout) atomicAdd(&p.dw[(size_t)ch * p.Kdim + kk], tile[chl * TNP + kl]);
+    }
+}
+
+// true + launched when the layer takes the split-mode weight-gradient kernel
+template <int KS>
+static bool try_launch_wgrad_s3(cr_ctx* ctx, WgP& p, int* rc) {
+    static const int on = env_int("CR_S3_WGRAD", 1);
+    if (!on || p.Cout < 64 || (p.Cout & 7) || (p.Cin & 7) || p.M < 512) return false;
+    const int nsteps = (p.M + 31) >> 5;
+    const int tn = (int)cr_cdiv(p.Kdim, 128);
+    const int TM = p.Cout >= 128 ? 128 : 64;
+    const int tm = (int)cr_cdiv(p.Cout, TM);
+    const int tiles = tm * tn;
+    // 110 KB of LDS per block of 8 waves: one block per CU; every block keeps >= 8 steps (4 per group)
+    static const int force_splits = env_int("CR_WG_SPLITS_S3", 0), target = env_int("CR_WG_S3_BLOCKS", 256);
+    int splits = target / tiles;
+    if (splits > nsteps / 8) splits = nsteps / 8;
+    if (force_splits > 0) splits = force_splits;
+    if (splits > nsteps) splits = nsteps;
+    if (splits < 1) splits = 1;
+    p.steps_per_split = (nsteps + splits - 1) / splits;
+    p.steps_per_split = (p.steps_per_split + 1) & ~1;             // whole step pairs (one step per group)
+    splits = (nsteps + p.steps_per_split - 1) / p.steps_per_split;
+    dim3 grid(tm * tn * splits);
+    p.tm = tm; p.tn = tn; p.xcd = xcd_enabled();
+    static const int dbg = env_int("CR_S3_DBG", 0);
+    p.dbg = dbg;
+    if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad_s3<128, KS>), grid, dim3(CONV_T * 2), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((k_conv_wgrad_s3<64, KS>), grid, dim3(CONV_T * 2), 0, ctx->stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cr_set_error("k_conv_wgrad_s3 launch failed: %s", hipGetErrorString(e)); *rc = CR_EHIP; }
+    else *rc = CR_OK;
+    return true;
+}
+
 template <int KS>
 static int launch_wgrad_ks(cr_ctx* ctx, WgP& p) {
     const int nsteps = (p.M + 31) >> 5;
@@ -1394,6 +1929,7 @@ static int conv2d_bwd_weight_impl(cr_ctx* ctx, const void* dy, const void* x, fl
     if (rc) return rc;
     const size_t es = act_f32 ? 4 : 2;
     WgP p;
+    p.dbg = 0;
     p.dy = dy; p.x = x; p.dw = dw; p.dbias = dbias;
     p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Cout = Cout;
     p.Hout = (H + 2 * pad - ks) / stride + 1;
@@ -1405,6 +1941,10 @@ static int conv2d_bwd_weight_impl(cr_ctx* ctx, const void* dy, const void* x, fl
         const int64_t nz = (int64_t)Cout * p.Kdim;
         hipLaunchKernelGGL(k_fill_zero_f32, dim3((unsigned)cr_cdiv(nz, 256)), dim3(256), 0, ctx->stream, dw, nz);
         CR_LAUNCH_CHECK();
+    }
+    if (act_f32 == 2 && ks != 7) {
+        int rc3 = CR_OK;
+        if (ks == 1 ? try_launch_wgrad_s3<1>(ctx, p, &rc3) : try_launch_wgrad_s3<3>(ctx, p, &rc3)) return rc3;
     }
     if (act_f32) {
         if (ks == 1) return launch_wgrad_f32_ks<1>(ctx, p);
@@ -2233,16 +2773,17 @@ extern "C" int cr_preprocess(cr_ctx* ctx, const unsigned char* img, void* y, int
 //   x (R,K), w (O,K), wt (K,O) in the activations' type (bf16 or f32 by act_f32); bias / dw / dbias f32.
 // ---------------------------------------------------------------------------
 extern "C" int cr_linear_fwd(cr_ctx* ctx, const void* x, const void* w, const float* bias, void* y, int R, int K, int O,
-                             int relu, int out_f32, int act_f32) {
+                             int relu, int out_f32, int act_f32, const void* w_split) {
     CR_CHECK_ARG(R >= 0, "cr_linear_fwd: bad row count");
     if (R == 0) return CR_OK;
-    return cr_conv2d_fwd(ctx, x, w, y, 1, 1, R, K, O, 1, 1, 0, bias, nullptr, relu, nullptr, out_f32, act_f32);
+    return cr_conv2d_fwd(ctx, x, w, y, 1, 1, R, K, O, 1, 1, 0, bias, nullptr, relu, nullptr, out_f32, act_f32, w_split);
 }
 
-extern "C" int cr_linear_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int R, int K, int O, int act_f32) {
+extern "C" int cr_linear_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int R, int K, int O, int act_f32,
+                                  const void* wt_split) {
     CR_CHECK_ARG(R >= 0, "cr_linear_bwd_data: bad row count");
     if (R == 0) return CR_OK;
-    return cr_conv2d_bwd_data(ctx, dy, wt, dx, 1, 1, R, K, O, 1, 1, 0, act_f32);
+    return cr_conv2d_bwd_data(ctx, dy, wt, dx, 1, 1, R, K, O, 1, 1, 0, act_f32, wt_split);
 }
 
 // dw (O,K) f32 (+)= dy^T x ; dbias (O) += column sums of dy when given (from the dy tiles the kernel stages anyway)

@@ -68,7 +68,7 @@ class GraphedDense:
         assert model.training, "capture the training-mode dense region"
         self.model = model
         self.shape = tuple(images_u8.shape)
-        self.dtype = ops.act_dtype()        # the captured kernels are those of this precision mode
+        self.dtype = ops.precision()        # the captured kernels are those of this precision mode
         dev = images_u8.device
         self.static_img = images_u8.clone()
         self.pre_bwd = None                 # optional callback run right before the backward graph is replayed
@@ -128,7 +128,7 @@ class GraphedDense:
 
     def matches(self, images_u8):
         return (tuple(images_u8.shape) == self.shape and images_u8.device == self.static_img.device
-                and ops.act_dtype() == self.dtype)
+                and ops.precision() == self.dtype)
 
     def __call__(self, images_u8):
         self.static_img.copy_(images_u8)
@@ -145,7 +145,7 @@ class GraphedDenseEval:
     def __init__(self, model, images_u8, warmup=2):
         assert not model.training, "capture the eval-mode dense region"
         self.shape = tuple(images_u8.shape)
-        self.dtype = ops.act_dtype()
+        self.dtype = ops.precision()
         dev = images_u8.device
         self.static_img = images_u8.clone()
         pg = model.proposal_generator
@@ -173,7 +173,7 @@ class GraphedDenseEval:
 
     def matches(self, images_u8):
         return (tuple(images_u8.shape) == self.shape and images_u8.device == self.static_img.device
-                and ops.act_dtype() == self.dtype)
+                and ops.precision() == self.dtype)
 
     def __call__(self, images_u8):
         self.static_img.copy_(images_u8)

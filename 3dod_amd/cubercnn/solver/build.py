@@ -119,7 +119,7 @@ class FlatSGD:
     def enable_weight_bank(self):
         """one-launch-per-step bf16 recast of every conv weight (hipops.WeightBank); training-step objects call this."""
         bank = getattr(self, "weight_bank", None)
-        if self.flat_p.is_cuda and hasattr(ops, "WeightBank") and (bank is None or bank.dtype != ops.act_dtype()):
+        if self.flat_p.is_cuda and hasattr(ops, "WeightBank") and (bank is None or getattr(bank, 'mode', None) != ops.precision()):
             convs = [p for p in self.params if p.dim() == 4 and p.shape[2] == p.shape[3] and
                      p.is_contiguous(memory_format=torch.channels_last)]
             if convs:
@@ -359,7 +359,7 @@ class GraphedTrainStep:
         from ..modeling.graphed import _fresh_leaves
         model, optimizer, dev, world_size = self.model, self.opt, self.dev, self.world
         optimizer.enable_weight_bank()
-        self.dtype = ops.act_dtype()
+        self.dtype = ops.precision()
         self.G = int(G)
         images, batch = model._stack_images(sample_data)
         self.image_sizes = [tuple(s) for s in images.image_sizes]
@@ -465,7 +465,7 @@ class GraphedTrainStep:
         self.meta.copy_(meta, non_blocking=True)
 
     def __call__(self, data):
-        if ops.act_dtype() != self.dtype:
+        if ops.precision() != self.dtype:
             raise RuntimeError("GraphedTrainStep was captured in another precision mode (hipops.set_precision)")
         self.load(data)
         self.graph_a.replay()

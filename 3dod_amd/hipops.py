@@ -26,33 +26,62 @@ bf16 = torch.bfloat16
 f32 = torch.float32
 STAT_REPL = 32
 
-_PRECISIONS = {"fp32": f32, "f32": f32, "float32": f32, "bf16": bf16, "bfloat16": bf16}
+# name -> (activation dtype, act_f32 flag of the C ABI)
+_PRECISIONS = {"fp32": (f32, 1), "f32": (f32, 1), "float32": (f32, 1), "fp32x3": (f32, 2), "bf16": (bf16, 0),
+               "bfloat16": (bf16, 0)}
 _ACT = [_PRECISIONS[os.environ.get("CR_PRECISION", "fp32").lower()]]
 
 
 def set_precision(name):
-    """"fp32" (reference precision, default) or "bf16" (fast mode): the dtype of the activations produced by
-    preprocess() and hence of everything downstream.  Returns the previous setting's name."""
+    """"fp32" (reference precision on the f32 MFMA, default), "fp32x3" (float32 storage and float32-accurate
+    contractions on the bf16 matrix cores: every operand split exactly into three bf16 values, six products per term --
+    include/cr3dod.h, act_f32 = 2) or "bf16" (fast mode).  Decides the dtype of the activations produced by preprocess()
+    and hence of everything downstream, and which kernels f32 tensors run on.  Returns the previous setting's name."""
     prev = precision()
     _ACT[0] = _PRECISIONS[str(name).lower()]
     return prev
 
 
 def precision():
-    return "fp32" if _ACT[0] == f32 else "bf16"
+    return {0: "bf16", 1: "fp32", 2: "fp32x3"}[_ACT[0][1]]
 
 
 def act_dtype():
-    return _ACT[0]
+    return _ACT[0][0]
 
 
 def _af(t):
-    """act_f32 flag of the C ABI from a tensor's dtype"""
+    """act_f32 flag of the C ABI from a tensor's dtype (f32 tensors: 1, or 2 in the split mode)"""
     if t.dtype == f32:
-        return 1
+        return _ACT[0][1] if _ACT[0][0] == f32 else 1
     if t.dtype == bf16:
         return 0
     raise _lib.CrError(f"activations must be float32 or bfloat16, got {t.dtype}")
+
+
+def _w3(w, af):
+    """split-mode companion (cr_weight_split3) of a prepared f32 weight matrix (rows, K), or None.  WeightBank views
+    carry theirs (refreshed with the bank); anything else is split on first use per weight epoch and cached on the tensor."""
+    if af != 2 or w.dtype != f32:
+        return None
+    ent = getattr(w, "_cr_w3", None)
+    if ent is not None and ent[0] == "bank":
+        return ent[1]
+    rows = w.shape[0]                      # (rows, K) or a channels_last (Cout,Cin,k,k) weight = physical [Cout][k*k*Cin]
+    K = w.numel() // rows
+    if K % 32:
+        return None
+    tag = (_WEIGHT_EPOCH[0], w.data_ptr(), w._version)
+    if ent is None or ent[0] != tag:
+        _p = _Args()
+        out = torch.empty((rows * K * 3,), dtype=bf16, device=w.device)
+        _chk(_lib.load().cr_weight_split3(_ctx(w), _p(w), _p(out), rows, K), "cr_weight_split3")
+        ent = (tag, out)
+        try:
+            w._cr_w3 = ent
+        except Exception:
+            pass
+    return ent[1]
 
 
 def _ctx(t):
@@ -120,11 +149,13 @@ class WeightBank:
     Activated by the training step objects; anything that changes weights outside the optimizer must call
     bump_weight_epoch() (the model's load_state_dict hook does)."""
 
-    def __init__(self, params, flat_p, dtype=None):
+    def __init__(self, params, flat_p, dtype=None, split=None):
         import numpy as np
         dev = flat_p.device
         self.flat_p = flat_p
         self.dtype = dtype = dtype if dtype is not None else act_dtype()
+        self.split = split = (dtype == f32 and _ACT[0][1] == 2) if split is None else bool(split and dtype == f32)
+        self.mode = "bf16" if dtype == bf16 else ("fp32x3" if split else "fp32")
         descs, tiles, self.shapes = [], [], []
         off = 0
         for i, p in enumerate(params):
@@ -154,6 +185,28 @@ class WeightBank:
         else:
             self.views = [(p.detach(), self.dstT[o:o + n].view(Cin, KK * Cout))
                           for p, (o, n, Cout, KK, Cin) in zip(params, self.shapes)]
+        if split:
+            # split-mode planes (6 bytes per element) of every weight whose k extent is a multiple of 32, forward layout
+            # from the flat parameter buffer and backward-data layout from dstT, one launch each
+            s3 = np.dtype([("src", "<i8"), ("dst", "<i8"), ("item0", "<i8"), ("rows", "<i4"), ("K", "<i4")])
+            assert s3.itemsize == 32
+            recs = ([], [])
+            tot, o3 = [0, 0], 0
+            for i, (p, (o, n, Cout, KK, Cin)) in enumerate(zip(params, self.shapes)):
+                src_off = (p.data_ptr() - flat_p.data_ptr()) // 4
+                for which, (soff, rows, K) in enumerate(((src_off, Cout, KK * Cin), (o, Cin, KK * Cout))):
+                    if K % 32 or soff % 4:
+                        continue
+                    recs[which].append((soff, o3, tot[which], rows, K, i))
+                    tot[which] += rows * K // 8
+                    o3 += rows * K * 3
+            self.w3 = torch.empty((max(o3, 8),), dtype=bf16, device=dev)
+            self.s3 = []
+            for which in (0, 1):
+                arr = np.array([r[:5] for r in recs[which]], dtype=s3) if recs[which] else np.zeros((0,), dtype=s3)
+                self.s3.append((torch.from_numpy(arr.view(np.uint8).copy()).to(dev), len(recs[which]), tot[which]))
+                for (soff, d3, _, rows, K, i) in recs[which]:
+                    self.views[i][which]._cr_w3 = ("bank", self.w3[d3:d3 + rows * K * 3])
         self.epoch = None
         for i, p in enumerate(params):
             p._cr_bank = (self, i)
@@ -164,6 +217,9 @@ class WeightBank:
             lib = _lib.load()
             _chk(lib.cr_weights_prepare(_ctx(self.flat_p), _p(self.flat_p), _p(self.dst), _p(self.dstT), _p(self.descs),
                                         _p(self.tiles), self.ntiles, int(self.dtype == f32)), "cr_weights_prepare")
+            if self.split:
+                for src, (descs, nd, tot) in zip((self.flat_p, self.dstT), self.s3):
+                    _chk(lib.cr_weights_split3(_ctx(self.flat_p), _p(src), _p(self.w3), _p(descs), nd, tot), "cr_weights_split3")
             self.epoch = _WEIGHT_EPOCH[0]
         return self.views[i]
 
@@ -176,7 +232,7 @@ def prepared_weights(weight, need_transposed, dtype=bf16):
     weight epoch."""
     _p = _Args()
     bk = getattr(weight, "_cr_bank", None)
-    if bk is not None and bk[0].dtype == dtype:
+    if bk is not None and bk[0].dtype == dtype and (dtype == bf16 or bk[0].split or _ACT[0][1] != 2):
         return bk[0].get(bk[1])
     attr = "_cr_wcache" if dtype == bf16 else "_cr_wcache32"
     ent = getattr(weight, attr, None)
@@ -217,7 +273,7 @@ def conv_fwd_raw(x, wb, Cout, k, stride, pad, bias=None, residual=None, relu=Fal
     y = torch.empty((N, Ho, Wo, Cout), dtype=f32 if (out_f32 or af) else bf16, device=x.device)
     lib = _lib.load()
     _chk(lib.cr_conv2d_fwd(_ctx(x), _p(x), _p(wb), _p(y), N, H, W, Cin, Cout, k, stride, pad, _p(bias), _p(residual),
-                           int(relu), _p(stats), int(out_f32), af), "cr_conv2d_fwd")
+                           int(relu), _p(stats), int(out_f32), af, _p(_w3(wb, af))), "cr_conv2d_fwd")
     return y
 
 
@@ -228,7 +284,8 @@ def conv_bwd_data_raw(dy, wt, in_shape, k, stride, pad):
     assert wt.dtype == dy.dtype
     dx = torch.empty((N, H, W, Cin), dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
-    _chk(lib.cr_conv2d_bwd_data(_ctx(dy), _p(dy), _p(wt), _p(dx), N, H, W, Cin, Cout, k, stride, pad, _af(dy)),
+    af = _af(dy)
+    _chk(lib.cr_conv2d_bwd_data(_ctx(dy), _p(dy), _p(wt), _p(dx), N, H, W, Cin, Cout, k, stride, pad, af, _p(_w3(wt, af))),
          "cr_conv2d_bwd_data")
     return dx
 
@@ -784,7 +841,8 @@ def linear_fwd_raw(x, w, bias, out_f32=False, relu=False):
         raise _lib.CrError(f"linear: the GEMM kernels need O and K multiples of 16 (got {O}x{K}); use linear_cat for predictors")
     assert w.dtype == x.dtype and x.is_contiguous() and w.is_contiguous()
     y = torch.empty((R, O), dtype=f32 if (out_f32 or af) else bf16, device=x.device)
-    _chk(_lib.load().cr_linear_fwd(_ctx(x), _p(x), _p(w), _p(bias), _p(y), R, K, O, int(relu), int(out_f32), af), "cr_linear_fwd")
+    _chk(_lib.load().cr_linear_fwd(_ctx(x), _p(x), _p(w), _p(bias), _p(y), R, K, O, int(relu), int(out_f32), af,
+                                   _p(_w3(w, af))), "cr_linear_fwd")
     return y
 
 
@@ -794,7 +852,8 @@ def linear_bwd_data_raw(dy, wt):
     K = wt.shape[0]
     assert wt.dtype == dy.dtype and dy.is_contiguous() and wt.is_contiguous()
     dx = torch.empty((R, K), dtype=dy.dtype, device=dy.device)
-    _chk(_lib.load().cr_linear_bwd_data(_ctx(dy), _p(dy), _p(wt), _p(dx), R, K, O, _af(dy)), "cr_linear_bwd_data")
+    af = _af(dy)
+    _chk(_lib.load().cr_linear_bwd_data(_ctx(dy), _p(dy), _p(wt), _p(dx), R, K, O, af, _p(_w3(wt, af))), "cr_linear_bwd_data")
     return dx
 
 

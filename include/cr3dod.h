@@ -184,6 +184,13 @@ int cr_resize_bilinear_ac(cr_ctx* ctx, const void* x, void* y, int B, int h, int
  *                tools/train_net.py:184-330 trains in float32, no autocast anywhere -- and the default of the Python host.
  *   act_f32 = 0  the same tensors are bfloat16 (v_mfma_f32_16x16x32_bf16, f32 accumulate, 2.5 PFLOP/s peak): the fast
  *                mode, opt-in; parameters, gradients of parameters and all statistics stay float32 in both modes.
+ *   act_f32 = 2  "split" mode: storage exactly as act_f32 = 1 (everything float32); the large contractions run on the
+ *                bf16 matrix cores with every f32 operand split EXACTLY into three bf16 values (8 + 8 + 8 significant
+ *                bits) and six of the nine cross products accumulated in f32 -- the dropped three are below 2^-23 of
+ *                the product, i.e. below f32 rounding -- 96 instead of 256 MFMA cycles per 32 of k.  Layers the split
+ *                kernels do not cover (k extent not a multiple of 32, tiny maps, stride-2 backward-data) run the f32 MFMA
+ *                kernels of act_f32 = 1.  Forward / backward-data take the pre-split weights (cr_weight_split3) in
+ *                `w_split` (NULL = not prepared: f32 MFMA kernels).  Entry points without a contraction treat 2 as 1.
  * "bf16" in the comments below reads "bf16 or f32 by act_f32".
  * Activations are NHWC (channels padded to a multiple of 8).  Conv weights
  * are [Cout][ks*ks][Cin] = the physical (channels_last) layout of a
@@ -198,11 +205,21 @@ int cr_resize_bilinear_ac(cr_ctx* ctx, const void* x, void* y, int B, int h, int
  * of the (pre-residual, pre-ReLU) conv output for BatchNorm (every entry is written; no atomics -> reproducible). */
 int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout,
                   int ks, int stride, int pad, const float* bias, const void* residual, int relu,
-                  float* stats, int out_f32, int act_f32);
+                  float* stats, int out_f32, int act_f32, const void* w_split);
 
-/* dx (N,H,W,Cin) bf16 from dy (N,Ho,Wo,Cout) bf16; wt = cr_weight_transpose(w). */
+/* dx (N,H,W,Cin) bf16 from dy (N,Ho,Wo,Cout) bf16; wt = cr_weight_transpose(w); wt_split = cr_weight_split3(wt) or NULL. */
 int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int N, int H, int W, int Cin,
-                       int Cout, int ks, int stride, int pad, int act_f32);
+                       int Cout, int ks, int stride, int pad, int act_f32, const void* wt_split);
+/* split-mode weight planes of an f32 matrix src (rows, K), K % 32 == 0: dst = bf16 [rows][K/32][3][32] (6 bytes per
+ * element): plane 0 / 1 / 2 = the top / middle / low 8 significant bits of each value (their sum is the value, exactly);
+ * inside a 64-byte plane row the 16-byte chunk c holds k = {4c..4c+3, 16+4c..16+4c+3} of the 32 (the order in which the
+ * split kernels' lanes read the f32 activations).  No counterpart in the reference (cuDNN consumes f32 weights). */
+int cr_weight_split3(cr_ctx* ctx, const float* src, void* dst, int64_t rows, int K);
+/* the same for many matrices in ONE launch: descs_dev = ndesc records {int64 src_off (floats from src_base), int64 dst_off
+ * (bf16 elements from dst_base), int64 item0, int32 rows, int32 K} (32 bytes), item0 = running sum of rows * K / 8 over
+ * the preceding records, total_items = that sum over all records.  Offsets must keep 16-byte alignment. */
+int cr_weights_split3(cr_ctx* ctx, const float* src_base, void* dst_base, const void* descs_dev, int ndesc,
+                      int64_t total_items);
 /* dw f32 (Cout, ks*ks*Cin); accumulate=0 zeroes it first (shared RPN-head weights accumulate over levels). */
 int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
                          int Cout, int ks, int stride, int pad, int accumulate, int act_f32);
@@ -293,10 +310,12 @@ int cr_fc_grad_accum(cr_ctx* ctx, const void* g, float* acc, int O, int C, int H
  * 161-168; the five predictors run as ONE GEMM over stacked weights).  x (R,K), w (O,K), wt (K,O), y / dy (R,O), dx (R,K) in
  * the activations' type (act_f32); bias, dw (O,K), dbias (O) float32.  K and O multiples of 16; K a multiple of 8.
  * cr_linear_bwd_weight: dw (+)= dy^T x (accumulate = 0 zeroes dw first), dbias += column sums of dy when non-NULL.
+ * w_split / wt_split: cr_weight_split3 of w / wt for act_f32 = 2, or NULL.
  * cr_transpose2d: dst (cols,rows) = src (rows,cols)^T for 2-byte (act_f32 = 0) or 4-byte elements: makes wt from w. */
 int cr_linear_fwd(cr_ctx* ctx, const void* x, const void* w, const float* bias, void* y, int R, int K, int O, int relu,
-                  int out_f32, int act_f32);
-int cr_linear_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int R, int K, int O, int act_f32);
+                  int out_f32, int act_f32, const void* w_split);
+int cr_linear_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int R, int K, int O, int act_f32,
+                       const void* wt_split);
 int cr_linear_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int R, int K, int O,
                          int accumulate, int act_f32);
 int cr_transpose2d(cr_ctx* ctx, const void* src, void* dst, int rows, int cols, int act_f32);
