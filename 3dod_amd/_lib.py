@@ -38,6 +38,10 @@ SIGNATURES = {
     "cr_conv2d_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, c_int, P],
     "cr_conv2d_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "cr_weight_split3": [P, P, P, c_int64, c_int],
+    "cr_relu_bwd": [P, P, P, P, c_int64, c_int],
+    "cr_multi_seg": [P, P, c_int, c_int64, c_int],
+    "cr_loss_guard": [P, P, c_int, c_float, P, P, P, c_int, c_float, c_float, P],
+    "cr_step_counters": [P, P, P, P],
     "cr_weights_split3": [P, P, P, P, c_int, c_int64],
     "cr_conv2d_bwd_weight": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "cr_conv2d_bwd_weight_bias": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],

@@ -508,8 +508,12 @@ __device__ __forceinline__ u32x4 lds_read16_asm(unsigned byte_addr) {
     return v;
 }
 
-template <int BN, int KS, int MODE, typename T = u16>
-__global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
+// KG = 2: two wave groups per block (8 waves) on alternating k stages, each with its own pair of LDS buffers; their
+// accumulators are summed through LDS before the epilogue.  For grids of <= one block per CU (the 64x64 ... 16x16 maps in
+// f32): two waves per SIMD cover each other's LDS / barrier latencies, which one wave per SIMD leaves exposed (87 -> ~110
+// TFLOP/s on the 3x3 128->128 layers), without the slab traffic of more split-K.
+template <int BN, int KS, int MODE, typename T = u16, int KG = 1>
+__global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm_dma(ConvP p) {
     constexpr int ES = (int)sizeof(T), SUB = 64 / ES;                        // k per 64-B LDS row: 32 bf16 / 16 f32
     constexpr int BM = 128, BK = 2 * SUB;
     constexpr int WAVES_M = BN == 128 ? 2 : 4, WAVES_N = 4 / WAVES_M;      // as k_conv_igemm: same statistics order
@@ -518,9 +522,11 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
     constexpr int XS = BM * 32, WS = BN * 32;                               // elements of one 32-deep sub-block
     constexpr int STAGE = 2 * XS + 2 * WS;                                  // X(u=0), X(u=1), W(u=0), W(u=1)
     constexpr int NDMA = 4 + 2 * NBW;                                       // DMA instructions per thread per stage
-    __shared__ __attribute__((aligned(1024))) u16 smem[2 * STAGE];          // 64 KiB (BN=128) / 48 KiB (BN=64)
+    __shared__ __attribute__((aligned(1024))) u16 smem_all[KG * 2 * STAGE]; // per group 64 KiB (BN=128) / 48 KiB (BN=64)
+    const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
+    u16* smem = smem_all + grp * 2 * STAGE;
     static_assert(4 * 2 * BN * sizeof(float) <= 2 * STAGE * sizeof(u16), "sStat must fit");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & (CONV_T - 1), lane = tid & 63, wave = tid >> 6;
     const int n_tiles = p.Cout / BN;
     const int tiles_total = (int)gridDim.x / p.ksplit;                      // ksplit == 1: the whole grid
     const int ks = (int)blockIdx.x / tiles_total, bt = (int)blockIdx.x - ks * tiles_total;
@@ -605,11 +611,15 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
 #pragma unroll
     for (int i = 0; i < TC; ++i) wa[i] = (unsigned)lds_off(coff + i * 16 + fr, fc) * 2u;
 
-    issue(st0, 0);
-    for (int st = st0; st < st1; ++st) {
-        const int buf = (st - st0) & 1;
-        if (st + 1 < st1) {
-            issue(st + 1, buf ^ 1);
+    // group g takes stages st0 + g, st0 + g + KG, ...; every group runs the same number of iterations (shared barriers), a
+    // group past its last stage neither fetches nor multiplies
+    const int niter = (st1 - st0 + KG - 1) / KG;
+    if (st0 + grp < st1) issue(st0 + grp, 0);
+    for (int it = 0; it < niter; ++it) {
+        const int st = st0 + grp + it * KG;
+        const int buf = it & 1;
+        if (st + KG < st1) {
+            issue(st + KG, buf ^ 1);
             if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage st has landed (this wave's DMAs)
             else           asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
@@ -617,6 +627,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
         }
         __builtin_amdgcn_s_barrier();                                        // ... and every other wave's
         const unsigned sb = lds0 + (unsigned)(buf * STAGE) * 2u;
+        if (KG == 1 || st < st1) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             u32x4 xf[TP], wf[TC];
@@ -630,11 +641,38 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
                                       "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]));
             mfma_substep<T, TC, TP>(wf, xf, acc);
         }
+        }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // everyone is done with `buf` before stage st+2 refills it
     }
+    if constexpr (KG > 1) {
+        // sum the groups' accumulators: register order through LDS (the operand buffers are dead), 16 B per lane
+        float4* red = reinterpret_cast<float4*>(smem_all);
+#pragma unroll
+        for (int gg = 1; gg < KG; ++gg) {
+            if (grp == gg) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+                        red[((wave * TC + i) * TP + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) {
+                        const float4 v = red[((wave * TC + i) * TP + j) * 64 + lane];
+                        acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
+                    }
+            }
+            __syncthreads();
+        }
+    }
     if (p.ksplit > 1) {
         // raw partial sums of this k range: part[ks][m][ch], 4 consecutive channels per lane (16-B stores)
+        if (grp != 0) return;
         const int g = lane >> 4, pl = lane & 15;
         float* dst = p.part + (size_t)ks * p.M * p.Cout;
 #pragma unroll
@@ -648,7 +686,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma(ConvP p) {
             }
         return;
     }
-    conv_epilogue<BM, BN, TC, TP, T, T>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt, poff, coff, tid, lane, wave, true);
+    conv_epilogue<BM, BN, TC, TP, T, T>(p, acc, reinterpret_cast<float*>(smem_all), m0, n0, mt, poff, coff, tid, lane, wave, grp == 0);
 }
 
 // k_conv_igemm_dma_s3: k_conv_igemm_dma in split mode (f32 activations and results, six bf16 MFMAs per tile pair and 32
@@ -991,8 +1029,12 @@ static void launch_dma_kernel(int bn, int ks, int mode, hipStream_t stream, cons
         CR_S3_CASE(64, 3, 0) CR_S3_CASE(64, 3, 1) CR_S3_CASE(64, 1, 0) CR_S3_CASE(64, 1, 1)
 #undef CR_S3_CASE
     }
+    // f32, at most one block per CU: two wave groups per block (see the kernel)
+    static const int kg_on = env_int("CR_CONV_KG2", 1);
+    const bool kg2 = kg_on && p.f32 && grid.x <= 256 && (p.Kdim / (p.f32 ? 32 : 64)) / p.ksplit >= 4;
 #define CR_DMA_CASE(B, K, M_) if (bn == B && ks == K && mode == M_) { \
-        if (p.f32) hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_, float>), grid, block, 0, stream, p); \
+        if (kg2) hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_, float, 2>), grid, dim3(CONV_T * 2), 0, stream, p); \
+        else if (p.f32) hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_, float>), grid, block, 0, stream, p); \
         else hipLaunchKernelGGL((k_conv_igemm_dma<B, K, M_, u16>), grid, block, 0, stream, p); \
         return; }
     CR_DMA_CASE(128, 3, 0) CR_DMA_CASE(128, 3, 1) CR_DMA_CASE(128, 1, 0) CR_DMA_CASE(128, 1, 1)
@@ -1023,7 +1065,8 @@ static bool try_launch_dma(cr_ctx* ctx, const ConvP& p, int out_f32, int* rc) {
             const int bn2 = p.Cout % 128 == 0 ? 128 : 64;
             const int64_t tiles = cr_cdiv(p.M, 128) * (p.Cout / bn2);
             const int nstage_all = p.Kdim / 32;
-            int S = (int)cr_cdiv(256, tiles);
+            static const int sk_target = env_int("CR_SPLITK_TARGET", 256);
+            int S = (int)cr_cdiv(sk_target, tiles);
             if (S > nstage_all / 4) S = nstage_all / 4;                      // >= 4 stages (128 of k) per block
             if (S > 16) S = 16;
             const int64_t cap = (int64_t)(ctx->ws_bytes / ((size_t)p.M * p.Cout * sizeof(float)));
@@ -2480,6 +2523,40 @@ extern "C" int cr_colsum_accum(cr_ctx* ctx, const void* x, int is_f32, int64_t M
         if (act_f32) hipLaunchKernelGGL((KERNEL<float>), grid, block, shm, stream, __VA_ARGS__);        \
         else hipLaunchKernelGGL((KERNEL<u16>), grid, block, shm, stream, __VA_ARGS__);                  \
     } while (0)
+
+// ReLU backward: g = y > 0 ? dy : 0 (y = the ReLU's OUTPUT), 4 elements per thread; the tail by the last thread
+template <typename T>
+__global__ __launch_bounds__(256) void k_relu_bwd(const void* __restrict__ yv, const void* __restrict__ dyv, void* __restrict__ gv, int64_t n) {
+    const T* y = (const T*)yv; const T* dy = (const T*)dyv; T* g = (T*)gv;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        if constexpr (sizeof(T) == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(y + i), d = *reinterpret_cast<const float4*>(dy + i);
+            *reinterpret_cast<float4*>(g + i) = make_float4(a.x > 0.f ? d.x : 0.f, a.y > 0.f ? d.y : 0.f, a.z > 0.f ? d.z : 0.f, a.w > 0.f ? d.w : 0.f);
+        } else {
+            const uint2 a = *reinterpret_cast<const uint2*>(y + i), d = *reinterpret_cast<const uint2*>(dy + i);
+            uint2 o;        // bf16: positive <=> sign bit clear and not zero
+            auto pos = [](unsigned h) { return (h & 0x8000u) == 0 && (h & 0x7fffu) != 0; };
+            o.x = (pos(a.x & 0xffffu) ? (d.x & 0xffffu) : 0u) | (pos(a.x >> 16) ? (d.x & 0xffff0000u) : 0u);
+            o.y = (pos(a.y & 0xffffu) ? (d.y & 0xffffu) : 0u) | (pos(a.y >> 16) ? (d.y & 0xffff0000u) : 0u);
+            *reinterpret_cast<uint2*>(g + i) = o;
+        }
+    } else {
+        for (int64_t j = i; j < n; ++j) {
+            if constexpr (sizeof(T) == 4) g[j] = y[j] > 0.f ? dy[j] : 0.f;
+            else g[j] = ((y[j] & 0x8000u) == 0 && (y[j] & 0x7fffu) != 0) ? dy[j] : (u16)0;
+        }
+    }
+}
+
+extern "C" int cr_relu_bwd(cr_ctx* ctx, const void* y, const void* dy, void* g, int64_t n, int act_f32) {
+    CR_CHECK_ARG(ctx && n >= 0, "cr_relu_bwd: bad args");
+    if (n == 0) return CR_OK;
+    CR_CHECK_ARG(y && dy && g && ((((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)g)) & 15) == 0, "cr_relu_bwd: NULL or misaligned pointer");
+    CR_DISPATCH_T(act_f32, k_relu_bwd, dim3((unsigned)cr_cdiv(cr_cdiv(n, 4), 256)), dim3(256), 0, ctx->stream, y, dy, g, n);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
 
 // window = 2: MaxPool2d(2,2) (dla.py:208); window = 1: max_pool2d(k=1,s=2) = subsample (dla.py:474)
 template <typename T>

@@ -70,3 +70,75 @@ extern "C" int cr_sgd_step(cr_ctx* ctx, float* p, const float* g, float* m, int6
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
+
+// Multi-segment copy / accumulate: segment d moves n floats from src to dst (mode 0: dst = src, 1: dst += src); one thread
+// per float, the segment found by binary search over the running item count.  Used to stack the predictor weights of a
+// head into one GEMM operand (and to route the stacked gradient back into the flat gradient) with ONE launch instead of
+// one cat / add per parameter (cube_head.py:113-149 of the reference: five nn.Linear predictors on the same input).
+struct cr_segdesc { const float* src; float* dst; int64_t n, item0; };
+__global__ __launch_bounds__(256) void k_multi_seg(const cr_segdesc* __restrict__ descs, int ndesc, int64_t total, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].item0 <= i) lo = mid; else hi = mid - 1;
+    }
+    const cr_segdesc d = descs[lo];
+    const int64_t j = i - d.item0;
+    if (mode) d.dst[j] += d.src[j]; else d.dst[j] = d.src[j];
+}
+
+extern "C" int cr_multi_seg(cr_ctx* ctx, const void* descs_dev, int ndesc, int64_t total, int accumulate) {
+    CR_CHECK_ARG(ctx && ndesc >= 0 && total >= 0, "cr_multi_seg: bad args");
+    if (ndesc == 0 || total == 0) return CR_OK;
+    CR_CHECK_ARG(descs_dev, "cr_multi_seg: NULL descriptor table");
+    hipLaunchKernelGGL(k_multi_seg, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream,
+                       (const cr_segdesc*)descs_dev, ndesc, total, accumulate ? 1 : 0);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// Loss-divergence guard of tools/train_net.py:202-220 on the device, one thread: vals (n) are this step's loss terms summed
+// over the ranks (scale = 1 / world size).  red[i] = vals[i] * scale, total = sum red; the step "diverges" when total is not
+// finite or exceeds tolerance x the rolling mean (first step: the mean starts at 2 x total); the mean is updated only on good
+// steps (gamma).  flag = diverging (stabilize) or 0; cr_nonfinite_flag ORs the gradient scan into it afterwards.
+__global__ void k_loss_guard(const float* __restrict__ vals, int n, float scale, float* __restrict__ red, float* __restrict__ total,
+                             float* __restrict__ recent, int stabilize, float tol, float gamma, int* __restrict__ flag) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float t = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float v = vals[i] * scale;
+        if (red) red[i] = v;
+        t += v;
+    }
+    *total = t;
+    const float r0 = *recent;
+    const float rec = (r0 != r0) ? t * 2.0f : r0;
+    bool div = (t > rec * tol) || !isfinite(t);
+    if (!stabilize) div = false;
+    *recent = div ? rec : rec * (1.f - gamma) + t * gamma;
+    *flag = div ? 1 : 0;
+}
+
+extern "C" int cr_loss_guard(cr_ctx* ctx, const float* vals, int n, float scale, float* red, float* total, float* recent,
+                             int stabilize, float tolerance, float gamma, int* flag) {
+    CR_CHECK_ARG(ctx && vals && total && recent && flag && n >= 0, "cr_loss_guard: bad args");
+    hipLaunchKernelGGL(k_loss_guard, dim3(1), dim3(64), 0, ctx->stream, vals, n, scale, red, total, recent, stabilize, tolerance,
+                       gamma, flag);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// iterations_explode += flag != 0, iterations_success += flag == 0 (train_net.py:259-266), after the update
+__global__ void k_step_counters(const int* __restrict__ flag, float* __restrict__ explode, float* __restrict__ success) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (*flag) *explode += 1.f; else *success += 1.f;
+}
+
+extern "C" int cr_step_counters(cr_ctx* ctx, const int* flag, float* explode, float* success) {
+    CR_CHECK_ARG(ctx && flag && explode && success, "cr_step_counters: NULL pointer");
+    hipLaunchKernelGGL(k_step_counters, dim3(1), dim3(64), 0, ctx->stream, flag, explode, success);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

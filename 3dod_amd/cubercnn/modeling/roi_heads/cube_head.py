@@ -18,9 +18,9 @@ ROI_CUBE_HEAD_REGISTRY = Registry("ROI_CUBE_HEAD")
 bf16 = torch.bfloat16
 
 
-def fc_nhwc(x_nhwc_flat, fc, chw):
-    """Linear whose weight columns are in (c,h,w) order applied to an (h,w,c)-flattened bf16 input."""
-    return ops.linear(x_nhwc_flat, fc.weight, fc.bias, chw=tuple(chw))
+def fc_nhwc(x_nhwc_flat, fc, chw, relu=False):
+    """Linear (+ ReLU in the GEMM epilogue) whose weight columns are in (c,h,w) order applied to an (h,w,c)-flattened input."""
+    return ops.linear(x_nhwc_flat, fc.weight, fc.bias, chw=tuple(chw), relu=relu)
 
 
 @ROI_CUBE_HEAD_REGISTRY.register()
@@ -71,9 +71,9 @@ class CubeHead(nn.Module):
         """x (n, H*W*C) bf16 in (h,w,c) order -> (deltas (n,K,2), z (n,K,1), dims (n,K,3), pose (n,K,3,3), uncert (n,K))."""
         n = x.shape[0]
         fcs = [m for m in self.feature_generator if isinstance(m, nn.Linear)]
-        h = F.relu(fc_nhwc(x, fcs[0], self._in_chw))
+        h = fc_nhwc(x, fcs[0], self._in_chw, relu=True)
         for fc in fcs[1:]:
-            h = F.relu(ops.linear(h, fc.weight, fc.bias))
+            h = ops.linear(h, fc.weight, fc.bias, relu=True)
         preds = [self.bbox_3D_center_deltas, self.bbox_3D_dims, self.bbox_3D_pose, self.bbox_3D_center_depth]
         if self.use_conf:
             preds.append(self.bbox_3D_uncertainty)
@@ -94,9 +94,9 @@ def _forward_fused(self, x):
     layout = column offsets of [deltas 2K, dims 3K, pose6d 6K, z K, uncert K]; the per-class gather, the 6D -> matrix
     conversion and the uncertainty clip happen in ops.cube_head_loss (only for each RoI's own class)."""
     fcs = [m for m in self.feature_generator if isinstance(m, nn.Linear)]
-    h = F.relu(fc_nhwc(x, fcs[0], self._in_chw))
+    h = fc_nhwc(x, fcs[0], self._in_chw, relu=True)
     for fc in fcs[1:]:
-        h = F.relu(ops.linear(h, fc.weight, fc.bias))
+        h = ops.linear(h, fc.weight, fc.bias, relu=True)
     assert self.use_conf
     preds = [self.bbox_3D_center_deltas, self.bbox_3D_dims, self.bbox_3D_pose, self.bbox_3D_center_depth,
              self.bbox_3D_uncertainty]

@@ -67,9 +67,9 @@ class FastRCNNConvFCHead(nn.Sequential):
 
     def forward(self, x):
         """x (R, H, W, C) bf16."""
-        h = F.relu(fc_nhwc(x.flatten(1), self.fcs[0], self._in_chw))
+        h = fc_nhwc(x.flatten(1), self.fcs[0], self._in_chw, relu=True)
         for fc in self.fcs[1:]:
-            h = F.relu(ops.linear(h, fc.weight, fc.bias))
+            h = ops.linear(h, fc.weight, fc.bias, relu=True)
         return h
 
     @property

@@ -278,23 +278,14 @@ class TrainStep:
             for a, b in self.buckets:
                 dist.all_reduce(opt.flat_g[a:b])
         # ---- divergence guard (rolling mean x4, train_net.py:202-220) on the reduced loss, on the device
-        if world > 1:
-            red = red / world
-        losses_reduced = red.sum()
-        first = torch.isnan(self.recent_loss)
-        recent = torch.where(first, losses_reduced * 2.0, self.recent_loss)
-        diverging = (losses_reduced > recent * self.TOLERANCE) | ~torch.isfinite(losses_reduced)
-        if not self.stabilize:
-            diverging = torch.zeros_like(diverging)
-        self.recent_loss = torch.where(diverging, recent, recent * (1 - self.GAMMA) + losses_reduced * self.GAMMA)
+        losses_reduced = torch.empty((), dtype=torch.float32, device=red.device)
+        ops.loss_guard(red, 1.0 / world, red, losses_reduced, self.recent_loss, self.stabilize, self.TOLERANCE, self.GAMMA,
+                       self.flag)
         # ---- non-finite scan of the (averaged) gradient + skip flag, all on device
-        self.flag.copy_(diverging.to(torch.int32).view(1))
         if self.stabilize:
             ops.nonfinite_flag(opt.flat_g, self.flag)
         opt.step(skip_flag=self.flag, grad_scale=1.0 / world)
-        bad = (self.flag[0] != 0).float()
-        self.iterations_explode += bad
-        self.iterations_success += 1 - bad
+        ops.step_counters(self.flag, self.iterations_explode, self.iterations_success)
         self.last = {"keys": keys, "values": red, "total": losses_reduced, "skipped": self.flag}
         return self.last
 
@@ -387,23 +378,12 @@ class GraphedTrainStep:
                 torch._foreach_add_(views, [g for g in grads if g is not None])
 
         def update():
-            red = self.vals / world_size
-            lr_ = red.sum()
-            first = torch.isnan(self.recent_loss)
-            recent = torch.where(first, lr_ * 2.0, self.recent_loss)
-            diverging = (lr_ > recent * self.TOLERANCE) | ~torch.isfinite(lr_)
-            if not self.stabilize:
-                diverging = torch.zeros_like(diverging)
-            self.recent_loss.copy_(torch.where(diverging, recent, recent * (1 - self.GAMMA) + lr_ * self.GAMMA))
-            self.flag.copy_(diverging.to(torch.int32).view(1))
+            ops.loss_guard(self.vals, 1.0 / world_size, self.red, self.total, self.recent_loss, self.stabilize, self.TOLERANCE,
+                           self.GAMMA, self.flag)
             if self.stabilize:
                 ops.nonfinite_flag(optimizer.flat_g, self.flag)
             optimizer.step(skip_flag=self.flag, grad_scale=1.0 / world_size)      # lr factor read from the device scalar
-            bad = (self.flag[0] != 0).float()
-            self.iterations_explode.add_(bad)
-            self.iterations_success.add_(1 - bad)
-            self.total.copy_(lr_)
-            self.red.copy_(red)
+            ops.step_counters(self.flag, self.iterations_explode, self.iterations_success)
 
         # warm-up (eager, side stream), then restore every piece of state the warm-up touched
         snap = [t.clone() for t in (optimizer.flat_p, optimizer.flat_m)]

@@ -440,6 +440,15 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride=1, pad
 # --------------------------------------------------------------------------
 # conv + bias (+ ReLU), bf16 or f32 output   (FPN laterals/outputs, RPN head)
 # --------------------------------------------------------------------------
+def relu_bwd(y, dy):
+    """dy masked by the ReLU whose OUTPUT is y (one kernel); dy is cast to y's dtype first if it differs"""
+    _p = _Args()
+    dy = _act_cast(dy, y.dtype)
+    g = torch.empty_like(dy)
+    _chk(_lib.load().cr_relu_bwd(_ctx(y), _p(y.contiguous()), _p(dy), _p(g), y.numel(), _af(y)), "cr_relu_bwd")
+    return g
+
+
 class _ConvBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, relu, out_f32):
@@ -457,10 +466,9 @@ class _ConvBias(torch.autograd.Function):
         _p = _Args()
         x, weight, y = ctx.saved_tensors
         k, stride, pad, relu, has_bias = ctx.cfg
-        g = dy
+        g = dy.contiguous()
         if relu:
-            g = torch.where(y > 0, g, torch.zeros((), dtype=g.dtype, device=g.device))
-        g = g.contiguous()
+            g = relu_bwd(y, g)
         db, acc = None, None
         want_db = has_bias and ctx.needs_input_grad[2]
         if want_db:
@@ -869,26 +877,28 @@ def linear_bwd_weight_raw(dy, x, dw, dbias, accumulate):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, chw):
+    def forward(ctx, x, weight, bias, chw, relu=False):
         _need_cuda(x, "linear input")
         dt = x.dtype
         wp = prepared_fc_weight(weight, chw, dt)
         xc = x.contiguous()
-        y = linear_fwd_raw(xc, wp, None if bias is None else bias.detach())
-        ctx.save_for_backward(xc)
+        y = linear_fwd_raw(xc, wp, None if bias is None else bias.detach(), relu=relu)
+        ctx.save_for_backward(xc, y if relu else None)
         ctx.refs = (weight, bias, chw)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         _p = _Args()
-        (xc,) = ctx.saved_tensors
+        xc, yr = ctx.saved_tensors
         weight, bias, chw = ctx.refs
         dt = xc.dtype
         lib = _lib.load()
         O, K = weight.shape
         C, HW = (chw[0], chw[1] * chw[2]) if chw is not None else (K, 1)
         dy = _act_cast(dy, dt)
+        if yr is not None:
+            dy = relu_bwd(yr, dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             _, wt = prepared_fc_weight(weight, chw, dt, need_transposed=True)
@@ -915,30 +925,135 @@ class _Linear(torch.autograd.Function):
         elif want_db:
             ws = torch.empty((1024, O), dtype=f32, device=dy.device)
             _chk(lib.cr_colsum_accum(_ctx(dy), _p(dy), int(dt == f32), dy.shape[0], O, _p(ws), _p(bacc)), "cr_colsum_accum")
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear(x, weight, bias=None, chw=None):
+def linear(x, weight, bias=None, chw=None, relu=False):
     """F.linear on the MFMA in x's precision (own implicit-GEMM kernels) with the weight copies cached per optimizer step
     and the gradients accumulated straight into the optimizer's flat gradient (when the parameters carry sinks).
     chw: see prepared_fc_weight.  Needs O % 16 == 0 (see linear_cat for predictors with odd widths)."""
-    return _Linear.apply(x, weight, bias, chw)
+    return _Linear.apply(x, weight, bias, chw, relu)
+
+
+class _CatPlan:
+    """persistent buffers of one head's stacked predictors: W (Op,K) / b (Op) f32, refreshed from the parameters by ONE
+    launch per weight epoch; the transposed / split copies for backward-data; dW / db that receive the stacked gradient;
+    the segment tables that move rows between the parameters (or their gradient sinks) and the stacks."""
+
+    def __init__(self, weights, biases):
+        import numpy as np
+        dev = weights[0].device
+        self.sizes = [int(w.shape[0]) for w in weights]
+        self.K = K = int(weights[0].shape[1])
+        O = sum(self.sizes)
+        self.Op = Op = (O + 15) // 16 * 16
+        self.W = torch.zeros((Op, K), dtype=f32, device=dev)
+        self.b = torch.zeros((Op,), dtype=f32, device=dev)
+        self.dW = torch.empty((Op, K), dtype=f32, device=dev)
+        self.db = torch.empty((Op,), dtype=f32, device=dev)
+        self.ptrs = tuple((w.data_ptr(), bb.data_ptr()) for w, bb in zip(weights, biases))
+        self.sinks = all(grad_sink(t) is not None for t in list(weights) + list(biases))
+        dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("n", "<i8"), ("item0", "<i8")])
+
+        def table(pairs):
+            recs, tot = [], 0
+            for src, dst, n in pairs:
+                recs.append((src, dst, n, tot))
+                tot += n
+            return torch.from_numpy(np.array(recs, dtype=dt).view(np.uint8).copy()).to(dev), len(recs), tot
+        fw, bw, off = [], [], 0
+        for w, bb, n in zip(weights, biases, self.sizes):
+            fw.append((w.data_ptr(), self.W.data_ptr() + off * K * 4, n * K))
+            fw.append((bb.data_ptr(), self.b.data_ptr() + off * 4, n))
+            if self.sinks:
+                bw.append((self.dW.data_ptr() + off * K * 4, grad_sink(w).data_ptr(), n * K))
+                bw.append((self.db.data_ptr() + off * 4, grad_sink(bb).data_ptr(), n))
+            off += n
+        self.fwd_table, self.bwd_table = table(fw), (table(bw) if self.sinks else None)
+        self.offs = [0]
+        for n in self.sizes:
+            self.offs.append(self.offs[-1] + n)
+        self.tag, self.compute, self.wt = None, {}, {}
+
+    def refresh(self):
+        tag = _WEIGHT_EPOCH[0]
+        if self.tag != tag:
+            t, nd, tot = self.fwd_table
+            _chk(_lib.load().cr_multi_seg(_ctx(self.W), _lib.ptr(t), nd, tot, 0), "cr_multi_seg")
+            self.tag, self.compute, self.wt = tag, {}, {}
+
+    def weight(self, dtype):
+        """the stacked weight in the activation dtype (f32: the stack itself)"""
+        if dtype not in self.compute:
+            self.compute[dtype] = self.W if dtype == f32 else _act_cast(self.W, dtype)
+        return self.compute[dtype]
+
+    def weight_t(self, dtype):
+        if dtype not in self.wt:
+            _p = _Args()
+            Wc = self.weight(dtype)
+            wt = torch.empty((self.K, self.Op), dtype=dtype, device=Wc.device)
+            _chk(_lib.load().cr_transpose2d(_ctx(Wc), _p(Wc), _p(wt), self.Op, self.K, int(dtype == f32)), "cr_transpose2d")
+            self.wt[dtype] = wt
+        return self.wt[dtype]
+
+
+_CAT_PLANS = {}
+
+
+def _cat_plan(weights, biases):
+    """plans are keyed by the parameters' addresses and shapes (not kept on the tensor objects: the whole-step graph runs
+    the model on fresh leaf tensors over the same storage, and a plan must exist BEFORE a capture starts -- building one
+    uploads its tables)"""
+    key = tuple((w.data_ptr(), b.data_ptr(), tuple(w.shape)) for w, b in zip(weights, biases))
+    sinks = all(grad_sink(t) is not None for t in list(weights) + list(biases))
+    plan = _CAT_PLANS.get(key)
+    if plan is None or plan.sinks != sinks:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.CrError("linear_cat: the stacked-predictor plan must be built before graph capture (run one eager step)")
+        plan = _CAT_PLANS[key] = _CatPlan(weights, biases)
+    return plan
+
+
+class _LinearCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan, *params):
+        plan.refresh()
+        xc = x.contiguous()
+        y = linear_fwd_raw(xc, plan.weight(xc.dtype), plan.b, out_f32=True)
+        ctx.save_for_backward(xc)
+        ctx.plan = plan
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        plan = ctx.plan
+        dt = xc.dtype
+        dy = _act_cast(dy, dt)
+        dx = linear_bwd_data_raw(dy, plan.weight_t(dt)) if ctx.needs_input_grad[0] else None
+        n = len(plan.sizes)
+        if not any(ctx.needs_input_grad[2:]):
+            return (dx, None) + (None,) * (2 * n)
+        plan.db.zero_()
+        linear_bwd_weight_raw(dy, xc, plan.dW, plan.db, accumulate=False)
+        if plan.sinks:
+            t, nd, tot = plan.bwd_table
+            _chk(_lib.load().cr_multi_seg(_ctx(plan.dW), _lib.ptr(t), nd, tot, 1), "cr_multi_seg")
+            return (dx, None) + (None,) * (2 * n)
+        gw = [plan.dW[plan.offs[i]:plan.offs[i + 1]].clone() for i in range(n)]
+        gb = [plan.db[plan.offs[i]:plan.offs[i + 1]].clone() for i in range(n)]
+        return (dx, None) + tuple(gw) + tuple(gb)
 
 
 def linear_cat(x, weights, biases):
     """[x @ w.T + b for w, b in zip(weights, biases)] as ONE GEMM: the predictor layers of a head share their input, so
-    their weights are stacked (rows zero-padded to a multiple of 16 for the MFMA tiles) and the output is returned as
-    the padded (R, O_pad) f32 matrix plus the column offset of each predictor.  Gradients are routed back into each
-    parameter (or its gradient sink) by cat_rows."""
-    sizes = [int(w.shape[0]) for w in weights]
-    O = sum(sizes)
-    Op = (O + 15) // 16 * 16
-    W = cat_rows(list(weights), Op)
-    b = cat_rows(list(biases), Op)
-    offs = [0]
-    for n in sizes:
-        offs.append(offs[-1] + n)
-    return _LinearPlain.apply(x, W, b), offs
+    their weights are stacked (rows zero-padded to a multiple of 16 for the MFMA tiles) in persistent buffers refreshed by
+    one launch per optimizer step; the output is the padded (R, O_pad) f32 matrix plus the column offset of each predictor.
+    The stacked gradient goes back into the parameters' gradient sinks with one launch (or as per-parameter slices)."""
+    weights, biases = list(weights), list(biases)
+    plan = _cat_plan(weights, biases)
+    return _LinearCat.apply(x, plan, *weights, *biases), list(plan.offs)
 
 
 class _LinearPlain(torch.autograd.Function):
@@ -1293,6 +1408,18 @@ def cube_reduce(L, u_sel, buf, dec, validf, inverse_z=False):
 # --------------------------------------------------------------------------
 # optimizer
 # --------------------------------------------------------------------------
+def loss_guard(vals, scale, red, total, recent, stabilize, tolerance, gamma, flag):
+    """divergence guard of train_net.py:202-220 in one launch (see include/cr3dod.h); all tensors on the device, in place"""
+    _p = _Args()
+    _chk(_lib.load().cr_loss_guard(_ctx(vals), _p(vals), vals.numel(), float(scale), _p(red), _p(total), _p(recent),
+                                   int(bool(stabilize)), float(tolerance), float(gamma), _p(flag)), "cr_loss_guard")
+
+
+def step_counters(flag, explode, success):
+    _p = _Args()
+    _chk(_lib.load().cr_step_counters(_ctx(flag), _p(flag), _p(explode), _p(success)), "cr_step_counters")
+
+
 def nonfinite_flag(flat_grad, flag):
     _p = _Args()
     lib = _lib.load()

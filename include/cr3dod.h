@@ -223,6 +223,23 @@ int cr_weights_split3(cr_ctx* ctx, const float* src_base, void* dst_base, const 
 /* dw f32 (Cout, ks*ks*Cin); accumulate=0 zeroes it first (shared RPN-head weights accumulate over levels). */
 int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
                          int Cout, int ks, int stride, int pad, int accumulate, int act_f32);
+/* Loss-divergence guard of tools/train_net.py:202-220 on the device (no host sync in the step): vals (n) = this step's loss
+ * terms summed over the ranks, scale = 1 / world size.  Writes red[i] = vals[i] * scale (red may be NULL), total = their sum,
+ * flag = 1 when stabilize and (total is not finite or total > tolerance * rolling mean), else 0, and updates the rolling mean
+ * `recent` (NaN = not started: starts at 2 * total; moves by gamma on good steps only).  cr_step_counters: the iteration
+ * counters of train_net.py:259-266 from the final skip flag (after cr_nonfinite_flag). */
+int cr_loss_guard(cr_ctx* ctx, const float* vals, int n, float scale, float* red, float* total, float* recent,
+                  int stabilize, float tolerance, float gamma, int* flag);
+int cr_step_counters(cr_ctx* ctx, const int* flag, float* explode, float* success);
+/* Multi-segment copy (accumulate = 0: dst = src) or accumulate (1: dst += src) of float32 data in ONE launch: descs_dev =
+ * ndesc records {const float* src; float* dst; int64 n; int64 item0} (32 bytes; item0 = sum of n over the preceding records),
+ * total = sum of n.  Segments of one call must not overlap.  Stacks the five predictor weights / biases of CubeHead
+ * (cube_head.py:113-149) and the two of FastRCNNOutputLayers into one GEMM operand and routes the stacked gradient back. */
+int cr_multi_seg(cr_ctx* ctx, const void* descs_dev, int ndesc, int64_t total, int accumulate);
+/* ReLU backward in one pass: g[i] = y[i] > 0 ? dy[i] : 0 with y the ReLU's output; y, dy, g in the activations' type
+ * (act_f32), n elements, 16-byte aligned (nn.ReLU / F.relu backward behind dla.py:40-68, the FPN / RPN-head convolutions and
+ * the FC layers of cube_head.py:75,161-168). */
+int cr_relu_bwd(cr_ctx* ctx, const void* y, const void* dy, void* g, int64_t n, int act_f32);
 /* Fold a frozen BatchNorm2d into the preceding convolution for inference: wf (Cout, K) bf16 = w * gamma / sqrt(var + eps),
  * bias (Cout) f32 = beta - mean * gamma / sqrt(var + eps); w (Cout, K) f32 in the kernels' [Cout][kh][kw][Cin] order.
  * conv(x, wf) + bias (+ residual, ReLU in the conv epilogue) == BatchNorm(conv(x, w)) in eval mode

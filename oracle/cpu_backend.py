@@ -159,13 +159,14 @@ def roi_align_pyramid(feats, rois, scales, out_size):
     return _q(out)
 
 
-def linear(x, weight, bias=None, chw=None):
-    """F.linear; chw = (C,H,W): x is flattened in (h,w,c) order while the weight columns are in (c,h,w) order."""
+def linear(x, weight, bias=None, chw=None, relu=False):
+    """F.linear (+ ReLU); chw = (C,H,W): x is flattened in (h,w,c) order while the weight columns are in (c,h,w) order."""
     w = weight
     if chw is not None:
         C, H, W = chw
         w = weight.view(weight.shape[0], C, H, W).permute(0, 2, 3, 1).reshape(weight.shape[0], -1)
-    return _q(F.linear(_q(x.float()), _q(w), None if bias is None else _q(bias)))
+    y = F.linear(_q(x.float()), _q(w), None if bias is None else _q(bias))
+    return _q(F.relu(y) if relu else y)
 
 
 def linear_cat(x, weights, biases):
@@ -199,6 +200,25 @@ def nms_grouped(boxes, counts, thresh):
             scores = torch.arange(n, 0, -1, dtype=f32)
             keep[g, R.nms(boxes[g, :n], scores, thresh)] = True
     return keep
+
+
+def loss_guard(vals, scale, red, total, recent, stabilize, tolerance, gamma, flag):
+    """mirror of hipops.loss_guard (tools/train_net.py:202-220)"""
+    r = vals * scale
+    if red is not None:
+        red.copy_(r)
+    t = r.sum()
+    total.copy_(t)
+    rec = torch.where(torch.isnan(recent), t * 2.0, recent)
+    div = ((t > rec * tolerance) | ~torch.isfinite(t)) & bool(stabilize)
+    recent.copy_(torch.where(div, rec, rec * (1 - gamma) + t * gamma))
+    flag.copy_(div.to(torch.int32).view(1))
+
+
+def step_counters(flag, explode, success):
+    bad = (flag[0] != 0).float()
+    explode.add_(bad)
+    success.add_(1 - bad)
 
 
 def nonfinite_flag(flat_grad, flag):
