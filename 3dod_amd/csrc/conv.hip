@@ -2313,11 +2313,102 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T* __restrict__ x, const
     }
 }
 
+// finalize + apply in ONE launch for the layers with few statistics rows (the 64x64 and smaller maps: 30 of DLA34's 39
+// BatchNorms): block (px chunk, channel slice of 32) first reduces the partial rows of ITS 32 channels (8 row lanes per
+// channel, double accumulation, fixed order: every block of a slice computes the same bits), then normalises its pixels.
+// The blocks of px chunk 0 publish mean / invstd for backward and update the running statistics.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_apply_fused(const T* __restrict__ x, const float* __restrict__ stats, int nparts,
+                                                        float count, float eps, float momentum, float* __restrict__ mean_invstd,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const T* __restrict__ res, T* __restrict__ y, int64_t M, int C, int relu,
+                                                        int px_per_block) {
+    __shared__ double sd[2][8][32];
+    __shared__ float sc[2][32];                          // mean, invstd of this slice
+    const int t = threadIdx.x, ch = t & 31, rl = t >> 5;
+    const int cbase = blockIdx.y * 32, c = cbase + ch;
+    {
+        double s = 0.0, q = 0.0;
+        for (int r = rl; r < nparts; r += 8) {
+            s += (double)stats[(size_t)r * 2 * C + c];
+            q += (double)stats[(size_t)r * 2 * C + C + c];
+        }
+        sd[0][rl][ch] = s; sd[1][rl][ch] = q;
+    }
+    __syncthreads();
+    if (t < 32) {
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { s += sd[0][r][t]; q += sd[1][r][t]; }
+        const double mean = s / (double)count;
+        double var = q / (double)count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)mean, isf = (float)(1.0 / sqrt(var + (double)eps));
+        sc[0][t] = mf;
+        sc[1][t] = isf;
+        if (blockIdx.x == 0) {
+            mean_invstd[cbase + t] = mf;
+            mean_invstd[C + cbase + t] = isf;
+            if (running_mean) {
+                const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+                running_mean[cbase + t] = (float)((1.0 - momentum) * running_mean[cbase + t] + momentum * mean);
+                running_var[cbase + t] = (float)((1.0 - momentum) * running_var[cbase + t] + momentum * unbiased);
+            }
+        }
+    }
+    __syncthreads();
+    const int cgl = t & 3;                               // 8-channel group inside the slice
+    float mu[8], is8[8], ga[8], be[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        mu[e] = sc[0][cgl * 8 + e]; is8[e] = sc[1][cgl * 8 + e];
+        ga[e] = gamma[cbase + cgl * 8 + e]; be[e] = beta[cbase + cgl * 8 + e];
+    }
+    const int64_t m0 = (int64_t)blockIdx.x * px_per_block, m1 = m0 + px_per_block < M ? m0 + px_per_block : M;
+    for (int64_t m = m0 + (t >> 2); m < m1; m += 64) {
+        const size_t i8 = (size_t)m * C + cbase + cgl * 8;
+        float xv[8], rv[8], o[8];
+        load8<T>(x, i8, xv);
+        if (res) load8<T>(res, i8, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = (xv[e] - mu[e]) * is8[e] * ga[e] + be[e];        // as k_bn_apply
+            if (res) v += rv[e];
+            o[e] = relu ? fmaxf(v, 0.f) : v;
+        }
+        store8<T>(y, i8, o);
+    }
+}
+
+static int bn_fuse_rows() {
+    static const int v = env_int("CR_BN_FUSE_ROWS", 256);
+    return v;
+}
+
 extern "C" int cr_bn_fwd(cr_ctx* ctx, const void* x, const float* stats, int nparts, const float* gamma,
                          const float* beta, const void* residual, void* y, int64_t M, int C, int relu, float eps,
                          float momentum, float* mean_invstd, float* running_mean, float* running_var, int act_f32) {
     CR_CHECK_ARG(ctx && x && stats && gamma && beta && y && mean_invstd, "cr_bn_fwd: NULL pointer");
     CR_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && nparts > 0, "cr_bn_fwd: bad dims M=%lld C=%d", (long long)M, C);
+    if (C % 32 == 0 && nparts <= bn_fuse_rows()) {
+        // ~1024 blocks; a block's statistics pass reads nparts x 64 floats
+        int64_t chunks = 1024 / (C / 32);
+        if (chunks < 1) chunks = 1;
+        int64_t ppb = cr_cdiv(M, chunks);
+        ppb = (ppb + 63) / 64 * 64;
+        const dim3 grid((unsigned)cr_cdiv(M, ppb), (unsigned)(C / 32));
+        if (act_f32)
+            hipLaunchKernelGGL(k_bn_apply_fused<float>, grid, dim3(256), 0, ctx->stream, (const float*)x, stats, nparts, (float)M,
+                               eps, momentum, mean_invstd, running_mean, running_var, gamma, beta, (const float*)residual,
+                               (float*)y, M, C, relu, (int)ppb);
+        else
+            hipLaunchKernelGGL(k_bn_apply_fused<u16>, grid, dim3(256), 0, ctx->stream, (const u16*)x, stats, nparts, (float)M,
+                               eps, momentum, mean_invstd, running_mean, running_var, gamma, beta, (const u16*)residual,
+                               (u16*)y, M, C, relu, (int)ppb);
+        CR_LAUNCH_CHECK();
+        return CR_OK;
+    }
     hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)C), dim3(256), 0, ctx->stream, stats, nparts, C, (float)M, eps,
                        momentum, mean_invstd, running_mean, running_var);
     CR_LAUNCH_CHECK();
@@ -2429,6 +2520,67 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ dy, 
     }
 }
 
+// finalize + apply of the backward in one launch (same scheme as k_bn_apply_fused): the blocks of px chunk 0 accumulate
+// dgamma / dbeta
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_fused(const T* __restrict__ dy, const T* __restrict__ out,
+                                                            const T* __restrict__ x, const float* __restrict__ mean_invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ partial,
+                                                            int nparts, T* __restrict__ dx, T* __restrict__ dres,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M,
+                                                            int C, int relu, int px_per_block) {
+    __shared__ double sd[2][8][32];
+    __shared__ float sc[4][32];                          // mean, invstd * gamma, sum_g / M, invstd * sum_gx / M
+    const int t = threadIdx.x, ch = t & 31, rl = t >> 5;
+    const int cbase = blockIdx.y * 32, c = cbase + ch;
+    {
+        double s = 0.0, q = 0.0;
+        for (int r = rl; r < nparts; r += 8) {
+            s += (double)partial[(size_t)r * 2 * C + c];
+            q += (double)partial[(size_t)r * 2 * C + C + c];
+        }
+        sd[0][rl][ch] = s; sd[1][rl][ch] = q;
+    }
+    __syncthreads();
+    if (t < 32) {
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { s += sd[0][r][t]; q += sd[1][r][t]; }
+        const float sg = (float)s, sgx = (float)q, invM = 1.f / (float)M;
+        const float is = mean_invstd[C + cbase + t];
+        sc[0][t] = mean_invstd[cbase + t];
+        sc[1][t] = is;
+        sc[2][t] = sg * invM;
+        sc[3][t] = sgx * invM;
+        if (blockIdx.x == 0) { dbeta[cbase + t] += sg; dgamma[cbase + t] += sgx; }
+    }
+    __syncthreads();
+    const int cgl = t & 3;
+    float mu[8], is8[8], ga[8], k1[8], k2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int cc = cgl * 8 + e;
+        mu[e] = sc[0][cc]; is8[e] = sc[1][cc]; ga[e] = gamma[cbase + cc]; k1[e] = sc[2][cc]; k2[e] = sc[3][cc];
+    }
+    const int64_t m0 = (int64_t)blockIdx.x * px_per_block, m1 = m0 + px_per_block < M ? m0 + px_per_block : M;
+    for (int64_t m = m0 + (t >> 2); m < m1; m += 64) {
+        const size_t i8 = (size_t)m * C + cbase + cgl * 8;
+        float dv[8], xv[8], ov[8], vd[8], vg[8];
+        load8<T>(dy, i8, dv);
+        load8<T>(x, i8, xv);
+        if (relu) load8<T>(out, i8, ov);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gq = (!relu || ov[e] > 0.f) ? dv[e] : 0.f;
+            const float xh = (xv[e] - mu[e]) * is8[e];
+            vd[e] = ga[e] * is8[e] * (gq - k1[e] - xh * k2[e]);
+            vg[e] = gq;
+        }
+        store8<T>(dx, i8, vd);
+        if (dres) store8<T>(dres, i8, vg);
+    }
+}
+
 // sums: f32 workspace of (CR_BN_BWD_WS_ROWS) x 2 x C floats (partials + the reduced [2][C] in the last row).
 // dgamma/dbeta are ACCUMULATED (+=).  No atomics: bitwise reproducible.
 extern "C" int cr_bn_bwd(cr_ctx* ctx, const void* dy, const void* out, const void* x, const float* mean_invstd,
@@ -2450,6 +2602,23 @@ extern "C" int cr_bn_bwd(cr_ctx* ctx, const void* dy, const void* out, const voi
         hipLaunchKernelGGL(k_bn_bwd_reduce<u16>, dim3((unsigned)nb), dim3(256), shm, ctx->stream, (const u16*)dy,
                            (const u16*)out, (const u16*)x, mean_invstd, sums, M, C, relu);
     CR_LAUNCH_CHECK();
+    if (C % 32 == 0 && nb <= bn_fuse_rows()) {
+        int64_t chunks = 1024 / (C / 32);
+        if (chunks < 1) chunks = 1;
+        int64_t ppb = cr_cdiv(M, chunks);
+        ppb = (ppb + 63) / 64 * 64;
+        const dim3 grid((unsigned)cr_cdiv(M, ppb), (unsigned)(C / 32));
+        if (act_f32)
+            hipLaunchKernelGGL(k_bn_bwd_apply_fused<float>, grid, dim3(256), 0, ctx->stream, (const float*)dy, (const float*)out,
+                               (const float*)x, mean_invstd, gamma, sums, (int)nb, (float*)dx, (float*)dres, dgamma, dbeta, M, C,
+                               relu, (int)ppb);
+        else
+            hipLaunchKernelGGL(k_bn_bwd_apply_fused<u16>, grid, dim3(256), 0, ctx->stream, (const u16*)dy, (const u16*)out,
+                               (const u16*)x, mean_invstd, gamma, sums, (int)nb, (u16*)dx, (u16*)dres, dgamma, dbeta, M, C, relu,
+                               (int)ppb);
+        CR_LAUNCH_CHECK();
+        return CR_OK;
+    }
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)C), dim3(256), 0, ctx->stream, sums, (int)nb, C, reduced, dgamma,
                        dbeta);
     CR_LAUNCH_CHECK();

@@ -1,1 +1,1 @@
-from .rpn import RPNWithIgnore, RPN, StandardRPNHead, subsample_labels, matched_pairwise_iou, build_proposal_generator
+from .rpn import RPNWithIgnore, RPN, StandardRPNHead, build_proposal_generator

@@ -163,6 +163,12 @@ class RPN(nn.Module):
             pred_objectness_logits, pred_anchor_deltas = head_outputs
         if self.training:
             assert gt_instances is not None, "RPN requires gt_instances in training!"
+            # training runs on the static-shape path (modeling/dense_train.py: rpn_label_and_sample / rpn_losses on fused
+            # kernels).  The per-image list formulation (label_and_sample_anchors / losses, rpn.py:41-354 of the reference)
+            # is test infrastructure: oracle/list_path.py attaches it (oracle.list_path.install).
+            if not hasattr(self, "label_and_sample_anchors"):
+                raise RuntimeError("RPN.forward(training) on instance lists: use the static-shape path (model.dense_train "
+                                   "= True); the list formulation is oracle/list_path.py")
             gt_labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances)
             losses = self.losses(anchors, pred_objectness_logits, gt_labels, pred_anchor_deltas, gt_boxes)
         else:
@@ -208,69 +214,6 @@ class RPN(nn.Module):
         return proposals
 
 
-def subsample_labels(labels, num_samples, positive_fraction, bg_label, matched_ious=None, eps=1e-4):
-    """rpn.py:275-328: IoU-weighted multinomial sampling of positives / negatives."""
-    positive = ((labels != -1) & (labels != bg_label)).nonzero(as_tuple=True)[0]
-    negative = (labels == bg_label).nonzero(as_tuple=True)[0]
-    num_pos = int(num_samples * positive_fraction)
-    num_pos = min(positive.numel(), num_pos)
-    num_neg = num_samples - num_pos
-    num_neg = min(negative.numel(), num_neg)
-    if num_pos > 0 and matched_ious is not None:
-        perm1 = torch.multinomial(matched_ious[positive] + eps, num_pos)
-    else:
-        perm1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
-    if num_neg > 0 and matched_ious is not None:
-        perm2 = torch.multinomial(matched_ious[negative] + eps, num_neg)
-    else:
-        perm2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
-    return positive[perm1], negative[perm2]
-
-
-def matched_pairwise_iou(boxes1: Boxes, boxes2: Boxes) -> torch.Tensor:
-    """rpn.py:330-354."""
-    assert len(boxes1) == len(boxes2)
-    area1, area2 = boxes1.area(), boxes2.area()
-    box1, box2 = boxes1.tensor, boxes2.tensor
-    lt = torch.max(box1[:, :2], box2[:, :2])
-    rb = torch.min(box1[:, 2:], box2[:, 2:])
-    wh = (rb - lt).clamp(min=0)
-    inter = wh[:, 0] * wh[:, 1]
-    return inter / (area1 + area2 - inter)
-
-
-def _dense_box_regression_loss_with_uncertainty(anchors, box2box_transform, pred_anchor_deltas, pred_objectness_logits,
-                                                gt_boxes, fg_mask, box_reg_loss_type="smooth_l1", smooth_l1_beta=0.0,
-                                                uncertainty_type="centerness"):
-    """rpn.py:206-273: objectness target = IoU(anchor, matched GT); both losses weighted by that IoU."""
-    anchors = Boxes.cat(anchors).tensor if isinstance(anchors[0], Boxes) else cat(anchors)
-    n = len(gt_boxes)
-    boxes_fg = Boxes(anchors.unsqueeze(0).repeat([n, 1, 1])[fg_mask])
-    gt_boxes_fg = Boxes(torch.stack(gt_boxes)[fg_mask].detach())
-    objectness_targets_anchors = matched_pairwise_iou(boxes_fg, gt_boxes_fg).detach()
-    objectness_logits = torch.cat(pred_objectness_logits, dim=1)
-    loss_box_conf = F.binary_cross_entropy_with_logits(objectness_logits[fg_mask], objectness_targets_anchors,
-                                                       reduction="none")
-    loss_box_conf = (loss_box_conf * objectness_targets_anchors).sum()
-    storage = get_event_storage()
-    with torch.no_grad():
-        sig = torch.sigmoid(objectness_logits)
-        storage.put_scalar("rpn/conf_pos_anchors", sig[fg_mask].mean())
-        storage.put_scalar("rpn/conf_neg_anchors", sig[~fg_mask].mean())
-    if box_reg_loss_type != "smooth_l1":
-        raise ValueError(f"Invalid dense box regression loss type '{box_reg_loss_type}'")
-    gt_anchor_deltas = torch.stack([box2box_transform.get_deltas(anchors, k) for k in gt_boxes])
-    pred = cat(pred_anchor_deltas, dim=1)[fg_mask]
-    tgt = gt_anchor_deltas[fg_mask]
-    if smooth_l1_beta < 1e-5:
-        loss_box_reg = torch.abs(pred - tgt)
-    else:
-        nd = torch.abs(pred - tgt)
-        loss_box_reg = torch.where(nd < smooth_l1_beta, 0.5 * nd ** 2 / smooth_l1_beta, nd - 0.5 * smooth_l1_beta)
-    loss_box_reg = (loss_box_reg.sum(dim=1) * objectness_targets_anchors).sum()
-    return loss_box_reg, loss_box_conf
-
-
 @PROPOSAL_GENERATOR_REGISTRY.register()
 class RPNWithIgnore(RPN):
     def __init__(self, *, ignore_thresh: float = 0.5, objectness_uncertainty: str = "none", **kwargs):
@@ -284,77 +227,6 @@ class RPNWithIgnore(RPN):
         ret["ignore_thresh"] = cfg.MODEL.RPN.IGNORE_THRESHOLD
         ret["objectness_uncertainty"] = cfg.MODEL.RPN.OBJECTNESS_UNCERTAINTY
         return ret
-
-    @torch.no_grad()
-    def label_and_sample_anchors(self, anchors: List[Boxes], gt_instances: List[Instances]):
-        """rpn.py:41-110."""
-        anchors = Boxes.cat(anchors)
-        gt_boxes_ign = [x.gt_boxes[x.gt_classes < 0] for x in gt_instances]
-        gt_boxes = [x.gt_boxes[x.gt_classes >= 0] for x in gt_instances]
-        gt_labels, matched_gt_boxes = [], []
-        for gt_boxes_i, gt_boxes_ign_i in zip(gt_boxes, gt_boxes_ign):
-            match_quality_matrix = pairwise_iou(gt_boxes_i, anchors)
-            matched_idxs, gt_labels_i = self.anchor_matcher(match_quality_matrix)
-            gt_labels_i = gt_labels_i.to(device=gt_boxes_i.device)
-            if len(gt_boxes_i) > 0:
-                gt_arange = torch.arange(match_quality_matrix.shape[1], device=matched_idxs.device)
-                matched_ious = match_quality_matrix[matched_idxs, gt_arange]
-                best_ious_gt_ind = match_quality_matrix.max(dim=1)[1]
-                # set(best per GT) & set(labelled foreground), rpn.py:75 (tensor form, no host round trip)
-                best_inds = best_ious_gt_ind[gt_labels_i[best_ious_gt_ind] == 1]
-            else:
-                matched_ious = match_quality_matrix.new_zeros(len(anchors))
-                best_inds = matched_idxs.new_zeros(0)
-            del match_quality_matrix
-            gt_labels_i = self._subsample_labels(gt_labels_i, matched_ious=matched_ious)
-            if best_inds.numel() > 0:
-                gt_labels_i[best_inds] = 1
-            if len(gt_boxes_i) == 0:
-                matched_gt_boxes_i = torch.zeros_like(anchors.tensor)
-            else:
-                matched_gt_boxes_i = gt_boxes_i[matched_idxs].tensor
-            if len(gt_boxes_ign_i) > 0:
-                background_inds = (gt_labels_i == 0).nonzero().squeeze()
-                if background_inds.numel() > 1:
-                    match_quality_matrix_ign = pairwise_ioa(gt_boxes_ign_i, anchors[background_inds])
-                    gt_labels_i[background_inds[match_quality_matrix_ign.max(0)[0] >= self.ignore_thresh]] = -1
-            gt_labels.append(gt_labels_i)
-            matched_gt_boxes.append(matched_gt_boxes_i)
-        return gt_labels, matched_gt_boxes
-
-    def _subsample_labels(self, label, matched_ious=None):
-        pos_idx, neg_idx = subsample_labels(label, self.batch_size_per_image, self.positive_fraction, 0,
-                                            matched_ious=matched_ious)
-        label.fill_(-1)
-        label.scatter_(0, pos_idx, 1)
-        label.scatter_(0, neg_idx, 0)
-        return label
-
-    def losses(self, anchors, pred_objectness_logits, gt_labels, pred_anchor_deltas, gt_boxes):
-        """rpn.py:129-204."""
-        num_images = len(gt_labels)
-        gt_labels = torch.stack(gt_labels)
-        pos_mask = gt_labels == 1
-        storage = get_event_storage()
-        storage.put_scalar("rpn/num_pos_anchors", pos_mask.sum() / num_images)
-        storage.put_scalar("rpn/num_neg_anchors", (gt_labels == 0).sum() / num_images)
-        if self.objectness_uncertainty.lower() not in ["none"]:
-            localization_loss, objectness_loss = _dense_box_regression_loss_with_uncertainty(
-                anchors, self.box2box_transform, pred_anchor_deltas, pred_objectness_logits, gt_boxes, pos_mask,
-                box_reg_loss_type=self.box_reg_loss_type, smooth_l1_beta=self.smooth_l1_beta,
-                uncertainty_type=self.objectness_uncertainty)
-        else:
-            anchors_t = Boxes.cat(anchors).tensor
-            gt_anchor_deltas = torch.stack([self.box2box_transform.get_deltas(anchors_t, k) for k in gt_boxes])
-            localization_loss = torch.abs(cat(pred_anchor_deltas, dim=1)[pos_mask] - gt_anchor_deltas[pos_mask]).sum()
-            valid_mask = gt_labels >= 0
-            objectness_loss = F.binary_cross_entropy_with_logits(cat(pred_objectness_logits, dim=1)[valid_mask],
-                                                                 gt_labels[valid_mask].to(torch.float32),
-                                                                 reduction="sum")
-        normalizer = self.batch_size_per_image * num_images
-        losses = {"rpn/cls": objectness_loss / normalizer, "rpn/loc": localization_loss / normalizer}
-        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
-
 
 def _construct(cls, cfg, *args, **kwargs):
     return cls(**cls.from_config(cfg, *args, **kwargs))

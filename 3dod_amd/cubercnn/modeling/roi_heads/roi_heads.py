@@ -16,7 +16,6 @@ from ....d2lite import (ROI_HEADS_REGISTRY, ROI_BOX_HEAD_REGISTRY, Boxes, Instan
 from .... import hipops as ops
 from ...util import math_util as util
 from ..backbone.fpn import c2_xavier_fill
-from ..proposal_generator.rpn import subsample_labels
 from .cube_head import build_cube_head, fc_nhwc
 from .fast_rcnn import FastRCNNOutputs
 
@@ -75,20 +74,6 @@ class FastRCNNConvFCHead(nn.Sequential):
     @property
     def output_shape(self):
         return ShapeSpec(channels=self._output_size)
-
-
-def add_ground_truth_to_proposals(gt, proposals):
-    """detectron2 add_ground_truth_to_proposals [third-party]: GT boxes join the proposals with logit(1-1e-10)."""
-    out = []
-    for gt_i, proposals_i in zip(gt, proposals):
-        device = proposals_i.objectness_logits.device
-        gt_logit_value = float(np.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10))))
-        gt_logits = gt_logit_value * torch.ones(len(gt_i), device=device)
-        gt_proposal = Instances(proposals_i.image_size)
-        gt_proposal.proposal_boxes = gt_i.gt_boxes
-        gt_proposal.objectness_logits = gt_logits
-        out.append(Instances.cat([proposals_i, gt_proposal]))
-    return out
 
 
 def select_foreground_proposals(proposals, bg_label):
@@ -198,6 +183,13 @@ class ROIHeads3D(StandardROIHeads):
         """roi_heads.py:2116-2157.  images: ImageList (only sizes are used)."""
         im_dims = [tuple(s) for s in images.image_sizes]
         if self.training:
+            # Training runs on the static-shape path (modeling/dense_train.py behind RCNN3D.dense_train): matching, ignore
+            # rule and IoU-weighted sampling are fused kernels there.  The per-image Instances-list formulation of
+            # label_and_sample_proposals (roi_heads.py:2737-2840 of the reference) is test infrastructure: it lives in
+            # oracle/list_path.py and is attached by oracle.list_path.install(roi_heads) (tests only).
+            if not hasattr(self, "label_and_sample_proposals"):
+                raise RuntimeError("ROIHeads3D.forward(training) on proposal lists: use the static-shape path "
+                                   "(model.dense_train = True); the list formulation is oracle/list_path.py")
             proposals = self.label_and_sample_proposals(proposals, targets)
             losses = self._forward_box(features, proposals)
             if self.loss_w_3d > 0:
@@ -584,63 +576,6 @@ class ROIHeads3D(StandardROIHeads):
                 inst.pred_dimensions = c3[:, 3:6]
                 inst.pred_pose = cp
         return pred_instances, losses
-
-    # ------------------------------------------------------------------ sampling
-    def _sample_proposals(self, matched_idxs, matched_labels, gt_classes, matched_ious=None):
-        """roi_heads.py:2737-2771."""
-        has_gt = gt_classes.numel() > 0
-        if has_gt:
-            gt_classes = gt_classes[matched_idxs]
-            gt_classes[matched_labels == 0] = self.num_classes
-            gt_classes[matched_labels == -1] = -1
-        else:
-            gt_classes = torch.zeros_like(matched_idxs) + self.num_classes
-        sampled_fg_idxs, sampled_bg_idxs = subsample_labels(gt_classes, self.batch_size_per_image,
-                                                            self.positive_fraction, self.num_classes,
-                                                            matched_ious=matched_ious)
-        sampled_idxs = torch.cat([sampled_fg_idxs, sampled_bg_idxs], dim=0)
-        return sampled_idxs, gt_classes[sampled_idxs]
-
-    @torch.no_grad()
-    def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]) -> List[Instances]:
-        """roi_heads.py:2773-2840."""
-        targets_ign = [target[target.gt_classes < 0] for target in targets]
-        targets = [target[target.gt_classes >= 0] for target in targets]
-        if self.proposal_append_gt:
-            proposals = add_ground_truth_to_proposals(targets, proposals)
-        proposals_with_gt = []
-        num_fg_samples, num_bg_samples = [], []
-        for proposals_per_image, targets_per_image, targets_ign_per_image in zip(proposals, targets, targets_ign):
-            has_gt = len(targets_per_image) > 0
-            match_quality_matrix = pairwise_iou(targets_per_image.gt_boxes, proposals_per_image.proposal_boxes)
-            matched_idxs, matched_labels = self.proposal_matcher(match_quality_matrix)
-            if len(targets_ign_per_image) > 0:
-                background_inds = (matched_labels == 0).nonzero().squeeze()
-                if background_inds.numel() > 1:
-                    mq_ign = pairwise_ioa(targets_ign_per_image.gt_boxes, proposals_per_image.proposal_boxes[background_inds])
-                    matched_labels[background_inds[mq_ign.max(0)[0] >= self.ignore_thresh]] = -1
-            if has_gt:
-                gt_arange = torch.arange(match_quality_matrix.shape[1], device=matched_idxs.device)
-                matched_ious = match_quality_matrix[matched_idxs, gt_arange]
-            else:
-                matched_ious = match_quality_matrix.new_zeros(match_quality_matrix.shape[1])
-            sampled_idxs, gt_classes = self._sample_proposals(matched_idxs, matched_labels,
-                                                              targets_per_image.gt_classes, matched_ious=matched_ious)
-            proposals_per_image = proposals_per_image[sampled_idxs]
-            proposals_per_image.gt_classes = gt_classes
-            if has_gt:
-                sampled_targets = matched_idxs[sampled_idxs]
-                for (trg_name, trg_value) in targets_per_image.get_fields().items():
-                    if trg_name.startswith("gt_") and not proposals_per_image.has(trg_name):
-                        proposals_per_image.set(trg_name, trg_value[sampled_targets])
-            nbg = (gt_classes == self.num_classes).sum()
-            num_bg_samples.append(nbg)
-            num_fg_samples.append(gt_classes.numel() - nbg)
-            proposals_with_gt.append(proposals_per_image)
-        storage = get_event_storage()
-        storage.put_scalar("roi_head/num_fg_samples", torch.stack([torch.as_tensor(v) for v in num_fg_samples]).float().mean())
-        storage.put_scalar("roi_head/num_bg_samples", torch.stack([torch.as_tensor(v) for v in num_bg_samples]).float().mean())
-        return proposals_with_gt
 
     def safely_reduce_losses(self, loss, absent_if_none=False):
         """roi_heads.py:2843-2851: mean over the finite entries; with none, `loss.mean()*0.0` exactly like the

@@ -28,8 +28,9 @@ def _oracle_ops():
 def parts():
     cfg = syn.make_cfg(overrides=["MODEL.DEVICE", "cpu", "VIS_PERIOD", 0, "log", False])
     shapes = {f"p{l}": d2.ShapeSpec(channels=256, stride=2 ** l) for l in range(2, 7)}
-    rpn = modeling.proposal_generator.build_proposal_generator(cfg, shapes).train()
-    rh = modeling.build_roi_heads(cfg, shapes).train()
+    from oracle import list_path
+    rpn = list_path.install_rpn(modeling.proposal_generator.build_proposal_generator(cfg, shapes).train())
+    rh = list_path.install_heads(modeling.build_roi_heads(cfg, shapes).train())
     batch = syn.make_batch(3, 3)
     batch[1]["instances"].gt_classes[2] = -1            # an ignore region
     gts = [b["instances"] for b in batch]

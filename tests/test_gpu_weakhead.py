@@ -153,6 +153,9 @@ def test_weak_model_trains_from_the_data_path(tmp_path, monkeypatch, dense):
     model = modeling.build_model(cfg, priors=util.compute_priors(cfg, omni)).train()
     assert type(model).__name__ == "RCNN3D_combined_features" and type(model.roi_heads).__name__ == "ROIHeads3DScore"
     model.dense_train = dense          # fused static-shape RPN / sampling / box head, or the instance-list path
+    if not dense:
+        from oracle import list_path
+        list_path.install(model)       # the per-image list formulation is test infrastructure (oracle/list_path.py)
     opt = solver.build_optimizer(cfg, model)
     step = solver.TrainStep(cfg, model, opt, world_size=1)
     feed = data.DevicePrefetcher(data.build_detection_train_loader(cfg, mapper=mapper, dataset_id_to_src=id_to_src,
@@ -190,6 +193,9 @@ def test_mask_losses_through_a_pluggable_segmentor(dense):
     torch.manual_seed(0)
     model = modeling.build_model(cfg).train()
     model.dense_train = dense
+    if not dense:
+        from oracle import list_path
+        list_path.install(model)
     opt = solver.build_optimizer(cfg, model)
     step = solver.TrainStep(cfg, model, opt, world_size=1)
     batch = syn.add_scene_maps(syn.make_batch(2, 31, size=256), 5)
