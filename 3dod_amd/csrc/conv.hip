@@ -512,16 +512,18 @@ __device__ __forceinline__ u32x4 lds_read16_asm(unsigned byte_addr) {
 // accumulators are summed through LDS before the epilogue.  For grids of <= one block per CU (the 64x64 ... 16x16 maps in
 // f32): two waves per SIMD cover each other's LDS / barrier latencies, which one wave per SIMD leaves exposed (87 -> ~110
 // TFLOP/s on the 3x3 128->128 layers), without the slab traffic of more split-K.
-template <int BN, int KS, int MODE, typename T = u16, int KG = 1>
+// BM = 64: half-height tiles for the f32 layers whose 128-pixel tiling gives fewer than one block per CU -- twice the
+// blocks without split-K slabs (a 64 x 128 tile moves 0.047 B/flop, 6 TB/s at the f32 peak: still under the L2 rate).
+template <int BN, int KS, int MODE, typename T = u16, int KG = 1, int BM = 128>
 __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm_dma(ConvP p) {
     constexpr int ES = (int)sizeof(T), SUB = 64 / ES;                        // k per 64-B LDS row: 32 bf16 / 16 f32
-    constexpr int BM = 128, BK = 2 * SUB;
+    constexpr int BK = 2 * SUB, NBX = BM / 64;                               // pixel rows per thread (chunks of 64 rows)
     constexpr int WAVES_M = BN == 128 ? 2 : 4, WAVES_N = 4 / WAVES_M;      // as k_conv_igemm: same statistics order
     constexpr int TP = BM / WAVES_M / 16, TC = BN / WAVES_N / 16;
     constexpr int NBW = BN / 64;                                            // weight rows per thread (chunks of 64 rows)
     constexpr int XS = BM * 32, WS = BN * 32;                               // elements of one 32-deep sub-block
     constexpr int STAGE = 2 * XS + 2 * WS;                                  // X(u=0), X(u=1), W(u=0), W(u=1)
-    constexpr int NDMA = 4 + 2 * NBW;                                       // DMA instructions per thread per stage
+    constexpr int NDMA = 2 * NBX + 2 * NBW;                                       // DMA instructions per thread per stage
     __shared__ __attribute__((aligned(1024))) u16 smem_all[KG * 2 * STAGE]; // per group 64 KiB (BN=128) / 48 KiB (BN=64)
     const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
     u16* smem = smem_all + grp * 2 * STAGE;
@@ -535,11 +537,11 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm_dma(ConvP p) {
     const int m0 = mt * BM, n0 = nt * BN;
 
     // rows this lane fetches: (tid >> 2) + 64 i  (wave w: rows 16 w .. 16 w + 15 of each 64-row half)
-    int nimg[2], hb[2], wb[2];
-    bool rv[2];
-    unsigned csrc[2];                                                        // logical chunk (bytes) fetched for row i
+    int nimg[NBX], hb[NBX], wb[NBX];
+    bool rv[NBX];
+    unsigned csrc[NBX];                                                        // logical chunk (bytes) fetched for row i
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NBX; ++i) {
         const int row = (tid >> 2) + 64 * i;
         const int m = m0 + row;
         rv[i] = m < p.M;
@@ -558,19 +560,21 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm_dma(ConvP p) {
     constexpr unsigned OOB = 0x80000000u;
     unsigned wrow[NBW];
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) wrow[i] = (unsigned)((n0 + (tid >> 2) + 64 * i) * p.Kdim) * (unsigned)ES + csrc[i];
+    for (int i = 0; i < NBW; ++i) wrow[i] = (unsigned)((n0 + (tid >> 2) + 64 * i) * p.Kdim) * (unsigned)ES + csrc[0];   // (the swizzle repeats every 64 rows)
 
     const int nstage_all = p.Kdim / BK;
     const int st0 = ks * p.kstages, st1 = min(st0 + p.kstages, nstage_all);  // this block's k stages (all of them when ksplit == 1)
     int cur_tap = -1;
-    unsigned tb[2] = {OOB, OOB};                     // byte offset of (pixel row i, current filter tap, this lane's chunk) or OOB
+    unsigned tb[NBX];
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) tb[i] = OOB;                     // byte offset of (pixel row i, current filter tap, this lane's chunk) or OOB
     auto issue = [&](int st, int buf) {
         const int k0 = st * BK;
         const int tap = KS == 1 ? 0 : (k0 >> p.cshift), cc = KS == 1 ? k0 : (k0 & (p.Cin - 1));
         if (tap != cur_tap) {                        // block-uniform: the tap decomposition and bounds test once per tap
             const int r = tap / KS, s2 = tap - r * KS;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NBX; ++i) {
                 int hi, wi;
                 bool ok = rv[i];
                 if (MODE == 0) { hi = hb[i] + r; wi = wb[i] + s2; }
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm_dma(ConvP p) {
         }
         u16* base = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NBX; ++i)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 dma16(rx, base + u * XS + (wave * 16 + 64 * i) * 32, tb[i] == OOB ? OOB : tb[i] + (unsigned)(cc + u * SUB) * (unsigned)ES);
@@ -620,8 +624,10 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm_dma(ConvP p) {
         const int buf = it & 1;
         if (st + KG < st1) {
             issue(st + KG, buf ^ 1);
-            if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage st has landed (this wave's DMAs)
-            else           asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            static_assert(NDMA == 8 || NDMA == 6 || NDMA == 4, "vmcnt literal");
+            if (NDMA == 8)      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage st has landed (this wave's DMAs)
+            else if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1020,8 +1026,14 @@ static int xcd_enabled() {
 }
 
 // literal template arguments from a plain function (the launch from inside a function template left the host stubs undefined)
-static void launch_dma_kernel(int bn, int ks, int mode, hipStream_t stream, const ConvP& p) {
-    const dim3 grid((unsigned)(cr_cdiv(p.M, 128) * (p.Cout / bn) * p.ksplit)), block(CONV_T);
+static void launch_dma_kernel(int bn, int ks, int mode, hipStream_t stream, const ConvP& p, int bm = 128) {
+    const dim3 grid((unsigned)(cr_cdiv(p.M, bm) * (p.Cout / bn) * p.ksplit)), block(CONV_T);
+    if (bm == 64) {         // f32, 64 x 128 tiles, two wave groups (callers: try_launch_dma)
+#define CR_BM64_CASE(K, M_) if (ks == K && mode == M_) { \
+        hipLaunchKernelGGL((k_conv_igemm_dma<128, K, M_, float, 2, 64>), grid, dim3(CONV_T * 2), 0, stream, p); return; }
+        CR_BM64_CASE(3, 0) CR_BM64_CASE(3, 1) CR_BM64_CASE(1, 0) CR_BM64_CASE(1, 1)
+#undef CR_BM64_CASE
+    }
     if (p.w3) {
 #define CR_S3_CASE(B, K, M_) if (bn == B && ks == K && mode == M_) { \
         hipLaunchKernelGGL((k_conv_igemm_dma_s3<B, K, M_>), grid, block, 0, stream, p); return; }
@@ -1063,20 +1075,31 @@ static bool try_launch_dma(cr_ctx* ctx, const ConvP& p, int out_f32, int* rc) {
             // per flop = 14.7 TB/s at the f32 MFMA peak, a 128 x 128 tile 0.031), so keep 128-wide tiles and split K over
             // workgroups until every CU has one; partial sums go to the ctx workspace, k_splitk_epilogue finishes
             const int bn2 = p.Cout % 128 == 0 ? 128 : 64;
-            const int64_t tiles = cr_cdiv(p.M, 128) * (p.Cout / bn2);
+            int64_t tiles = cr_cdiv(p.M, 128) * (p.Cout / bn2);
             const int nstage_all = p.Kdim / 32;
+            // half-height tiles first: twice the blocks before any k split (no slab traffic, often no epilogue launch)
+            static const int bm64_on = env_int("CR_CONV_BM64", 1);
+            const int bm = (bm64_on && !p.w3 && bn2 == 128 && p.M >= 128) ? 64 : 128;
+            if (bm == 64) tiles = cr_cdiv(p.M, 64) * (p.Cout / 128);
             static const int sk_target = env_int("CR_SPLITK_TARGET", 256);
             int S = (int)cr_cdiv(sk_target, tiles);
             if (S > nstage_all / 4) S = nstage_all / 4;                      // >= 4 stages (128 of k) per block
             if (S > 16) S = 16;
             const int64_t cap = (int64_t)(ctx->ws_bytes / ((size_t)p.M * p.Cout * sizeof(float)));
             if (S > cap) S = (int)cap;
+            if (S < 2 && bm == 64) {
+                launch_dma_kernel(128, KS, MODE, ctx->stream, p, 64);
+                hipError_t e3 = hipGetLastError();
+                if (e3 != hipSuccess) { cr_set_error("k_conv_igemm_dma launch failed: %s", hipGetErrorString(e3)); *rc = CR_EHIP; }
+                else *rc = CR_OK;
+                return true;
+            }
             if (S >= 2) {
                 ConvP q = p;
                 q.kstages = (int)cr_cdiv(nstage_all, S);
                 q.ksplit = (int)cr_cdiv(nstage_all, q.kstages);
                 q.part = (float*)ctx->ws;
-                launch_dma_kernel(bn2, KS, MODE, ctx->stream, q);
+                launch_dma_kernel(bn2, KS, MODE, ctx->stream, q, bm);
                 const dim3 g2((unsigned)cr_cdiv(p.M, 64), (unsigned)(p.Cout / 64));
                 hipLaunchKernelGGL(k_splitk_epilogue<float>, g2, dim3(256), 0, ctx->stream, q);
                 hipError_t e2 = hipGetLastError();
