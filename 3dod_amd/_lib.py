@@ -39,6 +39,8 @@ SIGNATURES = {
     "cr_conv2d_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "cr_weight_split3": [P, P, P, c_int64, c_int],
     "cr_relu_bwd": [P, P, P, P, c_int64, c_int],
+    "cr_topk_blocks": [c_int64, c_int],
+    "cr_topk": [P, P, c_int, c_int64, c_int, P, P, P],
     "cr_multi_seg": [P, P, c_int, c_int64, c_int],
     "cr_loss_guard": [P, P, c_int, c_float, P, P, P, c_int, c_float, c_float, P],
     "cr_step_counters": [P, P, P, P],

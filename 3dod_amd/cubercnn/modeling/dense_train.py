@@ -92,7 +92,7 @@ def rpn_label_and_sample(rpn, anchors, gt: GTBatch):
     k_pos = int(n_s * rpn.positive_fraction)
     # one top-k launch for both key sets (positives need the first k_pos of theirs; sorted output)
     kk = min(max(k_pos, n_s), A)
-    tkey, tidx = keys.view(2 * B, A).topk(kk, dim=1)
+    tkey, tidx = ops.topk(keys.view(2 * B, A), kk)
     pkey, pidx = tkey[:B, :min(k_pos, A)], tidx[:B, :min(k_pos, A)]
     nkey, nidx = tkey[B:, :min(n_s, A)], tidx[B:, :min(n_s, A)]
     # rpn.py:75 (forced arg-max anchors) is already in `out`; rpn.py:93-104 (ignore regions) inside the scatter
@@ -152,7 +152,9 @@ def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes, tr
         padded = torch.full((B, L, amax), float("-inf"), dtype=torch.float32, device=dev)
         for l, lg in enumerate(logits_per_level):
             padded[:, l, :sizes[l]] = lg.detach()
-        scores, idx = padded.topk(min(maxn, amax), dim=2)                     # (B, L, maxn), sorted descending
+        kq = min(maxn, amax)
+        scores, idx = ops.topk(padded.view(B * L, amax), kq)                  # sorted descending
+        scores, idx = scores.view(B, L, kq), idx.view(B, L, kq)
         idx = torch.where(torch.isfinite(scores), idx + cached[2], torch.full((), -1, dtype=torch.int64, device=dev))
         t = rpn.box2box_transform
         boxes, nms_boxes, valid = ops.rpn_decode_select(anchors, deltas.detach(), idx.view(B, -1), scores.view(B, -1),
@@ -160,7 +162,7 @@ def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes, tr
         keep = ops.nms_grouped(nms_boxes.view(B * L, maxn, 4), counts, rpn.nms_thresh).view(B, -1) & valid
         flat_scores = torch.where(keep, scores.view(B, -1), torch.full((), float("-inf"), device=dev))
         k_post = min(rpn.post_nms_topk[training], flat_scores.shape[1])
-        top_scores, top_idx = flat_scores.topk(k_post, dim=1)
+        top_scores, top_idx = ops.topk(flat_scores, k_post)
         return torch.gather(boxes, 1, top_idx[:, :, None].expand(-1, -1, 4)), top_scores
 
 
@@ -187,7 +189,7 @@ def roi_label_and_sample(rh, prop_boxes, prop_scores, gt: GTBatch):
     n_s = rh.batch_size_per_image
     k_fg = min(int(n_s * rh.positive_fraction), R)
     kk = min(max(k_fg, n_s), R)                       # one top-k launch for the foreground and background keys
-    tkey, tidx = keys.view(2 * B, R).topk(kk, dim=1)
+    tkey, tidx = ops.topk(keys.view(2 * B, R), kk)
     fkey, fidx = tkey[:B, :k_fg], tidx[:B, :k_fg]
     bkey, bidx = tkey[B:, :min(n_s, R)], tidx[B:, :min(n_s, R)]
     # at most n_s picks are valid; the stable compaction keeps "foreground first" (the k_fg leading slots hold every

@@ -311,7 +311,7 @@ class GraphedTrainStep:
     (:259-261), so running backward on the unclipped local loss and skipping the update gives the same parameters.
     Per step the host only refreshes the static input buffers (image batch, padded ground truth, camera constants) and
     the schedule's learning-rate factor (a device scalar the captured update reads).  Replays are enqueued back to back
-    with one host wait per step (CR_STEP_SYNC=0 lets the host run ahead: see the note in __init__).
+    (the host runs ahead of the device); CR_STEP_SYNC=1 makes the host wait for every step (debugging).
 
     Ownership: everything whose address is baked into the graphs is either a persistent buffer of this object / the
     optimizer (static inputs, flat parameter / gradient / momentum buffers, the weight bank, counters) or was allocated
@@ -327,13 +327,12 @@ class GraphedTrainStep:
         self.model, self.opt, self.world = model, optimizer, world_size
         self.stabilize = cfg.MODEL.STABILIZE > 0
         import os
-        # Back-to-back replays (host running ahead, CR_STEP_SYNC=0) still end in a GPU memory fault in bench.py's flow
-        # (6 steps after a device sync; the same 40 steps pass in tests/test_gpu_model.py), with one host wait per step
-        # they never do -- and the step is GPU-bound either way (18.17 ms in both modes).  What is left inside the captured
-        # region that this build does not own: torch.topk / sort (their multi-block paths zero counters with memset NODES,
-        # which round 1 already saw misbehave inside captured graphs on ROCm 7.2).  Until those are own kernels the safe
-        # mode is the default.
-        self.sync_each_step = os.environ.get("CR_STEP_SYNC", "1") == "1"
+        # Replays are enqueued back to back (the host runs ahead of the device); CR_STEP_SYNC=1 adds one host wait per step.
+        # The captured region must not contain memset NODES: torch.topk's multi-block path zeroes its counters with
+        # hipMemsetAsync, and with such nodes inside graph A back-to-back replays ended in GPU memory faults (5 of 5 runs of
+        # `CR_GRAPHS=step python bench.py`, none with a host wait per step); with the own top-k (csrc/topk.hip, no memset)
+        # 65 run-ahead replays per precision mode run clean.
+        self.sync_each_step = os.environ.get("CR_STEP_SYNC", "0") == "1"
         self._GTBatch, self._camera_meta = GTBatch, camera_meta
         dev = optimizer.flat_p.device
         self.dev = dev

@@ -1408,6 +1408,26 @@ def cube_reduce(L, u_sel, buf, dec, validf, inverse_z=False):
 # --------------------------------------------------------------------------
 # optimizer
 # --------------------------------------------------------------------------
+def topk(x, k):
+    """row-wise top-k of a 2-D float32 tensor: (values sorted descending, int64 indices), ties -> lower index first;
+    own radix-select + bitonic merge (csrc/topk.hip: two launches, no memset nodes).  Shapes outside the kernel's range
+    (k > 2048, too many candidates) fall back to torch.topk."""
+    _p = _Args()
+    _need_cuda(x, "topk input")
+    assert x.dim() == 2 and x.dtype == f32
+    rows, n = x.shape
+    lib = _lib.load()
+    nb = lib.cr_topk_blocks(n, k) if k >= 1 else 0
+    if k < 1 or k > 2048 or k > n or nb * k > 16384:
+        return x.topk(k, dim=1)
+    xc = x.contiguous()
+    ws = torch.empty((rows * nb * k,), dtype=torch.int64, device=x.device)
+    vals = torch.empty((rows, k), dtype=f32, device=x.device)
+    idx = torch.empty((rows, k), dtype=torch.int64, device=x.device)
+    _chk(lib.cr_topk(_ctx(x), _p(xc), rows, n, k, _p(ws), _p(vals), _p(idx)), "cr_topk")
+    return vals, idx
+
+
 def loss_guard(vals, scale, red, total, recent, stabilize, tolerance, gamma, flag):
     """divergence guard of train_net.py:202-220 in one launch (see include/cr3dod.h); all tensors on the device, in place"""
     _p = _Args()

@@ -223,6 +223,14 @@ int cr_weights_split3(cr_ctx* ctx, const float* src_base, void* dst_base, const 
 /* dw f32 (Cout, ks*ks*Cin); accumulate=0 zeroes it first (shared RPN-head weights accumulate over levels). */
 int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
                          int Cout, int ks, int stride, int pad, int accumulate, int act_f32);
+/* Row-wise top-k: x (rows, n) float32 -> vals (rows, k) sorted descending, idx (rows, k) int64; ties: lower index first; a
+ * positive NaN is the largest value (torch.topk's order).  k <= 2048, k <= n, cr_topk_blocks(n, k) * k <= 16384.  ws:
+ * rows * cr_topk_blocks(n, k) * k 64-bit words of scratch.  Two launches, no memset, deterministic.  Replaces torch.topk in
+ * subsample_labels' multinomial-without-replacement (cubercnn/modeling/proposal_generator/rpn.py:275-328, as the top-k of
+ * (IoU + eps) / Exp(1) keys), ROIHeads3D._sample_proposals (roi_heads.py:2737-2771) and detectron2's
+ * find_top_rpn_proposals (pre- and post-NMS top-k) [third-party]. */
+int cr_topk_blocks(int64_t n, int k);
+int cr_topk(cr_ctx* ctx, const float* x, int rows, int64_t n, int k, void* ws, float* vals, int64_t* idx);
 /* Loss-divergence guard of tools/train_net.py:202-220 on the device (no host sync in the step): vals (n) = this step's loss
  * terms summed over the ranks, scale = 1 / world size.  Writes red[i] = vals[i] * scale (red may be NULL), total = their sum,
  * flag = 1 when stabilize and (total is not finite or total > tolerance * rolling mean), else 0, and updates the rolling mean

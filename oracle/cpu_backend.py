@@ -202,6 +202,11 @@ def nms_grouped(boxes, counts, thresh):
     return keep
 
 
+def topk(x, k):
+    """mirror of hipops.topk (torch's own top-k; tie order unspecified there, lower index first in the kernel)"""
+    return x.topk(k, dim=1)
+
+
 def loss_guard(vals, scale, red, total, recent, stabilize, tolerance, gamma, flag):
     """mirror of hipops.loss_guard (tools/train_net.py:202-220)"""
     r = vals * scale

@@ -344,7 +344,7 @@ def test_whole_step_graph_run_ahead_lr_schedule_and_gt_overflow():
             d["image"] = d["image"].to(DEV); d["instances"] = d["instances"].to(DEV)
     with d2.EventStorage(0):
         step = solver.GraphedTrainStep(cfg, model, opt, batches[0])
-        assert step.G >= 32
+        assert not step.sync_each_step and step.G >= 32
         for i in range(40):                                   # enqueued back to back: nothing here waits for the device
             step(batches[i % 4])
         rep = step.report()                                   # the one sync
