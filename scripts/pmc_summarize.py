@@ -35,6 +35,10 @@ f32 = conv("f32", {"shape": "3x3 conv 256->256 on 4x128x128 f32 (x 67.1 MB, dy /
                    "bytes": {False: px * 4 * 2 + 2.36e6, True: px * 4 * 2 + 2.36e6}})
 b16 = conv("bf16", {"shape": "3x3 conv 256->256 on 4x128x128 bf16 (x 33.55 MB, dy / y 33.55 MB, w 1.18 MB, dW 2.36 MB f32)",
                     "bytes": {False: px * 2 * 2 + 1.18e6, True: px * 2 * 2 + 2.36e6}})
+x3 = conv("x3", {"shape": "3x3 conv 256->256 on 4x128x128, fp32x3 mode: f32 tensors, split-mode kernels (x 67.1 MB, dy / y 67.1 MB, "
+                          "w 2.36 MB f32 = 3.54 MB as three bf16 planes, dW 2.36 MB)",
+                 "bytes": {False: px * 4 * 2 + 3.54e6, True: px * 4 * 2 + 2.36e6}})
+json.dump(x3, open(os.path.join(ROOT, "profiles", "r02_pmc_conv_traffic_fp32x3.json"), "w"), indent=1)
 json.dump(f32, open(os.path.join(ROOT, "profiles", "r02_pmc_conv_traffic_fp32.json"), "w"), indent=1)
 json.dump(b16, open(os.path.join(ROOT, "profiles", "r02_pmc_conv_traffic_bf16.json"), "w"), indent=1)
 g = P("geo_fetch", "geo_write", m="k_project")
@@ -47,7 +51,7 @@ geo = {"shape": "k_project_score<4>: 1024 objects x 1000 cubes, full outputs (60
                        "hbm_write_bytes": wr, "traffic_bytes": rd + wr, "algorithmic_bytes": alg,
                        "traffic_over_algorithmic": (rd + wr) / alg, "duration_us_under_pmc": g[k]["duration_ns_under_pmc"] / 1e3}}}
 json.dump(geo, open(os.path.join(ROOT, "profiles", "r02_pmc_geometry_traffic.json"), "w"), indent=1)
-for name, d in (("fp32", f32), ("bf16", b16), ("geometry", geo)):
+for name, d in (("fp32", f32), ("fp32x3", x3), ("bf16", b16), ("geometry", geo)):
     for k, v in d["kernels"].items():
         print(name, k, "traffic %.1f MB (x%.2f algorithmic)" % (v["traffic_bytes"] / 1e6, v["traffic_over_algorithmic"]),
               ("MFMA util %.3f clock %.2f GHz" % (v["mfma_utilisation"], v["clock_GHz"])) if "mfma_utilisation" in v else "")
