@@ -596,3 +596,59 @@ extern "C" int cr_box_loss(cr_ctx* ctx, const float* scores, const float* deltas
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Ground truth of a batch -> the padded static-shape tensors of the training path in ONE launch (was a fill per tensor and a
+// slice copy per image and field): boxes (B,G,4) f32 zero-padded, classes (B,G) int64 with -2 = padding, boxes3D (B,G,9)
+// zero-padded, poses (B,G,3,3) identity-padded.  The per-image source pointers travel in the kernel argument (B <= 32).
+// Host side of: RPNWithIgnore.label_and_sample_anchors / ROIHeads3D.label_and_sample_proposals taking `gt_instances`
+// (cubercnn/modeling/proposal_generator/rpn.py:41-50, roi_heads/roi_heads.py:2773-2790 of the reference).
+// ---------------------------------------------------------------------------
+#define GT_MAXB 32
+struct GtSrc {
+    const float* boxes[GT_MAXB];
+    const int64_t* classes[GT_MAXB];
+    const float* boxes3d[GT_MAXB];
+    const float* poses[GT_MAXB];
+    int n[GT_MAXB];
+};
+__global__ __launch_bounds__(256) void k_gt_pack(GtSrc src, int B, int G, float* __restrict__ boxes, int64_t* __restrict__ classes,
+                                                 float* __restrict__ boxes3d, float* __restrict__ poses) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i - b * G;
+    const bool have = g < src.n[b];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) boxes[(size_t)i * 4 + e] = have ? src.boxes[b][g * 4 + e] : 0.f;
+    classes[i] = have ? src.classes[b][g] : (int64_t)-2;
+    const bool h3 = have && src.boxes3d[b] != nullptr;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+        boxes3d[(size_t)i * 9 + e] = h3 ? src.boxes3d[b][g * 9 + e] : 0.f;
+        poses[(size_t)i * 9 + e] = h3 ? src.poses[b][g * 9 + e] : ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+    }
+}
+
+extern "C" int cr_gt_pack(cr_ctx* ctx, const float* const* boxes_ptrs, const int64_t* const* classes_ptrs,
+                          const float* const* boxes3d_ptrs, const float* const* poses_ptrs, const int* counts, int B, int G,
+                          float* boxes, int64_t* classes, float* boxes3d, float* poses) {
+    CR_CHECK_ARG(ctx && boxes_ptrs && classes_ptrs && boxes3d_ptrs && poses_ptrs && counts, "cr_gt_pack: NULL table");
+    CR_CHECK_ARG(B >= 1 && B <= GT_MAXB && G >= 1, "cr_gt_pack: B=%d must be 1..%d and G=%d >= 1", B, GT_MAXB, G);
+    CR_CHECK_ARG(boxes && classes && boxes3d && poses, "cr_gt_pack: NULL output");
+    GtSrc s;
+    for (int b = 0; b < GT_MAXB; ++b) {
+        const bool in = b < B;
+        s.n[b] = in ? counts[b] : 0;
+        CR_CHECK_ARG(!in || (counts[b] >= 0 && counts[b] <= G), "cr_gt_pack: image %d has %d objects, G = %d", b, in ? counts[b] : 0, G);
+        s.boxes[b] = in ? boxes_ptrs[b] : nullptr;
+        s.classes[b] = in ? classes_ptrs[b] : nullptr;
+        s.boxes3d[b] = in ? boxes3d_ptrs[b] : nullptr;
+        s.poses[b] = in ? poses_ptrs[b] : nullptr;
+        CR_CHECK_ARG(!in || counts[b] == 0 || (s.boxes[b] && s.classes[b]), "cr_gt_pack: image %d: NULL boxes / classes", b);
+        CR_CHECK_ARG(!in || (s.boxes3d[b] == nullptr) == (s.poses[b] == nullptr), "cr_gt_pack: image %d: boxes3D and poses go together", b);
+    }
+    hipLaunchKernelGGL(k_gt_pack, dim3((unsigned)cr_cdiv((int64_t)B * G, 256)), dim3(256), 0, ctx->stream, s, B, G, boxes, classes,
+                       boxes3d, poses);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

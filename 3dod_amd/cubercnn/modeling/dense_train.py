@@ -33,6 +33,14 @@ class GTBatch:
         need = max(1, max(len(g) for g in gt_instances))
         G = need if G is None else G
         assert need <= G, f"{need} objects in an image but the static GT buffer holds {G}"
+        device = torch.device(device)
+        if device.type == "cuda" and hasattr(ops, "gt_pack") and B <= 32:
+            self.boxes = torch.empty((B, G, 4), device=device)
+            self.classes = torch.empty((B, G), dtype=torch.int64, device=device)    # -2 = padding, -1 = ignore
+            self.boxes3D = torch.empty((B, G, 9), device=device)
+            self.poses = torch.empty((B, G, 3, 3), device=device)
+            ops.gt_pack(gt_instances, G, self.boxes, self.classes, self.boxes3D, self.poses)        # one launch
+            return
         self.boxes = torch.zeros((B, G, 4), device=device)
         self.classes = torch.full((B, G), -2, dtype=torch.int64, device=device)     # -2 = padding, -1 = ignore
         self.boxes3D = torch.zeros((B, G, 9), device=device)
@@ -53,6 +61,15 @@ class GTBatch:
     @property
     def ignore(self):
         return self.classes == -1
+
+    def refill(self, gt_instances):
+        """in-place refresh of a static (graph-captured) buffer set from a new batch: one launch on the GPU"""
+        B, G = self.classes.shape
+        if self.boxes.is_cuda and hasattr(ops, "gt_pack") and B <= 32:
+            assert len(gt_instances) == B and max(len(g) for g in gt_instances) <= G
+            ops.gt_pack(gt_instances, G, self.boxes, self.classes, self.boxes3D, self.poses)
+        else:
+            self.copy_from(GTBatch(gt_instances, self.boxes.device, G=G))
 
     def copy_from(self, other):
         """in-place refresh of a static (graph-captured) buffer set."""

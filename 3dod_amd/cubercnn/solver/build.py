@@ -444,8 +444,7 @@ class GraphedTrainStep:
         _, batch = self.model._stack_images(data)
         assert tuple(batch.shape) == tuple(self.static_img.shape), "whole-step graph: the batch shape is fixed at capture"
         self.static_img.copy_(batch)
-        fresh = self._GTBatch([d["instances"].to(self.dev) for d in data], self.dev, G=self.G)
-        self.gt.copy_from(fresh)
+        self.gt.refill([d["instances"].to(self.dev) for d in data])
         meta = self._meta_of(data)
         self.meta.copy_(meta, non_blocking=True)
 

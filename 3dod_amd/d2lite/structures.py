@@ -239,6 +239,8 @@ class ImageList:
             max_size = [(m + (stride - 1)) // stride * stride for m in max_size]
         if len(tensors) == 1 and tuple(image_sizes[0]) == tuple(max_size):
             batched = tensors[0].unsqueeze(0)
+        elif all(tuple(s) == tuple(max_size) for s in image_sizes):
+            batched = torch.stack(list(tensors))                 # nothing to pad: one launch instead of a fill + a copy per image
         else:
             shape = [len(tensors)] + list(tensors[0].shape[:-2]) + list(max_size)
             batched = tensors[0].new_full(shape, pad_value)

@@ -1408,6 +1408,30 @@ def cube_reduce(L, u_sel, buf, dec, validf, inverse_z=False):
 # --------------------------------------------------------------------------
 # optimizer
 # --------------------------------------------------------------------------
+def gt_pack(gt_instances, G, boxes, classes, boxes3D, poses):
+    """fills the padded ground-truth tensors (B,G,...) of the static-shape training path from per-image Instances in one
+    launch (include/cr3dod.h, cr_gt_pack); the outputs may be freshly allocated or the static buffers of a captured graph"""
+    B = len(gt_instances)
+    keep = []
+
+    def dev(t, dt):
+        t = t.to(device=boxes.device, dtype=dt).contiguous()
+        keep.append(t)
+        return t.data_ptr()
+    PA, IA = _ct.c_void_p * B, _ct.c_int * B
+    bp, cp, b3, pp, cnt = PA(), PA(), PA(), PA(), IA()
+    for i, g in enumerate(gt_instances):
+        n = len(g)
+        cnt[i] = n
+        bp[i] = dev(g.gt_boxes.tensor, f32) if n else None
+        cp[i] = dev(g.gt_classes, torch.int64) if n else None
+        has3 = n and g.has("gt_boxes3D")
+        b3[i] = dev(g.gt_boxes3D, f32) if has3 else None
+        pp[i] = dev(g.gt_poses, f32) if has3 else None
+    _chk(_lib.load().cr_gt_pack(_ctx(boxes), bp, cp, b3, pp, cnt, B, int(G), _lib.ptr(boxes), _lib.ptr(classes), _lib.ptr(boxes3D),
+                                _lib.ptr(poses)), "cr_gt_pack")
+
+
 def topk(x, k):
     """row-wise top-k of a 2-D float32 tensor: (values sorted descending, int64 indices), ties -> lower index first;
     own radix-select + bitonic merge (csrc/topk.hip: two launches, no memset nodes).  Shapes outside the kernel's range

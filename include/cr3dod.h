@@ -223,6 +223,15 @@ int cr_weights_split3(cr_ctx* ctx, const float* src_base, void* dst_base, const 
 /* dw f32 (Cout, ks*ks*Cin); accumulate=0 zeroes it first (shared RPN-head weights accumulate over levels). */
 int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
                          int Cout, int ks, int stride, int pad, int accumulate, int act_f32);
+/* Ground truth of a batch of B <= 32 images -> the padded tensors of the static-shape training path, one launch:
+ * boxes (B,G,4) f32 zero-padded, classes (B,G) int64 (-2 = padding, -1 = ignore region as in the data), boxes3D (B,G,9)
+ * zero-padded, poses (B,G,3,3) identity-padded.  *_ptrs / counts are HOST arrays of B device pointers / object counts
+ * (boxes3d / poses entries may both be NULL for an image without 3D annotations).  Feeds what RPNWithIgnore.
+ * label_and_sample_anchors (rpn.py:41-50) and ROIHeads3D.label_and_sample_proposals (roi_heads.py:2773-2790) read from
+ * `gt_instances`. */
+int cr_gt_pack(cr_ctx* ctx, const float* const* boxes_ptrs, const int64_t* const* classes_ptrs,
+               const float* const* boxes3d_ptrs, const float* const* poses_ptrs, const int* counts, int B, int G,
+               float* boxes, int64_t* classes, float* boxes3d, float* poses);
 /* Row-wise top-k: x (rows, n) float32 -> vals (rows, k) sorted descending, idx (rows, k) int64; ties: lower index first; a
  * positive NaN is the largest value (torch.topk's order).  k <= 2048, k <= n, cr_topk_blocks(n, k) * k <= 16384.  ws:
  * rows * cr_topk_blocks(n, k) * k 64-bit words of scratch.  Two launches, no memset, deterministic.  Replaces torch.topk in
