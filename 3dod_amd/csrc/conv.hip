@@ -1249,6 +1249,8 @@ struct WgP {
     unsigned x_bytes, dy_bytes;   // extents for the buffer-load descriptors
     float* dbias;           // optional [Cout]: += column sums of dy (bias gradient), accumulated by the first k-tile's blocks
     int dbg;                // tuning only (CR_S3_DBG): 1 = no MFMAs, 2 = no LDS fragment reads either, 4 = no atomics
+    int cshift_w;           // log2(Wout) (k_conv_wgrad_s3_row)
+    int cshift_hw;          // log2(Hout * Wout) or -1
 };
 
 // transposing LDS read: 16-lane group reads a 4(row) x 16(col) block of 16-bit elements and
@@ -1886,6 +1888,245 @@ __global__ __launch_bounds__(CONV_T * 2) void k_conv_wgrad_s3(WgP p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_conv_wgrad_s3_row: split-mode weight gradient of a 3x3 / stride-1 / pad-1 convolution, one FILTER ROW per block.
+// The weight gradient is bound by L2 -> LDS bytes (k_conv_wgrad_s3 at 128 x 128 tiles reads 2.4 GB per launch on the
+// 4x128x128x256 layer: 0.65 ms in the step, 0.43 with warm caches).  The three horizontal taps (r, 0..2) of a filter row
+// read the SAME input pixels shifted by one column, so a block that owns all three needs per 32-pixel step ONE window of
+// 34 pixels x 128 input channels (not 3 x 32) and the 32 x 128 dy tile once (not three times): 33 KB per 3 x 128 x 128 x 32
+// multiply-adds instead of 32 KB per 128 x 128 x 32 -- a third of the bytes per flop.
+//   tile: 128 output channels x (3 taps x 128 input channels); 8 waves (2 x 4), wave tile 64 x 96 = 24 accumulator tiles;
+//   LDS: two buffers x three bf16 planes x (32 dy rows + 36 window rows) x 144 = 117.5 KB, one block per CU; staging of step
+//   i + 1 (global f32 -> split3 -> planes of the other buffer) is issued inside the MFMA stream of step i, one barrier per step;
+//   tap s of pixel j is window row j + s (a row offset of the transposing read); the pixels whose horizontal neighbour falls
+//   off the image row (w = 0 for s = 0, w = W - 1 for s = 2) are zeroed in the fragment by a per-step bit mask; vertical
+//   padding and image boundaries are zero-filled when the window is loaded.
+// Requires W a power of two >= 8, Cin % 128 == 0, Cout % 128 == 0, M % 32 == 0.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(CONV_T * 2) void k_conv_wgrad_s3_row(WgP p) {
+    constexpr int TM = 128, PP = 144, PQ = 144, WR = 36;           // window rows held (34 used)
+    constexpr int TI = 4, TJ = 6;                                   // wave tile 64 channels x 96 columns
+    constexpr int PE = 32 * PP, QE = WR * PQ;
+    constexpr int BUF = 3 * (PE + QE);
+    extern __shared__ __attribute__((aligned(16))) u16 smem_row[];  // [2][BUF]
+    auto rot = [](int row, int col) { return (col + (((row >> 3) & 1) << 6)) & 127; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int bx = bid % p.tm, by = (bid / p.tm) % p.tn, bz = bid / (p.tm * p.tn);
+    const int c0 = bx * TM;
+    const int nhalf = p.Cin >> 7;
+    const int r = by / nhalf, chalf = by - r * nhalf;               // filter row, input-channel chunk of 128
+    const int step0 = bz * p.steps_per_split;
+    const int nsteps_total = p.M >> 5;
+    const int step1 = min(step0 + p.steps_per_split, nsteps_total);
+    if (step0 >= step1) return;            // block-uniform
+
+    const int W = p.Wout, H = p.Hout, wsh = p.cshift_w;             // W = 1 << wsh
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int chunk = tid & 15, srow = tid >> 4;                    // staging: 16 chunks of 8 channels per row, 32 rows per pass
+    const int hw = H * W;
+    // window row wr of a step starting at pixel m is pixel m - 1 + wr, read r - 1 image rows away
+    auto win_off = [&](int pix) -> unsigned {
+        if (pix < 0 || pix >= p.M) return OOB;
+        const int n = p.cshift_hw >= 0 ? (pix >> p.cshift_hw) : pix / hw, rem = pix - n * hw;
+        const int h = (rem >> wsh) + r - 1, w = rem & (W - 1);
+        if ((unsigned)h >= (unsigned)H) return OOB;
+        return (unsigned)(((n * H + h) * W + w) * p.Cin + chalf * 128 + chunk * 8) * 4u;
+    };
+    u32x4 rq[2][2], rp[2], rqx[2];                                  // window rows srow / srow + 32 (tid < 32), dy row srow
+    auto load_stage = [&](int step) {
+        const int m = step << 5;
+        const unsigned o0 = win_off(m - 1 + srow);
+        rq[0][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, o0, 0, 0);
+        rq[0][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, o0 == OOB ? OOB : o0 + 16u, 0, 0);
+        if (tid < 32) {                                             // window rows 32, 33
+            const unsigned o1 = win_off(m - 1 + 32 + srow);
+            rqx[0] = __builtin_amdgcn_raw_buffer_load_b128(rx, o1, 0, 0);
+            rqx[1] = __builtin_amdgcn_raw_buffer_load_b128(rx, o1 == OOB ? OOB : o1 + 16u, 0, 0);
+        }
+        const unsigned od = (unsigned)((m + srow) * p.Cout + c0 + chunk * 8) * 4u;
+        rp[0] = __builtin_amdgcn_raw_buffer_load_b128(rdy, od, 0, 0);
+        rp[1] = __builtin_amdgcn_raw_buffer_load_b128(rdy, od + 16u, 0, 0);
+    };
+    auto store_stage = [&](int buf) {
+        u16* sP = smem_row + buf * BUF;
+        u16* sQ = sP + 3 * PE;
+        u32x4 Hh, Mm, Ll;
+        split3(rp[0], rp[1], Hh, Mm, Ll);
+        u16* d = &sP[srow * PP + rot(srow, chunk * 8)];
+        *reinterpret_cast<u32x4*>(d) = Hh; *reinterpret_cast<u32x4*>(d + PE) = Mm; *reinterpret_cast<u32x4*>(d + 2 * PE) = Ll;
+        split3(rq[0][0], rq[0][1], Hh, Mm, Ll);
+        d = &sQ[srow * PQ + rot(srow, chunk * 8)];
+        *reinterpret_cast<u32x4*>(d) = Hh; *reinterpret_cast<u32x4*>(d + QE) = Mm; *reinterpret_cast<u32x4*>(d + 2 * QE) = Ll;
+        if (tid < 32) {
+            split3(rqx[0], rqx[1], Hh, Mm, Ll);
+            d = &sQ[(32 + srow) * PQ + rot(32 + srow, chunk * 8)];
+            *reinterpret_cast<u32x4*>(d) = Hh; *reinterpret_cast<u32x4*>(d + QE) = Mm; *reinterpret_cast<u32x4*>(d + 2 * QE) = Ll;
+        }
+    };
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int moff = wm * 64, noff = wn * 96;
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    const bool do_bias = p.dbias != nullptr && by == 0 && tid < TM;
+    float bsum = 0.f;
+    // per column tile: tap s and channel offset inside the tap
+    int tap_s[TJ], tap_c[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) { const int col = noff + 16 * j; tap_s[j] = col >> 7; tap_c[j] = col & 127; }
+
+    auto compute = [&](int buf, unsigned mask0, unsigned mask2) {
+        const u16* sP = smem_row + buf * BUF;
+        const u16* sQ = sP + 3 * PE;
+        if (do_bias) {
+#pragma unroll 8
+            for (int rr = 0; rr < 32; ++rr) {
+                const u16* s0 = &sP[rr * PP + rot(rr, tid)];
+                bsum += (bf2f(s0[0]) + bf2f(s0[PE])) + bf2f(s0[2 * PE]);
+            }
+        }
+        // this lane's 8 pixels are 8g .. 8g+7: per-dword AND masks of the two edge taps
+        const unsigned b0m = (mask0 >> (8 * g)) & 0xffu, b2m = (mask2 >> (8 * g)) & 0xffu;
+        auto dy_plane = [&](int pl, bf16x8 (&a)[TI]) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const u16* b0 = &sP[pl * PE + (8 * g + tq) * PP + rot(8 * g + tq, moff + i * 16 + 4 * tp)];
+                const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b0 + 4 * PP);
+                a[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        };
+        auto x_frag = [&](int pb, int j) -> bf16x8 {
+            const int row0 = 8 * g + tq + tap_s[j];                      // window row of pixel 8g + tq for this tap
+            const u16* b0 = &sQ[pb * QE + row0 * PQ + rot(row0, tap_c[j] + 4 * tp)];
+            const int row1 = row0 + 4;
+            const u16* b1 = &sQ[pb * QE + row1 * PQ + rot(row1, tap_c[j] + 4 * tp)];
+            const s16x4 lo = lds_tr16(b0), hi = lds_tr16(b1);
+            u32x4 v = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            const unsigned bm = tap_s[j] == 0 ? b0m : (tap_s[j] == 2 ? b2m : 0xffu);
+            if (bm != 0xffu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[q] &= (((bm >> (2 * q)) & 1u) ? 0x0000ffffu : 0u) | (((bm >> (2 * q + 1)) & 1u) ? 0xffff0000u : 0u);
+            }
+            return __builtin_bit_cast(bf16x8, v);
+        };
+        // 96 accumulator registers leave room for two dy planes at a time: dy_l meets x_h first (and is dropped), then dy_m
+        // and dy_h meet x_h (read again), x_m, and dy_h alone x_l -- smallest terms first within each accumulator
+        {
+            bf16x8 al[TI];
+            dy_plane(2, al);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const bf16x8 bq = x_frag(0, j);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bq, acc[i][j], 0, 0, 0);
+            }
+        }
+        bf16x8 am[TI], ah[TI];
+        dy_plane(1, am);
+        dy_plane(0, ah);
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const bf16x8 bq = x_frag(pb, j);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bq, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bq, acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const bf16x8 bq = x_frag(2, j);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bq, acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // horizontal-edge masks of a step starting at pixel m (m % 32 == 0): bit j = pixel m + j has a left / right neighbour
+    auto edge_masks = [&](int step, unsigned& m0, unsigned& m2) {
+        if (W >= 32) {
+            const int w0 = (step << 5) & (W - 1);
+            m0 = w0 == 0 ? ~1u : ~0u;
+            m2 = (w0 + 32 == W) ? ~(1u << 31) : ~0u;
+        } else if (W == 16) { m0 = ~0x00010001u; m2 = ~0x80008000u; }
+        else { m0 = ~0x01010101u; m2 = ~0x80808080u; }              // W == 8
+    };
+
+    load_stage(step0);
+    store_stage(0);
+    if (step0 + 1 < step1) load_stage(step0 + 1);
+    __syncthreads();
+    for (int st = step0; st < step1; ++st) {
+        const int buf = (st - step0) & 1;
+        unsigned m0, m2;
+        edge_masks(st, m0, m2);
+        if (st + 1 < step1) store_stage(buf ^ 1);                    // data of step st + 1 (loaded one step ago)
+        if (st + 2 < step1) load_stage(st + 2);
+        compute(buf, m0, m2);
+        __syncthreads();
+    }
+    if (do_bias && c0 + tid < p.Cout) atomicAdd(&p.dbias[c0 + tid], bsum);
+    // D: col (lane&15) = column, row 4(lane>>4)+reg = channel; column -> (tap s, input channel)
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int kk = (r * 3 + tap_s[j]) * p.Cin + chalf * 128 + tap_c[j] + li;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = c0 + moff + i * 16 + 4 * g + e;
+                atomicAdd(&p.dw[(size_t)ch * p.Kdim + kk], acc[i][j][e]);
+            }
+        }
+}
+
+static bool try_launch_wgrad_s3_row(cr_ctx* ctx, WgP& p, int* rc) {
+    static const int on = env_int("CR_S3_WGRAD_ROW", 1);
+    const int W = p.Wout;
+    if (!on || p.stride != 1 || p.pad != 1 || (p.Cin & 127) || (p.Cout & 127) || W < 8 || (W & (W - 1)) || (p.M & 31) ||
+        p.Hin != p.Hout || p.Win != p.Wout || p.M < 1024)
+        return false;
+    const int nsteps = p.M >> 5;
+    const int tm = p.Cout / 128, tn = 3 * (p.Cin / 128);
+    const int tiles = tm * tn;
+    static const int force_splits = env_int("CR_WG_SPLITS_S3R", 0), target = env_int("CR_WG_S3R_BLOCKS", 256);
+    int splits = target / tiles;
+    // A row tile is three 128 x 128 tiles: the grid needs three times the pixel splits of k_conv_wgrad_s3 to fill the chip,
+    // each with a 128 x 384 set of atomics.  Measured (scripts/conv_shapes_bench.py, fp32x3): it pays on the 4x128x128x256
+    // layers (0.65 -> 0.47 ms in the step) and loses on the 64x64 and smaller maps (70 vs 43 us on 3x3 128->128), i.e. it needs
+    // >= 64 steps per block to amortise them.
+    static const int min_steps = env_int("CR_WG_S3R_MIN_STEPS", 64);
+    if (splits < 1 || nsteps / splits < min_steps) return false;
+    if (force_splits > 0) splits = force_splits;
+    if (splits > nsteps) splits = nsteps;
+    p.steps_per_split = (nsteps + splits - 1) / splits;
+    splits = (nsteps + p.steps_per_split - 1) / p.steps_per_split;
+    p.tm = tm; p.tn = tn; p.xcd = xcd_enabled();
+    p.cshift_w = ilog2_exact(W);
+    p.cshift_hw = ilog2_exact(p.Hout * W);            // -1: the image size is not a power of two (division per window row)
+    constexpr size_t LDS = 2 * 3 * (32 * 144 + 36 * 144) * sizeof(u16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t ea = hipFuncSetAttribute((const void*)k_conv_wgrad_s3_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (ea != hipSuccess) { cr_set_error("k_conv_wgrad_s3_row: LDS attribute: %s", hipGetErrorString(ea)); *rc = CR_EHIP; return true; }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_conv_wgrad_s3_row, dim3((unsigned)(tiles * splits)), dim3(CONV_T * 2), LDS, ctx->stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cr_set_error("k_conv_wgrad_s3_row launch failed: %s", hipGetErrorString(e)); *rc = CR_EHIP; }
+    else *rc = CR_OK;
+    return true;
+}
+
 // true + launched when the layer takes the split-mode weight-gradient kernel
 template <int KS>
 static bool try_launch_wgrad_s3(cr_ctx* ctx, WgP& p, int* rc) {
@@ -1995,7 +2236,7 @@ static int conv2d_bwd_weight_impl(cr_ctx* ctx, const void* dy, const void* x, fl
     if (rc) return rc;
     const size_t es = act_f32 ? 4 : 2;
     WgP p;
-    p.dbg = 0;
+    p.dbg = 0; p.cshift_w = 0; p.cshift_hw = -1;
     p.dy = dy; p.x = x; p.dw = dw; p.dbias = dbias;
     p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Cout = Cout;
     p.Hout = (H + 2 * pad - ks) / stride + 1;
@@ -2007,6 +2248,10 @@ static int conv2d_bwd_weight_impl(cr_ctx* ctx, const void* dy, const void* x, fl
         const int64_t nz = (int64_t)Cout * p.Kdim;
         hipLaunchKernelGGL(k_fill_zero_f32, dim3((unsigned)cr_cdiv(nz, 256)), dim3(256), 0, ctx->stream, dw, nz);
         CR_LAUNCH_CHECK();
+    }
+    if (act_f32 == 2 && ks == 3) {
+        int rcr = CR_OK;
+        if (try_launch_wgrad_s3_row(ctx, p, &rcr)) return rcr;
     }
     if (act_f32 == 2 && ks != 7) {
         int rc3 = CR_OK;

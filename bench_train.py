@@ -283,7 +283,7 @@ def dominant_kernel_roofline(dev, prec="fp32", reps=20):
     flop = 2.0 * N * H * W * C * 9 * C
     out = {}
     sink = torch.zeros(C * C * 9, device=dev)           # accumulate target (the flat gradient in the train step)
-    wg = {"fp32": "k_conv_wgrad_f32<128,3>", "fp32x3": "k_conv_wgrad_s3<128,3>", "bf16": "k_conv_wgrad<128,3>"}[prec]
+    wg = {"fp32": "k_conv_wgrad_f32<128,3>", "fp32x3": "k_conv_wgrad_s3_row", "bf16": "k_conv_wgrad<128,3>"}[prec]
     ig = {"fp32": "k_conv_igemm_dma<128,3,%d,float>", "fp32x3": "k_conv_igemm_dma_s3<128,3,%d>", "bf16": "k_conv_igemm_dma<128,3,%d>"}[prec]
     for name, fn in ((wg, lambda: ops.conv_bwd_weight_raw(dy, x, 3, 1, 1, sink=sink)),
                      (ig % 0 + " (fwd)", lambda: ops.conv_fwd_raw(x, wb, C, 3, 1, 1)),

@@ -71,6 +71,10 @@ RAW = [  # N, H, W, Cin, Cout, k, stride, pad
     (3, 75, 76, 128, 192, 1, 1, 0),      # M tail (17100 pixels), Cout = 3 x 64
     (1, 1, 2048, 1024, 1024, 1, 1, 0),   # FC-shaped: (R,K) x (O,K)^T
     (4, 128, 128, 64, 128, 3, 2, 1),     # stride 2: backward-data by parity class stays on the f32 MFMA
+    # the filter-row weight-gradient kernel takes a layer only with >= 64 pixel steps per block: batch sizes chosen for that
+    (168, 16, 16, 256, 256, 3, 1, 1),    # W = 16: two edge pixels per 32-pixel step
+    (2720, 8, 8, 128, 128, 3, 1, 1),     # W = 8: four edge pixels per step and tap
+    (42, 32, 64, 128, 256, 3, 1, 1),     # H != W, Cout = 2 tiles, image boundaries inside the pixel range of a block
 ]
 
 
@@ -128,3 +132,25 @@ def test_layers_outside_the_split_kernels_fall_back_to_f32_mfma():
         assert torch.equal(a[0], b[0])
         if Ci >= 16:
             assert torch.equal(a[1], b[1])
+
+
+def test_row_kernel_bias_gradient_and_accumulate():
+    """the filter-row weight-gradient kernel (3x3, 128-multiple channels): bias gradient from the staged dy planes, and
+    accumulation into an existing gradient buffer (the sink of the flat gradient)"""
+    g = torch.Generator().manual_seed(9)
+    N, H, W, C = 176, 32, 32, 128                      # 3 row tiles -> 85 splits x >= 64 steps
+    x = torch.randn(N, C, H, W, generator=g); dy = torch.randn(N, C, H, W, generator=g)
+    w64 = torch.zeros(C, C, 3, 3, dtype=f64, requires_grad=True)
+    y = F.conv2d(x.double(), w64, None, 1, 1)
+    y.backward(dy.double())
+    prev = ops.set_precision("fp32x3")
+    try:
+        xd, dyd = nhwc(x).to(DEV), nhwc(dy).to(DEV)
+        sink = torch.ones(C, C, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+        bias = torch.full((C,), 2.0, device=DEV)
+        ops.conv_bwd_weight_raw(dyd, xd, 3, 1, 1, sink=sink, bias_acc=bias)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(prev)
+    assert relerr(sink - 1.0, w64.grad) < 2e-6
+    assert relerr(bias - 2.0, dy.double().sum((0, 2, 3))) < 2e-6
