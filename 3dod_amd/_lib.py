@@ -40,6 +40,8 @@ SIGNATURES = {
     "cr_weight_split3": [P, P, P, c_int64, c_int],
     "cr_relu_bwd": [P, P, P, P, c_int64, c_int],
     "cr_gt_pack": [P, P, P, P, P, P, c_int, c_int, P, P, P, P],
+    "cr_rpn_unpack": [P, P, P, c_int, c_int, c_int, c_int, P, P, P],
+    "cr_rpn_pack_grad": [P, P, P, P, P, c_int, c_int, c_int, c_int],
     "cr_topk_blocks": [c_int64, c_int],
     "cr_topk": [P, P, c_int, c_int64, c_int, P, P, P],
     "cr_multi_seg": [P, P, c_int, c_int64, c_int],

@@ -652,3 +652,98 @@ extern "C" int cr_gt_pack(cr_ctx* ctx, const float* const* boxes_ptrs, const int
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// RPN head output -> the tensors the training path consumes, one launch: the head evaluates objectness and anchor deltas as
+// ONE 16-channel 1x1 convolution per level (y_l (B, H_l*W_l, 16) f32: A objectness logits, 4A deltas, padding); this kernel
+// writes the level-concatenated logits (B, Atot) and deltas (B, Atot, 4) (detectron2 RPN.forward's permute / flatten / cat
+// [third-party], rpn.py:153-170 here) and the per-level logits padded with -inf to the largest level, (B, L, amax), for the
+// batched pre-NMS top-k.  The backward kernel scatters the two gradients back into dy_l (B, H_l*W_l, 16), zeros elsewhere.
+// ---------------------------------------------------------------------------
+#define RPN_MAXL 8
+struct RpnLv { const float* y[RPN_MAXL]; float* dy[RPN_MAXL]; int n[RPN_MAXL]; int off[RPN_MAXL]; };   // n = H*W*A anchors of a level
+
+__global__ __launch_bounds__(256) void k_rpn_unpack(RpnLv lv, int B, int L, int A, int C, int amax, int atot,
+                                                    float* __restrict__ logits, float* __restrict__ deltas, float* __restrict__ padded) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * L * amax) return;
+    const int j = (int)(i % amax), l = (int)((i / amax) % L), b = (int)(i / ((int64_t)amax * L));
+    float lg = -INFINITY;
+    if (j < lv.n[l]) {
+        const int cell = j / A, a = j - cell * A;
+        const float* y = lv.y[l] + ((size_t)b * (lv.n[l] / A) + cell) * C;
+        lg = y[a];
+        const size_t o = (size_t)b * atot + lv.off[l] + j;
+        logits[o] = lg;
+        *reinterpret_cast<float4*>(deltas + o * 4) = make_float4(y[A + 4 * a], y[A + 4 * a + 1], y[A + 4 * a + 2], y[A + 4 * a + 3]);
+    }
+    if (padded) padded[i] = lg;
+}
+
+// one thread per (b, cell, channel) of a level's dy
+__global__ __launch_bounds__(256) void k_rpn_pack_grad(RpnLv lv, int B, int L, int A, int C, int atot, int64_t total,
+                                                       const float* __restrict__ dlogits, const float* __restrict__ ddeltas) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    // levels are laid out back to back in the index space: level l holds B * cells_l * C entries
+    int64_t r = i;
+    int l = 0;
+    for (; l < L - 1; ++l) {
+        const int64_t sz = (int64_t)B * (lv.n[l] / A) * C;
+        if (r < sz) break;
+        r -= sz;
+    }
+    const int cells = lv.n[l] / A;
+    const int c = (int)(r % C), cell = (int)((r / C) % cells), b = (int)(r / ((int64_t)C * cells));
+    float g = 0.f;
+    if (c < A) {
+        if (dlogits) g = dlogits[(size_t)b * atot + lv.off[l] + cell * A + c];
+    } else if (c < 5 * A) {
+        const int a = (c - A) >> 2, d = (c - A) & 3;
+        if (ddeltas) g = ddeltas[((size_t)b * atot + lv.off[l] + cell * A + a) * 4 + d];
+    }
+    lv.dy[l][r] = g;
+}
+
+static int rpn_levels(RpnLv& lv, const float* const* y, float* const* dy, const int* cells, int L, int A, int* atot, int* amax) {
+    CR_CHECK_ARG(L >= 1 && L <= RPN_MAXL && A >= 1 && cells, "cr_rpn_unpack: bad level table");
+    int off = 0, mx = 0;
+    for (int l = 0; l < RPN_MAXL; ++l) {
+        const bool in = l < L;
+        lv.y[l] = (in && y) ? y[l] : nullptr;
+        lv.dy[l] = (in && dy) ? dy[l] : nullptr;
+        lv.n[l] = in ? cells[l] * A : 0;
+        lv.off[l] = off;
+        if (in) { CR_CHECK_ARG(cells[l] > 0, "cr_rpn_unpack: empty level %d", l); off += lv.n[l]; if (lv.n[l] > mx) mx = lv.n[l]; }
+    }
+    *atot = off; *amax = mx;
+    return CR_OK;
+}
+
+extern "C" int cr_rpn_unpack(cr_ctx* ctx, const float* const* y_ptrs, const int* cells, int L, int B, int A, int C,
+                             float* logits, float* deltas, float* padded) {
+    CR_CHECK_ARG(ctx && y_ptrs && logits && deltas && B >= 1 && C >= 5 * A, "cr_rpn_unpack: bad args");
+    RpnLv lv; int atot, amax;
+    int rc = rpn_levels(lv, y_ptrs, nullptr, cells, L, A, &atot, &amax);
+    if (rc) return rc;
+    for (int l = 0; l < L; ++l) CR_CHECK_ARG(y_ptrs[l], "cr_rpn_unpack: NULL level %d", l);
+    const int64_t total = (int64_t)B * L * amax;
+    hipLaunchKernelGGL(k_rpn_unpack, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, lv, B, L, A, C, amax, atot,
+                       logits, deltas, padded);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+extern "C" int cr_rpn_pack_grad(cr_ctx* ctx, const float* dlogits, const float* ddeltas, float* const* dy_ptrs, const int* cells,
+                                int L, int B, int A, int C) {
+    CR_CHECK_ARG(ctx && dy_ptrs && B >= 1 && C >= 5 * A, "cr_rpn_pack_grad: bad args");
+    RpnLv lv; int atot, amax;
+    int rc = rpn_levels(lv, nullptr, dy_ptrs, cells, L, A, &atot, &amax);
+    if (rc) return rc;
+    int64_t total = 0;
+    for (int l = 0; l < L; ++l) { CR_CHECK_ARG(dy_ptrs[l], "cr_rpn_pack_grad: NULL level %d", l); total += (int64_t)B * cells[l] * C; }
+    hipLaunchKernelGGL(k_rpn_pack_grad, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, lv, B, L, A, C, atot, total,
+                       dlogits, ddeltas);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}

@@ -144,7 +144,27 @@ def rpn_losses(rpn, anchors, logits, deltas, labels, midx, gt: GTBatch):
 _PCONST = {}
 
 
-def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes, training=True):
+class RawRPNOutputs:
+    """the RPN head's per-level outputs y_l (B,H,W,16) as they leave the one 16-channel convolution (dense-region graph)"""
+    __slots__ = ("ys",)
+
+    def __init__(self, ys):
+        self.ys = list(ys)
+
+
+def rpn_tensors(rpn, feats, head_outputs):
+    """-> (logits (B,Atot), deltas (B,Atot,4), per-level logits padded with -inf (B,L,amax) or None, anchors per level).
+    head_outputs: None (run the head), RawRPNOutputs, or the (logits per level, deltas per level) lists of RPN.forward."""
+    A = rpn.rpn_head.num_anchors
+    if head_outputs is None or isinstance(head_outputs, RawRPNOutputs):
+        ys = head_outputs.ys if head_outputs is not None else rpn.rpn_head.forward_raw(feats)
+        logits, deltas, padded = ops.rpn_unpack(ys, A)               # one launch each way
+        return logits, deltas, padded, [int(y.shape[1] * y.shape[2] * A) for y in ys]
+    logits_lv, deltas_lv = head_outputs
+    return torch.cat(logits_lv, 1), torch.cat(deltas_lv, 1), None, [int(t.shape[1]) for t in logits_lv]
+
+
+def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes, training=True, padded=None, sizes=None):
     """RPN.predict_proposals / find_top_rpn_proposals (detectron2 [third-party], restated in proposal_generator/rpn.py)
     with a padded result: boxes (B,K,4), scores (B,K) (-inf = empty slot).  anchors (A,4) and deltas (B,A,4) are the
     level-concatenated tensors.  Only the per-level top-k candidates are decoded (one fused launch: decode, clip,
@@ -152,7 +172,8 @@ def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes, tr
     with torch.no_grad():
         B = deltas.shape[0]
         dev = deltas.device
-        sizes = [int(t.shape[1]) for t in logits_per_level]
+        if sizes is None:
+            sizes = [int(t.shape[1]) for t in logits_per_level]
         ks = [min(n, rpn.pre_nms_topk[training]) for n in sizes]
         maxn, L = max(ks), len(ks)
         ckey = (tuple(tuple(s) for s in image_sizes), tuple(sizes), tuple(ks), str(dev))
@@ -166,9 +187,10 @@ def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes, tr
         # ONE top-k for all levels: logits padded to the largest level with -inf (a per-level call costs as much as
         # this single batched one: the select is one workgroup per row either way)
         amax = max(sizes)
-        padded = torch.full((B, L, amax), float("-inf"), dtype=torch.float32, device=dev)
-        for l, lg in enumerate(logits_per_level):
-            padded[:, l, :sizes[l]] = lg.detach()
+        if padded is None:
+            padded = torch.full((B, L, amax), float("-inf"), dtype=torch.float32, device=dev)
+            for l, lg in enumerate(logits_per_level):
+                padded[:, l, :sizes[l]] = lg.detach()
         kq = min(maxn, amax)
         scores, idx = ops.topk(padded.view(B * L, amax), kq)                  # sorted descending
         scores, idx = scores.view(B, L, kq), idx.view(B, L, kq)
@@ -324,12 +346,12 @@ def forward_train(model, image_sizes, features, head_outputs, gt: GTBatch, meta)
     grid_sizes = [(f.shape[1], f.shape[2]) for f in feats]
     anchors_lv = rpn.anchor_generator(grid_sizes, dev)
     anchors = torch.cat([a.tensor for a in anchors_lv])
-    logits_lv, deltas_lv = head_outputs if head_outputs is not None else rpn.rpn_head(feats)
-    logits, deltas = torch.cat(logits_lv, 1), torch.cat(deltas_lv, 1)
+    logits, deltas, padded, sizes = rpn_tensors(rpn, feats, head_outputs)
     with torch.no_grad():
         labels, midx, _ = rpn_label_and_sample(rpn, anchors, gt)
     losses = rpn_losses(rpn, anchors, logits, deltas, labels, midx, gt)
-    pboxes, pscores = rpn_proposals_padded(rpn, anchors, logits_lv, deltas, image_sizes)
+    pboxes, pscores = rpn_proposals_padded(rpn, anchors, head_outputs[0] if padded is None else None, deltas, image_sizes,
+                                           padded=padded, sizes=sizes)
     samp = roi_label_and_sample(rh, pboxes, pscores, gt)
     box_pooled, cube_pooled = pool_roi_features(rh, features, samp)
     lb, pred_boxes = box_head_losses(rh, features, samp, gt, pooled=box_pooled)
@@ -351,12 +373,12 @@ def forward_train_weak(model, image_sizes, features, head_outputs, gt: GTBatch, 
     grid_sizes = [(f.shape[1], f.shape[2]) for f in feats]
     anchors_lv = rpn.anchor_generator(grid_sizes, dev)
     anchors = torch.cat([a.tensor for a in anchors_lv])
-    logits_lv, deltas_lv = head_outputs if head_outputs is not None else rpn.rpn_head(feats)
-    logits, deltas = torch.cat(logits_lv, 1), torch.cat(deltas_lv, 1)
+    logits, deltas, padded, sizes = rpn_tensors(rpn, feats, head_outputs)
     with torch.no_grad():
         labels, midx, _ = rpn_label_and_sample(rpn, anchors, gt)
     losses = rpn_losses(rpn, anchors, logits, deltas, labels, midx, gt)
-    pboxes, pscores = rpn_proposals_padded(rpn, anchors, logits_lv, deltas, image_sizes)
+    pboxes, pscores = rpn_proposals_padded(rpn, anchors, head_outputs[0] if padded is None else None, deltas, image_sizes,
+                                           padded=padded, sizes=sizes)
     samp = roi_label_and_sample(rh, pboxes, pscores, gt)
     box_pooled, cube_pooled = pool_roi_features(rh, features, samp)
     lb, _ = box_head_losses(rh, features, samp, gt, pooled=box_pooled)

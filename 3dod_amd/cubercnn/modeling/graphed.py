@@ -79,10 +79,10 @@ class GraphedDense:
         def dense():
             x = ops.preprocess(self.static_img, model.pixel_mean_list, model.pixel_std_list)
             feats = model.backbone(x)
-            logits, deltas = pg.rpn_head([feats[f] for f in pg.in_features])
+            ys = pg.rpn_head.forward_raw([feats[f] for f in pg.in_features])     # (B,H,W,16) per level: unpacked outside
             self.feat_names = list(feats.keys())
-            self.n_levels = len(logits)
-            return tuple(feats.values()) + tuple(logits) + tuple(deltas)
+            self.n_levels = len(ys)
+            return tuple(feats.values()) + tuple(ys)
 
         mods = [model.backbone, pg.rpn_head]
 
@@ -135,7 +135,7 @@ class GraphedDense:
         outs = _Replay.apply(self, self.trigger)
         nf, nl = len(self.feat_names), self.n_levels
         feats = dict(zip(self.feat_names, outs[:nf]))
-        return feats, list(outs[nf:nf + nl]), list(outs[nf + nl:nf + 2 * nl])
+        return feats, list(outs[nf:nf + nl])
 
 
 class GraphedDenseEval:

@@ -96,9 +96,7 @@ class RCNN3D(nn.Module):
         from ..dense_train import forward_train
         x = ops.preprocess(images_u8, self.pixel_mean_list, self.pixel_std_list)
         features = self.backbone(x)
-        pg = self.proposal_generator
-        head = pg.rpn_head([features[f] for f in pg.in_features])
-        return forward_train(self, image_sizes, features, head, gt, meta)
+        return forward_train(self, image_sizes, features, None, gt, meta)          # (runs the RPN head in its raw form)
 
     def _stack_images(self, batched_inputs):
         images = [x["image"].to(self.device) for x in batched_inputs]
@@ -136,8 +134,9 @@ class RCNN3D(nn.Module):
             images, batch = self._stack_images(batched_inputs)
             same = all(tuple(sz) == tuple(batch.shape[-2:]) for sz in images.image_sizes)
             if same and g.matches(batch):
-                features, logits, deltas = g(batch)
-                head_outputs = (logits, deltas)
+                from ..dense_train import RawRPNOutputs
+                features, ys = g(batch)
+                head_outputs = RawRPNOutputs(ys)
             else:
                 g = None
         if g is None:
@@ -151,6 +150,10 @@ class RCNN3D(nn.Module):
             gt_instances = None
         if self.dense_train and gt_instances is not None:
             return self._forward_dense(images, features, head_outputs, gt_instances, Ks, im_scales_ratio, batched_inputs)
+        if head_outputs is not None:                       # instance-list path (tests): the lists of RPN.forward
+            A, D = self.proposal_generator.rpn_head.num_anchors, self.proposal_generator.rpn_head.box_dim
+            head_outputs = ([y[..., :A].reshape(y.shape[0], -1) for y in head_outputs.ys],
+                            [y[..., A:A + A * D].reshape(y.shape[0], -1, D) for y in head_outputs.ys])
         proposals, proposal_losses = self.proposal_generator(images, features, gt_instances, head_outputs=head_outputs)
         instances, detector_losses = self._run_roi_heads(images, features, proposals, Ks, im_scales_ratio, gt_instances,
                                                          batched_inputs)

@@ -29,16 +29,24 @@ class StandardRPNHead(nn.Module):
         self.num_anchors, self.box_dim = num_anchors, box_dim
         to_channels_last(self)
 
-    def forward(self, features: List[torch.Tensor]):
+    def forward_raw(self, features: List[torch.Tensor]):
+        """per level y (N,H,W,16) f32 = [A objectness logits | 4A anchor deltas | padding]: both predictors as ONE conv"""
         A, D = self.num_anchors, self.box_dim
         n_out = A + A * D
         pad = (-n_out) % 16
         w = ops.cat_rows((self.objectness_logits.weight, self.anchor_deltas.weight), n_out + pad)
         b = ops.cat_rows((self.objectness_logits.bias, self.anchor_deltas.bias), n_out + pad)
-        pred_objectness_logits, pred_anchor_deltas = [], []
+        ys = []
         for x in features:
             t = ops.conv_bias_act(x, self.conv.weight, self.conv.bias, 1, 1, relu=True)
-            y = ops.conv_bias_act(t, w, b, 1, 0, relu=False, out_f32=True)             # (N,H,W,16) f32
+            ys.append(ops.conv_bias_act(t, w, b, 1, 0, relu=False, out_f32=True))
+        return ys
+
+    def forward(self, features: List[torch.Tensor]):
+        A, D = self.num_anchors, self.box_dim
+        n_out = A + A * D
+        pred_objectness_logits, pred_anchor_deltas = [], []
+        for y in self.forward_raw(features):
             N = y.shape[0]
             pred_objectness_logits.append(y[..., :A].reshape(N, -1))                    # (N, H*W*A)
             pred_anchor_deltas.append(y[..., A:n_out].reshape(N, -1, D))                # (N, H*W*A, 4)

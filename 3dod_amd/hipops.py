@@ -951,7 +951,6 @@ class _CatPlan:
         self.b = torch.zeros((Op,), dtype=f32, device=dev)
         self.dW = torch.empty((Op, K), dtype=f32, device=dev)
         self.db = torch.empty((Op,), dtype=f32, device=dev)
-        self.ptrs = tuple((w.data_ptr(), bb.data_ptr()) for w, bb in zip(weights, biases))
         self.sinks = all(grad_sink(t) is not None for t in list(weights) + list(biases))
         dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("n", "<i8"), ("item0", "<i8")])
 
@@ -1005,7 +1004,10 @@ def _cat_plan(weights, biases):
     """plans are keyed by the parameters' addresses and shapes (not kept on the tensor objects: the whole-step graph runs
     the model on fresh leaf tensors over the same storage, and a plan must exist BEFORE a capture starts -- building one
     uploads its tables)"""
-    key = tuple((w.data_ptr(), b.data_ptr(), tuple(w.shape)) for w, b in zip(weights, biases))
+    sink_ptr = lambda t: 0 if grad_sink(t) is None else grad_sink(t).data_ptr()
+    # (the gradient sinks are part of the key: a later model whose parameters land on a freed model's addresses has its own
+    # flat gradient, and the plan's backward table holds raw sink pointers)
+    key = tuple((w.data_ptr(), b.data_ptr(), tuple(w.shape), sink_ptr(w), sink_ptr(b)) for w, b in zip(weights, biases))
     sinks = all(grad_sink(t) is not None for t in list(weights) + list(biases))
     plan = _CAT_PLANS.get(key)
     if plan is None or plan.sinks != sinks:
@@ -1408,6 +1410,47 @@ def cube_reduce(L, u_sel, buf, dec, validf, inverse_z=False):
 # --------------------------------------------------------------------------
 # optimizer
 # --------------------------------------------------------------------------
+class _RPNUnpack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, *ys):
+        _p = _Args()
+        L, B, C = len(ys), ys[0].shape[0], ys[0].shape[-1]
+        ys = [y.contiguous() for y in ys]
+        cells = [y.numel() // (B * C) for y in ys]
+        atot, amax = sum(cells) * A, max(cells) * A
+        dev = ys[0].device
+        logits = torch.empty((B, atot), dtype=f32, device=dev)
+        deltas = torch.empty((B, atot, 4), dtype=f32, device=dev)
+        padded = torch.empty((B, L, amax), dtype=f32, device=dev)
+        yp, ca = (_ct.c_void_p * L)(*[y.data_ptr() for y in ys]), (_ct.c_int * L)(*cells)
+        _p.keep.extend(ys)
+        _chk(_lib.load().cr_rpn_unpack(_ctx(ys[0]), yp, ca, L, B, A, C, _lib.ptr(logits), _lib.ptr(deltas), _lib.ptr(padded)),
+             "cr_rpn_unpack")
+        ctx.cfg = (A, C, B, cells, [tuple(y.shape) for y in ys])
+        ctx.mark_non_differentiable(padded)
+        return logits, deltas, padded
+
+    @staticmethod
+    def backward(ctx, dlogits, ddeltas, _dpad):
+        _p = _Args()
+        A, C, B, cells, shapes = ctx.cfg
+        L = len(cells)
+        ref = dlogits if dlogits is not None else ddeltas
+        dys = [torch.empty(s, dtype=f32, device=ref.device) for s in shapes]
+        dl = None if dlogits is None else dlogits.contiguous()
+        dd = None if ddeltas is None else ddeltas.contiguous()
+        dp, ca = (_ct.c_void_p * L)(*[d.data_ptr() for d in dys]), (_ct.c_int * L)(*cells)
+        _chk(_lib.load().cr_rpn_pack_grad(_ctx(ref), _p(dl), _p(dd), dp, ca, L, B, A, C), "cr_rpn_pack_grad")
+        return (None,) + tuple(dys)
+
+
+def rpn_unpack(ys, A):
+    """per-level RPN head outputs y_l (B,H,W,16) f32 [A logits | 4A deltas | pad] -> (logits (B,Atot), deltas (B,Atot,4),
+    per-level logits padded with -inf (B,L,amax)) with ONE launch each way (was a slice copy per level and output, three cats,
+    a fill and five copies; backward: a zero-fill, a slice copy and an add per level and output)"""
+    return _RPNUnpack.apply(int(A), *ys)
+
+
 def gt_pack(gt_instances, G, boxes, classes, boxes3D, poses):
     """fills the padded ground-truth tensors (B,G,...) of the static-shape training path from per-image Instances in one
     launch (include/cr3dod.h, cr_gt_pack); the outputs may be freshly allocated or the static buffers of a captured graph"""

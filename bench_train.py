@@ -77,6 +77,7 @@ def _bench_train_mode(args, rank, world, dev, prec):
     if world > 1:
         import torch.distributed as dist
         dist.broadcast(opt.flat_p, 0)                 # DDP wrap-time parameter broadcast
+        importlib.import_module("3dod_amd.hipops").bump_weight_epoch()      # parameters changed outside the optimizer
     d2 = importlib.import_module("3dod_amd.d2lite")
     batches = [syn.make_batch(IMS_PER_GPU, 1234 + rank * 1000 + i) for i in range(4)]
     for b in batches:                                   # inputs resident in HBM before the timed region

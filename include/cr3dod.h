@@ -223,6 +223,16 @@ int cr_weights_split3(cr_ctx* ctx, const float* src_base, void* dst_base, const 
 /* dw f32 (Cout, ks*ks*Cin); accumulate=0 zeroes it first (shared RPN-head weights accumulate over levels). */
 int cr_conv2d_bwd_weight(cr_ctx* ctx, const void* dy, const void* x, float* dw, int N, int H, int W, int Cin,
                          int Cout, int ks, int stride, int pad, int accumulate, int act_f32);
+/* RPN head output -> training tensors in one launch.  The head evaluates objectness and anchor deltas as ONE C = 16-channel
+ * 1x1 convolution per level: y_l (B, cells_l, C) f32 with A objectness logits, 4 A deltas, padding per cell.  cr_rpn_unpack
+ * writes logits (B, Atot) and deltas (B, Atot, 4) level-concatenated in (cell, anchor) order (detectron2 RPN.forward's permute
+ * / flatten / cat [third-party]; rpn.py:153-170) and, when `padded` is non-NULL, the per-level logits padded with -inf to the
+ * largest level, (B, L, amax).  cr_rpn_pack_grad: the backward -- dy_l from dlogits / ddeltas (either may be NULL = zero).
+ * y_ptrs / dy_ptrs / cells: HOST arrays of L <= 8 entries. */
+int cr_rpn_unpack(cr_ctx* ctx, const float* const* y_ptrs, const int* cells, int L, int B, int A, int C, float* logits,
+                  float* deltas, float* padded);
+int cr_rpn_pack_grad(cr_ctx* ctx, const float* dlogits, const float* ddeltas, float* const* dy_ptrs, const int* cells, int L,
+                     int B, int A, int C);
 /* Ground truth of a batch of B <= 32 images -> the padded tensors of the static-shape training path, one launch:
  * boxes (B,G,4) f32 zero-padded, classes (B,G) int64 (-2 = padding, -1 = ignore region as in the data), boxes3D (B,G,9)
  * zero-padded, poses (B,G,3,3) identity-padded.  *_ptrs / counts are HOST arrays of B device pointers / object counts

@@ -202,6 +202,19 @@ def nms_grouped(boxes, counts, thresh):
     return keep
 
 
+def rpn_unpack(ys, A):
+    """mirror of hipops.rpn_unpack: per-level head outputs (B,H,W,16) -> logits (B,Atot), deltas (B,Atot,4), -inf-padded
+    per-level logits (B,L,amax)"""
+    B = ys[0].shape[0]
+    lg = [y[..., :A].reshape(B, -1) for y in ys]
+    dl = [y[..., A:5 * A].reshape(B, -1, 4) for y in ys]
+    amax = max(t.shape[1] for t in lg)
+    padded = torch.full((B, len(ys), amax), float("-inf"), dtype=torch.float32, device=ys[0].device)
+    for l, t in enumerate(lg):
+        padded[:, l, :t.shape[1]] = t.detach()
+    return torch.cat(lg, 1), torch.cat(dl, 1), padded
+
+
 def topk(x, k):
     """mirror of hipops.topk (torch's own top-k; tie order unspecified there, lower index first in the kernel)"""
     return x.topk(k, dim=1)

@@ -233,3 +233,27 @@ def test_cube_head_loss_and_reduce(inverse_z):
     ga, gb = rg.grad.cpu(), rr.grad
     assert float((ga - gb).abs().max()) <= 2e-3 * float(gb.abs().max()) + 1e-6, float((ga - gb).abs().max())
     assert float(gb.abs().max()) > 0
+
+
+def test_rpn_unpack_matches_slices_forward_and_backward():
+    """cr_rpn_unpack / cr_rpn_pack_grad against the slice / reshape / cat formulation (oracle/cpu_backend.rpn_unpack =
+    detectron2's RPN.forward layout [third-party], rpn.py:153-170): bit-exact forward, exact gradients"""
+    from oracle import cpu_backend as O
+    g = torch.Generator().manual_seed(4)
+    A, B = 3, 2
+    shapes = [(B, 16, 24, 16), (B, 8, 12, 16), (B, 4, 6, 16), (B, 2, 3, 16), (B, 1, 2, 16)]
+    ys_c = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    ys_d = [y.detach().to(DEV).requires_grad_(True) for y in ys_c]
+    lo, do, po = O.rpn_unpack(ys_c, A)
+    lg, dg, pg_ = ops.rpn_unpack(ys_d, A)
+    assert torch.equal(lg.cpu(), lo) and torch.equal(dg.cpu(), do) and torch.equal(pg_.cpu(), po)
+    wl, wd = torch.randn(lo.shape, generator=g), torch.randn(do.shape, generator=g)
+    ((lo * wl).sum() + (do * wd).sum()).backward()
+    ((lg * wl.to(DEV)).sum() + (dg * wd.to(DEV)).sum()).backward()
+    for a, b in zip(ys_c, ys_d):
+        assert torch.equal(a.grad, b.grad.cpu())
+    # only one of the two outputs used: the other gradient is None -> zeros
+    ys_e = [y.detach().to(DEV).requires_grad_(True) for y in ys_c]
+    l2, d2, _ = ops.rpn_unpack(ys_e, A)
+    l2.sum().backward()
+    assert all(float(y.grad[..., A:].abs().max()) == 0 and float(y.grad[..., :A].min()) == 1 for y in ys_e)

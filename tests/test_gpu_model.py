@@ -190,7 +190,10 @@ def test_graphed_dense_region_equals_eager(built):
     try:
         opt.zero_grad()
         images, u8 = model._stack_images(batch)
-        feats2, logits2, deltas2 = runner(u8)
+        feats2, ys2 = runner(u8)                          # the RPN head's raw per-level outputs (B,H,W,16): [A logits | 4A deltas | pad]
+        A = pg.rpn_head.num_anchors
+        logits2 = [y[..., :A].reshape(y.shape[0], -1) for y in ys2]
+        deltas2 = [y[..., A:5 * A].reshape(y.shape[0], -1, 4) for y in ys2]
         loss2 = sum((f.float() ** 2).mean() for f in feats2.values()) + sum(l.mean() for l in logits2) + sum((d ** 2).mean() for d in deltas2)
         loss2.backward()
         opt.collect_grads()
@@ -202,7 +205,7 @@ def test_graphed_dense_region_equals_eager(built):
         # replay again after a parameter update: the graphs must see the new weights
         opt.flat_p.mul_(1.01)
         importlib.import_module("3dod_amd.hipops").bump_weight_epoch()
-        feats3, _, _ = runner(u8)
+        feats3, _ = runner(u8)
         assert not torch.equal(feats3["p2"], f_eager["p2"])
         f4, _, _ = eager()
         assert torch.equal(f4["p2"], feats3["p2"])
