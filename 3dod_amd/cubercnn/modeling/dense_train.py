@@ -131,17 +131,20 @@ def rpn_losses(rpn, anchors, logits, deltas, labels, midx, gt: GTBatch):
     loss_conf, loss_loc, sums = ops.rpn_loss(logits, deltas, anchors, labels, midx, gt.boxes, rpn.box2box_transform.weights)
     storage = get_event_storage()
     with torch.no_grad():
-        npos = sums[2]
-        storage.put_scalar("rpn/num_pos_anchors", npos / B)
-        storage.put_scalar("rpn/num_neg_anchors", sums[3] / B)
-        storage.put_scalar("rpn/conf_pos_anchors", sums[4] / npos.clamp(min=1))
-        storage.put_scalar("rpn/conf_neg_anchors", sums[5] / (B * A - npos).clamp(min=1))
+        # the four logging values as ONE vector expression: [npos, nneg, conf_pos, conf_neg] / [B, B, max(npos,1), max(rest,1)]
+        cnt = sums[2:4] / B                                              # anchors per image: positive, negative
+        conf = sums[4:6] / torch.stack([sums[2], B * A - sums[2]]).clamp(min=1)
+        storage.put_scalar("rpn/num_pos_anchors", cnt[0])
+        storage.put_scalar("rpn/num_neg_anchors", cnt[1])
+        storage.put_scalar("rpn/conf_pos_anchors", conf[0])
+        storage.put_scalar("rpn/conf_neg_anchors", conf[1])
     normalizer = rpn.batch_size_per_image * B
-    losses = {"rpn/cls": loss_conf / normalizer, "rpn/loc": loss_loc / normalizer}
-    return {k: v * rpn.loss_weight.get(k, 1.0) for k, v in losses.items()}
+    return {"rpn/cls": loss_conf * (rpn.loss_weight.get("rpn/cls", 1.0) / normalizer),
+            "rpn/loc": loss_loc * (rpn.loss_weight.get("rpn/loc", 1.0) / normalizer)}
 
 
 _PCONST = {}
+_WVEC = {}
 
 
 class RawRPNOutputs:
@@ -181,7 +184,8 @@ def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes, tr
         if cached is None:       # constants of the configuration: made once, never inside a captured region
             cached = [torch.tensor([[float(s[0]), float(s[1])] for s in image_sizes], dtype=torch.float32, device=dev),
                       torch.tensor(ks, dtype=torch.int32, device=dev).repeat(B),
-                      torch.tensor([sum(sizes[:l]) for l in range(len(sizes))], dtype=torch.int64, device=dev).view(1, -1, 1)]
+                      torch.tensor([sum(sizes[:l]) for l in range(len(sizes))], dtype=torch.int64, device=dev).view(1, -1, 1),
+                      torch.full((), -1, dtype=torch.int64, device=dev)]
             _PCONST[ckey] = cached
         img_hw, counts = cached[0], cached[1]
         # ONE top-k for all levels: logits padded to the largest level with -inf (a per-level call costs as much as
@@ -194,7 +198,8 @@ def rpn_proposals_padded(rpn, anchors, logits_per_level, deltas, image_sizes, tr
         kq = min(maxn, amax)
         scores, idx = ops.topk(padded.view(B * L, amax), kq)                  # sorted descending
         scores, idx = scores.view(B, L, kq), idx.view(B, L, kq)
-        idx = torch.where(torch.isfinite(scores), idx + cached[2], torch.full((), -1, dtype=torch.int64, device=dev))
+        # (top-k values are finite logits or the -inf padding: one compare instead of isfinite's four kernels)
+        idx = torch.where(scores > -3.0e38, idx + cached[2], cached[3])
         t = rpn.box2box_transform
         boxes, nms_boxes, valid = ops.rpn_decode_select(anchors, deltas.detach(), idx.view(B, -1), scores.view(B, -1),
                                                         t.weights, t.scale_clamp, img_hw, rpn.min_box_size)
@@ -214,7 +219,7 @@ def roi_label_and_sample(rh, prop_boxes, prop_scores, gt: GTBatch):
     dev = prop_boxes.device
     B = prop_boxes.shape[0]
     K = rh.num_classes
-    prop_valid = torch.isfinite(prop_scores)
+    prop_valid = prop_scores > -3.0e38                  # proposal slots are finite scores or -inf (empty)
     if rh.proposal_append_gt:
         boxes = torch.cat([prop_boxes, gt.boxes], 1)
         valid = torch.cat([prop_valid, gt.valid], 1)
@@ -294,10 +299,11 @@ def box_head_losses(rh, features, samp, gt: GTBatch, pooled=None):
     t = rh.box_predictor.box2box_transform
     sum_ce, sum_l1, sums, pred = ops.box_loss(scores, deltas, samp["valid"], samp["classes"], samp["boxes"], samp["gt_idx"],
                                               gt.boxes, t.weights, t.scale_clamp)
-    n_valid = sums[2].clamp(min=1)
+    inv = sums[2].clamp(min=1).reciprocal()
     lw = rh.box_predictor.loss_weight
-    losses = {"BoxHead/loss_cls": sum_ce / n_valid * lw.get("BoxHead/loss_cls", 1.0),
-              "BoxHead/loss_box_reg": sum_l1 / n_valid * lw.get("BoxHead/loss_box_reg", 1.0)}
+    w_cls, w_reg = lw.get("BoxHead/loss_cls", 1.0), lw.get("BoxHead/loss_box_reg", 1.0)
+    losses = {"BoxHead/loss_cls": sum_ce * (inv if w_cls == 1.0 else inv * w_cls),
+              "BoxHead/loss_box_reg": sum_l1 * (inv if w_reg == 1.0 else inv * w_reg)}
     return losses, pred.view(B, S, 4)
 
 
@@ -321,15 +327,19 @@ def cube_head_losses(rh, features, samp, pred_boxes, gt: GTBatch, meta, pooled=N
     red, stats = ops.cube_reduce(L, u_sel, buf, dec, validf, inverse_z=bool(rh.inverse_z_weight))
     p = "Cube/"
     w3 = rh.loss_w_3d
-    # red = [dims, xy, z, pose, joint, uncert]
-    losses = {p + "uncert": red[5] * rh.use_confidence,
-              p + "loss_xy": red[1] * (rh.loss_w_xy * w3),
-              p + "loss_z": red[2] * (rh.loss_w_z * w3),
-              p + "loss_pose": red[3] * (rh.loss_w_pose * w3)}
+    # red = [dims, xy, z, pose, joint, uncert]: all six weighted by ONE vector multiply; the dict entries are views of it (their
+    # gradients come back through one stack instead of a zero-fill + copy + add per term)
+    wkey = (float(rh.loss_w_dims * w3), float(rh.loss_w_xy * w3), float(rh.loss_w_z * w3), float(rh.loss_w_pose * w3),
+            float(rh.loss_w_joint * w3), float(rh.use_confidence), str(red.device))
+    wv = _WVEC.get(wkey)
+    if wv is None:
+        wv = _WVEC[wkey] = torch.tensor(wkey[:6], dtype=torch.float32, device=red.device)
+    scaled = (red * wv).unbind(0)
+    losses = {p + "uncert": scaled[5], p + "loss_xy": scaled[1], p + "loss_z": scaled[2], p + "loss_pose": scaled[3]}
     if rh.loss_w_dims > 0:
-        losses[p + "loss_dims"] = red[0] * (rh.loss_w_dims * w3)
+        losses[p + "loss_dims"] = scaled[0]
     if rh.loss_w_joint > 0:
-        losses[p + "loss_joint"] = red[4] * (rh.loss_w_joint * w3)
+        losses[p + "loss_joint"] = scaled[4]
     storage = get_event_storage()
     storage.put_scalar(p + "z_error", stats[0], smoothing_hint=False)
     storage.put_scalar(p + "dims_error", stats[1], smoothing_hint=False)

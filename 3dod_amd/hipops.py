@@ -703,7 +703,13 @@ class _ROIAlign(torch.autograd.Function):
         (rois,) = ctx.saved_tensors
         scales, out_size, shapes, dt = ctx.cfg
         C = shapes[0][3]
-        grads = [torch.zeros(s, dtype=f32, device=rois.device) for s in shapes]
+        # one zero-fill for the whole pyramid (the levels are views of one buffer, each 16-B aligned)
+        sizes = [(int(s[0] * s[1] * s[2] * s[3]) + 3) // 4 * 4 for s in shapes]
+        flat = torch.zeros((sum(sizes),), dtype=f32, device=rois.device)
+        grads, off = [], 0
+        for s, n_ in zip(shapes, sizes):
+            grads.append(flat[off:off + int(s[0] * s[1] * s[2] * s[3])].view(s))
+            off += n_
         n, ptrs, Hs, Ws, sc, cast = _pyr_args(grads, scales)
         lib = _lib.load()
         dout = dout.to(dt).contiguous()
