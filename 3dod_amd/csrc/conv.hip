@@ -1635,7 +1635,12 @@ static int launch_wgrad_f32_ks(cr_ctx* ctx, WgP& p) {
     constexpr int PS = 16;
     const int nsteps = (p.M + PS - 1) / PS;
     const int tn = (int)cr_cdiv(p.Kdim, 128);
-    const int TM = p.Cout >= 128 ? 128 : (p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16));
+    static const int tm_cap = env_int("CR_WG_F32_TM", 128);
+    int TM = p.Cout >= 128 ? 128 : (p.Cout >= 64 ? 64 : (p.Cout >= 32 ? 32 : 16));
+    if (TM > tm_cap) TM = tm_cap;
+    // measured (scripts/wgrad_mid_tune.py): 64-channel tiles (twice the tiles, half the pixel splits and atomics) win on the
+    // 64x64 maps with 128 channels (69.7 -> 61.6 us) and the 32x32 maps with 256 (66.7 -> 60.1), lose elsewhere
+    if (TM == 128 && ((p.Cout == 128 && p.M <= 16384) || (p.Cout == 256 && p.M <= 4096))) TM = 64;
     const int tm = (int)cr_cdiv(p.Cout, TM);
     const int tiles = tm * tn;
     // Split the pixel range over blocks.  Measured on the 3x3 256->256 layers (scripts/wgrad_f32_tune.py): one block per CU

@@ -26,7 +26,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         out.append(f"{us:6.1f}us {gf / us * 1e3:4.0f}TF")
     print(" | ".join(out), flush=True)
     sys.exit(0)
-for splits in (0, 8, 14, 21, 28, 42, 56):
-    env = dict(os.environ, CR_WG_SPLITS_F32=str(splits))
-    r = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True, env=env)
-    print(f"splits={splits:2d}: {r.stdout.strip()} {r.stderr.strip()[-200:] if r.returncode else ''}", flush=True)
+for tmcap in (128, 64):
+    for splits in (0, 14, 21, 28, 42):
+        env = dict(os.environ, CR_WG_SPLITS_F32=str(splits), CR_WG_F32_TM=str(tmcap))
+        r = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True, env=env)
+        print(f"TM<={tmcap:3d} splits={splits:2d}: {r.stdout.strip()} {r.stderr.strip()[-200:] if r.returncode else ''}", flush=True)
