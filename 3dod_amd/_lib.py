@@ -36,7 +36,7 @@ SIGNATURES = {
     "cr_scale_residual": [P, P, P, P, P, c_int64, c_int],
     "cr_resize_bilinear_ac": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int],
     "cr_conv2d_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, c_int, P],
-    "cr_conv2d_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "cr_conv2d_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "cr_weight_split3": [P, P, P, c_int64, c_int],
     "cr_relu_bwd": [P, P, P, P, c_int64, c_int],
     "cr_gt_pack": [P, P, P, P, P, P, c_int, c_int, P, P, P, P],

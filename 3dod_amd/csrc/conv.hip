@@ -1209,7 +1209,8 @@ extern "C" int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y,
 // dX[n,h,w,c] = sum_{r,s,k} dY[n,(h+pad-r)/stride,(w+pad-s)/stride,k] * W[k,r,s,c]
 // wt = weights re-laid as [Cin][(r*KS+s)*Cout + k]  (cr_weight_transpose)
 extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int N, int H, int W,
-                                  int Cin, int Cout, int ks, int stride, int pad, int act_f32, const void* wt_split) {
+                                  int Cin, int Cout, int ks, int stride, int pad, int act_f32, const void* wt_split,
+                                  const void* accumulate) {
     CR_CHECK_ARG(ctx && dy && wt && dx, "cr_conv2d_bwd_data: NULL pointer");
     int rc = conv_common_checks("cr_conv2d_bwd_data", N, H, W, Cout, Cin, ks, stride, pad, act_f32);
     if (rc) return rc;
@@ -1217,7 +1218,7 @@ extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, v
     const size_t es = act_f32 ? 4 : 2;
     ConvP p;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
-    p.x = dy; p.w = wt; p.y = dx; p.res = nullptr; p.bias = nullptr; p.stats = nullptr;
+    p.x = dy; p.w = wt; p.y = dx; p.res = accumulate; p.bias = nullptr; p.stats = nullptr;   // res: dx = conv^T(dy) + accumulate
     p.N = N; p.Hin = Ho; p.Win = Wo; p.Cin = Cout;      // gather source = dY
     p.Hout = H; p.Wout = W; p.Cout = Cin;               // GEMM output = dX
     p.stride = stride; p.pad = pad; p.Kdim = ks * ks * Cout; p.M = N * H * W;
@@ -3302,7 +3303,7 @@ extern "C" int cr_linear_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, v
                                   const void* wt_split) {
     CR_CHECK_ARG(R >= 0, "cr_linear_bwd_data: bad row count");
     if (R == 0) return CR_OK;
-    return cr_conv2d_bwd_data(ctx, dy, wt, dx, 1, 1, R, K, O, 1, 1, 0, act_f32, wt_split);
+    return cr_conv2d_bwd_data(ctx, dy, wt, dx, 1, 1, R, K, O, 1, 1, 0, act_f32, wt_split, nullptr);
 }
 
 // dw (O,K) f32 (+)= dy^T x ; dbias (O) += column sums of dy when given (from the dy tiles the kernel stages anyway)

@@ -277,17 +277,78 @@ def conv_fwd_raw(x, wb, Cout, k, stride, pad, bias=None, residual=None, relu=Fal
     return y
 
 
-def conv_bwd_data_raw(dy, wt, in_shape, k, stride, pad):
+def conv_bwd_data_raw(dy, wt, in_shape, k, stride, pad, accumulate=None):
+    """accumulate: a tensor of the result's shape that is added in the kernel's epilogue (see _GradSlot)"""
     _p = _Args()
     N, H, W, Cin = in_shape
     Cout = dy.shape[3]
     assert wt.dtype == dy.dtype
     dx = torch.empty((N, H, W, Cin), dtype=dy.dtype, device=dy.device)
+    if accumulate is not None:
+        assert tuple(accumulate.shape) == (N, H, W, Cin), "accumulate must have the input's shape"
+        accumulate = accumulate.to(dy.dtype).contiguous()
     lib = _lib.load()
     af = _af(dy)
-    _chk(lib.cr_conv2d_bwd_data(_ctx(dy), _p(dy), _p(wt), _p(dx), N, H, W, Cin, Cout, k, stride, pad, af, _p(_w3(wt, af))),
-         "cr_conv2d_bwd_data")
+    _chk(lib.cr_conv2d_bwd_data(_ctx(dy), _p(dy), _p(wt), _p(dx), N, H, W, Cin, Cout, k, stride, pad, af, _p(_w3(wt, af)),
+                                _p(accumulate)), "cr_conv2d_bwd_data")
     return dx
+
+
+# --------------------------------------------------------------------------
+# Fan-in of gradients without add kernels.  An activation consumed by several of the ops below would have its gradient
+# contributions summed by autograd with one elementwise add per extra consumer (60 launches per train step).  Instead the
+# consumers of a tensor share a _GradSlot: the FIRST consumer registered in the forward pass must be a convolution -- its
+# backward runs last (autograd executes in reverse creation order, and where the later consumers feed the first one's
+# output, as in a residual block, also by dependency) and adds what the others left in the slot inside its backward-data
+# epilogue (`accumulate`).  The other consumers put their contribution into the slot and return None.  The order is
+# CHECKED: a contribution arriving after the first consumer's backward ran raises (a registered consumer that receives no
+# gradient at all simply never contributes).  Consumers that are plain torch ops do not take part (autograd adds their share
+# as before).
+# --------------------------------------------------------------------------
+class _GradSlot:
+    __slots__ = ("n_reg", "n_arr", "buf", "done", "what")
+
+    def __init__(self, what=""):
+        self.n_reg, self.n_arr, self.buf, self.done, self.what = 0, 0, None, False, what
+
+
+_SLOTS_ON = [os.environ.get("CR_GRAD_SLOTS", "1") == "1"]
+
+
+def _slot_register(x, accumulator):
+    """called in the forward pass by a consumer of x; -> (slot, index) or (None, 0).  accumulator: this consumer can add the
+    slot's content in its backward (a convolution's backward-data)"""
+    if not (_SLOTS_ON[0] and torch.is_grad_enabled() and torch.is_tensor(x) and x.requires_grad):
+        return None, 0
+    slot = getattr(x, "_cr_slot", None)
+    if slot is None:
+        if not accumulator:
+            return None, 0                    # the first consumer cannot accumulate: everybody returns gradients as usual
+        slot = _GradSlot(f"tensor {tuple(x.shape)}")
+        try:
+            x._cr_slot = slot
+        except Exception:
+            return None, 0
+    slot.n_reg += 1
+    return slot, slot.n_reg
+
+
+def _slot_put(slot, g):
+    """a later consumer leaves its gradient contribution (backward pass); the caller returns None for that input"""
+    if slot.done:
+        raise RuntimeError("gradient slot: a contribution arrived after the accumulating convolution's backward had run "
+                           "(set CR_GRAD_SLOTS=0 to fall back to autograd's adds)")
+    slot.buf = g if slot.buf is None else slot.buf + g
+    slot.n_arr += 1
+
+
+def _slot_take(slot):
+    """the first consumer (a convolution) collects what the others have contributed, in its backward.  A registered
+    consumer whose output receives no gradient never contributes (e.g. a pooled level nobody uses): that is a zero, not an
+    error; one that contributes AFTER this point raises in _slot_put -- nothing is ever dropped silently."""
+    slot.done = True
+    buf, slot.buf = slot.buf, None
+    return buf
 
 
 def grad_sink(t):
@@ -326,7 +387,8 @@ def conv_bwd_weight_raw(dy, x, k, stride, pad, sink=None, bias_acc=None):
 class _ConvBN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, relu, eps, momentum,
-                training):
+                training, slots=((None, 0), (None, 0))):
+        ctx.slots = slots
         _p = _Args()
         Cout, Cin, k, _ = weight.shape
         need_grad = x.requires_grad or weight.requires_grad
@@ -386,12 +448,22 @@ class _ConvBN(torch.autograd.Function):
             ret_g, ret_b = dgamma, dbeta
         _chk(lib.cr_bn_bwd(_ctx(x), _p(dout), _p(out), _p(y_raw), _p(mi), _p(gamma.detach()), _p(sums), _p(dx_raw),
                            _p(dres), _p(dgamma), _p(dbeta), M, Cout, int(relu), _af(x)), "cr_bn_bwd")
+        (xslot, xi), (rslot, ri) = ctx.slots
+        if rslot is not None and dres is not None:          # the residual's other consumer (a convolution) adds this
+            _slot_put(rslot, dres)
+            dres = None
         dx = None
         if ctx.needs_input_grad[0]:
             _, wt = prepared_weights(weight, True, x.dtype)
-            dx = conv_bwd_data_raw(dx_raw, wt, x.shape, k, stride, pad)
+            if xslot is not None and xi > 1:                # not the first consumer of x: leave the contribution in the slot
+                _slot_put(xslot, conv_bwd_data_raw(dx_raw, wt, x.shape, k, stride, pad))
+            else:
+                acc = _slot_take(xslot) if xslot is not None else None
+                dx = conv_bwd_data_raw(dx_raw, wt, x.shape, k, stride, pad, accumulate=acc)
+        elif xslot is not None:
+            raise RuntimeError("gradient slot registered for an input that needs no gradient")
         dw = conv_bwd_weight_raw(dx_raw, x, k, stride, pad, grad_sink(weight)) if ctx.needs_input_grad[1] else None
-        return dx, dw, ret_g, ret_b, dres, None, None, None, None, None, None, None, None
+        return dx, dw, ret_g, ret_b, dres, None, None, None, None, None, None, None, None, None
 
 
 _STATS_EPOCH = [0]          # bumped by every eager train-mode BatchNorm forward (running statistics change through raw pointers)
@@ -433,8 +505,10 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride=1, pad
     if not training and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or gamma.requires_grad
                                                           or (residual is not None and residual.requires_grad))):
         return conv_bn_folded(x, weight, gamma, beta, running_mean, running_var, stride, pad, relu, residual, eps)
+    xs = _slot_register(x, True)
+    rs = _slot_register(residual, False) if residual is not None else (None, 0)
     return _ConvBN.apply(x, as_krsc(weight), gamma, beta, residual, running_mean, running_var, stride, pad, relu, eps,
-                         momentum, training)
+                         momentum, training, (xs, rs))
 
 
 # --------------------------------------------------------------------------
@@ -451,7 +525,8 @@ def relu_bwd(y, dy):
 
 class _ConvBias(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, out_f32):
+    def forward(ctx, x, weight, bias, stride, pad, relu, out_f32, slot=(None, 0)):
+        ctx.slot = slot
         Cout, Cin, k, _ = weight.shape
         wb, _ = prepared_weights(weight, False, x.dtype)
         y = conv_fwd_raw(x, wb, Cout, k, stride, pad, bias=None if bias is None else bias.detach(), relu=relu,
@@ -485,12 +560,18 @@ class _ConvBias(torch.autograd.Function):
                 acc = None
         g = g.to(x.dtype).contiguous()
         dx = None
+        xslot, xi = ctx.slot
         if ctx.needs_input_grad[0]:
             _, wt = prepared_weights(weight, True, x.dtype)
-            dx = conv_bwd_data_raw(g, wt, x.shape, k, stride, pad)
+            if xslot is not None and xi > 1:
+                _slot_put(xslot, conv_bwd_data_raw(g, wt, x.shape, k, stride, pad))
+            else:
+                dx = conv_bwd_data_raw(g, wt, x.shape, k, stride, pad, accumulate=_slot_take(xslot) if xslot is not None else None)
+        elif xslot is not None:
+            raise RuntimeError("gradient slot registered for an input that needs no gradient")
         # the bias gradient (column sums of dy) is accumulated inside the weight-gradient kernel
         dw = conv_bwd_weight_raw(g, x, k, stride, pad, grad_sink(weight), bias_acc=acc) if ctx.needs_input_grad[1] else None
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class _PadInputChannels(torch.autograd.Function):
@@ -548,7 +629,7 @@ def cat_rows(params, rows):
 
 
 def conv_bias_act(x, weight, bias, stride=1, pad=0, relu=False, out_f32=False):
-    return _ConvBias.apply(x, as_krsc(weight), bias, stride, pad, relu, out_f32)
+    return _ConvBias.apply(x, as_krsc(weight), bias, stride, pad, relu, out_f32, _slot_register(x, True))
 
 
 # --------------------------------------------------------------------------
@@ -556,7 +637,8 @@ def conv_bias_act(x, weight, bias, stride=1, pad=0, relu=False, out_f32=False):
 # --------------------------------------------------------------------------
 class _Pool2x(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, window):
+    def forward(ctx, x, window, slot=(None, 0)):
+        ctx.slot = slot
         _p = _Args()
         _need_cuda(x, "pool input")
         N, H, W, C = x.shape
@@ -576,7 +658,11 @@ class _Pool2x(torch.autograd.Function):
         lib = _lib.load()
         dy = dy.to(x.dtype).contiguous()
         _chk(lib.cr_pool2x_bwd(_ctx(x), _p(x), _p(dy), _p(dx), N, H, W, C, ctx.window, _af(x)), "cr_pool2x_bwd")
-        return dx, None
+        xslot, _ = ctx.slot
+        if xslot is not None:
+            _slot_put(xslot, dx)
+            dx = None
+        return dx, None, None
 
 
 class _Pool3s2(torch.autograd.Function):
@@ -610,17 +696,18 @@ def maxpool3x3s2(x):
 
 def maxpool2x2(x):
     """nn.MaxPool2d(2, stride=2) -- dla.py:208."""
-    return _Pool2x.apply(x, 2)
+    return _Pool2x.apply(x, 2, _slot_register(x, False))
 
 
 def subsample2x(x):
     """F.max_pool2d(kernel_size=1, stride=2) -- dla.py:474."""
-    return _Pool2x.apply(x, 1)
+    return _Pool2x.apply(x, 1, _slot_register(x, False))
 
 
 class _UpsampleAdd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, lat, top):
+    def forward(ctx, lat, top, slot=(None, 0)):
+        ctx.slot = slot
         _p = _Args()
         _need_cuda(lat, "upsample_add input")
         N, H, W, C = lat.shape
@@ -640,12 +727,16 @@ class _UpsampleAdd(torch.autograd.Function):
         dtop = torch.empty((N, H // 2, W // 2, C), dtype=dy.dtype, device=dy.device)
         lib = _lib.load()
         _chk(lib.cr_sum2x2(_ctx(dy), _p(dy), _p(dtop), N, H, W, C, _af(dy)), "cr_sum2x2")
-        return dy, dtop
+        tslot, ti = ctx.slot
+        if tslot is not None:                                # the coarser level's output convolution adds this (see _GradSlot)
+            _slot_put(tslot, dtop)
+            dtop = None
+        return dy, dtop, None
 
 
 def upsample2x_add(lat, top):
     """detectron2 FPN top-down step: lateral + F.interpolate(top, scale_factor=2, mode='nearest')."""
-    return _UpsampleAdd.apply(lat, top)
+    return _UpsampleAdd.apply(lat, top, _slot_register(top, False))
 
 
 def preprocess(images_u8, mean, std, dtype=None):

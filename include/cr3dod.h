@@ -207,9 +207,11 @@ int cr_conv2d_fwd(cr_ctx* ctx, const void* x, const void* w, void* y, int N, int
                   int ks, int stride, int pad, const float* bias, const void* residual, int relu,
                   float* stats, int out_f32, int act_f32, const void* w_split);
 
-/* dx (N,H,W,Cin) bf16 from dy (N,Ho,Wo,Cout) bf16; wt = cr_weight_transpose(w); wt_split = cr_weight_split3(wt) or NULL. */
+/* dx (N,H,W,Cin) bf16 from dy (N,Ho,Wo,Cout) bf16; wt = cr_weight_transpose(w); wt_split = cr_weight_split3(wt) or NULL.
+ * accumulate: NULL, or a tensor of dx's shape and type that is added in the epilogue (dx = conv^T(dy) + accumulate): the
+ * gradient another consumer of the same input already produced -- the fan-in sum of autograd without an add kernel. */
 int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, void* dx, int N, int H, int W, int Cin,
-                       int Cout, int ks, int stride, int pad, int act_f32, const void* wt_split);
+                       int Cout, int ks, int stride, int pad, int act_f32, const void* wt_split, const void* accumulate);
 /* split-mode weight planes of an f32 matrix src (rows, K), K % 32 == 0: dst = bf16 [rows][K/32][3][32] (6 bytes per
  * element): plane 0 / 1 / 2 = the top / middle / low 8 significant bits of each value (their sum is the value, exactly);
  * inside a 64-byte plane row the 16-byte chunk c holds k = {4c..4c+3, 16+4c..16+4c+3} of the 32 (the order in which the

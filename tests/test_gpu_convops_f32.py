@@ -262,3 +262,39 @@ def test_linear_cat_predictors(prec):
         assert relerr(wd[i].grad.cpu(), wo[i].grad) < tol and relerr(bd[i].grad.cpu(), bo[i].grad) < tol
     assert relerr(xd.grad.float().cpu(), xo.grad) < tol
     assert float(y[:, 251:].abs().max()) == 0.0
+
+
+def test_gradient_slots_equal_autograd_adds():
+    """fan-in of gradients through the backward-data epilogue (hipops._GradSlot): a residual block (x feeds conv1 and the
+    residual input of conv2) and an FPN-style top-down step (prev feeds a 3x3 output conv and the next level's upsample)
+    give the same input gradients with the slots on (no add kernels) and off (autograd's adds)"""
+    g = torch.Generator().manual_seed(21)
+    N, H, W, C = 2, 16, 16, 64
+    x0 = torch.randn(N, H, W, C, generator=g).to(DEV)
+    lat0 = torch.randn(N, 2 * H, 2 * W, C, generator=g).to(DEV)
+    w1, w2, w3 = [(torch.randn(C, C, 3, 3, generator=g) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                  for _ in range(3)]
+    gam, bet = torch.ones(C, device=DEV, requires_grad=True), torch.zeros(C, device=DEV, requires_grad=True)
+    bias = torch.zeros(C, device=DEV, requires_grad=True)
+
+    def run(on):
+        prev = ops._SLOTS_ON[0]
+        ops._SLOTS_ON[0] = on
+        try:
+            x = x0.clone().requires_grad_(True)
+            lat = lat0.clone().requires_grad_(True)
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            xin = x * 1.0                                      # a non-leaf activation, as inside a network
+            out = ops.conv_bn_act(xin, w1, gam, bet, rm, rv, 1, 1, True)
+            blk = ops.conv_bn_act(out, w2, gam, bet, rm.clone(), rv.clone(), 1, 1, True, residual=xin)
+            p = ops.conv_bias_act(blk, w3, bias, 1, 1)          # "output conv" on blk ...
+            up = ops.upsample2x_add(lat, blk)                   # ... and the finer level's top-down step on the same blk
+            ((p ** 2).mean() + (up ** 2).mean()).backward()
+            torch.cuda.synchronize()
+            return x.grad.clone(), lat.grad.clone()
+        finally:
+            ops._SLOTS_ON[0] = prev
+    gx1, gl1 = run(True)
+    gx0, gl0 = run(False)
+    assert torch.equal(gl1, gl0)
+    assert relerr(gx1, gx0) < 1e-6
