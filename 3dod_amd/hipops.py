@@ -1155,40 +1155,6 @@ def linear_cat(x, weights, biases):
     return _LinearCat.apply(x, plan, *weights, *biases), list(plan.offs)
 
 
-class _LinearPlain(torch.autograd.Function):
-    """GEMM with the (f32) weight passed as a tensor in the graph (linear_cat's stacked predictor weights); f32 output"""
-    @staticmethod
-    def forward(ctx, x, W, b):
-        dt = x.dtype
-        xc = x.contiguous()
-        Wc = _act_cast(W.detach(), dt)
-        y = linear_fwd_raw(xc, Wc, b.detach().contiguous(), out_f32=True)
-        ctx.save_for_backward(xc, Wc)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        _p = _Args()
-        xc, Wc = ctx.saved_tensors
-        dt = xc.dtype
-        O, K = Wc.shape
-        dy = _act_cast(dy, dt)
-        dx = dW = db = None
-        if ctx.needs_input_grad[0]:
-            wt = torch.empty((K, O), dtype=dt, device=Wc.device)
-            _chk(_lib.load().cr_transpose2d(_ctx(Wc), _p(Wc), _p(wt), O, K, int(dt == f32)), "cr_transpose2d")
-            dx = linear_bwd_data_raw(dy, wt)
-        if ctx.needs_input_grad[2]:
-            db = torch.zeros((O,), dtype=f32, device=dy.device)
-        if ctx.needs_input_grad[1]:
-            dW = torch.empty((O, K), dtype=f32, device=dy.device)
-            linear_bwd_weight_raw(dy, xc, dW, db, accumulate=False)
-        elif db is not None:
-            ws = torch.empty((1024, O), dtype=f32, device=dy.device)
-            _chk(_lib.load().cr_colsum_accum(_ctx(dy), _p(dy), int(dt == f32), dy.shape[0], O, _p(ws), _p(db)), "cr_colsum_accum")
-        return dx, dW, db
-
-
 # --------------------------------------------------------------------------
 # NMS
 # --------------------------------------------------------------------------
