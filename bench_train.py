@@ -214,9 +214,9 @@ def dominant_kernel_in_step(model, step, batches, dev, n_steps=3):
         hit = tuple(x.shape) == shape and Cout == 256 and k == 3 and stride == 1
         return timed("fwd", orig[0], x, wb, Cout, k, stride, pad, **kw) if hit else orig[0](x, wb, Cout, k, stride, pad, **kw)
 
-    def bwd(dy, wt, in_shape, k, stride, pad):
+    def bwd(dy, wt, in_shape, k, stride, pad, **kw):
         hit = tuple(in_shape) == shape and dy.shape[3] == 256 and k == 3 and stride == 1
-        return timed("bwd-data", orig[1], dy, wt, in_shape, k, stride, pad) if hit else orig[1](dy, wt, in_shape, k, stride, pad)
+        return timed("bwd-data", orig[1], dy, wt, in_shape, k, stride, pad, **kw) if hit else orig[1](dy, wt, in_shape, k, stride, pad, **kw)
 
     def wg(dy, x, k, stride, pad, sink=None, bias_acc=None):
         hit = tuple(x.shape) == shape and dy.shape[3] == 256 and k == 3 and stride == 1
