@@ -1631,6 +1631,182 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad_f32(WgP p) {
         }
 }
 
+// ---------------------------------------------------------------------------
+// k_conv_wgrad_patch_f32: weight gradient of the stem convolutions (16 output channels, 512 x 512 maps: 7x7 on the 4-channel
+// image and 3x3 on 16 channels, stride 1).  In the im2col formulation (k_conv_wgrad_f32) these layers read every input pixel
+// once per filter tap -- 600 / 820 MB of L2 -> LDS traffic for 4.8 / 6.6 GFLOP, twice the matrix time -- and their 144 / 196 k
+// columns fill the 128-column k tiles to 56 / 77 %.  Here a block stages a 16 x 16 pixel tile of dy and the (16 + KS - 1)^2
+// input PATCH around it once, and every tap reads its shifted window from LDS:
+//   D[co][col] += sum_pixels dy[pixel][co] * x[pixel + tap][ci],  v_mfma_f32_16x16x4_f32 with k = 4 consecutive pixels of a
+//   tile row; A = dy (lane: row co = l & 15, pixel l >> 4), B = patch (lane: column l & 15, pixel l >> 4).
+//   Cin = 16 (3x3): a column is an input channel, one accumulator tile per tap (9).
+//   Cin = 4 (7x7):  a column is (tap-in-group q = col >> 2, channel col & 3): four taps per tile, 13 tiles for 49 taps.
+// Two blocks per CU (the blocks start and finish together, so prologues / epilogues of more, shorter blocks only add up);
+// block b walks tiles b, b + grid, ...: the next tile's loads are in flight under this tile's 144 / 208 MFMAs per wave and go
+// to the other LDS stage afterwards (one barrier per tile).  The accumulators stay in registers; at the end the four waves
+// are summed through LDS and added to dW in memory order with one set of atomics (and to dbias: column sums of the dy tiles).
+// Measured (4 x 512 x 512): 56 us (3x3) / 70 us (7x7) against 144 / 146 us of the im2col kernel; the MFMAs alone are 35 / 51.
+// ---------------------------------------------------------------------------
+template <int KS, int CIN>
+__global__ __launch_bounds__(256) void k_conv_wgrad_patch_f32(WgP p, int tiles_x, int tiles_per_img, int tiles_total) {
+    constexpr int PAD = KS / 2, PW = 16 + KS - 1;                    // patch width (pixels)
+    constexpr int TAPS = KS * KS;
+    constexpr int NT = CIN == 16 ? TAPS : (TAPS + 3) / 4;            // accumulator tiles
+    constexpr int C4 = CIN / 4, NXL = PW * PW * C4;                  // float4 loads of a patch
+    constexpr int NXR = (NXL + 255) / 256;                           // ... per thread
+    constexpr int SX = PW * PW * CIN;
+    constexpr int STAGE = 256 * 16 + SX;                             // one tile: dy + patch; two stages (the next tile is
+    constexpr int SMEM = 2 * STAGE > 4 * NT * 256 ? 2 * STAGE : 4 * NT * 256;   // stored while this one is multiplied)
+    __shared__ float smem[SMEM];
+    float* sDy = smem;                                               // [pixel][co]
+    float* sX = smem + 256 * 16;                                     // [py][px][ci]
+    float* sRed = smem;                                              // after the last tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const float* __restrict__ dy = reinterpret_cast<const float*>(p.dy);
+    const float* __restrict__ x = reinterpret_cast<const float*>(p.x);
+    const int H = p.Hout, W = p.Wout;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;                                                // bias gradient: thread (q = tid >> 4, co = tid & 15)
+    // this lane's B column -> (tap offset inside the tile's tap group, channel)
+    const int bq = CIN == 16 ? 0 : (l15 >> 2), bc = CIN == 16 ? l15 : (l15 & 3);
+    const float* ap0 = sDy + ((wave * 4) * 16 + g) * 16 + l15;
+    const float* bp0[NT];                                            // (the 7x7's last tile has one tap: the other columns
+#pragma unroll                                                       //  read a valid address and are never stored)
+    for (int t = 0; t < NT; ++t) {
+        const int tap = CIN == 16 ? t : min(t * 4 + bq, TAPS - 1);
+        const int r = tap / KS, s2 = tap - r * KS;
+        bp0[t] = sX + ((wave * 4 + r) * PW + g + s2) * CIN + bc;
+    }
+    // per-thread load slots (the same for every tile): dy pixel / chunk, patch pixel / chunk
+    int xpy[NXR], xpx[NXR], xc4[NXR];
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+        const int i = tid + j * 256;
+        const int pp = i / C4;
+        xc4[j] = i - pp * C4; xpy[j] = pp / PW; xpx[j] = pp - xpy[j] * PW;
+    }
+    // branch-free loads (out-of-image patch pixels read zero through an out-of-range offset); a tile's loads stay in
+    // registers while the previous tile is multiplied
+    const __amdgpu_buffer_rsrc_t bx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    // the loads of tile i + 1 are issued when tile i starts and stored to the free LDS stage after its MFMAs (a second
+    // register set fetching two tiles ahead was slower: 57.6 / 83 us against 56 / 70)
+    u32x4 rdyA[4], rxA[NXR];
+    auto load_tile = [&](int tile, u32x4 (&rdy)[4], u32x4 (&rx)[NXR]) {
+        // unconditional (a tile past the end fetches nothing: out-of-range offsets), so that the number of loads in flight
+        // is known at compile time and the waits before the LDS stores leave the newer set in flight
+        const bool live = tile < tiles_total;
+        const int n = tile / tiles_per_img, tr = tile - n * tiles_per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int y0 = ty * 16, x0 = tx * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + j * 256, pix = i >> 2, c4 = i & 3;
+            rdy[j] = __builtin_amdgcn_raw_buffer_load_b128(bdy, live ? (unsigned)((((n * H + y0 + (pix >> 4)) * W + x0 + (pix & 15)) * 16 + c4 * 4) * 4) : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NXR; ++j) {
+            const int yy = y0 + xpy[j] - PAD, xx = x0 + xpx[j] - PAD;
+            const bool ok = live && tid + j * 256 < NXL && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            rx[j] = __builtin_amdgcn_raw_buffer_load_b128(bx, ok ? (unsigned)((((n * H + yy) * W + xx) * CIN + xc4[j] * 4) * 4) : OOB, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf, const u32x4 (&rdy)[4], const u32x4 (&rx)[NXR]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(&sDy[buf * STAGE + (tid + j * 256) * 4]) = rdy[j];
+#pragma unroll
+        for (int j = 0; j < NXR; ++j)
+            if (tid + j * 256 < NXL) *reinterpret_cast<u32x4*>(&sX[buf * STAGE + (tid + j * 256) * 4]) = rx[j];
+    };
+    // one tile out of LDS stage `buf`.  Wave w: tile rows 4w .. 4w+3; k-step (ry, kx) = 4 consecutive pixels of a row.  The
+    // operands of step s + 1 are read from LDS before the MFMAs of step s are issued (the scheduler otherwise places every
+    // read next to its use)
+    auto compute = [&](int buf) {
+        const int so = buf * STAGE;
+        if (p.dbias != nullptr) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sacc += sDy[so + ((tid >> 4) * 16 + j) * 16 + (tid & 15)];
+            bsum += sacc;
+        }
+        const float* ap = ap0 + so;
+        float fa[2], fb[2][NT];
+        fa[0] = ap[0];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fb[0][t] = bp0[t][so];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            if (st + 1 < 16) {
+                const int ry = (st + 1) >> 2, kx = (st + 1) & 3;
+                fa[(st + 1) & 1] = ap[(ry * 16 + kx * 4) * 16];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) fb[(st + 1) & 1][t] = bp0[t][so + (ry * PW + kx * 4) * CIN];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st & 1], fb[st & 1][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int G = gridDim.x;
+    int tile = blockIdx.x, buf = 0;                                  // < tiles_total (grid <= tiles)
+    load_tile(tile, rdyA, rxA);
+    store_tile(0, rdyA, rxA);
+    __syncthreads();
+    for (; tile < tiles_total; tile += G, buf ^= 1) {
+        const bool more = tile + G < tiles_total;
+        if (more) load_tile(tile + G, rdyA, rxA);                    // in flight under this tile's MFMAs
+        compute(buf);
+        if (more) store_tile(buf ^ 1, rdyA, rxA);
+        __syncthreads();                                             // stage buf^1 is complete, stage buf is free
+    }
+    // D: row 4g + e = co, col l15 = column.  The four waves' tiles side by side in LDS, summed on the way to the atomics.
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sRed[wave * (NT * 256) + t * 256 + (4 * g + e) * 16 + l15] = acc[t][e];
+    __syncthreads();
+    // dW in memory order (a wave adds 64 consecutive floats: whole L2 lines; per-tile order costs the 7x7 -- 784-B rows --
+    // three times the line requests, and the blocks, which finish together, queue on them).  Each block starts elsewhere.
+    constexpr int NW = 16 * TAPS * CIN, NCH = (NW + 255) / 256;
+    for (int j = 0; j < NCH; ++j) {
+        const int f = ((j + (int)blockIdx.x) % NCH) * 256 + tid;
+        if (f < NW) {
+            const int co = f / (TAPS * CIN), k = f - co * (TAPS * CIN);
+            const int i = (k >> 4) * 256 + co * 16 + (k & 15);   // accumulator tile k / 16 (one tap x 16 ci, or four taps x 4 ci)
+            const float v = (sRed[i] + sRed[NT * 256 + i]) + (sRed[2 * NT * 256 + i] + sRed[3 * NT * 256 + i]);
+            atomicAdd(&p.dw[f], v);
+        }
+    }
+    if (p.dbias != nullptr) {
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) bsum += __shfl_xor(bsum, off, 64);   // the wave's four pixel groups
+        if (lane < 16) atomicAdd(&p.dbias[lane], bsum);
+    }
+}
+
+// true + launched if the layer takes the patch kernel
+static bool try_launch_wgrad_patch_f32(cr_ctx* ctx, WgP& p, int ks, int* rc) {
+    static const int on = env_int("CR_WG_PATCH", 1);
+    const bool shape_ok = p.Cout == 16 && p.stride == 1 && p.pad == ks / 2 && (p.Hout & 15) == 0 && (p.Wout & 15) == 0 &&
+                          p.Hin == p.Hout && p.Win == p.Wout && ((ks == 3 && p.Cin == 16) || (ks == 7 && p.Cin == 4));
+    if (!on || !shape_ok) return false;
+    const int tiles_x = p.Wout / 16, tiles_per_img = tiles_x * (p.Hout / 16), tiles_total = tiles_per_img * p.N;
+    static const int per_cu = env_int("CR_WG_PATCH_BLOCKS", 2);       // few long blocks: the prologue / epilogue of all blocks coincide
+    const dim3 grid((unsigned)std::min(tiles_total, 256 * per_cu));   // block b: tiles b, b + grid, ...
+    if (ks == 3) hipLaunchKernelGGL((k_conv_wgrad_patch_f32<3, 16>), grid, dim3(256), 0, ctx->stream, p, tiles_x, tiles_per_img, tiles_total);
+    else hipLaunchKernelGGL((k_conv_wgrad_patch_f32<7, 4>), grid, dim3(256), 0, ctx->stream, p, tiles_x, tiles_per_img, tiles_total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cr_set_error("k_conv_wgrad_patch_f32 launch failed: %s", hipGetErrorString(e)); *rc = CR_EHIP; }
+    else *rc = CR_OK;
+    return true;
+}
+
 template <int KS>
 static int launch_wgrad_f32_ks(cr_ctx* ctx, WgP& p) {
     constexpr int PS = 16;
@@ -2262,6 +2438,10 @@ static int conv2d_bwd_weight_impl(cr_ctx* ctx, const void* dy, const void* x, fl
     if (act_f32 == 2 && ks != 7) {
         int rc3 = CR_OK;
         if (ks == 1 ? try_launch_wgrad_s3<1>(ctx, p, &rc3) : try_launch_wgrad_s3<3>(ctx, p, &rc3)) return rc3;
+    }
+    if (act_f32 && ks != 1) {
+        int rcp = CR_OK;
+        if (try_launch_wgrad_patch_f32(ctx, p, ks, &rcp)) return rcp;
     }
     if (act_f32) {
         if (ks == 1) return launch_wgrad_f32_ks<1>(ctx, p);

@@ -58,6 +58,8 @@ CASES = [  # N, H, W, Cin, Cout, k, stride, pad
     (3, 10, 14, 64, 128, 1, 1, 0),      # project 1x1, odd sizes
     (2, 64, 64, 64, 128, 3, 1, 1),      # 64x64 tiles, >= 192 blocks
     (4, 64, 64, 128, 128, 3, 1, 1),     # 128x128 tiles through the LDS-DMA kernel (Cin % 32 == 0, >= 128 big tiles)
+    (3, 48, 32, 16, 16, 3, 1, 1),       # stem patch weight-gradient kernel: non-square, 18 tiles
+    (2, 32, 48, 4, 16, 7, 1, 3),        # ... its 7x7 / 4-channel form (four taps per accumulator tile, 49 = 12 * 4 + 1)
 ]
 
 
@@ -103,7 +105,8 @@ def test_conv_bn_act_fwd_bwd_f32(case, relu, use_res):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 256, 1, 1, 0), (2, 16, 16, 256, 256, 3, 1, 1),
-                                  (1, 8, 8, 512, 256, 1, 1, 0), (2, 16, 16, 256, 16, 1, 1, 0)])
+                                  (1, 8, 8, 512, 256, 1, 1, 0), (2, 16, 16, 256, 16, 1, 1, 0),
+                                  (2, 32, 48, 16, 16, 3, 1, 1)])     # last: patch weight-gradient kernel with bias
 @pytest.mark.parametrize("relu", [False, True])
 def test_conv_bias_act_fwd_bwd_f32(case, relu):
     N, H, W, Ci, Co, k, st, pd = case
