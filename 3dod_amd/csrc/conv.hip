@@ -1079,10 +1079,13 @@ static bool try_launch_dma(cr_ctx* ctx, const ConvP& p, int out_f32, int* rc) {
             const int nstage_all = p.Kdim / 32;
             // half-height tiles first: twice the blocks before any k split (no slab traffic, often no epilogue launch)
             static const int bm64_on = env_int("CR_CONV_BM64", 1);
-            const int bm = (bm64_on && !p.w3 && bn2 == 128 && p.M >= 128) ? 64 : 128;
+            // very long k with >= 128 big tiles (the box head's first FC layer: 2048 x 12544 -> 1024): 128 x 128 tiles, split k
+            // until there are two blocks per CU (scripts/fc_bench.py: 509 -> 450 us; the slabs are 1 % of the operand reads)
+            const bool long_k = KS == 1 && p.Kdim >= 8192 && tiles >= 128;
+            const int bm = (bm64_on && !p.w3 && bn2 == 128 && p.M >= 128 && !long_k) ? 64 : 128;
             if (bm == 64) tiles = cr_cdiv(p.M, 64) * (p.Cout / 128);
             static const int sk_target = env_int("CR_SPLITK_TARGET", 256);
-            int S = (int)cr_cdiv(sk_target, tiles);
+            int S = (int)cr_cdiv(long_k ? 2 * sk_target : sk_target, tiles);
             if (S > nstage_all / 4) S = nstage_all / 4;                      // >= 4 stages (128 of k) per block
             if (S > 16) S = 16;
             const int64_t cap = (int64_t)(ctx->ws_bytes / ((size_t)p.M * p.Cout * sizeof(float)));
@@ -1818,6 +1821,9 @@ static int launch_wgrad_f32_ks(cr_ctx* ctx, WgP& p) {
     // measured (scripts/wgrad_mid_tune.py): 64-channel tiles (twice the tiles, half the pixel splits and atomics) win on the
     // 64x64 maps with 128 channels (69.7 -> 61.6 us) and the 32x32 maps with 256 (66.7 -> 60.1), lose elsewhere
     if (TM == 128 && ((p.Cout == 128 && p.M <= 16384) || (p.Cout == 256 && p.M <= 4096))) TM = 64;
+    // the RoI heads' FC layers (1024 outputs, <= 2048 rows; scripts/fc_bench.py): 64-row tiles, 63 -> 52 us (1024 x 1024),
+    // 158 -> 137 (12544 x 1024, 512 rows); see the split rule below for the 1568-tile layer
+    if (TM == 128 && KS == 1 && p.Cout >= 1024) TM = 64;
     const int tm = (int)cr_cdiv(p.Cout, TM);
     const int tiles = tm * tn;
     // Split the pixel range over blocks.  Measured on the 3x3 256->256 layers (scripts/wgrad_f32_tune.py): one block per CU
@@ -1827,6 +1833,9 @@ static int launch_wgrad_f32_ks(cr_ctx* ctx, WgP& p) {
     static const int force_splits = env_int("CR_WG_SPLITS_F32", 0);
     const int max_splits = nsteps / 8 > 1 ? nsteps / 8 : 1;
     int splits = 768 / tiles;
+    // more tiles than the chip holds at once (12544 x 1024: 1568): the grid is a little over a whole number of rounds and
+    // the last few blocks cost a round of their own; halving the blocks halves that tail (567 -> 480 us)
+    if (tiles > 768 && nsteps >= 32) splits = 2;
     if (splits > max_splits) splits = max_splits;
     if (force_splits > 0) splits = force_splits;
     if (splits > nsteps) splits = nsteps;

@@ -7,11 +7,40 @@ The dynamic parts of the step (anchor/proposal sampling, RoI heads on a data-dep
 eager and talk to the graphs through static input / output / gradient buffers.
 """
 import contextlib
+import gc
 
 import torch
 import torch.nn as nn
 
 from ... import hipops as ops
+
+
+@contextlib.contextmanager
+def capture_guard():
+    """No cyclic garbage collection while a stream capture is open: a collection may run the destructor of an older
+    CUDAGraph (graph-owning objects sit in reference cycles through their closures), and a graph / pool teardown inside
+    a capture aborts the process on ROCm 7.2 (seen once as `Fatal Python error: Aborted ... Garbage-collecting`)."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
+class GraphOwner:
+    """Base of the objects that own captured graphs: replays may still be in flight when the last reference goes away
+    (run-ahead steps); the device is drained before the graphs are destroyed."""
+    dev = None
+
+    def __del__(self):
+        try:
+            if self.dev is not None:
+                torch.cuda.synchronize(self.dev)
+        except Exception:
+            pass
 
 
 @contextlib.contextmanager
@@ -63,13 +92,13 @@ class _Replay(torch.autograd.Function):
         return None, None
 
 
-class GraphedDense:
+class GraphedDense(GraphOwner):
     def __init__(self, model, images_u8, warmup=2):
         assert model.training, "capture the training-mode dense region"
         self.model = model
         self.shape = tuple(images_u8.shape)
         self.dtype = ops.precision()        # the captured kernels are those of this precision mode
-        dev = images_u8.device
+        dev = self.dev = images_u8.device
         self.static_img = images_u8.clone()
         self.pre_bwd = None                 # optional callback run right before the backward graph is replayed
         self.trigger = torch.zeros((), device=dev, requires_grad=True)
@@ -116,7 +145,7 @@ class GraphedDense:
 
         # ---- capture.  The bf16 weight copies must be re-made INSIDE the graphs on every replay.
         ops.bump_weight_epoch()
-        with _fresh_leaves(mods):
+        with capture_guard(), _fresh_leaves(mods):
             self.fwd_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.fwd_graph):
                 self.static_outs = dense()
@@ -138,7 +167,7 @@ class GraphedDense:
         return feats, list(outs[nf:nf + nl])
 
 
-class GraphedDenseEval:
+class GraphedDenseEval(GraphOwner):
     """Forward-only HIP graph of the static dense region in eval mode (preprocess, trunk with BatchNorm on running
     statistics, FPN, RPN head) for one image-batch shape: inference is launch-bound at 8 images per step."""
 
@@ -146,7 +175,7 @@ class GraphedDenseEval:
         assert not model.training, "capture the eval-mode dense region"
         self.shape = tuple(images_u8.shape)
         self.dtype = ops.precision()
-        dev = images_u8.device
+        dev = self.dev = images_u8.device
         self.static_img = images_u8.clone()
         pg = model.proposal_generator
 
@@ -167,7 +196,7 @@ class GraphedDenseEval:
         torch.cuda.synchronize(dev)
         ops.bump_weight_epoch()          # the bf16 weight copies are made inside the graph (cheap; weights may change)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with capture_guard(), torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_outs = dense()
         torch.cuda.synchronize(dev)
 

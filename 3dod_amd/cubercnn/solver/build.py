@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from ... import hipops as ops
+from ..modeling.graphed import GraphOwner as _GraphOwner
 
 NORM_TYPES = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.SyncBatchNorm,
               torch.nn.GroupNorm, torch.nn.InstanceNorm1d, torch.nn.InstanceNorm2d, torch.nn.InstanceNorm3d,
@@ -298,7 +299,7 @@ class TrainStep:
         return d
 
 
-class GraphedTrainStep:
+class GraphedTrainStep(_GraphOwner):
     """The whole training step as two HIP graphs around the (eager) RCCL all-reduces:
 
         graph A   preprocess, trunk, FPN, RPN, static-shape labelling/sampling, RoI heads, losses, backward
@@ -352,7 +353,7 @@ class GraphedTrainStep:
 
     def _capture(self, sample_data, G):
         """(re)build the static buffers for G ground-truth rows per image and capture both graphs"""
-        from ..modeling.graphed import _fresh_leaves
+        from ..modeling.graphed import _fresh_leaves, capture_guard
         model, optimizer, dev, world_size = self.model, self.opt, self.dev, self.world
         optimizer.enable_weight_bank()
         self.dtype = ops.precision()
@@ -412,12 +413,12 @@ class GraphedTrainStep:
                 t.copy_(v)
         restore()
         ops.bump_weight_epoch()
-        with _fresh_leaves([model]):
+        with capture_guard(), _fresh_leaves([model]):
             self.graph_a = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a):
                 fwd_bwd()
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+        with capture_guard(), torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
             update()
         torch.cuda.synchronize(dev)
         restore()
