@@ -168,14 +168,21 @@ __device__ __forceinline__ Lin1 lin1(float y, int H) {
     return s;
 }
 
-template <int P, typename T>
+// XG = 8: the block index is (RoI, channel group blockIdx % 8) and a block covers C / 8 channels.  Workgroups are dealt
+// round-robin to the 8 XCDs, so group x runs on XCD x and every 128-B line of the gradient maps (32 f32 channels of a pixel)
+// is only ever added to from ONE XCD: the atomics stay in that XCD's L2 instead of the line migrating between the L2s of
+// all the XCDs whose RoIs overlap there.  (Performance only: the L2s are coherent, any other dispatch order gives the same
+// sums.)  The block's threads split the footprint rows: thread = (row phase t / CB, channel t % CB).
+template <int P, typename T, int XG>
 __global__ __launch_bounds__(256) void k_roi_align_bwd_sep(Pyramid py, const float* __restrict__ rois, int R,
                                                            const T* __restrict__ dout, int maxH) {
     extern __shared__ float sm[];                        // Ay [maxH][P] | Ax [maxW][P]
     __shared__ int s_lo[2], s_hi[2];
     float* Ay = sm;
     float* Ax = sm + (size_t)maxH * P;
-    const int r = blockIdx.x, t = threadIdx.x, C = py.C;
+    const int r = blockIdx.x / XG, t = threadIdx.x, C = py.C;
+    const int CB = C / XG, cbase = (blockIdx.x % XG) * CB;   // this block's channels
+    const int nph = XG == 1 ? 1 : (int)blockDim.x / CB;      // row phases (XG = 1: a thread walks every footprint row)
     const float* rb = rois + (size_t)r * 5;
     const int n = (int)rb[0];
     const int lv = roi_level(rb + 1, py);
@@ -203,8 +210,8 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd_sep(Pyramid py, const flo
     __syncthreads();
     const int y0 = s_lo[0], Py = s_hi[0] - y0 + 1, x0 = s_lo[1], Px = s_hi[1] - x0 + 1;
     if (s_hi[0] < 0 || s_hi[1] < 0 || n < 0) return;     // no valid sample at all (block-uniform)
-    for (int i = t; i < Py * P; i += 256) Ay[i] = 0.f;
-    for (int i = t; i < Px * P; i += 256) Ax[i] = 0.f;
+    for (int i = t; i < Py * P; i += (int)blockDim.x) Ay[i] = 0.f;
+    for (int i = t; i < Px * P; i += (int)blockDim.x) Ax[i] = 0.f;
     __syncthreads();
     if (builder) {                                       // pass 2: column p of Ay / Ax is owned by one thread
         float* A = ax ? Ax : Ay;
@@ -218,7 +225,8 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd_sep(Pyramid py, const flo
         }
     }
     __syncthreads();
-    for (int c = t; c < C; c += 256) {
+    for (int c = cbase + (XG == 1 ? t : t % CB); c < cbase + CB; c += (XG == 1 ? 256 : CB)) {
+        const int ph0 = XG == 1 ? 0 : t / CB;
         float G[P][P];
         bool any = false;
 #pragma unroll
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd_sep(Pyramid py, const flo
             }
         if (!any) continue;                              // masked (padding) RoIs carry zero gradient
         float* gq = py.grad[lv] + (((size_t)n * H + y0) * W + x0) * C + c;
-        for (int yy = 0; yy < Py; ++yy) {
+        for (int yy = ph0; yy < Py; yy += nph) {
             float tr[P];
 #pragma unroll
             for (int pw = 0; pw < P; ++pw) tr[pw] = 0.f;
@@ -303,11 +311,21 @@ extern "C" int cr_roi_align_bwd(cr_ctx* ctx, float* const* grads, const int* Hs,
         for (int l = 0; l < nlev; ++l) { maxH = Hs[l] > maxH ? Hs[l] : maxH; maxW = Ws[l] > maxW ? Ws[l] : maxW; }
         const size_t lds = (size_t)(maxH + maxW) * 7 * sizeof(float);
         if (lds <= 60 * 1024) {
-            if (act_f32)
-                hipLaunchKernelGGL((k_roi_align_bwd_sep<7, float>), dim3((unsigned)R), dim3(256), lds, ctx->stream, py, rois,
+            static const int xg_on = getenv("CR_ROI_BWD_XCD") ? atoi(getenv("CR_ROI_BWD_XCD")) : 1;
+            static const int xg_threads = getenv("CR_ROI_BWD_T") ? atoi(getenv("CR_ROI_BWD_T")) : 128;   // 4 row phases x 32 channels
+            if (xg_on && C % 256 == 0 && R * 8 < 0x7fffffff) {       // C / 8 channels per block, a multiple of a 128-B line
+                const int nt = (C / 8) * (xg_threads / (C / 8) > 0 ? xg_threads / (C / 8) : 1);
+                if (act_f32)
+                    hipLaunchKernelGGL((k_roi_align_bwd_sep<7, float, 8>), dim3((unsigned)R * 8), dim3(nt), lds, ctx->stream, py,
+                                       rois, (int)R, (const float*)dout, maxH);
+                else
+                    hipLaunchKernelGGL((k_roi_align_bwd_sep<7, u16, 8>), dim3((unsigned)R * 8), dim3(nt), lds, ctx->stream, py,
+                                       rois, (int)R, (const u16*)dout, maxH);
+            } else if (act_f32)
+                hipLaunchKernelGGL((k_roi_align_bwd_sep<7, float, 1>), dim3((unsigned)R), dim3(256), lds, ctx->stream, py, rois,
                                    (int)R, (const float*)dout, maxH);
             else
-                hipLaunchKernelGGL((k_roi_align_bwd_sep<7, u16>), dim3((unsigned)R), dim3(256), lds, ctx->stream, py, rois,
+                hipLaunchKernelGGL((k_roi_align_bwd_sep<7, u16, 1>), dim3((unsigned)R), dim3(256), lds, ctx->stream, py, rois,
                                    (int)R, (const u16*)dout, maxH);
             CR_LAUNCH_CHECK();
             return CR_OK;

@@ -86,7 +86,7 @@ class _Replay(torch.autograd.Function):
         for sg, g in zip(r.static_grads, grads):
             if g is None:
                 sg.zero_()
-            else:
+            elif g.data_ptr() != sg.data_ptr():      # RoIAlign scatters straight into the static buffer (_cr_grad_dst)
                 sg.copy_(g)
         r.bwd_graph.replay()
         return None, None
@@ -127,7 +127,16 @@ class GraphedDense(GraphOwner):
             # themselves and return None; what comes back here went through plain autograd (biases, the stem and
             # predictor weights) and is added to the flat gradient inside the captured region.
             ps = leaves()
-            res = torch.autograd.grad(outs, ps, grads, allow_unused=True)
+            # an output that a convolution of the region consumed first (the pyramid maps -> RPN head) has a gradient slot:
+            # the incoming gradient goes there and that convolution's backward-data adds it in its epilogue
+            keep_o, keep_g = [], []
+            for o, g in zip(outs, grads):
+                slot = getattr(o, "_cr_slot", None)
+                if slot is not None and ops._SLOTS_ON[0]:
+                    ops._slot_put(slot, g)
+                else:
+                    keep_o.append(o); keep_g.append(g)
+            res = torch.autograd.grad(keep_o, ps, keep_g, allow_unused=True)
             for p, g in zip(ps, res):
                 if g is not None:
                     ops.grad_sink(p).add_(g)
@@ -163,6 +172,8 @@ class GraphedDense(GraphOwner):
         self.static_img.copy_(images_u8)
         outs = _Replay.apply(self, self.trigger)
         nf, nl = len(self.feat_names), self.n_levels
+        for o, sg in zip(outs[:nf], self.static_grads):
+            o._cr_grad_dst = sg            # hipops._ROIAlign: scatter the pyramid gradient straight into the static buffer
         feats = dict(zip(self.feat_names, outs[:nf]))
         return feats, list(outs[nf:nf + nl])
 

@@ -770,8 +770,15 @@ def _pyr_args(feats, scales):
 
 
 class _ROIAlign(torch.autograd.Function):
+    """Where the pyramid gradient goes (backward), per level, in this order of preference:
+      * a gradient slot of the level's map (the RPN head's convolution consumed it first, in the same autograd graph: its
+        backward-data adds this contribution in its epilogue -- no fan-in add kernel);
+      * the static gradient buffer of a captured dense region (`_cr_grad_dst` on the region's output, GraphedDense): the
+        scatter lands where the backward graph reads it -- no copy;
+      * a fresh zero-filled buffer returned to autograd."""
+
     @staticmethod
-    def forward(ctx, rois, scales, out_size, *feats):
+    def forward(ctx, rois, scales, out_size, slots, *feats):
         _p = _Args()
         _need_cuda(rois, "rois")
         C = feats[0].shape[3]
@@ -785,6 +792,9 @@ class _ROIAlign(torch.autograd.Function):
         _chk(lib.cr_roi_align_fwd(_ctx(rois), cast(ptrs), cast(Hs), cast(Ws), cast(sc), n, C, _p(rois), R, out_size,
                                   out_size, _p(out), _af(out)), "cr_roi_align_fwd")
         ctx.cfg = (scales, out_size, [tuple(f.shape) for f in feats], dt)
+        ctx.slots = slots
+        # claimed (popped): a second RoIAlign over the same maps takes the ordinary path and autograd adds the two
+        ctx.dsts = [f.__dict__.pop("_cr_grad_dst", None) if f.requires_grad else None for f in feats]
         ctx.save_for_backward(rois)
         return out
 
@@ -794,19 +804,31 @@ class _ROIAlign(torch.autograd.Function):
         (rois,) = ctx.saved_tensors
         scales, out_size, shapes, dt = ctx.cfg
         C = shapes[0][3]
-        # one zero-fill for the whole pyramid (the levels are views of one buffer, each 16-B aligned)
-        sizes = [(int(s[0] * s[1] * s[2] * s[3]) + 3) // 4 * 4 for s in shapes]
-        flat = torch.zeros((sum(sizes),), dtype=f32, device=rois.device)
-        grads, off = [], 0
-        for s, n_ in zip(shapes, sizes):
-            grads.append(flat[off:off + int(s[0] * s[1] * s[2] * s[3])].view(s))
-            off += n_
+        dsts = ctx.dsts
+        if all(d is not None and d.dtype == f32 and tuple(d.shape) == tuple(s) for d, s in zip(dsts, shapes)):
+            grads = dsts
+            torch._foreach_zero_(grads)
+        else:
+            # one zero-fill for the whole pyramid (the levels are views of one buffer, each 16-B aligned)
+            sizes = [(int(s[0] * s[1] * s[2] * s[3]) + 3) // 4 * 4 for s in shapes]
+            flat = torch.zeros((sum(sizes),), dtype=f32, device=rois.device)
+            grads, off = [], 0
+            for s, n_ in zip(shapes, sizes):
+                grads.append(flat[off:off + int(s[0] * s[1] * s[2] * s[3])].view(s))
+                off += n_
         n, ptrs, Hs, Ws, sc, cast = _pyr_args(grads, scales)
         lib = _lib.load()
         dout = dout.to(dt).contiguous()
         _chk(lib.cr_roi_align_bwd(_ctx(rois), cast(ptrs), cast(Hs), cast(Ws), cast(sc), n, C, _p(rois), rois.shape[0],
                                   out_size, out_size, _p(dout), _af(dout)), "cr_roi_align_bwd")
-        return (None, None, None) + tuple(g if dt == f32 else g.to(dt) for g in grads)
+        res = []
+        for g, (slot, _i) in zip(grads, ctx.slots):
+            g = g if dt == f32 else g.to(dt)
+            if slot is not None:
+                _slot_put(slot, g)
+                g = None
+            res.append(g)
+        return (None, None, None, None) + tuple(res)
 
 
 class _SharedPrefix(torch.autograd.Function):
@@ -837,7 +859,8 @@ def shared_prefix(pooled, B, S, kf):
 
 def roi_align_pyramid(feats, rois, scales, out_size):
     """feats: list of NHWC maps (fine -> coarse) in the activation dtype; rois (R,5) f32 [batch,x1,y1,x2,y2]."""
-    return _ROIAlign.apply(rois.to(f32), tuple(scales), out_size, *feats)
+    slots = tuple(_slot_register(f, False) for f in feats)
+    return _ROIAlign.apply(rois.to(f32), tuple(scales), out_size, slots, *feats)
 
 
 # --------------------------------------------------------------------------

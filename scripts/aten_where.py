@@ -20,6 +20,7 @@ SKIP = ("view", "reshape", "as_strided", "detach", "alias", "expand", "permute",
         "unsqueeze", "squeeze", "_unsafe_view", "empty", "unbind", "split", "narrow", "unflatten", "size", "stride", "is_", "sym_",
         "_local_scalar_dense", "lift_fresh", "new_empty", "chunk", "flatten", "result_type", "set_", "record_stream")
 agg = collections.defaultdict(lambda: [0, 0])
+shapes = collections.Counter()
 
 
 class Count(TorchDispatchMode):
@@ -39,6 +40,8 @@ class Count(TorchDispatchMode):
             if ("3dod_amd" in fr.filename or "bench_train" in fr.filename) and "aten_where" not in fr.filename:
                 where = f"{fr.filename.split('repo/')[-1]}:{fr.lineno} {fr.name}"
                 break
+        if where == 'autograd engine' and short.startswith('add.Tensor'):
+            shapes[tuple(out.shape)] += 1
         a = agg[(short, where)]
         a[0] += 1
         a[1] += max((t.numel() for t in ts), default=0)
@@ -58,3 +61,7 @@ rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
 print("aten ops on device tensors per step:", sum(v[0] for v in agg.values()) / NSTEP)
 for (name, where), (n, el) in rows[:150]:
     print(f"n={n / NSTEP:5.1f} maxnumel/op={el / n:11.0f}  {name:28s} {where[:130]}")
+
+print('autograd-engine fan-in adds by shape (per step):')
+for sh, n in sorted(shapes.items(), key=lambda kv: -kv[1] * torch.Size(kv[0]).numel()):
+    print(f'  {n / NSTEP:4.1f} x {sh}')
