@@ -237,13 +237,84 @@ def bench_boxnet(args, rank, world, dev):
             run()
         barrier(world)
         dt = max_over_ranks(time.perf_counter() - t0, world, dev)
-    return {"metric": "images/sec BoxNet 1000-cube proposal-and-scoring pipeline on GT boxes (BASELINE configs[2], end to end)",
+    # roofline of the pipeline's dominant stage (rocprofv3: k_ccl_merge / k_mask_rect / k_ccl_sizes lead the kernel time):
+    # the six kernels of cr_mask_rects on this batch's masks, HIP events on the launch stream.  Algorithmic bytes (DESIGN
+    # section 2): the mask once (1 B / pixel of every 512 x 512 mask: the bounding-window search reads all of it) + one
+    # 4-B label written and read once per pixel of each mask's bounding window.
+    geo = importlib.import_module("3dod_amd.geometry")
+    masks = [b["masks"] for b in batch]
+    for _ in range(3):
+        geo.mask_rects(masks)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        geo.mask_rects(masks)
+    ev1.record()
+    torch.cuda.synchronize()
+    stage_ms = ev0.elapsed_time(ev1) / 10
+    win_px = 0
+    for b in batch:
+        bb = b["instances"].gt_boxes.tensor.round().long().clamp(0, 511).cpu()
+        win_px += int(((bb[:, 2] - bb[:, 0] + 1) * (bb[:, 3] - bb[:, 1] + 1)).sum())
+    alg_bytes = nobj * 512 * 512 + 8 * win_px
+    achieved = alg_bytes / (stage_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "cr_mask_rects = k_mask_bbox + k_ccl_init/merge/sizes/best + k_mask_rect (mask -> largest "
+                                          "component -> hull -> minimum-area rectangle)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms": stage_ms, "note": "union-find label passes are latency-bound (atomicMin parent chains), not "
+                                               "bandwidth-bound; share of the step = kernel_ms / ms_per_step"}
+    extra = {"roofline": roofline}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        extra["cpu_baseline"] = cpu_baseline_boxnet(batch[0], n_obj)
+    return {**extra,
+            "metric": "images/sec BoxNet 1000-cube proposal-and-scoring pipeline on GT boxes (BASELINE configs[2], end to end)",
             "value": B * world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BoxNet.inference(use_pred_boxes=False): {B} images x {nobj // B} objects x 1000 cubes per GPU, "
                                    "depth + ground + object masks in HBM", "objects_per_gpu": nobj,
                        "cubes_per_s": nobj * 1000 * world * args.steps / dt, "parallelism": f"images sharded x{world}, no collective"}}
+
+
+def cpu_baseline_boxnet(sample, n_obj, P=1000):
+    """the oracle's stages of the same pipeline on ONE image (16 objects x 1000 cubes), numpy on one host core: ground-plane
+    RANSAC on the back-projected ground pixels (oracle.geometry.ransac_plane), mask -> minimum-area rectangle
+    (oracle.rect.rect_from_mask, scipy labelling), proposals from supplied draws (propose_from_draws), project + score +
+    argmax (project_and_score)."""
+    import numpy as np
+    from oracle import geometry as og, rect as orect
+    rng = np.random.default_rng(0)
+    depth = sample["depth_map"].cpu().numpy().astype(np.float32)
+    ground = sample["ground_map"].cpu().numpy().astype(bool)
+    masks = sample["masks"].cpu().numpy()
+    boxes = sample["instances"].gt_boxes.tensor.cpu().numpy().astype(np.float32)[:n_obj]
+    f = 600.0
+    K = np.array([[f, 0, 256], [0, f, 256], [0, 0, 1]], dtype=np.float32)
+    mu = rng.uniform(0.3, 1.1, (n_obj, 3)).astype(np.float32)
+    sg = (0.2 * mu).astype(np.float32)
+    n_rep = 0                                                        # whole images for ~12 s of host work
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 12.0:
+        n_rep += 1
+        ys, xs = np.nonzero(ground)
+        sel = rng.choice(len(ys), min(len(ys), 20000), replace=False)     # bounded: the 1000 x points distance matrix is host RAM
+        ys, xs = ys[sel], xs[sel]
+        z = depth[ys, xs]
+        pts = np.stack([(xs - 256) * z / f, (ys - 256) * z / f, z], 1).astype(np.float32)
+        triples = rng.integers(0, len(pts), (1000, 3))
+        eq = og.ransac_plane(pts, triples, 0.05)[0]
+        normal = og.fix_ground_normal(-eq[:3] / (np.linalg.norm(eq[:3]) + 1e-12))
+        rects = []
+        for m, b in zip(masks[:n_obj], boxes):
+            r = orect.rect_from_mask(m)
+            rects.append(r if r is not None else np.array([[b[0], b[1]], [b[2], b[1]], [b[2], b[3]], [b[0], b[3]]], np.float32))
+        cubes = og.propose_from_draws(boxes.clip(0, 511), depth, mu, sg, K, P, rng.standard_normal((4, 3, n_obj, P)).astype(np.float32),
+                                      rng.standard_normal((3, n_obj, P)).astype(np.float32), rng.integers(0, 36, (n_obj, P)), normal)
+        og.project_and_score(cubes, K, (512, 512), boxes, mu, sg, np.stack(rects).astype(np.float32))
+    dt = time.perf_counter() - t0
+    return {"value": n_rep / dt, "unit": "images/s", "cores": 1, "kind": "port",
+            "sample": f"{n_rep} x 1 image x {n_obj} objects x {P} cubes through the oracle's stages (numpy / scipy, float32; RANSAC on 20000 of the "
+                      f"ground pixels), {dt:.2f} s"}
 
 
 def bench_weak(args, rank, world, dev):

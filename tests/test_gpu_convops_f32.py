@@ -187,9 +187,10 @@ def test_pool_upsample_preprocess_f32():
     assert relerr(y[..., :3], nhwc(ref)) < 1e-6 and (y[..., 3:] == 0).all()
 
 
-def test_roi_align_fwd_bwd_f32():
+@pytest.mark.parametrize("C", [16, 256])       # 256: a block per (RoI, 32-channel group = XCD) in the backward
+def test_roi_align_fwd_bwd_f32(C):
     g = torch.Generator().manual_seed(5)
-    C, N = 16, 2
+    N = 2
     sizes = [(32, 40), (16, 20), (8, 10), (4, 5), (2, 3)]
     scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32, 1 / 64]
     feats = [torch.randn(N, C, h, w, generator=g) for h, w in sizes]
@@ -301,3 +302,24 @@ def test_gradient_slots_equal_autograd_adds():
     gx0, gl0 = run(False)
     assert torch.equal(gl1, gl0)
     assert relerr(gx1, gx0) < 1e-6
+
+
+def test_linear_head_fc1_full_size():
+    """the box head's first FC layer at the train step's size (2048 RoIs x 12544 -> 1024): the forward takes the long-k
+    split (128 x 128 tiles, 4 k ranges + epilogue), the weight gradient 64-row tiles with two row splits (1568 tiles);
+    against torch's f32 GEMM (same arithmetic up to summation order)."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    R, K, O = 2048, 12544, 1024
+    x = torch.randn(R, K, device=DEV, generator=g)
+    w = torch.randn(O, K, device=DEV, generator=g) * 0.01
+    b = torch.randn(O, device=DEV, generator=g) * 0.1
+    dy = torch.randn(R, O, device=DEV, generator=g)
+    y = ops.linear_fwd_raw(x, w, b, relu=True)
+    ref = torch.relu(x @ w.t() + b)
+    assert relerr(y, ref) < 2e-5
+    dx = ops.linear_bwd_data_raw(dy, w.t().contiguous())
+    assert relerr(dx, dy @ w) < 2e-5
+    dw = torch.zeros(O, K, device=DEV); db = torch.zeros(O, device=DEV)
+    ops.linear_bwd_weight_raw(dy, x, dw, db, True)
+    assert relerr(dw, dy.t() @ x) < 2e-5
+    assert relerr(db, dy.sum(0)) < 2e-5
