@@ -29,7 +29,7 @@ __global__ __launch_bounds__(TK_T) void k_topk_select(const float* __restrict__ 
                                                       unsigned long long* __restrict__ cand) {
     extern __shared__ unsigned sk[];                             // chunk keys [m]
     __shared__ unsigned hist[4096];
-    __shared__ unsigned s_prefix, s_need, s_cnt, s_scan[TK_T / 64], s_base;
+    __shared__ unsigned s_prefix, s_need, s_nties, s_cnt, s_scan[TK_T / 64], s_base;
     const int row = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
     const int64_t chunk = (n + nb - 1) / nb;
     const int64_t c0 = (int64_t)b * chunk;
@@ -55,9 +55,20 @@ __global__ __launch_bounds__(TK_T) void k_topk_select(const float* __restrict__ 
         const int nbins = 1 << bits, per = nbins / TK_T;          // bins per thread: 4 or 1
         for (int i = t; i < nbins; i += TK_T) hist[i] = 0;
         __syncthreads();
-        for (int i = t; i < m; i += TK_T) {
-            const unsigned key = sk[i];
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & dmask], 1u);
+        // the digit of the wave's first active lane is counted once for all lanes that share it (padding / suppressed
+        // scores are thousands of equal keys: 64 lanes on one LDS address serialise), the others add one each
+        for (int i0 = 0; i0 < m; i0 += TK_T) {
+            const int i = i0 + t;
+            const unsigned key = i < m ? sk[i] : 0u;
+            const bool act = i < m && (key & mask) == prefix;
+            const unsigned d = (key >> shift) & dmask;
+            const unsigned long long am = __ballot(act);
+            if (am == 0ull) continue;                                // wave-uniform
+            const int first = __ffsll((long long)am) - 1;
+            const unsigned d0 = (unsigned)__shfl((int)d, first, 64);
+            const unsigned long long same = __ballot(act && d == d0);
+            if (lane0 == first) atomicAdd(&hist[d0], (unsigned)__popcll(same));
+            else if (act && d != d0) atomicAdd(&hist[d], 1u);
         }
         __syncthreads();
         // thread t owns the bins [top - per*t - (per-1), top - per*t] (top = nbins - 1): counts from the largest digit down
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(TK_T) void k_topk_select(const float* __restrict__ 
             unsigned acc = before;
             for (int q = 0; q < per; ++q) {
                 const int bin = nbins - 1 - (per * t + q);
-                if (acc + hist[bin] >= need) { s_prefix = prefix | ((unsigned)bin << shift); s_need = need - acc; break; }
+                if (acc + hist[bin] >= need) { s_prefix = prefix | ((unsigned)bin << shift); s_need = need - acc; s_nties = hist[bin]; break; }
                 acc += hist[bin];
             }
         }
@@ -88,17 +99,29 @@ __global__ __launch_bounds__(TK_T) void k_topk_select(const float* __restrict__ 
         __syncthreads();
     }
     const unsigned T = prefix;                                   // the kk-th largest key; `need` ties (== T) are taken, lowest index first
+    // after the last pass s_nties = number of keys equal to T: when all of them are needed (the usual case: distinct keys,
+    // one tie) they go out with the keys above T and the index-ordered tie loop (three barriers per 1024 keys) is skipped
+    const bool all_ties = s_nties == need;
     if (t == 0) { s_cnt = 0; s_base = 0; }
     __syncthreads();
     // keys above T: any order (the merge sorts)
-    for (int i = t; i < m; i += TK_T) {
-        const unsigned key = sk[i];
-        if (key > T) {
-            const unsigned pos = atomicAdd(&s_cnt, 1u);
+    for (int i0 = 0; i0 < m; i0 += TK_T) {
+        const int i = i0 + t;
+        const unsigned key = i < m ? sk[i] : 0u;
+        const bool gt = i < m && (key > T || (all_ties && key == T));
+        const unsigned long long bal = __ballot(gt);
+        if (bal == 0ull) continue;                                   // wave-uniform
+        const int first = __ffsll((long long)bal) - 1;
+        unsigned base = 0;
+        if (lane0 == first) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));      // one LDS atomic per wave
+        base = (unsigned)__shfl((int)base, first, 64);
+        if (gt) {
+            const unsigned pos = base + (unsigned)__popcll(bal & ((1ull << lane0) - 1ull));
             out[pos] = ((unsigned long long)key << 32) | (unsigned long long)(~(unsigned)(c0 + i));
         }
     }
     __syncthreads();
+    if (all_ties) return;                                        // block-uniform
     const unsigned n_gt = s_cnt;                                  // == kk - need
     // ties in index order: block-wide running rank
     const int lane = t & 63, wave = t >> 6;
@@ -121,30 +144,67 @@ __global__ __launch_bounds__(TK_T) void k_topk_select(const float* __restrict__ 
     }
 }
 
+// E = npad / 1024 words per thread (element g = t * E + e) stay in registers: compare-exchange distances below E are
+// register swaps, below 64 E lane shuffles inside the wave, and only the rest (10 of the 66 steps at npad = 2048) go through
+// LDS with barriers -- the LDS-only version spent ~0.8 us per step on barriers and dependent LDS round trips.
+template <int E>
 __global__ __launch_bounds__(TK_T) void k_topk_merge(const unsigned long long* __restrict__ cand, int ncand, int k, int npad,
                                                      float* __restrict__ vals, int64_t* __restrict__ idx) {
-    extern __shared__ unsigned long long sw[];                   // [npad], npad = power of two >= ncand
+    extern __shared__ unsigned long long sw[];                   // [npad] (cross-wave steps), word g at (g % E) * 1024 + g / E
     const int row = blockIdx.x, t = threadIdx.x;
     const unsigned long long* c = cand + (size_t)row * ncand;
-    for (int i = t; i < npad; i += TK_T) sw[i] = i < ncand ? c[i] : 0ull;
-    __syncthreads();
+    unsigned long long v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int g = t * E + e;
+        v[e] = g < ncand ? c[g] : 0ull;
+    }
+    // g's partner is g ^ j; the pair keeps (larger, smaller) in index order where (g & len) == 0 (descending overall)
     for (int len = 2; len <= npad; len <<= 1) {
         for (int j = len >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < npad; i += TK_T) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const bool desc = (i & len) == 0;            // descending overall
-                    const unsigned long long a = sw[i], bq = sw[p];
-                    if (desc ? a < bq : a > bq) { sw[i] = bq; sw[p] = a; }
+            if (j >= 64 * E) {
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) sw[e * TK_T + t] = v[e];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int g = t * E + e, pg = g ^ j;
+                    const unsigned long long pv = sw[(pg % E) * TK_T + pg / E];
+                    const bool take_max = ((g & len) == 0) == ((g & j) == 0);
+                    v[e] = take_max ? (v[e] > pv ? v[e] : pv) : (v[e] < pv ? v[e] : pv);
+                }
+            } else if (j >= E) {
+                const int lx = j / E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int g = t * E + e;
+                    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v[e] & 0xffffffffull), lx, 64);
+                    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v[e] >> 32), lx, 64);
+                    const unsigned long long pv = ((unsigned long long)hi << 32) | lo;
+                    const bool take_max = ((g & len) == 0) == ((g & j) == 0);
+                    v[e] = take_max ? (v[e] > pv ? v[e] : pv) : (v[e] < pv ? v[e] : pv);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & j) == 0) {
+                        const int g = t * E + e;
+                        const unsigned long long a = v[e], bq = v[e | j];
+                        const bool desc = (g & len) == 0;
+                        if (desc ? a < bq : a > bq) { v[e] = bq; v[e | j] = a; }
+                    }
                 }
             }
-            __syncthreads();
         }
     }
-    for (int i = t; i < k; i += TK_T) {
-        const unsigned long long w = sw[i];
-        vals[(size_t)row * k + i] = tk_val((unsigned)(w >> 32));
-        idx[(size_t)row * k + i] = (int64_t)(~(unsigned)(w & 0xffffffffull));
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int g = t * E + e;
+        if (g < k) {
+            vals[(size_t)row * k + g] = tk_val((unsigned)(v[e] >> 32));
+            idx[(size_t)row * k + g] = (int64_t)(~(unsigned)(v[e] & 0xffffffffull));
+        }
     }
 }
 
@@ -169,14 +229,20 @@ extern "C" int cr_topk(cr_ctx* ctx, const float* x, int rows, int64_t n, int k, 
     static bool attr_done = false;
     if (!attr_done) {
         CR_HIP(hipFuncSetAttribute((const void*)k_topk_select, hipFuncAttributeMaxDynamicSharedMemorySize, TK_CH * 4));
-        CR_HIP(hipFuncSetAttribute((const void*)k_topk_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+        CR_HIP(hipFuncSetAttribute((const void*)k_topk_merge<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+        CR_HIP(hipFuncSetAttribute((const void*)k_topk_merge<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
         attr_done = true;
     }
     hipLaunchKernelGGL(k_topk_select, dim3((unsigned)rows, (unsigned)nb), dim3(TK_T), (size_t)chunk * 4, ctx->stream, x, n, k, nb,
                        (unsigned long long*)ws);
     CR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)rows), dim3(TK_T), (size_t)npad * 8, ctx->stream,
-                       (const unsigned long long*)ws, ncand, k, npad, vals, idx);
+    const int E = npad <= TK_T ? 1 : npad / TK_T;
+    const size_t lds = (size_t)E * TK_T * 8;                      // [E][1024] words
+#define CR_TK_MERGE(E_) hipLaunchKernelGGL(k_topk_merge<E_>, dim3((unsigned)rows), dim3(TK_T), lds, ctx->stream, \
+                                           (const unsigned long long*)ws, ncand, k, npad, vals, idx)
+    if (E == 1) CR_TK_MERGE(1); else if (E == 2) CR_TK_MERGE(2); else if (E == 4) CR_TK_MERGE(4);
+    else if (E == 8) CR_TK_MERGE(8); else CR_TK_MERGE(16);
+#undef CR_TK_MERGE
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
