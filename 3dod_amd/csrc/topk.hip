@@ -161,7 +161,7 @@ __global__ __launch_bounds__(TK_T) void k_topk_merge(const unsigned long long* _
     }
     // g's partner is g ^ j; the pair keeps (larger, smaller) in index order where (g & len) == 0 (descending overall)
     for (int len = 2; len <= npad; len <<= 1) {
-        for (int j = len >> 1; j > 0; j >>= 1) {
+        for (int j = len >> 1; j >= E; j >>= 1) {
             if (j >= 64 * E) {
                 __syncthreads();
 #pragma unroll
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(TK_T) void k_topk_merge(const unsigned long long* _
                     const bool take_max = ((g & len) == 0) == ((g & j) == 0);
                     v[e] = take_max ? (v[e] > pv ? v[e] : pv) : (v[e] < pv ? v[e] : pv);
                 }
-            } else if (j >= E) {
+            } else {
                 const int lx = j / E;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
@@ -185,14 +185,19 @@ __global__ __launch_bounds__(TK_T) void k_topk_merge(const unsigned long long* _
                     const bool take_max = ((g & len) == 0) == ((g & j) == 0);
                     v[e] = take_max ? (v[e] > pv ? v[e] : pv) : (v[e] < pv ? v[e] : pv);
                 }
-            } else {
+            }
+        }
+        // distances below E: inside the thread (compile-time register indices)
+#pragma unroll
+        for (int jj = E >> 1; jj > 0; jj >>= 1) {
+            if (jj < len) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    if ((e & j) == 0) {
+                    if ((e & jj) == 0) {
                         const int g = t * E + e;
-                        const unsigned long long a = v[e], bq = v[e | j];
+                        const unsigned long long a = v[e], bq = v[e | jj];
                         const bool desc = (g & len) == 0;
-                        if (desc ? a < bq : a > bq) { v[e] = bq; v[e | j] = a; }
+                        if (desc ? a < bq : a > bq) { v[e] = bq; v[e | jj] = a; }
                     }
                 }
             }
