@@ -89,11 +89,20 @@ class _Replay(torch.autograd.Function):
             elif g.data_ptr() != sg.data_ptr():      # RoIAlign scatters straight into the static buffer (_cr_grad_dst)
                 sg.copy_(g)
         r.bwd_graph.replay()
+        if r.bwd_graph2 is not None:       # two-segment backward: level5 + FPN + RPN head | the rest of the trunk
+            if r.mid_bwd is not None:      # the first segment's gradients are final: their all-reduce overlaps the second
+                r.mid_bwd()
+            r.bwd_graph2.replay()
         return None, None
 
 
 class GraphedDense(GraphOwner):
-    def __init__(self, model, images_u8, warmup=2):
+    """split_backward=True (data-parallel runs) captures the backward as TWO graphs cut at the input of the trunk's last
+    level: [RPN head, FPN, DLA level5] first, [level4 ... stem] second.  The first segment owns 2/3 of the region's
+    parameters and a small part of its backward time, so their gradient all-reduce (TrainStep, `mid_bwd`) runs on the
+    communication stream under the second segment."""
+
+    def __init__(self, model, images_u8, warmup=2, split_backward=False):
         assert model.training, "capture the training-mode dense region"
         self.model = model
         self.shape = tuple(images_u8.shape)
@@ -101,6 +110,12 @@ class GraphedDense(GraphOwner):
         dev = self.dev = images_u8.device
         self.static_img = images_u8.clone()
         self.pre_bwd = None                 # optional callback run right before the backward graph is replayed
+        self.mid_bwd = None                 # optional callback run between the two backward segments
+        self.bwd_graph2 = None
+        bu = getattr(model.backbone, "bottom_up", None)
+        lower = [getattr(bu, n, None) for n in ("base_layer", "level0", "level1", "level2", "level3", "level4")]
+        self.split = bool(split_backward) and bu is not None and all(m is not None for m in lower) and hasattr(bu, "level5")
+        cut = {}
         self.trigger = torch.zeros((), device=dev, requires_grad=True)
         pg = model.proposal_generator
         self.feat_names = None
@@ -121,6 +136,15 @@ class GraphedDense(GraphOwner):
                 assert ops.grad_sink(p) is not None, "build the optimizer (FlatSGD) before capturing graphs"
             return ps
 
+        def lower_ids():
+            return {id(p) for m in lower for p in m.parameters()}
+
+        def segment_params(first):
+            """parameters (of the live modules) whose gradients the first / second backward segment produces"""
+            low = lower_ids()
+            return [p for m in mods for p in m.parameters() if p.requires_grad and ((id(p) not in low) == first)]
+        self.segment_params = segment_params
+
         def run_backward(outs, grads):
             # torch.autograd.grad, not .backward(): no AccumulateGrad nodes (they are pinned to the stream they were
             # first created on, which breaks capture).  Conv / BN kernels accumulate into the flat gradient
@@ -136,18 +160,42 @@ class GraphedDense(GraphOwner):
                     ops._slot_put(slot, g)
                 else:
                     keep_o.append(o); keep_g.append(g)
-            res = torch.autograd.grad(keep_o, ps, keep_g, allow_unused=True)
-            for p, g in zip(ps, res):
+            if not self.split:
+                res = torch.autograd.grad(keep_o, ps, keep_g, allow_unused=True)
+                for p, g in zip(ps, res):
+                    if g is not None:
+                        ops.grad_sink(p).add_(g)
+                return None
+            # first segment: everything downstream of the cut tensor (level4's output: consumed by level5 and the FPN
+            # lateral, both in this segment; the laterals of the lower levels leave their contributions in the gradient
+            # slots of level2 / level3's outputs, where the second segment's convolutions pick them up)
+            low = lower_ids()
+            ps1 = [p for p in ps if id(p) not in low]
+            res = torch.autograd.grad(keep_o, ps1 + [cut["x"]], keep_g, allow_unused=True, retain_graph=True)
+            for p, g in zip(ps1, res[:-1]):
+                if g is not None:
+                    ops.grad_sink(p).add_(g)
+            assert res[-1] is not None, "two-segment backward: no gradient reaches the trunk"
+            return res[-1]
+
+        def run_backward2(gx):
+            low = lower_ids()
+            ps2 = [p for p in leaves() if id(p) in low]
+            res = torch.autograd.grad([cut["x"]], ps2, [gx], allow_unused=True)
+            for p, g in zip(ps2, res):
                 if g is not None:
                     ops.grad_sink(p).add_(g)
 
         # ---- eager warm-up on a side stream (allocator / lazy-init effects out of the capture)
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
+        hook = bu.level4.register_forward_hook(lambda m, i, o: cut.__setitem__("x", o)) if self.split else None
         with torch.cuda.stream(s), _fresh_leaves(mods):
             for _ in range(warmup):
                 outs = dense()
-                run_backward(outs, tuple(torch.zeros_like(o) for o in outs))
+                gx = run_backward(outs, tuple(torch.zeros_like(o) for o in outs))
+                if self.split:
+                    run_backward2(gx)
             del outs
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
@@ -161,7 +209,14 @@ class GraphedDense(GraphOwner):
             self.static_grads = tuple(torch.zeros_like(o) for o in self.static_outs)
             self.bwd_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool()):
-                run_backward(self.static_outs, self.static_grads)
+                gx = run_backward(self.static_outs, self.static_grads)
+            if self.split:
+                self.bwd_graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.bwd_graph2, pool=self.fwd_graph.pool()):
+                    run_backward2(gx)
+        if hook is not None:
+            hook.remove()
+        cut.clear()
         torch.cuda.synchronize(dev)
 
     def matches(self, images_u8):

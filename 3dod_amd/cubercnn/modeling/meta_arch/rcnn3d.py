@@ -48,12 +48,14 @@ class RCNN3D(nn.Module):
         # static-shape training path (modeling/dense_train.py): same rules, no host<->device syncs
         self.dense_train = True
 
-    def enable_graphs(self, sample_batched_inputs):
+    def enable_graphs(self, sample_batched_inputs, split_backward=False):
         """capture the static dense region (trunk + FPN + RPN head, forward and backward) as HIP graphs for the
-        image-batch shape of `sample_batched_inputs`.  Call after the optimizer (FlatSGD) has been built."""
+        image-batch shape of `sample_batched_inputs`.  Call after the optimizer (FlatSGD) has been built.
+        split_backward: two backward graphs, so that a data-parallel step all-reduces the first segment's gradients under
+        the second (graphed.GraphedDense)."""
         from ..graphed import GraphedDense
         il, batch = self._stack_images(sample_batched_inputs)
-        self._graphed = GraphedDense(self, batch)
+        self._graphed = GraphedDense(self, batch, split_backward=split_backward)
         return self._graphed
 
     def enable_graphs_eval(self, sample_batched_inputs=None, max_shapes=0):

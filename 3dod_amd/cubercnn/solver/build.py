@@ -192,6 +192,25 @@ def early_allreduce_ranges(model, optimizer):
     return merged
 
 
+def param_ranges(params, optimizer):
+    """merged [start, end) ranges of the flat gradient covered by the sinks of `params` (16-B padded segments, FlatSGD)"""
+    out = []
+    for p in params:
+        sink = ops.grad_sink(p) if hasattr(ops, "grad_sink") else None
+        if sink is not None and sink.untyped_storage().data_ptr() == optimizer.flat_g.untyped_storage().data_ptr():
+            a = sink.storage_offset()
+            out.append((a, a + (p.numel() + 3) // 4 * 4))
+    out.sort()
+    merged = []
+    for a, b in out:
+        if merged and a <= merged[-1][1]:
+            merged[-1] = (merged[-1][0], max(b, merged[-1][1]))
+        else:
+            merged.append((a, b))
+    n = optimizer.flat_g.numel()
+    return [(a, min(b, n)) for a, b in merged]
+
+
 def complement_ranges(ranges, n, bucket):
     """[0,n) minus `ranges`, chopped into buckets of at most `bucket` elements, last parameters first."""
     out, pos = [], 0
@@ -230,7 +249,19 @@ class TrainStep:
         self.early_ranges = early_allreduce_ranges(model, optimizer)
         self.late_ranges = complement_ranges(self.early_ranges, n, be)
         self._early_done = False
+        self.mid_ranges, self._mid_done, self._bucket = [], False, be
         self.last = {}
+
+    def _mid_allreduce(self):
+        """between the two captured backward segments (GraphedDense.split): the gradients of the RPN head, the FPN and the
+        trunk's last level are final; their all-reduce runs on the communication stream under the second segment"""
+        if self.comm_stream is None or not self.mid_ranges:
+            return
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            for a, b in self.mid_ranges:
+                dist.all_reduce(self.opt.flat_g[a:b])
+        self._mid_done = True
 
     def _early_allreduce(self):
         if self.comm_stream is None or not self.early_ranges:
@@ -264,7 +295,14 @@ class TrainStep:
         g = getattr(self.model, "_graphed", None)
         if g is not None and self.comm_stream is not None and g.pre_bwd is None:
             g.pre_bwd = self._early_allreduce
-        self._early_done = False
+        if g is not None and self.comm_stream is not None and getattr(g, "bwd_graph2", None) is not None and g.mid_bwd is None:
+            early = set(self.early_ranges)
+            mid = [r for r in param_ranges(g.segment_params(True), opt) if r not in early]
+            # bucket-sized pieces, like the other phases
+            self.mid_ranges = [(x, min(x + self._bucket, b)) for a, b in mid for x in range(a, b, self._bucket)]
+            self.late_after_mid = complement_ranges(sorted(self.early_ranges + mid), opt.flat_g.numel(), self._bucket)
+            g.mid_bwd = self._mid_allreduce
+        self._early_done = self._mid_done = False
         losses.backward()
         opt.collect_grads()
         # ---- gradient all-reduce (DDP, train_net.py:477-480), bucketed, on a side stream; the RoI heads' part was
@@ -272,7 +310,13 @@ class TrainStep:
         if self.comm_stream is not None and (world > 1 or self.force_comm):
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                for a, b in (self.late_ranges if self._early_done else self.buckets):
+                if self._early_done and self._mid_done:
+                    rest = self.late_after_mid
+                elif self._early_done:
+                    rest = self.late_ranges
+                else:
+                    rest = self.buckets
+                for a, b in rest:
                     dist.all_reduce(opt.flat_g[a:b])
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         elif world > 1:                      # gloo / CPU rehearsal of the same protocol

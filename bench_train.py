@@ -97,7 +97,9 @@ def _bench_train_mode(args, rank, world, dev, prec):
     if step is None:
         step = solver.TrainStep(cfg, model, opt, world_size=world)
         if mode == "dense":
-            model.enable_graphs(batches[0])
+            # data-parallel runs: two backward graphs, the first segment's gradients are all-reduced under the second
+            split = os.environ.get("CR_BWD_SPLIT", "1")            # 1: when data-parallel | 0: never | force: also on one GPU (A/B)
+            model.enable_graphs(batches[0], split_backward=(world > 1 and split == "1") or split == "force")
             opt.zero_grad()
     trace = os.environ.get("CR_TRACE") == "1"
     def note(msg):

@@ -330,6 +330,45 @@ def test_whole_step_graph_trains_like_eager():
     assert tg[-1]["total_loss"] < tg[0]["total_loss"]
 
 
+def test_two_segment_backward_equals_single_graph(built):
+    """GraphedDense(split_backward=True): the backward captured as [RPN head, FPN, level5] | [level4 ... stem] gives the
+    flat gradient of the single backward graph (same upstream gradient; float sums reorder through atomics only), every
+    parameter of the region belongs to exactly one segment, and the first segment holds most of the region's parameters."""
+    cfg, model, opt, syn, solver = built
+    batch = syn.make_batch(2, 34, with_gt=False)
+    model.train()
+    pg = model.proposal_generator
+    images, u8 = model._stack_images(batch)
+    A = pg.rpn_head.num_anchors
+
+    def run(split):
+        runner = model.enable_graphs(batch, split_backward=split)
+        assert (runner.bwd_graph2 is not None) == split
+        opt.zero_grad()
+        feats, ys = runner(u8)
+        logits = [y[..., :A].reshape(y.shape[0], -1) for y in ys]
+        deltas = [y[..., A:5 * A].reshape(y.shape[0], -1, 4) for y in ys]
+        loss = sum((f.float() ** 2).mean() for f in feats.values()) + sum(l.mean() for l in logits) + sum((d ** 2).mean() for d in deltas)
+        loss.backward()
+        opt.collect_grads()
+        return runner, opt.flat_g.clone()
+    try:
+        _, g1 = run(False)
+        runner, g2 = run(True)
+        rel = float((g2 - g1).norm() / g1.norm())
+        assert rel < 1e-4, rel
+        first, second = runner.segment_params(True), runner.segment_params(False)
+        region = [p for m in (model.backbone, pg.rpn_head) for p in m.parameters() if p.requires_grad]
+        assert len(first) + len(second) == len(region) and not ({id(p) for p in first} & {id(p) for p in second})
+        n1, n2 = sum(p.numel() for p in first), sum(p.numel() for p in second)
+        assert n1 > n2 > 1_000_000, (n1, n2)
+        # every gradient of the second segment is non-zero only through the second graph
+        r1 = solver.param_ranges(first, opt); r2 = solver.param_ranges(second, opt)
+        assert all(float(g2[a:b].abs().max()) > 0 for a, b in r1) and all(float(g2[a:b].abs().max()) > 0 for a, b in r2)
+    finally:
+        model._graphed = None
+
+
 def test_whole_step_graph_run_ahead_lr_schedule_and_gt_overflow():
     """GraphedTrainStep with the host running ahead of the device (the default: no per-step sync) at the bench's batch
     size -- the mode that faulted in round 1 (garbage sampling indices from aliased `.contiguous()` temporaries whose
@@ -393,14 +432,18 @@ def test_train_step_comm_protocol_single_rank_group(built):
         cover = sorted(step.early_ranges + step.late_ranges)
         assert cover[0][0] == 0 and cover[-1][1] == n and all(x[1] == y[0] for x, y in zip(cover, cover[1:]))
         batch = syn.make_batch(4, 9)
-        if model._graphed is None or not model._graphed.matches(model._stack_images(batch)[1]):
-            model.enable_graphs(batch)
+        model.enable_graphs(batch, split_backward=True)      # two backward graphs, as bench.py --gpus N > 1 runs
         opt.zero_grad()
         p0 = opt.flat_p.clone()
         with d2.EventStorage(0):
             for _ in range(3):
                 step(batch)
                 assert step._early_done                      # the hook fired before the backward graph
+                assert step._mid_done                        # ... and the second one between the two backward segments
+        # the three phases partition the flat gradient
+        cover = sorted(step.early_ranges + step.mid_ranges + step.late_after_mid)
+        assert cover[0][0] == 0 and cover[-1][1] == n and all(x[1] == y[0] for x, y in zip(cover, cover[1:]))
+        assert sum(b - a for a, b in step.mid_ranges) > 10_000_000       # RPN head + FPN + DLA level5
         rep = step.report()
         assert rep["total_loss"] == rep["total_loss"] and rep["iterations_explode"] == 0, rep
         assert not torch.equal(p0, opt.flat_p)
