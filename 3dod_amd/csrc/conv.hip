@@ -1122,9 +1122,205 @@ static bool try_launch_dma(cr_ctx* ctx, const ConvP& p, int out_f32, int* rc) {
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// k_conv_patch_f32: forward (MODE 0) / backward-data (MODE 1) of the stem convolutions in f32 (16 output channels of the
+// GEMM, stride 1, "same" padding, 512 x 512 maps: 7x7 on the 4-channel image, 3x3 16 -> 16).  Same idea as
+// k_conv_wgrad_patch_f32: the im2col kernels gather every input pixel once per filter tap from L2 (98 / 87 / 79 us for
+// 6.6 / 4.8 / 4.8 GFLOP); here a block stages the (16 + KS - 1)^2 input patch of a 16 x 16 pixel tile in LDS once and every
+// tap reads its shifted window:  D[co 4g+e][pixel l15] += W[co][tap][c] * X[row + r][l15 + s][c].
+//   A = weights, all of them in registers for the whole kernel (lane: row co = l & 15, k = l >> 4):
+//       Cin = 16: a float4 per tap = w[co][tap][4g .. 4g+3]; k-step j of a tap multiplies channels 4g + j;
+//       Cin = 4:  a float per tap  = w[co][tap][g]; one k-step per tap.
+//   B = patch (lane: column pixel l15, k = g): ONE ds_read_b128 per (patch row, s) = the four k-steps' channels 4g .. 4g+3
+//       of pixel l15 + s (a wave reads 1 KB contiguous: conflict-free), used by the up to KS output rows it belongs to;
+//       Cin = 4: one ds_read_b32 per (patch row, s).
+// Wave w owns tile rows 4w .. 4w+3 (four accumulators); a lane ends with four consecutive channels of a pixel: the tile
+// row goes out as one 1-KB store per wave.  The next tile's patch is in flight under the MFMAs and lands in the other
+// LDS stage.  BN statistics: per-tile sums to statistics row 4 * tile (rows are per 64 pixels), zeros to the next three.
+// MODE 1 reads the transposed weights (cr_weight_transpose: [Cin][(r,s)][Cout]) with the taps mirrored, and adds the
+// `accumulate` tensor (gradient fan-in) in the epilogue.
+// ---------------------------------------------------------------------------
+template <int KS, int CIN, int MODE>
+__global__ __launch_bounds__(256) void k_conv_patch_f32(ConvP p, int tiles_x, int tiles_per_img, int tiles_total) {
+    constexpr int PAD = KS / 2, PW = 16 + KS - 1, TAPS = KS * KS;
+    constexpr int C4 = CIN / 4, NXL = PW * PW * C4, NXR = (NXL + 255) / 256;
+    constexpr int STAGE = PW * PW * CIN;
+    constexpr int NQ = 4 + KS - 1;                                   // patch rows a wave touches
+    __shared__ float smem[2 * STAGE];
+    __shared__ float sStatAll[2][4 * 2 * 16];                        // per LDS stage: a tile's sums are read after the barrier
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int H = p.Hout, W = p.Wout;
+    const float* __restrict__ wsrc = reinterpret_cast<const float*>(p.w);
+    // weights -> registers.  Patch offset (r', s') multiplies filter tap (r', s') forward, (KS-1-r', KS-1-s') backward.
+    f32x4 w4[CIN == 16 ? TAPS : 1];
+    float w1[CIN == 4 ? TAPS : 1];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        const int r = t / KS, s2 = t - r * KS;
+        const int tap = MODE == 0 ? t : (KS - 1 - r) * KS + (KS - 1 - s2);
+        if (CIN == 16) w4[t] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)l15 * p.Kdim + tap * CIN + 4 * g);
+        else w1[t] = wsrc[(size_t)l15 * p.Kdim + tap * CIN + g];
+    }
+    int xpy[NXR], xpx[NXR], xc4[NXR];
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+        const int i = tid + j * 256;
+        const int pp = i / C4;
+        xc4[j] = i - pp * C4; xpy[j] = pp / PW; xpx[j] = pp - xpy[j] * PW;
+    }
+    const __amdgpu_buffer_rsrc_t bx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    u32x4 rx[NXR];
+    auto load_tile = [&](int tile) {
+        const int n = tile / tiles_per_img, tr = tile - n * tiles_per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int y0 = ty * 16, x0 = tx * 16;
+#pragma unroll
+        for (int j = 0; j < NXR; ++j) {
+            const int yy = y0 + xpy[j] - PAD, xx = x0 + xpx[j] - PAD;
+            const bool ok = tid + j * 256 < NXL && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            rx[j] = __builtin_amdgcn_raw_buffer_load_b128(bx, ok ? (unsigned)((((n * H + yy) * W + xx) * CIN + xc4[j] * 4) * 4) : OOB, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NXR; ++j)
+            if (tid + j * 256 < NXL) *reinterpret_cast<u32x4*>(&smem[buf * STAGE + (tid + j * 256) * 4]) = rx[j];
+    };
+    const int G = gridDim.x;
+    int tile = blockIdx.x, buf = 0;
+    load_tile(tile);
+    store_tile(0);
+    __syncthreads();
+    for (; tile < tiles_total; tile += G, buf ^= 1) {
+        const bool more = tile + G < tiles_total;
+        if (more) load_tile(tile + G);
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // this lane's pixel column in the wave's first patch row; channel chunk g (Cin = 16) / channel g (Cin = 4)
+        const float* xb = smem + buf * STAGE + ((wave * 4) * PW + l15) * CIN + (CIN == 16 ? 4 * g : g);
+        if constexpr (CIN == 16) {
+            f32x4 xv[2][KS];
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) xv[0][s2] = *reinterpret_cast<const f32x4*>(xb + s2 * CIN);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + 1 < NQ) {
+#pragma unroll
+                    for (int s2 = 0; s2 < KS; ++s2) xv[(q + 1) & 1][s2] = *reinterpret_cast<const f32x4*>(xb + ((q + 1) * PW + s2) * CIN);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 0; s2 < KS; ++s2)
+#pragma unroll
+                    for (int r = 0; r < KS; ++r) {
+                        const int row = q - r;                       // output row of this wave fed by patch row q through tap row r
+                        if (row >= 0 && row < 4) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[row] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r * KS + s2][j], xv[q & 1][s2][j], acc[row], 0, 0, 0);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            float xv[2][KS];
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) xv[0][s2] = xb[s2 * CIN];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + 1 < NQ) {
+#pragma unroll
+                    for (int s2 = 0; s2 < KS; ++s2) xv[(q + 1) & 1][s2] = xb[((q + 1) * PW + s2) * CIN];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 0; s2 < KS; ++s2)
+#pragma unroll
+                    for (int r = 0; r < KS; ++r) {
+                        const int row = q - r;
+                        if (row >= 0 && row < 4)
+                            acc[row] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[r * KS + s2], xv[q & 1][s2], acc[row], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // epilogue: lane = channels 4g .. 4g+3 of pixel l15 of tile rows 4w .. 4w+3
+        float* sStat = sStatAll[buf];
+        const int n = tile / tiles_per_img, tr = tile - n * tiles_per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {
+            const size_t o = ((size_t)(n * H + ty * 16 + wave * 4 + row) * W + tx * 16 + l15) * 16 + 4 * g;
+            f32x4 v = acc[row];
+            if (MODE == 1 && p.res != nullptr) {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + o);
+                v += rr;
+            }
+            if (MODE == 0 && p.stats != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+            }
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + o) = v;
+        }
+        if (MODE == 0 && p.stats != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    ssum[e] += __shfl_xor(ssum[e], off, 64);
+                    ssq[e] += __shfl_xor(ssq[e], off, 64);
+                }
+            if (l15 == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sStat[(wave * 2 + 0) * 16 + 4 * g + e] = ssum[e]; sStat[(wave * 2 + 1) * 16 + 4 * g + e] = ssq[e]; }
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();                                             // stage buf^1 complete, stage buf free, sStat visible
+        if (MODE == 0 && p.stats != nullptr) {
+            float* dst = p.stats + (size_t)(4 * tile) * 2 * 16;      // statistics rows are per 64 pixels: 4 per tile
+            if (tid < 32) {
+                const int which = tid >> 4, c = tid & 15;
+                dst[which * 16 + c] = ((sStat[(0 * 2 + which) * 16 + c] + sStat[(1 * 2 + which) * 16 + c]) + sStat[(2 * 2 + which) * 16 + c]) + sStat[(3 * 2 + which) * 16 + c];
+            } else if (tid < 128) {
+                dst[tid] = 0.f;                                      // rows 4 tile + 1 .. + 3
+            }
+        }
+    }
+}
+
+// true + launched if the layer takes the patch kernel
+template <int KS, int MODE>
+static bool try_launch_conv_patch_f32(cr_ctx* ctx, const ConvP& p, int* rc) {
+    if constexpr (KS == 1 || (KS == 7 && MODE == 1)) {
+        return false;
+    } else {
+        static const int on = env_int("CR_CONV_PATCH", 1);
+        const int cin_ok = KS == 3 ? 16 : 4;
+        if (!on || !p.f32 || p.w3 || p.cls || p.Cout != 16 || p.Cin != cin_ok || p.stride != 1 || p.pad != KS / 2 ||
+            p.Hin != p.Hout || p.Win != p.Wout || (p.Hout & 15) || (p.Wout & 15) || p.bias || p.relu || p.ksplit != 1 ||
+            (MODE == 0 && p.res) || (MODE == 1 && p.stats))
+            return false;
+        const int tiles_x = p.Wout / 16, tiles_per_img = tiles_x * (p.Hout / 16), tiles_total = tiles_per_img * p.N;
+        static const int per_cu = env_int("CR_CONV_PATCH_BLOCKS", 2);
+        const dim3 grid((unsigned)std::min(tiles_total, 256 * per_cu));
+        if (KS == 3) hipLaunchKernelGGL((k_conv_patch_f32<3, 16, MODE>), grid, dim3(256), 0, ctx->stream, p, tiles_x, tiles_per_img, tiles_total);
+        else hipLaunchKernelGGL((k_conv_patch_f32<7, 4, 0>), grid, dim3(256), 0, ctx->stream, p, tiles_x, tiles_per_img, tiles_total);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { cr_set_error("k_conv_patch_f32 launch failed: %s", hipGetErrorString(e)); *rc = CR_EHIP; }
+        else *rc = CR_OK;
+        return true;
+    }
+}
+
 template <int KS, int MODE>
 static int launch_igemm_ks(cr_ctx* ctx, const ConvP& p, int out_f32) {
     int rc_dma = CR_OK;
+    if (try_launch_conv_patch_f32<KS, MODE>(ctx, p, &rc_dma)) return rc_dma;
     if (try_launch_dma<KS, MODE>(ctx, p, out_f32, &rc_dma)) return rc_dma;
     if (p.f32) {
         // f32 MFMA runs at 1/16 of the bf16 rate: the kernels are MFMA-bound, one wave per SIMD with >= 2 independent

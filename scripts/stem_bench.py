@@ -24,6 +24,19 @@ for (N, H, W, Cin, Cout, k, st, pd) in [(4, 512, 512, 4, 16, 7, 1, 3), (4, 512, 
     Ho = (H + 2 * pd - k) // st + 1
     dy = torch.randn(N, Ho, Ho, Cout, device=dev).to(dt)
     sink = torch.zeros(Cout * Cin * k * k, device=dev)
+    w = (torch.randn(Cout, Cin, k, k, device=dev) * 0.1).contiguous(memory_format=torch.channels_last)
+    wb, wt = ops.prepared_weights(w, True, dt)
+    tf = timeit(lambda: ops.conv_fwd_raw(x, wb, Cout, k, st, pd))
+    yk = ops.conv_fwd_raw(x, wb, Cout, k, st, pd)
+    yr = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w, None, st, pd).permute(0, 2, 3, 1)
+    ef = float((yk.float() - yr).abs().max() / yr.abs().max())
+    tb, eb = float("nan"), float("nan")
+    if Cin >= 16:
+        tb = timeit(lambda: ops.conv_bwd_data_raw(dy, wt, tuple(x.shape), k, st, pd))
+        dxk = ops.conv_bwd_data_raw(dy, wt, tuple(x.shape), k, st, pd)
+        dxr = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy.float().permute(0, 3, 1, 2), stride=st, padding=pd).permute(0, 2, 3, 1)
+        eb = float((dxk.float() - dxr).abs().max() / dxr.abs().max())
+    print(f"{(N,H,W,Cin,Cout,k,st)}: fwd {tf:7.1f} us relerr {ef:.1e} | bwd-data {tb:7.1f} us relerr {eb:.1e}", flush=True)
     tw = timeit(lambda: ops.conv_bwd_weight_raw(dy, x, k, st, pd, sink=sink))
     sink.zero_()
     ops.conv_bwd_weight_raw(dy, x, k, st, pd, sink=sink)
