@@ -249,7 +249,7 @@ class TrainStep:
         self.early_ranges = early_allreduce_ranges(model, optimizer)
         self.late_ranges = complement_ranges(self.early_ranges, n, be)
         self._early_done = False
-        self.mid_ranges, self._mid_done, self._bucket = [], False, be
+        self.mid_ranges, self._mid_whole, self._mid_done, self._bucket = [], [], False, be
         self.last = {}
 
     def _mid_allreduce(self):
@@ -262,6 +262,15 @@ class TrainStep:
             for a, b in self.mid_ranges:
                 dist.all_reduce(self.opt.flat_g[a:b])
         self._mid_done = True
+
+    def _rest_ranges(self):
+        """what the phases that ran in this step's backward have NOT all-reduced yet, in buckets (cached per combination)"""
+        key = (self._early_done, self._mid_done)
+        cache = self.__dict__.setdefault("_rest_cache", {})
+        if key not in cache:
+            done = (list(self.early_ranges) if self._early_done else []) + (list(self._mid_whole) if self._mid_done else [])
+            cache[key] = complement_ranges(sorted(done), self.opt.flat_g.numel(), self._bucket) if done else self.buckets
+        return cache[key]
 
     def _early_allreduce(self):
         if self.comm_stream is None or not self.early_ranges:
@@ -300,7 +309,9 @@ class TrainStep:
             mid = [r for r in param_ranges(g.segment_params(True), opt) if r not in early]
             # bucket-sized pieces, like the other phases
             self.mid_ranges = [(x, min(x + self._bucket, b)) for a, b in mid for x in range(a, b, self._bucket)]
+            self._mid_whole = mid
             self.late_after_mid = complement_ranges(sorted(self.early_ranges + mid), opt.flat_g.numel(), self._bucket)
+            self.__dict__.pop("_rest_cache", None)
             g.mid_bwd = self._mid_allreduce
         self._early_done = self._mid_done = False
         losses.backward()
@@ -310,13 +321,7 @@ class TrainStep:
         if self.comm_stream is not None and (world > 1 or self.force_comm):
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                if self._early_done and self._mid_done:
-                    rest = self.late_after_mid
-                elif self._early_done:
-                    rest = self.late_ranges
-                else:
-                    rest = self.buckets
-                for a, b in rest:
+                for a, b in self._rest_ranges():
                     dist.all_reduce(opt.flat_g[a:b])
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         elif world > 1:                      # gloo / CPU rehearsal of the same protocol

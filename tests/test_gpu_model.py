@@ -444,6 +444,7 @@ def test_train_step_comm_protocol_single_rank_group(built):
         cover = sorted(step.early_ranges + step.mid_ranges + step.late_after_mid)
         assert cover[0][0] == 0 and cover[-1][1] == n and all(x[1] == y[0] for x, y in zip(cover, cover[1:]))
         assert sum(b - a for a, b in step.mid_ranges) > 10_000_000       # RPN head + FPN + DLA level5
+        assert step._rest_ranges() == step.late_after_mid                # the third phase = exactly what the first two left
         rep = step.report()
         assert rep["total_loss"] == rep["total_loss"] and rep["iterations_explode"] == 0, rep
         assert not torch.equal(p0, opt.flat_p)
