@@ -33,11 +33,19 @@ def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # CR_REHEARSE_ONE_GPU=1: every rank on cuda:0 with gloo collectives on the device tensors -- a functional rehearsal of the
+    # N > 1 code path (two-segment backward, three all-reduce phases, broadcast) on a one-GPU box; not a measurement
+    rehearse = os.environ.get("CR_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     return rank, world, local
 
 

@@ -138,10 +138,22 @@ def _bench_train_mode(args, rank, world, dev, prec):
         torch.cuda.synchronize(dev)
         ar = B.max_over_ranks((time.perf_counter() - t1) / 5, world, dev)
         nbytes = buf.numel() * 4
-        comm = {"world_size": world, "backend": "nccl (RCCL over xGMI), one process per GPU", "allreduce_bytes": nbytes,
+        # data-parallel invariant: every rank holds the same parameters after the timed steps (same updates from the same
+        # all-reduced gradients); max - min over ranks of a strided parameter checksum must be exactly 0
+        chk = opt.flat_p[::997].double().sum().reshape(1)
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        in_sync = bool((hi == lo).item())
+        g_ = getattr(model, "_graphed", None)
+        comm = {"world_size": world, "backend": dist.get_backend() + (" (RCCL over xGMI), one process per GPU" if dist.get_backend() == "nccl"
+                                                                      else " (one-GPU rehearsal of the N > 1 path, not a measurement)"),
+                "params_in_sync_after_run": in_sync, "two_segment_backward": bool(g_ is not None and getattr(g_, "bwd_graph2", None) is not None),
+                "allreduce_bytes": nbytes,
                 "allreduce_ms_alone": ar * 1e3, "bus_GBps": 2.0 * (world - 1) / world * nbytes / ar / 1e9,
-                "overlap": "RoI-head FC gradients (58 %) all-reduced under the trunk backward graph, loss vector under "
-                           "backward, the rest after backward"}
+                "overlap": "RoI-head FC gradients (58 %) all-reduced under the dense-region backward, RPN head + FPN + DLA "
+                           "level5 (27 %) under its second segment, loss vector under backward, the rest after backward"}
+        if not in_sync:
+            raise RuntimeError("data-parallel ranks hold different parameters after the run")
         del buf
     ins, ins_err = None, None
     try:                             # (before the micro-benchmark: the profile's last three optimizer updates are these steps)
