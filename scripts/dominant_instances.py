@@ -11,6 +11,8 @@ cut = next((i for i, r in enumerate(rows) if "unsigned short" in r[0]), len(rows
 out = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline", "phases": {}}
 for phase, part, roof in (("fp32", rows[:cut], bench["roofline"]), ("bf16", rows[cut:], bench.get("bf16_mode", {}).get("roofline", {}))):
     ends = [i for i, r in enumerate(part) if "k_sgd" in r[0]]
+    if len(ends) < 8:                                    # phase not run (CR_BENCH_BF16=0)
+        continue
     bounds = [i for k, i in enumerate(ends) if k + 1 == len(ends) or ends[k + 1] != i + 1]
     last3 = part[bounds[-4] + 1:bounds[-1] + 1]
     ph = {}
