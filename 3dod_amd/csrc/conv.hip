@@ -1293,6 +1293,116 @@ __global__ __launch_bounds__(256) void k_conv_patch_f32(ConvP p, int tiles_x, in
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_conv_patch_bwd_s2_f32: backward-data of the stem's stride-2 3x3 convolution 16 -> 32 (dx 512 x 512 x 16 from dy
+// 256 x 256 x 32) in f32.  The im2col kernel by output-parity class (k_conv_igemm<128,16,3,1>, cls) takes 78 us for 2.4 GFLOP:
+// 16-wide tiles and a gather per tap.  Here a block owns a 16 x 16 tile of dx; the 9 x 9 x 32 patch of dy it depends on is
+// staged in LDS once, as eight 4-channel planes ([chunk][row][col][4]: sixteen pixel lanes of one chunk read consecutive
+// 16-B items).  A dx pixel (y0 + 2a + ph, x0 + 2b + pw) only receives the taps r = ph + 1 (mod 2), s likewise: 1 / 2 / 2 / 4
+// taps for the four parity classes, dy pixel (a + dr, b + ds) with dr = 1 for r = 0, else 0.  MFMA column = 16 pixels of
+// one class (two a-rows x eight b); wave w takes a-rows 2w, 2w+1 of EVERY class (four accumulators, 72 MFMAs: balanced).
+//   A = transposed weights wt[ci][tap][co] in registers (lane: row ci = l & 15, k = l >> 4: co = 4g + j and 16 + 4g + j),
+//   B = dy plane chunk g / 4 + g (two ds_read_b128 per tap).  A lane ends with 4 consecutive channels of a dx pixel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv_patch_bwd_s2_f32(ConvP p, int tiles_x, int tiles_per_img, int tiles_total) {
+    constexpr int PR = 9, PLANE = PR * PR * 4, STAGE = 8 * PLANE;   // floats
+    constexpr int NXL = PR * PR * 8, NXR = (NXL + 255) / 256;       // 16-B items of a patch / per thread
+    __shared__ float smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int H = p.Hout, W = p.Wout, Hd = p.Hin, Wd = p.Win;       // dx / dy extents
+    const float* __restrict__ wsrc = reinterpret_cast<const float*>(p.w);
+    f32x4 wlo[9], whi[9];                                           // wt[ci = l15][tap][4g ..] and [16 + 4g ..]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        wlo[t] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)l15 * p.Kdim + t * 32 + 4 * g);
+        whi[t] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)l15 * p.Kdim + t * 32 + 16 + 4 * g);
+    }
+    int xrow[NXR], xcol[NXR], xch[NXR];
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+        const int i = tid + j * 256;                                 // item = (pixel, chunk), chunk fastest in global memory
+        const int pp = i >> 3;
+        xch[j] = i & 7; xrow[j] = pp / PR; xcol[j] = pp - xrow[j] * PR;
+    }
+    const __amdgpu_buffer_rsrc_t bx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    u32x4 rx[NXR];
+    auto load_tile = [&](int tile) {
+        const int n = tile / tiles_per_img, tr = tile - n * tiles_per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+#pragma unroll
+        for (int j = 0; j < NXR; ++j) {
+            const int yy = ty * 8 + xrow[j], xx = tx * 8 + xcol[j];
+            const bool ok = tid + j * 256 < NXL && yy < Hd && xx < Wd;
+            rx[j] = __builtin_amdgcn_raw_buffer_load_b128(bx, ok ? (unsigned)((((n * Hd + yy) * Wd + xx) * 32 + xch[j] * 4) * 4) : OOB, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NXR; ++j)
+            if (tid + j * 256 < NXL)
+                *reinterpret_cast<u32x4*>(&smem[buf * STAGE + xch[j] * PLANE + (xrow[j] * PR + xcol[j]) * 4]) = rx[j];
+    };
+    const int G = gridDim.x;
+    int tile = blockIdx.x, buf = 0;
+    load_tile(tile);
+    store_tile(0);
+    __syncthreads();
+    const int a = 2 * wave + (l15 >> 3), b = l15 & 7;                // this lane's pixel pair index inside the tile
+    for (; tile < tiles_total; tile += G, buf ^= 1) {
+        const bool more = tile + G < tiles_total;
+        if (more) load_tile(tile + G);
+        // planes g (channels 4g ..) and 4 + g (16 + 4g ..) at dy pixel (a, b) of the patch
+        const float* plo = smem + buf * STAGE + g * PLANE + (a * PR + b) * 4;
+        const float* phi = plo + 4 * PLANE;
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the four dy pixels a lane ever needs: (a + dr, b + ds), dr, ds in {0, 1}
+        f32x4 dlo[2][2], dhi[2][2];
+#pragma unroll
+        for (int dr = 0; dr < 2; ++dr)
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                dlo[dr][ds] = *reinterpret_cast<const f32x4*>(plo + (dr * PR + ds) * 4);
+                dhi[dr][ds] = *reinterpret_cast<const f32x4*>(phi + (dr * PR + ds) * 4);
+            }
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2) {
+                        // dx row 2a + ph takes tap r iff (2a + ph + 1 - r) is even: r = ph + 1 (mod 2); dy row a + (ph + 1 - r) / 2
+                        if (((ph + 1 - r) & 1) == 0 && ((pw + 1 - s2) & 1) == 0) {
+                            const int dr = (ph + 1 - r) / 2, ds = (pw + 1 - s2) / 2;      // 0 or 1 (r = 0 -> 1 for ph = 1)
+                            const int t = r * 3 + s2, c = ph * 2 + pw;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wlo[t][j], dlo[dr][ds][j], acc[c], 0, 0, 0);
+                                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(whi[t][j], dhi[dr][ds][j], acc[c], 0, 0, 0);
+                            }
+                        }
+                    }
+        const int n = tile / tiles_per_img, tr = tile - n * tiles_per_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int pw = 0; pw < 2; ++pw) {
+                const size_t o = ((size_t)(n * H + ty * 16 + 2 * a + ph) * W + tx * 16 + 2 * b + pw) * 16 + 4 * g;
+                f32x4 v = acc[ph * 2 + pw];
+                if (p.res != nullptr) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + o);
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + o) = v;
+            }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+}
+
 // true + launched if the layer takes the patch kernel
 template <int KS, int MODE>
 static bool try_launch_conv_patch_f32(cr_ctx* ctx, const ConvP& p, int* rc) {
@@ -1425,6 +1535,16 @@ extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, v
     p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim; p.cls = 0; p.Hfull = p.Hout; p.Wfull = p.Wout; p.wstride = p.Kdim;
     p.x_bytes = (unsigned)((size_t)N * Ho * Wo * Cout * es); p.w_bytes = (unsigned)((size_t)Cin * p.Kdim * es);
     p.w3 = (act_f32 == 2 && (p.Kdim & 31) == 0) ? wt_split : nullptr; p.w3_bytes = (unsigned)((size_t)Cin * p.Kdim * 6);
+    static const int patch_s2 = env_int("CR_CONV_PATCH", 1);
+    if (patch_s2 && act_f32 && stride == 2 && ks == 3 && pad == 1 && Cout == 32 && Cin == 16 && (H & 15) == 0 && (W & 15) == 0 &&
+        Ho * 2 == H && Wo * 2 == W) {
+        const int tiles_x = W / 16, tiles_per_img = tiles_x * (H / 16), tiles_total = tiles_per_img * N;
+        static const int per_cu = env_int("CR_CONV_PATCH_BLOCKS", 2);
+        const dim3 grid((unsigned)std::min(tiles_total, 256 * per_cu));
+        hipLaunchKernelGGL(k_conv_patch_bwd_s2_f32, grid, dim3(256), 0, ctx->stream, p, tiles_x, tiles_per_img, tiles_total);
+        CR_LAUNCH_CHECK();
+        return CR_OK;
+    }
     static const int cls_on = env_int("CR_BWD_S2_CLASSES", 1);
     if (cls_on && stride == 2 && ks == 3 && (H & 1) == 0 && (W & 1) == 0 && (Cout & (act_f32 ? 15 : 31)) == 0) {
         // by output-pixel parity class (see ConvP): H/2 x W/2 pixels per class, 4 classes in one grid
