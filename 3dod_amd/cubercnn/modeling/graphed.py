@@ -76,6 +76,7 @@ class _Replay(torch.autograd.Function):
     def forward(ctx, runner, trigger):
         runner.fwd_graph.replay()
         ctx.runner = runner
+        ctx.set_materialize_grads(False)       # an output nobody differentiates arrives as None (one fill below, not fill + copy)
         return tuple(o.detach() for o in runner.static_outs)
 
     @staticmethod
