@@ -19,6 +19,7 @@
 
 __device__ __forceinline__ unsigned tk_key(float v) {
     const unsigned u = __float_as_uint(v);
+    if (v != v) return 0xffffffffu;                              // every NaN (either sign) is the largest value, like torch.topk
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // ascending uint order == ascending float order
 }
 __device__ __forceinline__ float tk_val(unsigned k) {

@@ -22,23 +22,48 @@ def capture_guard():
     a capture aborts the process on ROCm 7.2 (seen once as `Fatal Python error: Aborted ... Garbage-collecting`)."""
     was = gc.isenabled()
     gc.collect()
+    _empty_graveyard()
     gc.disable()
+    keep, prev = [], ops._PLAN_KEEP[0]
+    ops._PLAN_KEEP[0] = keep       # objects whose buffers the captured kernels point into; the owner stores the list
     try:
-        yield
+        yield keep
     finally:
+        ops._PLAN_KEEP[0] = prev
         if was:
             gc.enable()
+        _empty_graveyard()
+
+
+_GRAVEYARD = []      # state of graph owners whose destructor ran while a capture was open; emptied outside captures
+
+
+def _bury_or_drain(owner):
+    if owner.dev is None:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        # destroying a graph (or waiting for the device) inside an open capture invalidates it / aborts on ROCm 7.2: keep
+        # the dead owner's graphs and buffers alive until the capture has closed (capture_guard empties the list)
+        _GRAVEYARD.append(dict(owner.__dict__))
+        return
+    torch.cuda.synchronize(owner.dev)
+
+
+def _empty_graveyard():
+    if _GRAVEYARD and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
+        _GRAVEYARD.clear()
 
 
 class GraphOwner:
     """Base of the objects that own captured graphs: replays may still be in flight when the last reference goes away
-    (run-ahead steps); the device is drained before the graphs are destroyed."""
+    (run-ahead steps); the device is drained before the graphs are destroyed.  A destructor that runs while a stream
+    capture is open (an explicit gc.collect(), a reference dropped by captured code) parks the graphs instead."""
     dev = None
 
     def __del__(self):
         try:
-            if self.dev is not None:
-                torch.cuda.synchronize(self.dev)
+            _bury_or_drain(self)
         except Exception:
             pass
 
@@ -187,6 +212,13 @@ class GraphedDense(GraphOwner):
                 if g is not None:
                     ops.grad_sink(p).add_(g)
 
+        # the warm-up and capture passes below run the BatchNorm layers in training mode: their running statistics are
+        # put back afterwards, so capturing a shape in the middle of a run (RCNN3D._train_graph_for) leaves no trace
+        bn_state = [(m, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone())
+                    for mod in mods for m in mod.modules()
+                    if isinstance(m, nn.BatchNorm2d) and m.running_mean is not None]
+        # the weight bank whose buffers the captured kernels read (FlatSGD keeps one bank per precision mode alive)
+        self.bank = next((getattr(p, "_cr_bank")[0] for mod in mods for p in mod.parameters() if hasattr(p, "_cr_bank")), None)
         # ---- eager warm-up on a side stream (allocator / lazy-init effects out of the capture)
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
@@ -203,7 +235,7 @@ class GraphedDense(GraphOwner):
 
         # ---- capture.  The bf16 weight copies must be re-made INSIDE the graphs on every replay.
         ops.bump_weight_epoch()
-        with capture_guard(), _fresh_leaves(mods):
+        with capture_guard() as self._keep, _fresh_leaves(mods):
             self.fwd_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.fwd_graph):
                 self.static_outs = dense()
@@ -219,10 +251,17 @@ class GraphedDense(GraphOwner):
             hook.remove()
         cut.clear()
         torch.cuda.synchronize(dev)
+        for m, a, b, c in bn_state:
+            m.running_mean.copy_(a); m.running_var.copy_(b); m.num_batches_tracked.copy_(c)
+        self._bank_param = next((p for mod in mods for p in mod.parameters() if hasattr(p, "_cr_bank")), None)
 
     def matches(self, images_u8):
+        """same batch shape, device and precision mode, and the weight bank the graphs were captured against is still the
+        one attached to the parameters (a bank rebuilt by the optimizer means new compute-copy buffers)"""
+        bp = self._bank_param
+        bank_now = getattr(bp, "_cr_bank", (None,))[0] if bp is not None else None
         return (tuple(images_u8.shape) == self.shape and images_u8.device == self.static_img.device
-                and ops.precision() == self.dtype)
+                and ops.precision() == self.dtype and bank_now is self.bank)
 
     def __call__(self, images_u8):
         self.static_img.copy_(images_u8)
@@ -263,7 +302,7 @@ class GraphedDenseEval(GraphOwner):
         torch.cuda.synchronize(dev)
         ops.bump_weight_epoch()          # the bf16 weight copies are made inside the graph (cheap; weights may change)
         self.graph = torch.cuda.CUDAGraph()
-        with capture_guard(), torch.no_grad(), torch.cuda.graph(self.graph):
+        with capture_guard() as self._keep, torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_outs = dense()
         torch.cuda.synchronize(dev)
 

@@ -43,20 +43,61 @@ class RCNN3D(nn.Module):
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
         self._graphed = None
+        self._graphed_cache, self._graphed_max, self._graphed_split = None, 0, False
         self._graphed_eval = None
         self._graphed_eval_cache, self._graphed_eval_max = None, 0
         # static-shape training path (modeling/dense_train.py): same rules, no host<->device syncs
         self.dense_train = True
 
-    def enable_graphs(self, sample_batched_inputs, split_backward=False):
-        """capture the static dense region (trunk + FPN + RPN head, forward and backward) as HIP graphs for the
-        image-batch shape of `sample_batched_inputs`.  Call after the optimizer (FlatSGD) has been built.
+    def enable_graphs(self, sample_batched_inputs=None, split_backward=False, max_shapes=0):
+        """capture the static dense region (trunk + FPN + RPN head, forward and backward) as HIP graphs.  Call after the
+        optimizer (FlatSGD) has been built.
+        sample_batched_inputs: capture now for this image-batch shape.
+        max_shapes > 0: additionally keep one captured region per image-batch shape met in training, captured on first sight
+        and kept for the `max_shapes` most recently used shapes (what `do_train` turns on: with INPUT.MIN_SIZE_TRAIN a run
+        meets a handful of padded resolutions).  A batch whose images differ in size, or any shape beyond the cache when
+        max_shapes == 0, runs eagerly.
         split_backward: two backward graphs, so that a data-parallel step all-reduces the first segment's gradients under
         the second (graphed.GraphedDense)."""
+        from collections import OrderedDict
         from ..graphed import GraphedDense
-        il, batch = self._stack_images(sample_batched_inputs)
-        self._graphed = GraphedDense(self, batch, split_backward=split_backward)
+        self._graphed_max, self._graphed_split = int(max_shapes), bool(split_backward)
+        if self._graphed_cache is None:
+            self._graphed_cache = OrderedDict()
+        if sample_batched_inputs is not None:
+            il, batch = self._stack_images(sample_batched_inputs)
+            self._graphed = GraphedDense(self, batch, split_backward=split_backward)
+            if self._graphed_max > 0:
+                self._graphed_cache[(self._graphed.shape, ops.precision())] = self._graphed
         return self._graphed
+
+    def disable_graphs(self):
+        """back to eager launches of the dense region (captured graphs are dropped)"""
+        self._graphed, self._graphed_cache, self._graphed_max = None, None, 0
+
+    def _train_graph_for(self, batch):
+        """the captured dense region for this uint8 image batch: the one used last, one from the per-shape cache, or a new
+        capture if the cache is on (least recently used shape evicted)"""
+        g = self._graphed
+        if g is not None and g.matches(batch):
+            return g
+        cache = self._graphed_cache
+        if not self._graphed_max or cache is None:
+            return None
+        key = (tuple(batch.shape), ops.precision())
+        g = cache.get(key)
+        if g is not None and not g.matches(batch):            # e.g. the optimizer's weight bank was rebuilt: capture again
+            del cache[key]
+            g = None
+        if g is None:
+            from ..graphed import GraphedDense
+            while len(cache) >= self._graphed_max:
+                cache.popitem(last=False)
+            g = cache[key] = GraphedDense(self, batch, split_backward=self._graphed_split)
+        else:
+            cache.move_to_end(key)
+        self._graphed = g
+        return g
 
     def enable_graphs_eval(self, sample_batched_inputs=None, max_shapes=0):
         """eval-mode counterpart of enable_graphs: forward-only graph of preprocess + trunk + FPN + RPN head for the
@@ -131,16 +172,15 @@ class RCNN3D(nn.Module):
         if not self.training:
             return self.inference(batched_inputs)
         head_outputs = None
-        g = self._graphed
-        if g is not None:
+        g = None
+        if self._graphed is not None or self._graphed_max:
             images, batch = self._stack_images(batched_inputs)
-            same = all(tuple(sz) == tuple(batch.shape[-2:]) for sz in images.image_sizes)
-            if same and g.matches(batch):
+            if all(tuple(sz) == tuple(batch.shape[-2:]) for sz in images.image_sizes):
+                g = self._train_graph_for(batch)
+            if g is not None:
                 from ..dense_train import RawRPNOutputs
                 features, ys = g(batch)
                 head_outputs = RawRPNOutputs(ys)
-            else:
-                g = None
         if g is None:
             images, x = self.preprocess_image(batched_inputs)
             features = self.backbone(x)

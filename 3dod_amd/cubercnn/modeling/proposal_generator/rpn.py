@@ -68,7 +68,7 @@ def find_top_rpn_proposals(proposals, pred_objectness_logits, image_sizes, nms_t
     boxes_pad = proposals[0].new_zeros((num_images, L, maxn, 4))
     scores_pad = proposals[0].new_full((num_images, L, maxn), float("-inf"))
     for l, (props, logits, k) in enumerate(zip(proposals, pred_objectness_logits, ks)):
-        topk_scores, topk_idx = logits.topk(k, dim=1)
+        topk_scores, topk_idx = ops.topk(logits.float(), k)        # csrc/topk.hip (ties -> lower index, like a stable sort)
         boxes_pad[:, l, :k] = torch.gather(props, 1, topk_idx[:, :, None].expand(-1, -1, 4))
         scores_pad[:, l, :k] = topk_scores
     ckey = (tuple(tuple(s) for s in image_sizes), tuple(ks), str(device))
@@ -90,7 +90,7 @@ def find_top_rpn_proposals(proposals, pred_objectness_logits, image_sizes, nms_t
     flat_scores = torch.where(keep, scores_pad, torch.full((), float("-inf"), device=device)).view(num_images, -1)
     flat_boxes = boxes_pad.view(num_images, -1, 4)
     k_post = min(post_nms_topk, flat_scores.shape[1])
-    top_scores, top_idx = flat_scores.topk(k_post, dim=1)
+    top_scores, top_idx = ops.topk(flat_scores, k_post)
     if padded:       # fixed-shape result for the sync-free training path: empty slots carry score -inf
         return torch.gather(flat_boxes, 1, top_idx[:, :, None].expand(-1, -1, 4)), top_scores
     n_keep = keep.view(num_images, -1).sum(1).clamp(max=k_post).tolist()                 # one host sync

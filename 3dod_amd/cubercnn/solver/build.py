@@ -118,15 +118,27 @@ class FlatSGD:
             self._lr_dev_value = self._lr_scale
 
     def enable_weight_bank(self):
-        """one-launch-per-step bf16 recast of every conv weight (hipops.WeightBank); training-step objects call this."""
-        bank = getattr(self, "weight_bank", None)
-        if self.flat_p.is_cuda and hasattr(ops, "WeightBank") and (bank is None or getattr(bank, 'mode', None) != ops.precision()):
+        """one-launch-per-step recast / transpose of every conv weight (hipops.WeightBank); training-step objects call this.
+        One bank PER PRECISION MODE is kept alive for the optimizer's life: captured graphs (GraphedDense, GraphedTrainStep)
+        have the bank's buffer addresses baked in, so going fp32 -> bf16 -> fp32 re-attaches the same fp32 bank instead of
+        freeing and re-allocating it under the graphs."""
+        if not (self.flat_p.is_cuda and hasattr(ops, "WeightBank")):
+            return getattr(self, "weight_bank", None)
+        banks = self.__dict__.setdefault("_banks", {})
+        mode = ops.precision()
+        bank = banks.get(mode)
+        if bank is None:
             convs = [p for p in self.params if p.dim() == 4 and p.shape[2] == p.shape[3] and
                      p.is_contiguous(memory_format=torch.channels_last)]
-            if convs:
-                self.weight_bank = ops.WeightBank(convs, self.flat_p)     # in the precision mode of the process
-                ops.bump_weight_epoch()
-        return getattr(self, "weight_bank", None)
+            if not convs:
+                return None
+            bank = banks[mode] = ops.WeightBank(convs, self.flat_p)     # in the precision mode of the process
+            ops.bump_weight_epoch()
+        elif getattr(self, "weight_bank", None) is not bank:
+            bank.attach()
+            ops.bump_weight_epoch()
+        self.weight_bank = bank
+        return bank
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -462,7 +474,7 @@ class GraphedTrainStep(_GraphOwner):
                 t.copy_(v)
         restore()
         ops.bump_weight_epoch()
-        with capture_guard(), _fresh_leaves([model]):
+        with capture_guard() as self._keep, _fresh_leaves([model]):
             self.graph_a = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a):
                 fwd_bwd()

@@ -216,6 +216,22 @@ class PeriodicCheckpointerOnlyOne:
             self.checkpointer.save(f"{self.file_prefix}_final", iteration=iteration, **kwargs)
 
 
+def make_train_step(cfg, model, optimizer, world_size=1):
+    """The step object `do_train` runs (and `bench.py` times): `TrainStep` with the dense region (preprocess, trunk, FPN,
+    RPN head: forward and backward) replayed from HIP graphs, one captured region per image-batch shape met, captured on
+    first sight and kept for the CR_GRAPH_SHAPES (8) most recently used shapes -- the eager dense region is ~500 launches
+    and bound by the host's launch rate.  Data-parallel runs capture the backward as two graphs so that the first
+    segment's gradient all-reduce travels under the second (graphed.GraphedDense).  CR_GRAPHS=none: eager launches.
+    Batches whose images differ in size run eagerly (the padded border is masked after normalisation)."""
+    step = TrainStep(cfg, model, optimizer, world_size=world_size)
+    mode = os.environ.get("CR_GRAPHS", "dense")
+    dev = optimizer.flat_p.device
+    if mode != "none" and dev.type == "cuda" and getattr(model, "dense_train", False) and hasattr(model, "enable_graphs"):
+        model.enable_graphs(None, split_backward=world_size > 1 and os.environ.get("CR_BWD_SPLIT", "1") != "0",
+                            max_shapes=int(os.environ.get("CR_GRAPH_SHAPES", "8")))
+    return step
+
+
 def do_train(cfg, model, data_loader, resume=False, world_size=None, rank=None, do_test=None, check_period=20):
     """tools/train_net.py:127-333.  `data_loader`: iterable of per-rank batches (build_detection_train_loader, ideally
     wrapped in DevicePrefetcher).  Returns True on success, False when the run should be restarted from the last
@@ -229,7 +245,7 @@ def do_train(cfg, model, data_loader, resume=False, world_size=None, rank=None, 
     model.train()
     optimizer = build_optimizer(cfg, model)
     scheduler = build_lr_scheduler(cfg, optimizer)
-    step = TrainStep(cfg, model, optimizer, world_size=world_size)
+    step = make_train_step(cfg, model, optimizer, world_size=world_size)
     checkpointer = Checkpointer(model, cfg.OUTPUT_DIR, optimizer=optimizer, scheduler=scheduler, step=step,
                                 save_to_disk=rank == 0)
     periodic = PeriodicCheckpointerOnlyOne(checkpointer, cfg.SOLVER.CHECKPOINT_PERIOD, max_iter=max_iter)

@@ -20,10 +20,14 @@ def deconv_ks(x, m):
     assert m.stride[0] == k and m.padding[0] == 0
     B, h, w, Cin = x.shape
     Cout = m.weight.shape[1]
-    wm = m.weight.detach().permute(0, 2, 3, 1).reshape(Cin, k * k * Cout).to(torch.bfloat16)
-    y = torch.mm(x.reshape(B * h * w, Cin), wm).view(B, h, w, k, k, Cout)
-    if m.bias is not None:
-        y = y + m.bias.detach().to(torch.bfloat16)
+    # the GEMM operand (k*k*Cout, Cin) and the bias repeated per patch position are cached on the module per weight version
+    ent = getattr(m, "_cr_deconv", None)
+    tag = (m.weight._version, m.weight.data_ptr(), None if m.bias is None else m.bias._version)
+    if ent is None or ent[0] != tag:
+        wm = m.weight.detach().permute(2, 3, 1, 0).reshape(k * k * Cout, Cin).to(torch.bfloat16).contiguous()
+        bias = None if m.bias is None else m.bias.detach().float().repeat(k * k).contiguous()
+        ent = m._cr_deconv = (tag, wm, bias)
+    y = ops.linear_fwd_raw(x.reshape(B * h * w, Cin), ent[1], ent[2]).view(B, h, w, k, k, Cout)      # cr_linear_fwd
     return y.permute(0, 1, 3, 2, 4, 5).reshape(B, h * k, w * k, Cout).contiguous()
 
 

@@ -208,7 +208,12 @@ class WeightBank:
                 for (soff, d3, _, rows, K, i) in recs[which]:
                     self.views[i][which]._cr_w3 = ("bank", self.w3[d3:d3 + rows * K * 3])
         self.epoch = None
-        for i, p in enumerate(params):
+        self.params = list(params)
+        self.attach()
+
+    def attach(self):
+        """make this bank the one the parameters' compute copies come from (FlatSGD keeps one bank per precision mode)"""
+        for i, p in enumerate(self.params):
             p._cr_bank = (self, i)
 
     def get(self, i):
@@ -1117,7 +1122,10 @@ class _CatPlan:
         return self.wt[dtype]
 
 
-_CAT_PLANS = {}
+import collections as _collections
+_CAT_PLANS = _collections.OrderedDict()      # least recently used plans are dropped beyond _CAT_PLANS_MAX
+_CAT_PLANS_MAX = 64
+_PLAN_KEEP = [None]     # a list while a graph capture is open (graphed.capture_guard): the plans the captured kernels point into
 
 
 def _cat_plan(weights, biases):
@@ -1134,6 +1142,12 @@ def _cat_plan(weights, biases):
         if torch.cuda.is_current_stream_capturing():
             raise _lib.CrError("linear_cat: the stacked-predictor plan must be built before graph capture (run one eager step)")
         plan = _CAT_PLANS[key] = _CatPlan(weights, biases)
+        while len(_CAT_PLANS) > _CAT_PLANS_MAX:
+            _CAT_PLANS.popitem(last=False)
+    else:
+        _CAT_PLANS.move_to_end(key)
+    if _PLAN_KEEP[0] is not None:
+        _PLAN_KEEP[0].append(plan)          # the graph owner keeps the plan (its raw buffers) alive past an eviction
     return plan
 
 
@@ -1572,6 +1586,12 @@ def topk(x, k):
     lib = _lib.load()
     nb = lib.cr_topk_blocks(n, k) if k >= 1 else 0
     if k < 1 or k > 2048 or k > n or nb * k > 16384:
+        if torch.cuda.is_current_stream_capturing():
+            # torch.topk's multi-block path zeroes its counters with hipMemsetAsync = memset NODES in the captured graph,
+            # the cause of the memory faults between back-to-back replays of the whole-step graph
+            raise _lib.CrError(f"topk: rows of {n} values with k = {k} are outside the range of csrc/topk.hip (k <= 2048, "
+                               f"chunks x k <= 16384) and the torch.topk fallback must not be captured into a HIP graph; "
+                               f"run this configuration with CR_GRAPHS=dense or none")
         return x.topk(k, dim=1)
     xc = x.contiguous()
     ws = torch.empty((rows * nb * k,), dtype=torch.int64, device=x.device)

@@ -103,15 +103,19 @@ def pmc_traffic(fname, kernel_prefix):
         return None
 
 
-def bench_geometry(args, rank, world, dev):
+def bench_geometry(args, rank, world, dev, argmax_only=False, inp=None, cpu_baseline=True):
+    """argmax_only: the AP path of roi_heads.py:501-505 -- only the best cube's index and score leave the kernel
+    (60 B/cube read, O(1) per object written); default: corners, boxes and the four score planes are written too (156 B/cube)"""
     geo = importlib.import_module("3dod_amd.geometry")
     n_img, n_obj_img, P = 64, 16, 1000
     n_obj = n_img * n_obj_img
-    inp = geometry_inputs(n_obj, P, 1234 + rank, dev)
+    if inp is None:
+        inp = geometry_inputs(n_obj, P, 1234 + rank, dev)
+    want = () if argmax_only else ("corners", "boxes", "iou", "dim", "corner", "combined")
 
     def step():
         return geo.cubes_project_score(inp["cubes"], inp["K"], inp["im_wh"], inp["ref"], inp["mu"], inp["sg"],
-                                       inp["rect"])
+                                       inp["rect"], want=want)
     for _ in range(args.warmup):
         step()
     barrier(world)
@@ -127,22 +131,29 @@ def bench_geometry(args, rank, world, dev):
     kern_ms = ev0.elapsed_time(ev1) / args.steps       # events on the stream the kernel is launched on
     cubes_total = n_obj * P * world
     value = cubes_total * args.steps / dt
-    bytes_per_cube = 60 + 64 + 16 + 16               # read 60 B + corners 64 + box 16 + 4 score planes
+    bytes_per_cube = 60 if argmax_only else 60 + 64 + 16 + 16    # read 60 B (+ corners 64 + box 16 + 4 score planes)
     achieved = bytes_per_cube * n_obj * P / (kern_ms * 1e-3) / 1e9
     res = {
-        "metric": "cubes/sec ProposalNetwork 1000-cube project+score+argmax (BASELINE configs[2])",
+        "metric": "cubes/sec ProposalNetwork 1000-cube project+score+argmax (BASELINE configs[2])"
+                  + (", argmax-only outputs" if argmax_only else ""),
         "value": value, "unit": "cubes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "geometry: 64 images x 16 objects x 1000 cubes per GPU, full outputs (156 B/cube), one launch",
+        "config": {"workload": "geometry: 64 images x 16 objects x 1000 cubes per GPU, "
+                               + ("argmax + best score only (60 B/cube)" if argmax_only else "full outputs (156 B/cube)") + ", one launch",
                    "objects_per_gpu": n_obj, "proposals": P, "parallelism": f"objects sharded x{world}, no collective"},
-        "roofline": {"bound": "hbm", "kernel": "k_project_score<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("r02_pmc_geometry_traffic.json", "k_project_score"),
+        "roofline": {"bound": "hbm", "kernel": GEOMETRY_KERNEL[argmax_only], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic(GEOMETRY_PMC[argmax_only], "k_project_score"),
                      "algorithmic_bytes_per_launch": bytes_per_cube * n_obj * P, "kernel_ms": kern_ms},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and cpu_baseline and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_geometry(inp, P)
     return res
+
+
+GEOMETRY_KERNEL = {False: "k_project_score<4>", True: "k_project_score<4> (no output planes)"}
+GEOMETRY_PMC = {False: "r02_pmc_geometry_traffic.json", True: "r03_pmc_geometry_argmax_traffic.json"}
 
 
 def cpu_baseline_geometry(inp, P):
@@ -189,8 +200,10 @@ def bench_inference(args, rank, world, dev):
     gflop_img = 116.8                    # 58.4 GMAC per 512x512 image with 1000 RoIs
     ach = gflop_img * B / (dt / args.steps) / 1e3
     res = _inference_result(args, world, B, dt, n_det, prec, ach, bt.MFMA_PEAK[prec], gflop_img)
+    del model, opt
+    torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = bt.cpu_baseline_train(inference=True)
+        res["cpu_baseline"] = bt.cpu_baseline_train(inference=True, steps=getattr(args, "cpu_steps", None))
     return res
 
 
@@ -469,6 +482,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="train", choices=["train", "geometry", "inference", "weak", "depth", "boxnet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-only", action="store_true", help="train workload without the geometry / inference keys")
+    ap.add_argument("--lean", action="store_true", help="headline measurement only (no eager / do_train / other-precision lines)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 200 if args.workload == "geometry" else 20
@@ -490,7 +505,22 @@ def main():
         bt = importlib.import_module("bench_train")
         res = bt.bench_train(args, rank, world, dev)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = bt.cpu_baseline_train()
+            res["cpu_baseline"] = bt.cpu_baseline_train(steps=2)
+        if world == 1 and not args.train_only:
+            # the other two workloads north_star names, in the SAME line (labelled keys; each with its own roofline and
+            # cpu_baseline): the 1000-cube geometry (BASELINE configs[2]; full outputs and the argmax-only AP path) and
+            # detector inference at 8 x 512 x 512 (configs[1]).  `value` above stays the train step.
+            sub = argparse.Namespace(**vars(args))
+            keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "cpu_baseline")
+            for key, fn, st, wu, kw in (("geometry", bench_geometry, 200, 20, {}),
+                                        ("geometry_argmax_only", bench_geometry, 200, 20, {"argmax_only": True, "cpu_baseline": False}),
+                                        ("inference", bench_inference, 20, 5, {})):
+                sub.steps, sub.warmup, sub.cpu_steps = st, wu, 1
+                try:
+                    r = fn(sub, rank, world, dev, **kw)
+                    res[key] = {k: r[k] for k in keep if k in r}
+                except Exception as e:            # never lose the headline to a secondary workload
+                    res[key] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

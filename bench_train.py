@@ -56,11 +56,16 @@ def bench_train(args, rank, world, dev):
                        "accuracy, opt-in: CR_PRECISION=fp32x3); not the headline",
              "bf16": "same step with bf16 activations / operands (fast mode, opt-in); not the headline; deviation from "
                      "the fp32 mode bounded by tests/test_gpu_precision_parity.py"}
-    if main_prec == "fp32" and world == 1 and os.environ.get("CR_BENCH_BF16", "1") == "1":
+    if world == 1 and os.environ.get("CR_BENCH_DO_TRAIN", "1") == "1" and not getattr(args, "lean", False):
+        try:
+            res["do_train_loop"] = bench_do_train(args, rank, world, dev)
+        except Exception as e:           # never lose the headline to a secondary measurement
+            res["do_train_loop"] = {"error": f"{type(e).__name__}: {e}"}
+    if main_prec == "fp32" and world == 1 and os.environ.get("CR_BENCH_BF16", "1") == "1" and not getattr(args, "lean", False):
         for extra in ("fp32x3", "bf16"):
             prev = ops.set_precision(extra)
             try:
-                fast = _bench_train_mode(args, rank, world, dev, extra)
+                fast = _bench_train_mode(args, rank, world, dev, extra, is_main=False)
                 res[extra + "_mode"] = {k: fast[k] for k in ("value", "unit", "ms_per_step", "dtype", "roofline")}
                 res[extra + "_mode"]["note"] = notes[extra]
                 res[extra + "_mode"]["final_loss"] = fast["config"]["final_loss"]
@@ -70,7 +75,7 @@ def bench_train(args, rank, world, dev):
     return res
 
 
-def _bench_train_mode(args, rank, world, dev, prec):
+def _bench_train_mode(args, rank, world, dev, prec, is_main=True):
     import bench as B
     peak = MFMA_PEAK[prec]
     cfg, model, opt, syn, solver = build(dev, world=world)
@@ -84,7 +89,9 @@ def _bench_train_mode(args, rank, world, dev, prec):
         for d in b:
             d["image"] = d["image"].to(dev)
             d["instances"] = d["instances"].to(dev)
-    mode = os.environ.get("CR_GRAPHS", "dense")         # dense (default) | step (whole-step graphs, opt-in) | none
+    # launch mode = the product's: solver.make_train_step is what do_train (tools/train_net.py) runs -- TrainStep with the
+    # dense region replayed from per-shape HIP graphs (CR_GRAPHS=dense, the default) | step (whole-step graphs, opt-in) | none
+    mode = os.environ.get("CR_GRAPHS", "dense")
     step = None
     if mode == "step":
         try:
@@ -95,12 +102,14 @@ def _bench_train_mode(args, rank, world, dev, prec):
             print(f"[bench] whole-step graph capture failed ({type(e).__name__}: {e}); falling back", file=sys.stderr, flush=True)
             mode = "dense"
     if step is None:
-        step = solver.TrainStep(cfg, model, opt, world_size=world)
-        if mode == "dense":
-            # data-parallel runs: two backward graphs, the first segment's gradients are all-reduced under the second
-            split = os.environ.get("CR_BWD_SPLIT", "1")            # 1: when data-parallel | 0: never | force: also on one GPU (A/B)
-            model.enable_graphs(batches[0], split_backward=(world > 1 and split == "1") or split == "force")
-            opt.zero_grad()
+        if mode == "step":
+            mode = "dense"
+        # data-parallel runs: two backward graphs, the first segment's gradients are all-reduced under the second
+        step = solver.make_train_step(cfg, model, opt, world_size=world)
+        if os.environ.get("CR_BWD_SPLIT") == "force" and mode == "dense":            # A/B: the two-segment backward on one GPU
+            model.enable_graphs(None, split_backward=True, max_shapes=8)
+        with d2.EventStorage(0):
+            step(batches[0])                            # first sight of the batch shape: the dense region is captured here
     trace = os.environ.get("CR_TRACE") == "1"
     def note(msg):
         if trace:
@@ -155,6 +164,27 @@ def _bench_train_mode(args, rank, world, dev, prec):
         if not in_sync:
             raise RuntimeError("data-parallel ranks hold different parameters after the run")
         del buf
+    eager = None
+    if world == 1 and mode != "none" and is_main and os.environ.get("CR_BENCH_EAGER", "1") == "1" \
+            and not getattr(args, "lean", False):
+        # the same step with every kernel launched eagerly (CR_GRAPHS=none): what the dense-region graphs buy
+        saved = (model._graphed, model._graphed_cache, model._graphed_max)
+        model._graphed, model._graphed_cache, model._graphed_max = None, None, 0
+        try:
+            n_e = max(1, min(10, args.steps))
+            with d2.EventStorage(0):
+                for i in range(2):
+                    step(batches[i % len(batches)])
+                B.barrier(world)
+                t1 = time.perf_counter()
+                for i in range(n_e):
+                    step(batches[i % len(batches)])
+                B.barrier(world)
+                e_dt = (time.perf_counter() - t1) / n_e
+            eager = {"ms_per_step": e_dt * 1e3, "value": IMS_PER_GPU / e_dt, "unit": "images/s", "steps": n_e,
+                     "launch_mode": "eager (CR_GRAPHS=none): every kernel of the dense region enqueued by the host"}
+        finally:
+            model._graphed, model._graphed_cache, model._graphed_max = saved
     ins, ins_err = None, None
     try:                             # (before the micro-benchmark: the profile's last three optimizer updates are these steps)
         with d2.EventStorage(0):
@@ -190,7 +220,10 @@ def _bench_train_mode(args, rank, world, dev, prec):
                                "Base_Omni3D.yaml semantics (BASELINE configs[3] per-GPU shard)",
                    "global_batch": IMS_PER_GPU * world, "parallelism": f"dp{world}", "base_lr": cfg.SOLVER.BASE_LR,
                    "precision": PRECISION_TEXT[prec],
-                   "launch_mode": {"step": "whole-step HIP graphs", "dense": "dense-region HIP graphs", "none": "eager"}[mode],
+                   "launch_mode": {"step": "whole-step HIP graphs (solver.GraphedTrainStep, opt-in)",
+                                   "dense": "solver.make_train_step = the step object of do_train / tools/train_net.py: dense region "
+                                            "(preprocess, trunk, FPN, RPN head; forward and backward) replayed from per-shape HIP graphs",
+                                   "none": "eager"}[mode],
                    "final_loss": rep.get("total_loss"), "skipped_steps": rep.get("iterations_explode"),
                    "valid": bool(rep.get("iterations_explode") == 0 and rep.get("total_loss") == rep.get("total_loss")),
                    "comm": comm},
@@ -198,9 +231,67 @@ def _bench_train_mode(args, rank, world, dev, prec):
                                            "frac": achieved_tf / peak,
                                            "algorithmic_gflop_per_step": TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU}),
     }
+    if eager is not None:
+        res["eager"] = eager
     del step, model, opt
     torch.cuda.empty_cache()
     return res
+
+
+def bench_do_train(args, rank, world, dev):
+    """The product's own loop: `solver.do_train` (what tools/train_net.py calls) for warmup + steps + 1 iterations on host-resident
+    uint8 batches fed through `data.DevicePrefetcher` -- pinned staging and the H2D copy of batch i+1 on a side stream under
+    step i, LR schedule, the periodic host check of the divergence counters.  The clock runs between the loader handing out
+    batch `warmup` and batch `warmup + steps` (device drained at both ends), so it includes the H2D copies the headline leaves out."""
+    import shutil
+    import tempfile
+    syn = importlib.import_module("3dod_amd.synthetic")
+    modeling = importlib.import_module("3dod_amd.cubercnn.modeling")
+    solver = importlib.import_module("3dod_amd.cubercnn.solver")
+    data = importlib.import_module("3dod_amd.cubercnn.data")
+    out_dir = tempfile.mkdtemp(prefix="cr3dod_bench_")
+    W, K = max(args.warmup, 2), args.steps
+    cfg = syn.make_cfg(None, overrides=["MODEL.DEVICE", str(dev), "VIS_PERIOD", 0, "log", False, "SOLVER.IMS_PER_BATCH", 32,
+                                        "SOLVER.BASE_LR", 0.02 * IMS_PER_GPU * world / 32.0, "SOLVER.MAX_ITER", W + K + 1,
+                                        "SOLVER.CHECKPOINT_PERIOD", 10 ** 9, "TEST.EVAL_PERIOD", 0, "OUTPUT_DIR", out_dir])
+    torch.manual_seed(0)
+    model = modeling.build_model(cfg)
+    host_batches = [syn.make_batch(IMS_PER_GPU, 1234 + rank * 1000 + i) for i in range(4)]      # CPU uint8 images + CPU instances
+
+    def endless():
+        i = 0
+        while True:
+            yield host_batches[i % len(host_batches)]
+            i += 1
+
+    class Clock:
+        def __init__(self, it):
+            self.it, self.n, self.t0, self.t1 = it, 0, None, None
+
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            if self.n == W:
+                torch.cuda.synchronize(dev)
+                self.t0 = time.perf_counter()
+            elif self.n == W + K:
+                torch.cuda.synchronize(dev)
+                self.t1 = time.perf_counter()
+            self.n += 1
+            return next(self.it)
+    clock = Clock(data.DevicePrefetcher(endless(), dev))
+    try:
+        ok = solver.do_train(cfg, model, clock, world_size=world, rank=rank)
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    dt = (clock.t1 - clock.t0) / K
+    del model
+    torch.cuda.empty_cache()
+    return {"ms_per_step": dt * 1e3, "value": IMS_PER_GPU * world / dt, "unit": "images/s", "steps": K, "warmup": W,
+            "completed": bool(ok),
+            "what": "solver.do_train (tools/train_net.py's loop): DevicePrefetcher feeding host uint8 batches (H2D inside the "
+                    "step, overlapped), per-shape dense-region graphs, WarmupMultiStepLR, host check every 20 iterations"}
 
 
 def dominant_kernel_in_step(model, step, batches, dev, n_steps=3):
@@ -255,7 +346,7 @@ def dominant_kernel_in_step(model, step, batches, dev, n_steps=3):
     return out
 
 
-def cpu_baseline_train(inference=False):
+def cpu_baseline_train(inference=False, steps=None):
     """the oracle's float32 torch-CPU train step (oracle/cpu_train_step.py) on the box's host cores, in a separate
     process, on a bounded sample (1 warm-up + 4 timed steps of 4 images; inference: 1 + 3 batches of 8 images)."""
     import json
@@ -267,10 +358,10 @@ def cpu_baseline_train(inference=False):
     except Exception:
         ncpu = os.cpu_count() or 1
     threads = max(1, min(16, ncpu))          # a 1-GPU box gives this job a 16-core share
-    cmd = [sys.executable, os.path.join(here, "oracle", "cpu_train_step.py"), "--images", "4", "--steps", "4",
+    cmd = [sys.executable, os.path.join(here, "oracle", "cpu_train_step.py"), "--images", "4", "--steps", str(steps or 4),
            "--warmup", "1", "--threads", str(threads)]
     if inference:
-        cmd = cmd[:2] + ["--inference", "--images", "8", "--steps", "3", "--warmup", "1", "--threads", str(threads)]
+        cmd = cmd[:2] + ["--inference", "--images", "8", "--steps", str(steps or 3), "--warmup", "1", "--threads", str(threads)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads),
                MKL_NUM_THREADS=str(threads))
     print(f"[bench] cpu baseline: {' '.join(cmd[1:])}", file=sys.stderr, flush=True)

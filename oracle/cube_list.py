@@ -1,0 +1,310 @@
+"""TEST INFRASTRUCTURE (oracle/): the per-image, Instances-list formulation of the Cube R-CNN 3D branch written as plain
+torch expressions in the order of the reference -- ROIHeads3D._forward_cube, cubercnn/modeling/roi_heads/roi_heads.py:2237-2735
+(class gather :2353-2369, decode :2371-2436, disentangled corner sets and losses :2446-2679, Instances packing :2682-2735).
+
+It is the CPU statement of the arithmetic that the product runs as fused kernels (cr_cube_head_loss / cr_cube_decode_infer behind
+dense_train.cube_head_losses and ROIHeads3D._infer_cube_fused): tests/test_cubehead_golden.py pins THIS code to the outputs of
+the reference's own function (tests/golden/cubehead_{train,eval}.npz), tests/test_gpu_model.py compares the kernels with it.  On
+CUDA tensors in training mode it calls the per-RoI kernel pair cr_cube_loss_fwd/_bwd (hipops.cube_decode_loss) so that the same
+goldens check that kernel through the C ABI.  Attached to a head by oracle.list_path.install_heads(); nothing under 3dod_amd/
+imports this file."""
+import importlib
+
+import numpy as np
+import torch
+
+_d2 = importlib.import_module("3dod_amd.d2lite")
+Instances, get_event_storage = _d2.Instances, _d2.get_event_storage
+ops = importlib.import_module("3dod_amd.hipops")
+util = importlib.import_module("3dod_amd.cubercnn.util.math_util")
+_rh = importlib.import_module("3dod_amd.cubercnn.modeling.roi_heads.roi_heads")
+select_foreground_proposals = _rh.select_foreground_proposals
+E_CONSTANT, SQRT_2_CONSTANT = _rh.E_CONSTANT, _rh.SQRT_2_CONSTANT
+
+
+def forward_cube_list(self, features, instances, Ks, im_current_dims, im_scales_ratio):
+    """roi_heads.py:2237-2735 for the configuration of configs/Base.yaml (disentangled + chamfer + allocentric +
+    virtual depth + exp dims priors + confidence)."""
+    feats = [features[f] for f in self.in_features]
+    if self.training:
+        losses = {}
+        self.normalize_factor = max(sum([i.gt_classes.numel() for i in instances]), 1.0)
+        proposals, _ = select_foreground_proposals(instances, self.num_classes)
+        proposal_boxes = [x.proposal_boxes for x in proposals]
+        pred_boxes = [x.pred_boxes for x in proposals]
+        box_classes = torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals) else torch.empty(0)
+        gt_boxes3D = torch.cat([p.gt_boxes3D for p in proposals], dim=0)
+        gt_poses = torch.cat([p.gt_poses for p in proposals], dim=0)
+        assert len(gt_poses) == len(gt_boxes3D) == len(box_classes)
+    else:
+        proposals = instances
+        pred_boxes = [x.pred_boxes for x in instances]
+        proposal_boxes = pred_boxes
+        box_classes = torch.cat([x.pred_classes for x in instances])
+    proposal_boxes_scaled = self.scale_proposals(proposal_boxes)
+    n = sum(len(b) for b in proposal_boxes_scaled)
+    if n == 0:
+        return instances if not self.training else (instances, {})
+    cube_features = self.cube_pooler(feats, proposal_boxes_scaled).flatten(1)
+    device = cube_features.device
+    num_boxes_per_image = [len(i) for i in proposals]
+
+    Ks_dev = [torch.as_tensor(K, dtype=torch.float32) for K in Ks]
+    Ks_scaled_per_box = torch.cat([(Ks_dev[i] / im_scales_ratio[i]).unsqueeze(0).repeat([num, 1, 1])
+                                   for (i, num) in enumerate(num_boxes_per_image)]).to(device)
+    Ks_scaled_per_box[:, -1, -1] = 1
+    focal_lengths_per_box = torch.cat([(Ks_dev[i][1, 1]).unsqueeze(0).repeat([num])
+                                       for (i, num) in enumerate(num_boxes_per_image)]).to(device)
+    im_ratios_per_box = torch.cat([torch.FloatTensor([im_scales_ratio[i]]).repeat(num)
+                                   for (i, num) in enumerate(num_boxes_per_image)]).to(device)
+    im_scales_per_box = torch.cat([torch.FloatTensor([im_current_dims[i][0]]).repeat(num)
+                                   for (i, num) in enumerate(num_boxes_per_image)]).to(device)
+    im_scales_original_per_box = im_scales_per_box * im_ratios_per_box
+    if self.virtual_depth:
+        virtual_to_real = util.compute_virtual_scale_from_focal_spaces(
+            focal_lengths_per_box, im_scales_original_per_box, self.virtual_focal, im_scales_per_box)
+    else:
+        virtual_to_real = 1.0
+
+    src_boxes = torch.cat([b.tensor for b in proposal_boxes], dim=0)
+    src_widths = src_boxes[:, 2] - src_boxes[:, 0]
+    src_heights = src_boxes[:, 3] - src_boxes[:, 1]
+    src_ctr_x = src_boxes[:, 0] + 0.5 * src_widths
+    src_ctr_y = src_boxes[:, 1] + 0.5 * src_heights
+
+    cube_2d_deltas, cube_z, cube_dims, cube_pose, cube_uncert = self.cube_head(cube_features)
+    fg_inds = torch.arange(n, device=device)
+    cube_z = cube_z[fg_inds, box_classes, :]
+    cube_dims = cube_dims[fg_inds, box_classes, :]
+    cube_pose = cube_pose[fg_inds, box_classes, :, :]
+    if self.use_confidence:
+        cube_uncert = cube_uncert[fg_inds, box_classes]
+    cube_2d_deltas = cube_2d_deltas[fg_inds, box_classes, :]
+
+    fused = None
+    if self.training and cube_2d_deltas.is_cuda and self.use_confidence > 0 and self.dims_priors_func == 'exp' \
+            and hasattr(ops, "cube_decode_loss"):
+        # K15/K16 in one kernel each way (cr_cube_loss_fwd / _bwd); the torch expressions below are the same
+        # arithmetic and remain the path for eval-mode decode
+        K = Ks_scaled_per_box
+        K4 = torch.stack((K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]), 1)
+        v2r = virtual_to_real if self.virtual_depth else torch.ones(n, device=device)
+        pm = self.priors_dims_per_cat.detach()[0][box_classes][:, 0, :] if self.dims_priors_enabled \
+            else torch.ones(n, 3, device=device)
+        fused = ops.cube_decode_loss(cube_2d_deltas, cube_z[:, 0], cube_dims, cube_pose, cube_uncert, src_boxes, K4,
+                                     v2r, pm, gt_boxes3D[:, :2], gt_boxes3D[:, 2], gt_boxes3D[:, 3:6], gt_poses,
+                                     allocentric=self.allocentric_pose, chamfer_pose=self.chamfer_pose,
+                                     use_conf=True, joint=self.loss_w_joint > 0)
+    if fused is not None:
+        return finish_fused_cube(self, fused, cube_uncert, gt_boxes3D, num_boxes_per_image, im_ratios_per_box,
+                                       im_current_dims, box_classes, pred_boxes, n)
+    cube_x = src_ctr_x + src_widths * cube_2d_deltas[:, 0]
+    cube_y = src_ctr_y + src_heights * cube_2d_deltas[:, 1]
+    cube_xy = torch.cat((cube_x.unsqueeze(1), cube_y.unsqueeze(1)), dim=1)
+    cube_dims_norm = cube_dims
+    if self.dims_priors_enabled:
+        prior_dims = self.priors_dims_per_cat.detach()[0][box_classes]          # (n,2,3)
+        prior_dims_mean = prior_dims[:, 0, :]
+        prior_dims_std = prior_dims[:, 1, :]
+        if self.dims_priors_func == 'sigmoid':
+            prior_dims_min = (prior_dims_mean - 3 * prior_dims_std).clip(0.0)
+            prior_dims_max = (prior_dims_mean + 3 * prior_dims_std)
+            cube_dims = util.scaled_sigmoid(cube_dims_norm, min=prior_dims_min, max=prior_dims_max)
+        elif self.dims_priors_func == 'exp':
+            cube_dims = torch.exp(cube_dims_norm.clip(max=5)) * prior_dims_mean
+    else:
+        cube_dims = torch.exp(cube_dims_norm.clip(max=5))
+    if self.allocentric_pose:
+        cube_pose = util.R_from_allocentric(Ks_scaled_per_box, cube_pose, u=cube_x.detach(), v=cube_y.detach())
+    cube_z = cube_z.squeeze(1)          # (n,) also for n == 1
+    if self.virtual_depth:
+        cube_z = cube_z * virtual_to_real
+
+    if self.training:
+        prefix = 'Cube/'
+        storage = get_event_storage()
+        K = Ks_scaled_per_box
+        gt_2d = gt_boxes3D[:, :2]
+        gt_z = gt_boxes3D[:, 2]
+        gt_dims = gt_boxes3D[:, 3:6]
+        gt_x3d = gt_z * (gt_2d[:, 0] - K[:, 0, 2]) / K[:, 0, 0]
+        gt_y3d = gt_z * (gt_2d[:, 1] - K[:, 1, 2]) / K[:, 1, 1]
+        gt_3d = torch.stack((gt_x3d, gt_y3d, gt_z)).T
+        gt_box3d = torch.cat((gt_3d, gt_dims), dim=1)
+        gt_corners = util.get_cuboid_verts_faces(gt_box3d, gt_poses)[0]
+
+        # disentangled corner sets (roi_heads.py:2471-2508)
+        cube_dis_x3d_from_z = cube_z * (gt_2d[:, 0] - K[:, 0, 2]) / K[:, 0, 0]
+        cube_dis_y3d_from_z = cube_z * (gt_2d[:, 1] - K[:, 1, 2]) / K[:, 1, 1]
+        cube_dis_z = torch.cat((torch.stack((cube_dis_x3d_from_z, cube_dis_y3d_from_z, cube_z)).T, gt_dims), dim=1)
+        dis_z_corners = util.get_cuboid_verts_faces(cube_dis_z, gt_poses)[0]
+        cube_dis_x3d = gt_z * (cube_x - K[:, 0, 2]) / K[:, 0, 0]
+        cube_dis_y3d = gt_z * (cube_y - K[:, 1, 2]) / K[:, 1, 1]
+        cube_dis_XY = torch.cat((torch.stack((cube_dis_x3d, cube_dis_y3d, gt_z)).T, gt_dims), dim=1)
+        dis_XY_corners = util.get_cuboid_verts_faces(cube_dis_XY, gt_poses)[0]
+        loss_xy = self.l1_loss(dis_XY_corners, gt_corners).contiguous().view(n, -1).mean(dim=1)
+        dis_pose_corners = util.get_cuboid_verts_faces(gt_box3d, cube_pose)[0]
+        dis_dims_corners = util.get_cuboid_verts_faces(torch.cat((gt_3d, cube_dims), dim=1), gt_poses)[0]
+        loss_dims = self.l1_loss(dis_dims_corners, gt_corners).contiguous().view(n, -1).mean(dim=1)
+        loss_z = self.l1_loss(dis_z_corners, gt_corners).contiguous().view(n, -1).mean(dim=1)
+        if self.chamfer_pose:
+            loss_pose = self.chamfer_loss(dis_pose_corners, gt_corners)
+        else:
+            loss_pose = self.l1_loss(dis_pose_corners, gt_corners).contiguous().view(n, -1).mean(dim=1)
+
+        total_3D_loss_for_reporting = loss_dims * self.loss_w_dims
+        total_3D_loss_for_reporting = total_3D_loss_for_reporting + loss_pose * self.loss_w_pose
+        total_3D_loss_for_reporting = total_3D_loss_for_reporting + loss_xy * self.loss_w_xy
+        total_3D_loss_for_reporting = total_3D_loss_for_reporting + loss_z * self.loss_w_z
+        total_3D_loss_for_reporting = total_3D_loss_for_reporting.detach()
+
+        if self.loss_w_joint > 0:
+            cube_j_x3d = cube_z * (cube_x - K[:, 0, 2]) / K[:, 0, 0]
+            cube_j_y3d = cube_z * (cube_y - K[:, 1, 2]) / K[:, 1, 1]
+            cube_j = torch.cat((torch.stack((cube_j_x3d, cube_j_y3d, cube_z)).T, cube_dims), dim=1)
+            dis_z_corners_joint = util.get_cuboid_verts_faces(cube_j, cube_pose)[0]
+            if self.chamfer_pose and self.disentangled_loss:
+                loss_joint = self.chamfer_loss(dis_z_corners_joint, gt_corners)
+            else:
+                loss_joint = self.l1_loss(dis_z_corners_joint, gt_corners).contiguous().view(n, -1).mean(dim=1)
+            valid_joint = loss_joint < np.inf
+            total_3D_loss_for_reporting = total_3D_loss_for_reporting + (loss_joint * self.loss_w_joint).detach()
+
+        # tracking scalars stay on the device (no .item() host syncs, unlike roi_heads.py:2601-2606)
+        with torch.no_grad():
+            z_error = (cube_z - gt_z).abs()
+            storage.put_scalar(prefix + 'z_error', z_error.mean(), smoothing_hint=False)
+            storage.put_scalar(prefix + 'dims_error', (cube_dims - gt_dims).abs().mean(), smoothing_hint=False)
+            storage.put_scalar(prefix + 'xy_error', (cube_xy - gt_2d).abs().mean(), smoothing_hint=False)
+            storage.put_scalar(prefix + 'z_close', (z_error < 0.20).float().mean(), smoothing_hint=False)
+            storage.put_scalar(prefix + 'total_3D_loss',
+                               self.loss_w_3d * self.safely_reduce_losses(total_3D_loss_for_reporting),
+                               smoothing_hint=False)
+
+        if self.inverse_z_weight:
+            inverse_z_w = 1 / torch.log(gt_boxes3D[:, 2].clip(E_CONSTANT))
+            loss_dims = loss_dims * inverse_z_w
+            loss_xy = loss_xy * inverse_z_w
+            loss_z = loss_z * inverse_z_w
+            loss_pose = loss_pose * inverse_z_w
+            if self.loss_w_joint > 0:
+                loss_joint = loss_joint * inverse_z_w
+
+        if self.use_confidence > 0:
+            uncert_sf = SQRT_2_CONSTANT * torch.exp(-cube_uncert)
+            loss_dims = loss_dims * uncert_sf
+            loss_xy = loss_xy * uncert_sf
+            loss_z = loss_z * uncert_sf
+            loss_pose = loss_pose * uncert_sf
+            if self.loss_w_joint > 0:
+                loss_joint = loss_joint * uncert_sf
+            losses.update({prefix + 'uncert': self.use_confidence * self.safely_reduce_losses(cube_uncert.clone())})
+            storage.put_scalar(prefix + 'conf', torch.exp(-cube_uncert.detach()).mean(), smoothing_hint=False)
+
+        if self.loss_w_dims > 0:
+            losses.update({prefix + 'loss_dims': self.safely_reduce_losses(loss_dims) * self.loss_w_dims * self.loss_w_3d})
+        losses.update({prefix + 'loss_xy': self.safely_reduce_losses(loss_xy) * self.loss_w_xy * self.loss_w_3d})
+        losses.update({prefix + 'loss_z': self.safely_reduce_losses(loss_z) * self.loss_w_z * self.loss_w_3d})
+        losses.update({prefix + 'loss_pose': self.safely_reduce_losses(loss_pose) * self.loss_w_pose * self.loss_w_3d})
+        if self.loss_w_joint > 0:
+            # loss_joint[valid_joint] with `if valid_joint.any()` (roi_heads.py:2676-2677) without a host sync:
+            # safely_reduce_losses already averages the finite entries only
+            losses.update({prefix + 'loss_joint': self.safely_reduce_losses(
+                torch.where(valid_joint, loss_joint, torch.full_like(loss_joint, float('inf'))),
+                absent_if_none=True) * self.loss_w_joint * self.loss_w_3d})
+
+    # ---- inference packing (roi_heads.py:2682-2735)
+    if len(cube_z.shape) == 0:
+        cube_z = cube_z.unsqueeze(0)
+    K = Ks_scaled_per_box
+    cube_x3d = cube_z * (cube_x - K[:, 0, 2]) / K[:, 0, 0]
+    cube_y3d = cube_z * (cube_y - K[:, 1, 2]) / K[:, 1, 1]
+    cube_3D = torch.cat((torch.stack((cube_x3d, cube_y3d, cube_z)).T, cube_dims,
+                         cube_xy * im_ratios_per_box.unsqueeze(1)), dim=1)
+    if self.use_confidence:
+        cube_conf = torch.exp(-cube_uncert)
+        cube_3D = torch.cat((cube_3D, cube_conf.unsqueeze(1)), dim=1)
+    cube_3D = cube_3D.split(num_boxes_per_image)
+    cube_pose = cube_pose.split(num_boxes_per_image)
+    box_classes = box_classes.split(num_boxes_per_image)
+    pred_instances = instances if not self.training else [Instances(image_size) for image_size in im_current_dims]
+    for cube_3D_i, cube_pose_i, instances_i, box_classes_i, pred_boxes_i in \
+            zip(cube_3D, cube_pose, pred_instances, box_classes, pred_boxes):
+        if instances_i.has('scores'):
+            instances_i.scores = (instances_i.scores * cube_3D_i[:, -1]) ** (1 / 2)
+        else:
+            instances_i.scores = cube_3D_i[:, -1]
+        if not instances_i.has('pred_classes'):
+            instances_i.pred_classes = box_classes_i
+        if not instances_i.has('pred_boxes'):
+            instances_i.pred_boxes = pred_boxes_i
+        instances_i.pred_bbox3D = util.get_cuboid_verts_faces(cube_3D_i[:, :6], cube_pose_i)[0]
+        instances_i.pred_center_cam = cube_3D_i[:, :3]
+        instances_i.pred_center_2D = cube_3D_i[:, 6:8]
+        instances_i.pred_dimensions = cube_3D_i[:, 3:6]
+        instances_i.pred_pose = cube_pose_i
+    if self.training:
+        return pred_instances, losses
+    return pred_instances
+
+
+
+def finish_fused_cube(self, fused, cube_uncert, gt_boxes3D, num_boxes_per_image, im_ratios_per_box,
+                       im_current_dims, box_classes, pred_boxes, n):
+    """reductions, tracking scalars and the training-time Instances packing on top of the fused kernel's
+    per-RoI outputs (roi_heads.py:2562-2735)."""
+    L, dec = fused
+    prefix = 'Cube/'
+    storage = get_event_storage()
+    losses = {}
+    loss_dims, loss_xy, loss_z, loss_pose, loss_joint = L.unbind(1)
+    cube_x3d_y3d_z = torch.stack((dec[:, 15], dec[:, 16], dec[:, 2]), 1)
+    cube_z, cube_dims, cube_xy = dec[:, 2], dec[:, 3:6], dec[:, 0:2]
+    cube_pose = dec[:, 6:15].reshape(n, 3, 3)
+    gt_z, gt_dims, gt_2d = gt_boxes3D[:, 2], gt_boxes3D[:, 3:6], gt_boxes3D[:, :2]
+    with torch.no_grad():
+        sf = SQRT_2_CONSTANT * torch.exp(-cube_uncert)
+        Lr = L / sf[:, None]
+        total = Lr[:, 0] * self.loss_w_dims + Lr[:, 3] * self.loss_w_pose + Lr[:, 1] * self.loss_w_xy + \
+            Lr[:, 2] * self.loss_w_z
+        if self.loss_w_joint > 0:
+            total = total + Lr[:, 4] * self.loss_w_joint
+        z_error = (cube_z - gt_z).abs()
+        storage.put_scalar(prefix + 'z_error', z_error.mean(), smoothing_hint=False)
+        storage.put_scalar(prefix + 'dims_error', (cube_dims - gt_dims).abs().mean(), smoothing_hint=False)
+        storage.put_scalar(prefix + 'xy_error', (cube_xy - gt_2d).abs().mean(), smoothing_hint=False)
+        storage.put_scalar(prefix + 'z_close', (z_error < 0.20).float().mean(), smoothing_hint=False)
+        storage.put_scalar(prefix + 'total_3D_loss', self.loss_w_3d * self.safely_reduce_losses(total),
+                           smoothing_hint=False)
+        storage.put_scalar(prefix + 'conf', torch.exp(-cube_uncert).mean(), smoothing_hint=False)
+    if self.inverse_z_weight:
+        inverse_z_w = 1 / torch.log(gt_z.clip(E_CONSTANT))
+        loss_dims, loss_xy, loss_z, loss_pose, loss_joint = [t * inverse_z_w for t in
+                                                             (loss_dims, loss_xy, loss_z, loss_pose, loss_joint)]
+    losses[prefix + 'uncert'] = self.use_confidence * self.safely_reduce_losses(cube_uncert.clone())
+    if self.loss_w_dims > 0:
+        losses[prefix + 'loss_dims'] = self.safely_reduce_losses(loss_dims) * self.loss_w_dims * self.loss_w_3d
+    losses[prefix + 'loss_xy'] = self.safely_reduce_losses(loss_xy) * self.loss_w_xy * self.loss_w_3d
+    losses[prefix + 'loss_z'] = self.safely_reduce_losses(loss_z) * self.loss_w_z * self.loss_w_3d
+    losses[prefix + 'loss_pose'] = self.safely_reduce_losses(loss_pose) * self.loss_w_pose * self.loss_w_3d
+    if self.loss_w_joint > 0:
+        lj = torch.where(loss_joint < np.inf, loss_joint, torch.full_like(loss_joint, float('inf')))
+        losses[prefix + 'loss_joint'] = self.safely_reduce_losses(lj, absent_if_none=True) * self.loss_w_joint * self.loss_w_3d
+    with torch.no_grad():
+        cube_3D = torch.cat((cube_x3d_y3d_z, cube_dims, cube_xy * im_ratios_per_box.unsqueeze(1),
+                             torch.exp(-cube_uncert).unsqueeze(1)), dim=1)
+        verts = util.get_cuboid_verts_faces(cube_3D[:, :6], cube_pose)[0]
+        pred_instances = [Instances(image_size) for image_size in im_current_dims]
+        for c3, cp, vv, inst, cls_i, pb in zip(cube_3D.split(num_boxes_per_image), cube_pose.split(num_boxes_per_image),
+                                               verts.split(num_boxes_per_image), pred_instances,
+                                               box_classes.split(num_boxes_per_image), pred_boxes):
+            inst.scores = c3[:, -1]
+            inst.pred_classes = cls_i
+            inst.pred_boxes = pb
+            inst.pred_bbox3D = vv
+            inst.pred_center_cam = c3[:, :3]
+            inst.pred_center_2D = c3[:, 6:8]
+            inst.pred_dimensions = c3[:, 3:6]
+            inst.pred_pose = cp
+    return pred_instances, losses
+

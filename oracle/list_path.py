@@ -241,8 +241,7 @@ def install(model):
             setattr(pg, f.__name__, types.MethodType(f, pg))
     rh = getattr(model, "roi_heads", None)
     if rh is not None:
-        for f in (_sample_proposals, label_and_sample_proposals):
-            setattr(rh, f.__name__, types.MethodType(f, rh))
+        install_heads(rh)
     if hasattr(model, "dense_train"):
         model.dense_train = False
     return model
@@ -251,6 +250,9 @@ def install(model):
 def install_heads(rh):
     for f in (_sample_proposals, label_and_sample_proposals):
         setattr(rh, f.__name__, types.MethodType(f, rh))
+    if hasattr(rh, "cube_head") or hasattr(rh, "priors_dims_per_cat"):
+        from . import cube_list              # the torch-expression statement of ROIHeads3D._forward_cube
+        rh._forward_cube_list = types.MethodType(cube_list.forward_cube_list, rh)
     return rh
 
 

@@ -1,0 +1,190 @@
+"""GPU: the launch mode of the PRODUCT's train loop (solver.make_train_step, used by do_train / tools/train_net.py and timed
+by bench.py): one captured dense region per image-batch shape, captured on first sight, least recently used shape evicted;
+the guards around captures (no torch.topk fallback inside a capture, graph owners that die while a capture is open, the
+optimizer's weight bank per precision mode)."""
+import gc
+import importlib
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _build(**kw):
+    bt = importlib.import_module("bench_train")
+    return bt.build(DEV, seed=0, lr=0.0025, **kw)
+
+
+def _to_dev(batch):
+    for d in batch:
+        d["image"] = d["image"].to(DEV)
+        d["instances"] = d["instances"].to(DEV)
+    return batch
+
+
+def test_make_train_step_captures_per_shape_and_matches_eager(monkeypatch):
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    graphed = importlib.import_module("3dod_amd.cubercnn.modeling.graphed")
+
+    def run(mode):
+        monkeypatch.setenv("CR_GRAPHS", mode)
+        monkeypatch.setenv("CR_GRAPH_SHAPES", "2")
+        cfg, model, opt, syn, solver = _build()
+        step = solver.make_train_step(cfg, model, opt, world_size=1)
+        sizes = [256, 320, 256, 320, 384, 256]               # three shapes through a two-entry cache
+        batches = [_to_dev(syn.make_batch(2, 900 + i, size=s)) for i, s in enumerate(sizes)]
+        torch.manual_seed(5)
+        tr, shapes = [], []
+        with d2.EventStorage(0):
+            for b in batches:
+                step(b)
+                tr.append(step.report()["total_loss"])
+                shapes.append(None if model._graphed is None else model._graphed.shape)
+        return tr, shapes, step.report()["iterations_explode"], model, syn
+    te, se, xe, _, _ = run("none")
+    tg, sg, xg, model, syn = run("dense")
+    assert all(s is None for s in se)
+    assert [s[-1] for s in sg] == [256, 320, 256, 320, 384, 256], sg          # every step ran from the graph of ITS shape
+    assert len(model._graphed_cache) == 2 and model._graphed_max == 2          # 384 evicted the least recently used (256), then back
+    assert all(isinstance(g, graphed.GraphedDense) for g in model._graphed_cache.values())
+    # a capture in the middle of a run leaves no trace in the BatchNorm running statistics (its warm-up / capture passes run
+    # the layers in training mode; the statistics are put back)
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    before = [(m.running_mean.clone(), m.running_var.clone()) for m in bns]
+    _, u8 = model._stack_images(_to_dev(syn.make_batch(2, 77, size=448)))
+    g_new = model._train_graph_for(u8)
+    assert g_new is not None and g_new.shape[-1] == 448
+    assert all(torch.equal(m.running_mean, a) and torch.equal(m.running_var, b) for m, (a, b) in zip(bns, before))
+    assert xe == 0 and xg == 0
+    assert abs(tg[0] - te[0]) < 1e-3 * abs(te[0]), (tg, te)                    # identical weights and samples
+    assert all(t == t and abs(a - t) < 0.08 * abs(a) for a, t in zip(te, tg)), (te, tg)
+
+
+def test_mixed_size_batch_runs_eagerly_with_the_cache_on(monkeypatch):
+    monkeypatch.setenv("CR_GRAPHS", "dense")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    cfg, model, opt, syn, solver = _build()
+    step = solver.make_train_step(cfg, model, opt, world_size=1)
+    batch = _to_dev(syn.make_batch(1, 1, size=256) + syn.make_batch(1, 2, size=320))
+    with d2.EventStorage(0):
+        step(batch)
+        rep = step.report()
+    assert rep["total_loss"] == rep["total_loss"] and not model._graphed_cache
+
+
+def test_whole_step_graph_refuses_a_top_k_outside_the_kernel_range():
+    """PRE_NMS_TOPK_TRAIN = 3000 > 2048: the eager step takes the torch.topk fallback, a whole-step capture must raise
+    instead of recording torch.topk's memset nodes (the memory fault of DESIGN section 6)"""
+    lib = importlib.import_module("3dod_amd._lib")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    cfg, model, opt, syn, solver = _build(extra=["MODEL.RPN.PRE_NMS_TOPK_TRAIN", 3000])
+    batch = _to_dev(syn.make_batch(2, 3, size=256))
+    with d2.EventStorage(0):
+        step = solver.TrainStep(cfg, model, opt)
+        step(batch)                                            # eager: allowed
+        assert step.report()["total_loss"] == step.report()["total_loss"]
+        with pytest.raises(lib.CrError, match="must not be captured"):
+            solver.GraphedTrainStep(cfg, model, opt, batch)
+    torch.cuda.synchronize()
+    with d2.EventStorage(0):                                   # the process is still usable afterwards
+        step(batch)
+        assert step.report()["total_loss"] == step.report()["total_loss"]
+
+
+def test_dead_graph_owner_collected_while_a_capture_is_open():
+    """a graph-owning object whose destructor runs INSIDE an open capture (explicit gc.collect(): capture_guard only switches
+    the automatic collector off) must neither wait for the device nor destroy its graphs there: it is parked and released
+    once the capture has closed.  Also: capture_guard collects garbage BEFORE the capture opens and keeps the automatic
+    collector off inside."""
+    graphed = importlib.import_module("3dod_amd.cubercnn.modeling.graphed")
+
+    class Owner(graphed.GraphOwner):
+        def __init__(self):
+            self.dev = DEV
+            self.buf = torch.zeros(1024, device=DEV)
+            self.graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.buf.add_(1)
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(self.graph):
+                self.buf.add_(1)
+            self.cycle = self                                  # only the cyclic collector can free it
+
+    def make_dead():
+        o = Owner()
+        o.graph.replay()
+        return None
+    x = torch.zeros(256, device=DEV)
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        make_dead()                                            # dead, in a cycle, not yet collected
+        seen = []
+        cb = lambda phase, info: seen.append((phase, torch.cuda.is_current_stream_capturing()))
+        gc.callbacks.append(cb)
+        try:
+            with graphed.capture_guard():
+                # the guard collected the first owner before any capture was open
+                assert seen and not any(c for _, c in seen)
+                n0 = len(seen)
+                assert not gc.isenabled()
+                holder = [Owner()]                             # alive until the capture is open (torch.cuda.graph itself
+                holder[0].graph.replay()                       # collects garbage before it begins capturing)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    x.add_(1)
+                    holder.clear()                             # dies while the capture is open
+                    assert gc.collect() >= 1                   # destructor runs here, inside the capture
+                    assert len(graphed._GRAVEYARD) == 1
+                    x.add_(1)
+                assert len(seen) > n0
+            assert not graphed._GRAVEYARD                      # released after the capture closed
+        finally:
+            gc.callbacks.remove(cb)
+    finally:
+        if was:
+            gc.enable()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(x[0]) == 2.0                                  # the capture stayed valid (capture itself does not execute)
+
+
+def test_weight_bank_is_kept_per_precision_mode_under_captured_graphs():
+    """fp32 -> bf16 -> fp32 on one model / optimizer: the fp32 bank the graphs were captured against is re-attached, not
+    rebuilt (its buffer addresses are baked into the graphs), and a graph only `matches` while its bank is attached"""
+    ops = importlib.import_module("3dod_amd.hipops")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    cfg, model, opt, syn, solver = _build()
+    batch = _to_dev(syn.make_batch(2, 12, size=256))
+    prev = ops.set_precision("fp32")
+    try:
+        step = solver.TrainStep(cfg, model, opt)
+        bank32 = opt.weight_bank
+        g = model.enable_graphs(batch)
+        opt.zero_grad()
+        _, u8 = model._stack_images(batch)
+        assert g.matches(u8) and g.bank is bank32
+        with d2.EventStorage(0):
+            step(batch)
+            l0 = step.report()["total_loss"]
+        ops.set_precision("bf16")
+        assert opt.enable_weight_bank() is not bank32
+        assert not g.matches(u8)                               # other precision, other bank
+        with d2.EventStorage(0):
+            step(batch)                                        # runs eagerly in bf16
+        ops.set_precision("fp32")
+        assert opt.enable_weight_bank() is bank32              # the SAME object (and buffers) again
+        assert g.matches(u8)
+        with d2.EventStorage(0):
+            step(batch)
+            l2 = step.report()["total_loss"]
+        assert l2 == l2 and abs(l2 - l0) < 0.5 * abs(l0)
+    finally:
+        ops.set_precision(prev)
+        model.disable_graphs()

@@ -228,7 +228,8 @@ def test_fused_cube_kernel_matches_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "cubehead_train.npz"), allow_pickle=False)
     cfg = syn.make_cfg(overrides=["MODEL.DEVICE", "cuda:0", "VIS_PERIOD", 0, "log", False])
     shapes = {f"p{l}": d2.ShapeSpec(channels=256, stride=2 ** l) for l in range(2, 7)}
-    heads = modeling.build_roi_heads(cfg, shapes).to(DEV).train()
+    from oracle import list_path
+    heads = list_path.install_heads(modeling.build_roi_heads(cfg, shapes).to(DEV).train())     # list-shaped caller of the kernel pair
     n_per = g["n_per"].tolist()
     T = lambda k: torch.tensor(g[k]).to(DEV)
     insts = []
@@ -480,7 +481,7 @@ def test_batched_fast_rcnn_inference_equals_per_image():
 
 
 def test_fused_cube_inference_equals_torch_path(built):
-    """the fused inference decode (cr_cube_decode_infer) against the reference-shaped torch expressions of _forward_cube
+    """the fused inference decode (cr_cube_decode_infer) against the reference-shaped torch expressions of oracle/cube_list.py
     on the same detections (the torch path is what tests/test_cubehead_golden.py pins to the reference)."""
     cfg, model, opt, syn, solver = built
     ops = importlib.import_module("3dod_amd.hipops")
@@ -508,12 +509,8 @@ def test_fused_cube_inference_equals_torch_path(built):
             clone = lambda L: [d2.Instances(i.image_size, **{k: (v.clone() if torch.is_tensor(v) else d2.Boxes(v.tensor.clone()))
                                                              for k, v in i.get_fields().items()}) for i in L]
             fused = rh._forward_cube(feats, clone(dets), Ks, dims, ratios)
-            f = ops.cube_decode_infer
-            try:
-                del ops.cube_decode_infer                     # force the torch expressions
-                ref = rh._forward_cube(feats, clone(dets), Ks, dims, ratios)
-            finally:
-                ops.cube_decode_infer = f
+            from oracle import cube_list                       # the torch expressions (pinned to the reference on the CPU)
+            ref = cube_list.forward_cube_list(rh, feats, clone(dets), Ks, dims, ratios)
         for a, b in zip(fused, ref):
             for k in ("scores", "pred_bbox3D", "pred_center_cam", "pred_center_2D", "pred_dimensions", "pred_pose"):
                 x1, x2 = a.get(k).float(), b.get(k).float()

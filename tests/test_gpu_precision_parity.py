@@ -95,14 +95,45 @@ def _train(cfg, priors, batches, prec, steps):
     return model, traj
 
 
-def _evaluate(cfg, fs, model, tag, tmp_path):
+def _evaluate(cfg, fs, model, tag, tmp_path, batch_size=4):
     model.eval()
-    loader = data.build_detection_test_loader(cfg, "Synth_mem", batch_size=4, rank=0, world_size=1, num_workers=0)
+    loader = data.build_detection_test_loader(cfg, "Synth_mem", batch_size=batch_size, rank=0, world_size=1, num_workers=0)
     out = ev_mod.inference_on_dataset(model, loader)
     helper = ev_mod.Omni3DEvaluationHelper(["Synth_mem"], fs, str(tmp_path / ("eval_" + tag)))
     helper.add_predictions("Synth_mem", out)
     res = helper.evaluate("Synth_mem")
     return float(res["bbox_2D"]["AP"]), float(res["bbox_3D"]["AP"]), out
+
+
+def _compare_detections(a, b, min_score=0.05):
+    """prediction records of two runs over the same images: detections with score >= min_score in either run are paired by
+    (image, class, 2D IoU > 0.9); returns ({field: worst relative deviation over the pairs}, pairs, detections considered)"""
+    by_img = lambda recs: {r["image_id"]: [d for d in r["instances"] if d["score"] >= min_score] for r in recs}
+    A, B = by_img(a), by_img(b)
+    worst = {"score": 0.0, "bbox": 0.0, "center_cam": 0.0, "dimensions": 0.0, "bbox3D": 0.0}
+    n_match = n_tot = 0
+
+    def iou(p, q):
+        ax0, ay0, aw, ah = p
+        bx0, by0, bw, bh = q
+        iw = max(0.0, min(ax0 + aw, bx0 + bw) - max(ax0, bx0))
+        ih = max(0.0, min(ay0 + ah, by0 + bh) - max(ay0, by0))
+        return iw * ih / max(aw * ah + bw * bh - iw * ih, 1e-12)
+    for img in A:
+        da, db = A[img], list(B.get(img, []))
+        n_tot += max(len(da), len(db))
+        for d in da:
+            cand = [(iou(d["bbox"], e["bbox"]), j) for j, e in enumerate(db) if e["category_id"] == d["category_id"]]
+            if not cand or max(cand)[0] <= 0.9:
+                continue
+            e = db.pop(max(cand)[1])
+            n_match += 1
+            worst["score"] = max(worst["score"], abs(d["score"] - e["score"]) / max(abs(e["score"]), 0.05))
+            for k, scale in (("bbox", 512.0), ("center_cam", None), ("dimensions", None), ("bbox3D", None)):
+                x, y = np.asarray(d[k], np.float64), np.asarray(e[k], np.float64)
+                den = scale if scale is not None else max(float(np.abs(y).max()), 1e-6)
+                worst[k] = max(worst[k], float(np.abs(x - y).max()) / den)
+    return worst, n_match, n_tot
 
 
 def test_loss_trajectory_bf16_mode_follows_fp32(tmp_path, monkeypatch):
@@ -140,6 +171,35 @@ def test_ap3d_fp32_hip_equals_cpu_oracle_and_bf16_is_bounded(tmp_path, monkeypat
     n_hip, n_cpu = sum(len(p["instances"]) for p in out), sum(len(p["instances"]) for p in outc)
     assert abs(ap3 - ap3c) <= 1e-3 and abs(ap2 - ap2c) <= 1e-3, ("AP3D / AP2D HIP-fp32 vs CPU oracle", ap3, ap3c, ap2, ap2c,
                                                                    n_hip, n_cpu)
+    # ---- BASELINE configs[1] at size: ONE batch of 8 x 512 x 512 through the HIP path and through the CPU oracle with the same
+    # weights -- detection by detection (same image, same class, 2D IoU > 0.9): scores, 2D boxes, 3D centres, dimensions and
+    # the 8 corners.  float32 on both sides; what differs is the summation order of the f32 MFMA tiles vs ATen's CPU kernels
+    # through ~60 layers, so the bound is 1e-3 relative (measured: printed), and the sets of detections must be the same
+    # up to score-threshold / NMS ties (<= 2 % unmatched).
+    ap2_8, ap3_8, out8 = _evaluate(cfg, fs, model, "hip_fp32_bs8", tmp_path, batch_size=8)
+    assert abs(ap3_8 - ap3) <= 1e-3 and abs(ap2_8 - ap2) <= 1e-3, ("batch size must not change the detections", ap3_8, ap3)
+    try:
+        cpu_backend.install()
+        _, _, outc8 = _evaluate(cfg_cpu, fs, ref, "cpu_oracle_bs8", tmp_path, batch_size=8)
+    finally:
+        for n, o in saved.items():
+            importlib.import_module(n).ops = o
+    worst, n_match, n_tot = _compare_detections(out8, outc8)
+    print("bs=8 HIP-fp32 vs CPU oracle: matched %d of %d detections; worst relative deviations %s" % (n_match, n_tot, worst))
+    assert n_match >= 0.98 * n_tot, (n_match, n_tot)
+    assert all(v <= 1e-3 for v in worst.values()), worst
+    # ---- the fp32x3 mode (float32 storage, contractions through the exact three-way bf16 split) on the same weights: held to
+    # the SAME criterion as the default mode -- AP2D / AP3D within 1e-3 of the float32 CPU oracle
+    prev = ops.set_precision("fp32x3")
+    try:
+        ap2x, ap3x, outx = _evaluate(cfg, fs, model, "hip_fp32x3", tmp_path)
+    finally:
+        ops.set_precision(prev)
+    print(f"AP3D fp32x3 {ap3x:.4f} (cpu {ap3c:.4f}); AP2D fp32x3 {ap2x:.4f} (cpu {ap2c:.4f})")
+    assert abs(ap3x - ap3c) <= 1e-3 and abs(ap2x - ap2c) <= 1e-3, ("AP3D / AP2D HIP-fp32x3 vs CPU oracle", ap3x, ap3c, ap2x, ap2c)
+    worstx, n_mx, n_tx = _compare_detections(outx, outc)
+    print("fp32x3 vs CPU oracle: matched %d of %d detections; worst relative deviations %s" % (n_mx, n_tx, worstx))
+    assert n_mx >= 0.98 * n_tx and all(v <= 1e-3 for v in worstx.values()), (n_mx, n_tx, worstx)
     # ---- the bf16 fast mode on the same weights: measured deviation, stated bound
     prev = ops.set_precision("bf16")
     try:

@@ -52,3 +52,50 @@ def test_topk_padding_ties_nan():
     x[5] = -torch.rand(70000, generator=g)
     check(x, 300)
     check(x, 2048)
+
+
+def test_topk_negative_nan_sorts_first_like_torch():
+    """torch.topk treats EVERY NaN as the largest value; a NaN with the sign bit set (0xffc00000, what 0 * -inf or
+    -(0/0) produce) must not sort as the smallest key"""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 5000, generator=g)
+    neg_nan = torch.tensor([0xffc00000 - (1 << 32)], dtype=torch.int32).view(torch.float32)[0]
+    x[0, 17] = neg_nan
+    x[1, ::9] = neg_nan
+    x[1, 1::9] = float("nan")
+    v, i = ops.topk(x.to(DEV), 40)
+    v, i = v.cpu(), i.cpu()
+    assert bool(torch.isnan(v[0, 0])) and int(i[0, 0]) == 17 and not bool(torch.isnan(v[0, 1:]).any())
+    assert bool(torch.isnan(v[1]).all())
+    rv, _ = x.topk(40, dim=1)
+    assert torch.equal(torch.isnan(v), torch.isnan(rv))
+    assert torch.equal(torch.nan_to_num(v, nan=0.0), torch.nan_to_num(rv, nan=0.0))
+
+
+def test_topk_out_of_range_refuses_capture():
+    """shapes outside the kernel's range fall back to torch.topk in eager mode, but NOT inside a stream capture: torch.topk's
+    multi-block path would put hipMemsetAsync nodes into the graph (memory faults between replays)"""
+    lib = importlib.import_module("3dod_amd._lib")
+    x = torch.randn(2, 20000, device=DEV)
+    v, i = ops.topk(x, 3000)                        # eager: allowed (k > 2048 -> torch.topk)
+    assert torch.equal(v, x.topk(3000, dim=1)[0])
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.topk(x, 256)                            # lazy initialisation outside the capture
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    raised = False
+    try:
+        with torch.cuda.graph(g):
+            ops.topk(x, 256)                        # in range: capturable
+            try:
+                ops.topk(x, 3000)
+            except lib.CrError as e:
+                raised = "must not be captured" in str(e)
+    finally:
+        torch.cuda.synchronize()
+    assert raised
+    g.replay()                                      # the capture itself stayed valid
+    torch.cuda.synchronize()
