@@ -162,26 +162,38 @@ def dataset_id_maps(datasets, num_classes, id_map):
 
 
 class DevicePrefetcher:
-    """Wraps a loader of list[dict] batches: tensors of batch i+1 ('image', 'depth_map', 'ground_map' and the fields
-    of 'instances') are staged through pinned memory and copied to `device` on a side stream while batch i is in use.
+    """Wraps a loader of list[dict] batches: the host tensors of batch i+1 ('image', 'depth_map', 'ground_map' and the fields
+    of 'instances') are packed into ONE pinned staging buffer and copied to `device` with ONE asynchronous H2D transfer on
+    a side stream while batch i is in use; the batch's tensors are views into that device buffer.
 
-    The consumer's stream waits on the copy's event, and the staged tensors are recorded on it, so the caching
-    allocator does not recycle them while the step still reads them."""
+    The staging buffers are a ring of three persistent pinned allocations (grown on demand): `Tensor.pin_memory()` per
+    tensor costs a hipHostMalloc + hipHostFree each -- ~20 per batch, every one a device-wide synchronisation -- which made
+    the loop twice as slow as the step it feeds (35 ms vs 17 ms per 4-image step).
+
+    The consumer's stream waits on the copy's event, and the device buffer is recorded on it, so the caching allocator does
+    not recycle it while the step still reads it."""
 
     TENSOR_KEYS = ("image", "depth_map", "ground_map")
+    ALIGN = 256
 
     def __init__(self, loader, device):
         self.device = torch.device(device)
         assert self.device.type == "cuda", "DevicePrefetcher stages onto a GPU"
         self._it = iter(loader)
         self._stream = torch.cuda.Stream(device=self.device)
+        self._ring = [[None, None] for _ in range(3)]          # [pinned uint8 buffer, event of the last copy out of it]
+        self._turn = 0
         self._next = None
         self._preload()
 
-    def _stage(self, t):
-        if not isinstance(t, torch.Tensor) or t.is_cuda:
-            return t
-        return t.pin_memory().to(self.device, non_blocking=True)
+    def _staging(self, nbytes):
+        slot = self._ring[self._turn]
+        self._turn = (self._turn + 1) % len(self._ring)
+        if slot[1] is not None:
+            slot[1].synchronize()                               # the copy that last read this buffer (3 batches ago) is done
+        if slot[0] is None or slot[0].numel() < nbytes:
+            slot[0] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8).pin_memory()
+        return slot
 
     def _preload(self):
         try:
@@ -189,27 +201,52 @@ class DevicePrefetcher:
         except StopIteration:
             self._next = None
             return
-        with torch.cuda.stream(self._stream):
-            out = []
-            for d in batch:
-                d = dict(d)
-                for k in self.TENSOR_KEYS:
-                    if d.get(k) is not None:
-                        d[k] = self._stage(d[k])
-                inst = d.get("instances")
-                if inst is not None:
-                    staged = type(inst)(inst.image_size)
-                    for name, v in inst.get_fields().items():
-                        if isinstance(v, torch.Tensor):
-                            v = self._stage(v)
-                        elif hasattr(v, "tensor"):
-                            v = type(v)(self._stage(v.tensor))
+        out, jobs, total = [], [], 0
+
+        def want(t, assign):
+            """host tensor -> a slot of the packed buffer; `assign(device_view)` puts the result where the tensor was"""
+            nonlocal total
+            if not isinstance(t, torch.Tensor) or t.is_cuda:
+                assign(t)
+                return
+            jobs.append((t, total, assign))
+            total += (t.numel() * t.element_size() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        for d in batch:
+            d = dict(d)
+            for k in self.TENSOR_KEYS:
+                if d.get(k) is not None:
+                    want(d[k], lambda v, d=d, k=k: d.__setitem__(k, v))
+            inst = d.get("instances")
+            if inst is not None:
+                staged = type(inst)(inst.image_size)
+                for name, v in inst.get_fields().items():
+                    if isinstance(v, torch.Tensor):
+                        want(v, lambda x, s=staged, n=name: s.set(n, x))
+                    elif hasattr(v, "tensor"):
+                        want(v.tensor, lambda x, s=staged, n=name, T=type(v): s.set(n, T(x)))
+                    else:
                         staged.set(name, v)
-                    d["instances"] = staged
-                out.append(d)
-            ev = torch.cuda.Event()
-            ev.record(self._stream)
-        self._next = (out, ev)
+                d["instances"] = staged
+            out.append(d)
+        dev_buf = None
+        if jobs:
+            slot = self._staging(total)
+            pin = slot[0]
+            for t, off, _ in jobs:
+                n = t.numel() * t.element_size()
+                if n:
+                    pin[off:off + n].view(t.dtype).view(t.shape).copy_(t)
+            with torch.cuda.stream(self._stream):
+                dev_buf = torch.empty(total, dtype=torch.uint8, device=self.device)
+                dev_buf.copy_(pin[:total], non_blocking=True)
+                slot[1] = torch.cuda.Event()
+                slot[1].record(self._stream)
+            for t, off, assign in jobs:
+                n = t.numel() * t.element_size()
+                assign(dev_buf[off:off + n].view(t.dtype).view(t.shape))
+        ev = torch.cuda.Event()
+        ev.record(self._stream)
+        self._next = (out, ev, dev_buf)
 
     def __iter__(self):
         return self
@@ -217,18 +254,10 @@ class DevicePrefetcher:
     def __next__(self):
         if self._next is None:
             raise StopIteration
-        batch, ev = self._next
+        batch, ev, dev_buf = self._next
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
-        for d in batch:
-            for k in self.TENSOR_KEYS:
-                if isinstance(d.get(k), torch.Tensor) and d[k].is_cuda:
-                    d[k].record_stream(cur)
-            inst = d.get("instances")
-            if inst is not None:
-                for v in inst.get_fields().values():
-                    t = v if isinstance(v, torch.Tensor) else getattr(v, "tensor", None)
-                    if isinstance(t, torch.Tensor) and t.is_cuda:
-                        t.record_stream(cur)
+        if dev_buf is not None:
+            dev_buf.record_stream(cur)          # every tensor of the batch is a view of this one allocation
         self._preload()
         return batch

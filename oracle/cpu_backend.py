@@ -543,5 +543,17 @@ def install():
     return me
 
 
+def attach(model):
+    """a model built on the CPU under install(): the 3D branch of its RoI heads runs the torch-expression statement
+    (oracle/cube_list.py) -- the product's own `_forward_cube` is the fused device path and refuses CPU tensors"""
+    from . import list_path
+    rh = getattr(model, "roi_heads", None)
+    if rh is not None and hasattr(rh, "cube_head"):
+        import types
+        from . import cube_list
+        rh._forward_cube_list = types.MethodType(cube_list.forward_cube_list, rh)
+    return model
+
+
 class TorchCpuOps:
     pass

@@ -34,7 +34,7 @@ def main():
     d2 = importlib.import_module("3dod_amd.d2lite")
     cfg = syn.make_cfg(overrides=["MODEL.DEVICE", "cpu", "VIS_PERIOD", 0, "log", False, "SOLVER.BASE_LR", 0.02])
     torch.manual_seed(0)
-    model = modeling.build_model(cfg)
+    model = cpu_backend.attach(modeling.build_model(cfg))
     if args.inference:
         model.eval()
         batches = [syn.make_batch(args.images, 4321 + i, size=args.size, with_gt=False) for i in range(2)]

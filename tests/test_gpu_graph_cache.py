@@ -140,7 +140,8 @@ def test_dead_graph_owner_collected_while_a_capture_is_open():
                 with torch.cuda.graph(g):
                     x.add_(1)
                     holder.clear()                             # dies while the capture is open
-                    assert gc.collect() >= 1                   # destructor runs here, inside the capture
+                    gc.collect()                               # destructor runs here, inside the capture (the parked
+                    #                                            state references the owner: it counts as resurrected)
                     assert len(graphed._GRAVEYARD) == 1
                     x.add_(1)
                 assert len(seen) > n0

@@ -162,7 +162,7 @@ def test_ap3d_fp32_hip_equals_cpu_oracle_and_bf16_is_bounded(tmp_path, monkeypat
     try:
         cpu_backend.install()
         cfg_cpu = syn.make_cfg(overrides=["MODEL.DEVICE", "cpu"] + over)
-        ref = modeling.build_model(cfg_cpu, priors=priors)
+        ref = cpu_backend.attach(modeling.build_model(cfg_cpu, priors=priors))
         ref.load_state_dict(sd)
         ap2c, ap3c, outc = _evaluate(cfg_cpu, fs, ref, "cpu_oracle", tmp_path)
     finally:
