@@ -13,6 +13,8 @@ import math
 from collections import defaultdict
 
 import numpy as np
+import ctypes
+
 import torch
 import torch.utils.data as tud
 
@@ -232,10 +234,15 @@ class DevicePrefetcher:
         if jobs:
             slot = self._staging(total)
             pin = slot[0]
+            base = pin.data_ptr()
             for t, off, _ in jobs:
                 n = t.numel() * t.element_size()
                 if n:
-                    pin[off:off + n].view(t.dtype).view(t.shape).copy_(t)
+                    # plain memcpy on the calling thread: a torch copy_ of an image-sized CPU tensor opens an OpenMP region,
+                    # and on a box whose CPU quota is far below its visible core count the spinning workers stall the
+                    # launching thread for tens of ms every few batches (DESIGN: findings worth keeping)
+                    tc = t if t.is_contiguous() else t.contiguous()
+                    ctypes.memmove(base + off, tc.data_ptr(), n)
             with torch.cuda.stream(self._stream):
                 dev_buf = torch.empty(total, dtype=torch.uint8, device=self.device)
                 dev_buf.copy_(pin[:total], non_blocking=True)
