@@ -261,6 +261,319 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd_sep(Pyramid py, const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tile-owner backward (no global atomics, bit-reproducible).  The gradient maps are cut into 16 x 16 pixel tiles; a block
+// owns (tile, 64 channels), walks the RoIs whose footprint touches its tile IN RoI ORDER, accumulates their  Ay . G . Ax^T
+// contributions in registers (lane = channel, wave w = tile rows 4w .. 4w+3: 64 accumulators per lane) and stores every
+// pixel of its tile once -- 256 contiguous bytes per wave store, zeros where no RoI reaches, so the maps need no zero
+// fill either.  k_roi_align_bwd_sep adds 2048 RoIs x ~256 footprint pixels x 256 channels through f32 atomics, which run
+// at ~1.3 TB/s of added bytes (MI355X_MICROARCH.md "Global float atomics"): 422 us per train step; here dY is read about
+// once per tile it touches (~4x, from L2) and the maps are written once.
+//   k_roi_bbox        one thread per RoI: level, image, footprint extent (same sample walk as the separable kernel)
+//   k_roi_bwd_tiles   per block: ordered scan of the RoI boxes (chunks of 256, wave ballots -> LDS queue), then batches
+//                     of 16 RoIs: their Ay / Ax columns restricted to the tile are built in LDS by 14 threads per RoI,
+//                     every wave then runs the two small contractions per RoI with LDS-broadcast weights.
+// ---------------------------------------------------------------------------------------------------------------
+#define RT_TILE 16
+#define RT_BATCH 16
+struct RoiExt { int lv, n, y0, y1, x0, x1, pad0, pad1; };      // footprint rows y0..y1 / columns x0..x1 (y1 < y0: none)
+
+template <int P>
+__global__ __launch_bounds__(256) void k_roi_bbox(Pyramid py, const float* __restrict__ rois, int R, int N,
+                                                  RoiExt* __restrict__ ext) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float* rb = rois + (size_t)r * 5;
+    RoiExt e;
+    e.n = (int)rb[0];
+    e.lv = roi_level(rb + 1, py);
+    e.pad0 = e.pad1 = 0;
+    const int H = py.H[e.lv], W = py.W[e.lv];
+    const float sc = py.scale[e.lv];
+    const float x1 = rb[1] * sc - 0.5f, y1 = rb[2] * sc - 0.5f;
+    const float rw = (rb[3] - rb[1]) * sc, rh = (rb[4] - rb[2]) * sc;
+    const float bw = rw / (float)P, bh = rh / (float)P;
+    const int gh = min((int)ceilf(rh / (float)P), 4096), gw = min((int)ceilf(rw / (float)P), 4096);
+    int lo[2] = {0x7fffffff, 0x7fffffff}, hi[2] = {-1, -1};
+#pragma unroll
+    for (int ax = 0; ax < 2; ++ax) {
+        const int gN = ax ? gw : gh, L = ax ? W : H;
+        const float o1 = ax ? x1 : y1, bsz = ax ? bw : bh;
+        // the sample positions grow with (p, i): the extent is [lo of the first valid sample, hi of the last valid one]
+        const int tot = P * gN;
+        for (int k = 0; k < tot; ++k) {
+            const Lin1 s = lin1(o1 + (k / gN) * bsz + ((k % gN) + 0.5f) * bsz / (float)gN, L);
+            if (s.ok) { lo[ax] = s.lo; hi[ax] = s.hi; break; }
+        }
+        for (int k = tot - 1; k >= 0 && hi[ax] >= 0; --k) {
+            const Lin1 s = lin1(o1 + (k / gN) * bsz + ((k % gN) + 0.5f) * bsz / (float)gN, L);
+            if (s.ok) { hi[ax] = max(hi[ax], s.hi); lo[ax] = min(lo[ax], s.lo); break; }
+        }
+    }
+    const bool none = hi[0] < 0 || hi[1] < 0 || e.n < 0 || e.n >= N;
+    // one pixel of slack per side: the weights themselves are rebuilt exactly per tile (zero where no sample reaches), the
+    // extent only selects tiles, so a float rounding of a sample position across an integer cannot lose a contribution
+    e.y0 = none ? 0 : max(lo[0] - 1, 0); e.y1 = none ? -1 : min(hi[0] + 1, H - 1);
+    e.x0 = none ? 0 : max(lo[1] - 1, 0); e.x1 = none ? -1 : min(hi[1] + 1, W - 1);
+    ext[r] = e;
+}
+
+struct TileMap { int base[MAX_LEVELS + 1], ty[MAX_LEVELS], tx[MAX_LEVELS]; int N; };
+
+#define RT_QCAP 2048
+#define RT_RING 4                      // G slots per block: the dY tiles of up to three RoIs are in flight under the current one
+typedef __attribute__((address_space(3))) void* rt_lds_ptr_t;
+// one LDS-DMA: 64 lanes x 16 B from the resource's base + voff[lane] (zeros past its extent) to dst + 16 lane.  A plain
+// function (not inside the kernel template): the address-space cast and the target builtin are re-checked per instantiation
+// there and fail silently in the host pass (see conv.hip).
+__device__ __forceinline__ void rt_dma16(__amdgpu_buffer_rsrc_t r, void* dst, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (rt_lds_ptr_t)dst, 16, voff, 0, 0, 0);
+}
+
+// G comes out of the ring through inline-asm LDS reads: for a compiler-visible read of an array that an LDS-DMA writes,
+// hipcc drains EVERY outstanding DMA (s_waitcnt vmcnt(0)) first, which would serialise the ring; completion of slot j is
+// established by the counted vmcnt + barrier at the top of the RoI loop instead.
+template <int OFF> __device__ __forceinline__ float rt_lds_f32(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF> __device__ __forceinline__ unsigned rt_lds_u32(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ unsigned rt_lds_addr(const void* p) { return (unsigned)(size_t)(rt_lds_ptr_t)p; }
+template <typename T, int A, int P> __device__ __forceinline__ void rt_read_row(unsigned addr, float (&g)[P]) {
+    // the P bins of bin-row A of one RoI's 64-channel slice: [A * P + b][64] elements of T, this lane's channel
+    constexpr int ES = (int)sizeof(T);
+    if (ES == 4) {
+        g[0] = rt_lds_f32<(A * P + 0) * 64 * 4>(addr); g[1] = rt_lds_f32<(A * P + 1) * 64 * 4>(addr);
+        g[2] = rt_lds_f32<(A * P + 2) * 64 * 4>(addr); g[3] = rt_lds_f32<(A * P + 3) * 64 * 4>(addr);
+        g[4] = rt_lds_f32<(A * P + 4) * 64 * 4>(addr); g[5] = rt_lds_f32<(A * P + 5) * 64 * 4>(addr);
+        g[6] = rt_lds_f32<(A * P + 6) * 64 * 4>(addr);
+        // the loaded registers are in/out operands of the wait: no use of them may be scheduled above it (the compiler does
+        // not know that an asm ds_read's destination is still in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6])
+                     :: "memory");
+    } else {
+        // bf16: the 32-bit word holding this lane's channel (even lanes the low half, odd lanes the high half)
+        const unsigned a4 = addr & ~3u;
+        unsigned u[P];
+        u[0] = rt_lds_u32<(A * P + 0) * 64 * 2>(a4); u[1] = rt_lds_u32<(A * P + 1) * 64 * 2>(a4);
+        u[2] = rt_lds_u32<(A * P + 2) * 64 * 2>(a4); u[3] = rt_lds_u32<(A * P + 3) * 64 * 2>(a4);
+        u[4] = rt_lds_u32<(A * P + 4) * 64 * 2>(a4); u[5] = rt_lds_u32<(A * P + 5) * 64 * 2>(a4);
+        u[6] = rt_lds_u32<(A * P + 6) * 64 * 2>(a4);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6])
+                     :: "memory");
+        const bool hi = (addr & 2u) != 0;
+#pragma unroll
+        for (int b = 0; b < P; ++b) g[b] = __uint_as_float(hi ? (u[b] & 0xffff0000u) : (u[b] << 16));
+    }
+}
+
+template <int P, typename T>
+__global__ __launch_bounds__(256, 2) void k_roi_bwd_tiles(Pyramid py, TileMap tm, const float* __restrict__ rois, int R,
+                                                          const T* __restrict__ dout, const RoiExt* __restrict__ ext) {
+    static_assert(P == 7, "built for 7 x 7 pooling");
+    constexpr int RB = 64 * (int)sizeof(T);              // bytes of one bin's 64-channel row of dY
+    constexpr int RPD = 1024 / RB;                        // rows per LDS-DMA instruction (1 KiB each)
+    constexpr int NDMA = (P * P + RPD - 1) / RPD;         // DMA instructions per RoI: 13 (f32) / 7 (bf16)
+    constexpr int SLOT = NDMA * 1024;                     // bytes of one ring slot
+    __shared__ __attribute__((aligned(1024))) unsigned char s_G[RT_RING * SLOT];
+    __shared__ int s_queue[RT_QCAP];
+    __shared__ int s_wcnt[4];
+    __shared__ __attribute__((aligned(16))) float s_A[RT_BATCH][2][P][RT_TILE];   // [RoI of the batch][y | x][bin][tile pixel]
+    __shared__ int s_meta[RT_BATCH][4];                                            // tile-relative rows r0..r1, (bin, quarter) mask of x
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, C = py.C;
+    const int cgs = C >> 6;
+    const int tile = blockIdx.x / cgs, cg = blockIdx.x % cgs, c = cg * 64 + lane;
+    int lv = 0;
+    while (lv + 1 < py.nlev && tile >= tm.base[lv + 1]) ++lv;
+    const int rel = tile - tm.base[lv];
+    const int H = py.H[lv], W = py.W[lv];
+    const int n = rel / (tm.ty[lv] * tm.tx[lv]);
+    const int ty0 = ((rel / tm.tx[lv]) % tm.ty[lv]) * RT_TILE, tx0 = (rel % tm.tx[lv]) * RT_TILE;
+    const float sc = py.scale[lv];
+
+    float acc[4][RT_TILE];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < RT_TILE; ++j) acc[i][j] = 0.f;
+
+    const unsigned g_base = rt_lds_addr(s_G) + (unsigned)(lane * (int)sizeof(T));     // this lane's channel inside a ring slot
+    // this wave's share of the DMA instructions of a RoI: m = w, w + 4, ... (4 for the first NDMA % 4 waves, else 3 / ...)
+    const int my_dma = (NDMA - w + 3) / 4;
+    // per-lane source offset inside a RoI's (P*P, C) block for DMA instruction m: row m * RPD + lane / (64 / RPD), 16 B per lane
+    constexpr int LPR = 64 / RPD;                         // lanes per row
+    const unsigned lane_row = (unsigned)(lane / LPR), lane_col = (unsigned)((lane % LPR) * 16);
+    auto issue = [&](int rq, int slot) {
+        // the 64-channel slice of RoI rq's dY -> ring slot (rows past P*P read zeros through the resource's range check)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(dout + (size_t)rq * (P * P) * (size_t)C), 0, (int)(P * P * C * sizeof(T)), 0x00020000);
+        for (int m = w; m < NDMA; m += 4) {
+            const unsigned row = (unsigned)(m * RPD) + lane_row;
+            const unsigned voff = row < (unsigned)(P * P) ? row * (unsigned)(C * sizeof(T)) + (unsigned)(cg * RB) + lane_col
+                                                          : 0x7fffffffu;
+            rt_dma16(rs, s_G + slot * SLOT + m * 1024, voff);
+        }
+    };
+
+    // ---- the batches of RT_BATCH queued RoIs s_queue[0 .. qn)
+    auto run_queue = [&](int qn) {
+        for (int q0 = 0; q0 < qn; q0 += RT_BATCH) {
+            const int nb = min(RT_BATCH, qn - q0);
+            // the first RT_RING - 1 dY tiles of the batch start moving before the weights are built
+#pragma unroll
+            for (int k = 0; k < RT_RING - 1; ++k)
+                if (k < nb) issue(__builtin_amdgcn_readfirstlane(s_queue[q0 + k]), k);
+            for (int u = t; u < nb * 2 * P; u += 256) {
+                // thread (RoI j of the batch, axis, bin p): column p of Ay / Ax restricted to the tile's 16 rows / columns
+                const int j = u / (2 * P), ax = (u / P) & 1, p = u % P;
+                const float* rb = rois + (size_t)s_queue[q0 + j] * 5;
+                const float o1 = (ax ? rb[1] : rb[2]) * sc - 0.5f;
+                const float len = ((ax ? rb[3] : rb[4]) - (ax ? rb[1] : rb[2])) * sc;
+                const float bsz = len / (float)P;
+                const int gN = min((int)ceilf(len / (float)P), 4096), L = ax ? W : H, base = ax ? tx0 : ty0;
+                float* A = s_A[j][ax][p];
+#pragma unroll
+                for (int i = 0; i < RT_TILE; i += 4) *reinterpret_cast<float4*>(A + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float inv = 1.f / (float)gN;
+                for (int i = 0; i < gN; ++i) {
+                    const Lin1 s = lin1(o1 + p * bsz + (i + 0.5f) * bsz / (float)gN, L);
+                    if (!s.ok) continue;
+                    // (the two adds of a sample stay in the separable kernel's order: lo first, then hi)
+                    const int a = s.lo - base, b = s.hi - base;
+                    if (a >= 0 && a < RT_TILE) A[a] += s.wlo * inv;
+                    if (b >= 0 && b < RT_TILE) A[b] += s.whi * inv;
+                }
+            }
+            if (t < nb) {
+                // rows of the tile RoI t of the batch reaches
+                const RoiExt e = ext[s_queue[q0 + t]];
+                s_meta[t][0] = max(e.y0 - ty0, 0);
+                s_meta[t][1] = min(e.y1 - ty0, RT_TILE - 1);
+                s_meta[t][2] = 0;
+            }
+            __syncthreads();
+            if (t < nb * P) {
+                // which x bins have any weight on which QUARTER (4 columns) of the tile: bit 4 p + q of s_meta[j][2].  A bin is
+                // 2-4 feature pixels wide, so it reaches one or two of the four quarters: the column contraction below only
+                // runs the (bin, quarter) pairs that are set
+                const int j = t / P, p = t % P;
+                int m = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(&s_A[j][1][p][4 * q]);
+                    if (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f) m |= 1 << (4 * p + q);
+                }
+                if (m) atomicOr(&s_meta[j][2], m);
+            }
+            // (the barrier of iteration 0 below publishes the masks)
+            for (int j = 0; j < nb; ++j) {
+                // ---- slot j % RT_RING is complete once every wave's share of RoI j has landed: a wave's DMAs complete in
+                // issue order, so leaving the shares of the (up to two) younger RoIs outstanding is a counted vmcnt
+                const int younger = min(nb - 1 - j, RT_RING - 2);
+                if (younger >= 2) {
+                    if (my_dma == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else if (my_dma == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else if (my_dma == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else if (younger == 1) {
+                    if (my_dma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (my_dma == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else if (my_dma == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();           // slot j ready for everyone; everyone is done reading slot (j - 1) % RT_RING
+                if (j + RT_RING - 1 < nb)
+                    issue(__builtin_amdgcn_readfirstlane(s_queue[q0 + j + RT_RING - 1]), (j + RT_RING - 1) % RT_RING);
+                const int xmask = s_meta[j][2];
+                if (s_meta[j][1] < 4 * w || s_meta[j][0] > 4 * w + 3 || xmask == 0) continue;   // wave-uniform: none of this wave's rows
+                const unsigned gaddr = g_base + (unsigned)((j % RT_RING) * SLOT);
+                float tr[4][P];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int b = 0; b < P; ++b) tr[rr][b] = 0.f;
+#define RT_TROW(A)                                                                                                  \
+                {                                                                                                   \
+                    const float4 ay = *reinterpret_cast<const float4*>(&s_A[j][0][A][4 * w]);     /* LDS broadcast */ \
+                    const float ayv[4] = {ay.x, ay.y, ay.z, ay.w};                                                  \
+                    if (ay.x != 0.f || ay.y != 0.f || ay.z != 0.f || ay.w != 0.f) {                /* wave-uniform */ \
+                        float g[P];                                                                                 \
+                        rt_read_row<T, A, P>(gaddr, g);                                                             \
+                        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                            \
+                            _Pragma("unroll") for (int b = 0; b < P; ++b) tr[rr][b] += ayv[rr] * g[b];              \
+                    }                                                                                               \
+                }
+                RT_TROW(0) RT_TROW(1) RT_TROW(2) RT_TROW(3) RT_TROW(4) RT_TROW(5) RT_TROW(6)
+#undef RT_TROW
+#pragma unroll
+                for (int b = 0; b < P; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (!((xmask >> (4 * b + q)) & 1)) continue;               // wave-uniform
+                        const float4 v = *reinterpret_cast<const float4*>(&s_A[j][1][b][4 * q]);   // LDS broadcast
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const float tv = tr[rr][b];
+                            acc[rr][4 * q + 0] += v.x * tv; acc[rr][4 * q + 1] += v.y * tv;
+                            acc[rr][4 * q + 2] += v.z * tv; acc[rr][4 * q + 3] += v.w * tv;
+                        }
+                    }
+            }
+            __syncthreads();               // s_A, s_meta and the ring are free for the next batch
+        }
+    };
+
+    // ---- ordered scan of the RoI extents: super-chunks of 8 x 256 RoIs with all eight loads of a thread in flight at once,
+    // ordered compaction (wave ballots) into the LDS queue, drained after every super-chunk
+    int qn = 0;
+#pragma unroll 1
+    for (int rbase = 0; rbase < R; rbase += 8 * 256) {
+        RoiExt e8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = rbase + k * 256 + t;
+            if (r < R) e8[k] = ext[r]; else { e8[k].lv = -1; e8[k].n = -1; e8[k].y0 = e8[k].x0 = 0; e8[k].y1 = e8[k].x1 = -1; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (rbase + k * 256 >= R) break;                                       // block-uniform
+            const RoiExt& e = e8[k];
+            const bool hit = e.lv == lv && e.n == n && e.y1 >= ty0 && e.y0 < ty0 + RT_TILE && e.x1 >= tx0 && e.x0 < tx0 + RT_TILE;
+            const unsigned long long bal = __ballot(hit);
+            __syncthreads();                                                       // s_wcnt free again (previous round's readers done)
+            if (lane == 0) s_wcnt[w] = __popcll(bal);
+            __syncthreads();
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { off += i < w ? s_wcnt[i] : 0; tot += s_wcnt[i]; }
+            if (hit) s_queue[qn + off + __popcll(bal & ((1ull << lane) - 1ull))] = rbase + k * 256 + t;
+            qn += tot;
+        }
+        __syncthreads();
+        run_queue(qn);                     // (the queue holds at most the 2048 RoIs of one super-chunk)
+        qn = 0;
+    }
+    // ---- every pixel of the tile is written once (64 consecutive channels per wave store)
+    float* g = py.grad[lv];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int y = ty0 + 4 * w + rr;
+        if (y >= H) continue;
+#pragma unroll
+        for (int i = 0; i < RT_TILE; ++i) {
+            const int x = tx0 + i;
+            if (x < W) g[(((size_t)n * H + y) * W + x) * C + c] = acc[rr][i];
+        }
+    }
+}
+
 static int fill_pyramid(Pyramid& py, const void* const* feats, float* const* grads, const int* Hs, const int* Ws,
                         const float* scales, int nlev, int C) {
     CR_CHECK_ARG(nlev >= 1 && nlev <= MAX_LEVELS, "roi_align: 1..%d levels", MAX_LEVELS);
@@ -339,6 +652,42 @@ extern "C" int cr_roi_align_bwd(cr_ctx* ctx, float* const* grads, const int* Hs,
     else
         hipLaunchKernelGGL(k_roi_align_bwd<u16>, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, py, rois,
                            (int)R, PH, PW, (const u16*)dout);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// Deterministic variant of cr_roi_align_bwd: the maps are OVERWRITTEN (every pixel of every level is stored once, no zero
+// fill needed) and no global atomic is used -> bit-reproducible.  N = images in the batch.  7 x 7 pooling, C % 64 == 0.
+extern "C" int cr_roi_align_bwd_set(cr_ctx* ctx, float* const* grads, const int* Hs, const int* Ws, const float* scales,
+                                    int nlev, int C, int N, const float* rois, int64_t R, int PH, int PW, const void* dout,
+                                    int act_f32) {
+    CR_CHECK_ARG(ctx && grads && Hs && Ws && scales, "cr_roi_align_bwd_set: NULL pointer");
+    CR_CHECK_ARG(PH == 7 && PW == 7 && C % 64 == 0 && N >= 1, "cr_roi_align_bwd_set: built for 7x7 pooling, C %% 64 == 0");
+    CR_CHECK_ARG(R >= 0 && R <= (int64_t)(ctx->ws_bytes / sizeof(RoiExt)) && (R == 0 || (rois && dout)),
+                 "cr_roi_align_bwd_set: bad RoI arguments");
+    Pyramid py;
+    int rc = fill_pyramid(py, nullptr, grads, Hs, Ws, scales, nlev, C);
+    if (rc) return rc;
+    TileMap tm;
+    tm.N = N;
+    int total = 0;
+    for (int l = 0; l < nlev; ++l) {
+        tm.base[l] = total;
+        tm.ty[l] = (Hs[l] + RT_TILE - 1) / RT_TILE;
+        tm.tx[l] = (Ws[l] + RT_TILE - 1) / RT_TILE;
+        total += N * tm.ty[l] * tm.tx[l];
+    }
+    for (int l = nlev; l <= MAX_LEVELS; ++l) tm.base[l] = total;
+    RoiExt* ext = (RoiExt*)ctx->ws;
+    if (R > 0)
+        hipLaunchKernelGGL(k_roi_bbox<7>, dim3((unsigned)cr_cdiv(R, 256)), dim3(256), 0, ctx->stream, py, rois, (int)R, N, ext);
+    const unsigned nblk = (unsigned)total * (unsigned)(C / 64);
+    if (act_f32)
+        hipLaunchKernelGGL((k_roi_bwd_tiles<7, float>), dim3(nblk), dim3(256), 0, ctx->stream, py, tm, rois, (int)R,
+                           (const float*)dout, ext);
+    else
+        hipLaunchKernelGGL((k_roi_bwd_tiles<7, u16>), dim3(nblk), dim3(256), 0, ctx->stream, py, tm, rois, (int)R,
+                           (const u16*)dout, ext);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -774,6 +774,9 @@ def _pyr_args(feats, scales):
     return n, ptrs, Hs, Ws, sc, cast
 
 
+_ROI_BWD_TILES = [os.environ.get("CR_ROI_BWD_TILES", "1") == "1"]
+
+
 class _ROIAlign(torch.autograd.Function):
     """Where the pyramid gradient goes (backward), per level, in this order of preference:
       * a gradient slot of the level's map (the RPN head's convolution consumed it first, in the same autograd graph: its
@@ -810,13 +813,17 @@ class _ROIAlign(torch.autograd.Function):
         scales, out_size, shapes, dt = ctx.cfg
         C = shapes[0][3]
         dsts = ctx.dsts
+        # tile-owner kernel (cr_roi_align_bwd_set): writes every pixel of every level once, no atomics, bit-reproducible,
+        # and the maps need no zero fill.  CR_ROI_BWD_TILES=0: the separable atomic kernel (A/B).
+        tiles = _ROI_BWD_TILES[0] and out_size == 7 and C % 64 == 0 and len({s[0] for s in shapes}) == 1
         if all(d is not None and d.dtype == f32 and tuple(d.shape) == tuple(s) for d, s in zip(dsts, shapes)):
             grads = dsts
-            torch._foreach_zero_(grads)
+            if not tiles:
+                torch._foreach_zero_(grads)
         else:
-            # one zero-fill for the whole pyramid (the levels are views of one buffer, each 16-B aligned)
+            # one buffer for the whole pyramid (the levels are views of it, each 16-B aligned); zero-filled for the atomics
             sizes = [(int(s[0] * s[1] * s[2] * s[3]) + 3) // 4 * 4 for s in shapes]
-            flat = torch.zeros((sum(sizes),), dtype=f32, device=rois.device)
+            flat = (torch.empty if tiles else torch.zeros)((sum(sizes),), dtype=f32, device=rois.device)
             grads, off = [], 0
             for s, n_ in zip(shapes, sizes):
                 grads.append(flat[off:off + int(s[0] * s[1] * s[2] * s[3])].view(s))
@@ -824,8 +831,12 @@ class _ROIAlign(torch.autograd.Function):
         n, ptrs, Hs, Ws, sc, cast = _pyr_args(grads, scales)
         lib = _lib.load()
         dout = dout.to(dt).contiguous()
-        _chk(lib.cr_roi_align_bwd(_ctx(rois), cast(ptrs), cast(Hs), cast(Ws), cast(sc), n, C, _p(rois), rois.shape[0],
-                                  out_size, out_size, _p(dout), _af(dout)), "cr_roi_align_bwd")
+        if tiles:
+            _chk(lib.cr_roi_align_bwd_set(_ctx(rois), cast(ptrs), cast(Hs), cast(Ws), cast(sc), n, C, int(shapes[0][0]), _p(rois),
+                                          rois.shape[0], out_size, out_size, _p(dout), _af(dout)), "cr_roi_align_bwd_set")
+        else:
+            _chk(lib.cr_roi_align_bwd(_ctx(rois), cast(ptrs), cast(Hs), cast(Ws), cast(sc), n, C, _p(rois), rois.shape[0],
+                                      out_size, out_size, _p(dout), _af(dout)), "cr_roi_align_bwd")
         res = []
         for g, (slot, _i) in zip(grads, ctx.slots):
             g = g if dt == f32 else g.to(dt)

@@ -318,6 +318,12 @@ int cr_roi_align_fwd(cr_ctx* ctx, const void* const* feats, const int* Hs, const
                      int nlev, int C, const float* rois, int64_t R, int PH, int PW, void* out, int act_f32);
 int cr_roi_align_bwd(cr_ctx* ctx, float* const* grads, const int* Hs, const int* Ws, const float* scales,
                      int nlev, int C, const float* rois, int64_t R, int PH, int PW, const void* dout, int act_f32);
+/* cr_roi_align_bwd without atomics: every pixel of every level's map is WRITTEN once (no zero fill needed), RoI
+ * contributions are summed in RoI order -> bit-reproducible.  One block owns a 16x16-pixel tile x 64 channels of a map.
+ * 7x7 pooling, C % 64 == 0; N = images in the batch (rois[:,0] in [0,N)).  roi_heads.py:2178,2273 (backward of the pooler). */
+int cr_roi_align_bwd_set(cr_ctx* ctx, float* const* grads, const int* Hs, const int* Ws, const float* scales,
+                         int nlev, int C, int N, const float* rois, int64_t R, int PH, int PW, const void* dout,
+                         int act_f32);
 /* batched NMS over G independent groups; boxes (G,maxn,4) sorted by descending score per group, counts (G)
  * int32; keep (G,maxn) uint8; mask_ws: G*maxn*ceil(maxn/64)*8 bytes.  fast_rcnn.py:105, detectron2 RPN. */
 int cr_nms_grouped(cr_ctx* ctx, const float* boxes, const int* counts, int G, int maxn, float thresh,
