@@ -2,6 +2,8 @@
 cr_propose; this wrapper draws the random variates on the device (torch.randn / torch.randint, like the
 reference's torch.normal / torch.randint) and redraws while the truncated-normal rejection rounds are exhausted
 (sample_normal_in_range loops up to 10 000 rounds, utils.py:42-60)."""
+import math
+
 import torch
 
 from ... import geometry as geo
@@ -40,7 +42,15 @@ def propose(reference_box, depth_image, priors, im_shape, K, number_of_proposals
         rounds *= 2
     else:
         raise RuntimeError("truncated-normal rejection sampling did not converge (prior std too large for its range?)")
-    return Cubes(cubes), None, None
+    if gt_cubes is None:
+        return Cubes(cubes), None, None
+    # proposals.py:416-424: where the ground truth lies inside the sampled ranges, and the ranges the offset statistics of
+    # the MABO branch are normalised by (spread of the sampled centres, prior spreads of the dimensions, pi for the angles)
+    x, y, z, w, h, l = cubes[..., :6].unbind(2)
+    pi = torch.full((N,), math.pi, device=dev)
+    ranges = torch.stack([x.std(dim=1) * 1.2, y.std(dim=1) * 0.8, z.std(dim=1) * 1.2, sg[:, 0], sg[:, 1] * 1.1, sg[:, 2],
+                          pi, pi, pi], dim=1).cpu().numpy()
+    return Cubes(cubes), statistics(gt_cubes, x, y, z, w, h, l), ranges
 
 
 def propose_batched(boxes, img_idx, depth_images, priors, K, number_of_proposals, ground_normals, generator=None,

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
     const float* __restrict__ prior_sigma, const float* __restrict__ rect_pts,
     float* __restrict__ out_corners, float* __restrict__ out_boxes, float* __restrict__ out_iou,
     float* __restrict__ out_dim, float* __restrict__ out_corner, float* __restrict__ out_combined,
-    int64_t* __restrict__ out_argmax, float* __restrict__ out_best) {
+    int64_t* __restrict__ out_argmax, float* __restrict__ out_best, const float* __restrict__ iou_boxes) {
     __shared__ __attribute__((aligned(16))) float s_cubes[GEO_T * 15];
     __shared__ double s_red64[GEO_W * 4];
     __shared__ float s_red[GEO_W * 2];
@@ -175,12 +175,15 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
 #pragma unroll
         for (int i = 0; i < 9; ++i) K[i] = kp[i];
     }
-    const float r0 = ref_boxes[obj * 4 + 0], r1 = ref_boxes[obj * 4 + 1];
-    const float r2 = ref_boxes[obj * 4 + 2], r3 = ref_boxes[obj * 4 + 3];
+    // the box of the IoU term: the object's reference box, or a separate one (the MABO / pseudo-GT branches score IoU
+    // against the PROJECTED ground-truth cube and the aspect ratio against the annotated box: roi_heads.py:459-460,530-537)
+    const float* ib = iou_boxes ? iou_boxes : ref_boxes;
+    const float r0 = ib[obj * 4 + 0], r1 = ib[obj * 4 + 1];
+    const float r2 = ib[obj * 4 + 2], r3 = ib[obj * 4 + 3];
     const float mu0 = prior_mu[obj * 3 + 0], mu1 = prior_mu[obj * 3 + 1], mu2 = prior_mu[obj * 3 + 2];
     const float sg0 = prior_sigma[obj * 3 + 0], sg1 = prior_sigma[obj * 3 + 1], sg2 = prior_sigma[obj * 3 + 2];
     const float a1 = (r2 - r0) * (r3 - r1);
-    const float gt_ratio = (r2 - r0) / (r3 - r1);
+    const float gt_ratio = (ref_boxes[obj * 4 + 2] - ref_boxes[obj * 4 + 0]) / (ref_boxes[obj * 4 + 3] - ref_boxes[obj * 4 + 1]);
 
     // no rectangle at all, or a NaN row for this object (empty mask, cr_mask_rects): the no-contour fallback below
     const bool have_rect = rect_pts != nullptr && rect_pts[obj * 8] == rect_pts[obj * 8];
@@ -387,7 +390,7 @@ extern "C" int cr_cubes_project_score(cr_ctx* ctx, const float* cubes, int64_t N
                                       const float* ref_boxes, const float* prior_mu, const float* prior_sigma,
                                       const float* rect_pts, float* out_corners, float* out_boxes,
                                       float* out_iou, float* out_dim, float* out_corner, float* out_combined,
-                                      int64_t* out_argmax, float* out_best) {
+                                      int64_t* out_argmax, float* out_best, const float* iou_boxes) {
     CR_CHECK_ARG(ctx != nullptr, "cr_cubes_project_score: ctx is NULL");
     CR_CHECK_ARG(N >= 0 && P >= 0, "cr_cubes_project_score: negative N/P");
     if (N == 0) return CR_OK;
@@ -406,16 +409,16 @@ extern "C" int cr_cubes_project_score(cr_ctx* ctx, const float* cubes, int64_t N
 #define GEO_EXP_CASE(E) if (geo_exp == E && P <= 4 * GEO_T) { \
         hipLaunchKernelGGL((k_project_score<4, E>), grid, block, 0, ctx->stream, cubes, (int)P, K, k_per_object, cl, \
                            ref_boxes, prior_mu, prior_sigma, rect_pts, out_corners, out_boxes, out_iou, out_dim, \
-                           out_corner, out_combined, out_argmax, out_best); CR_LAUNCH_CHECK(); return CR_OK; }
+                           out_corner, out_combined, out_argmax, out_best, iou_boxes); CR_LAUNCH_CHECK(); return CR_OK; }
     GEO_EXP_CASE(1) GEO_EXP_CASE(2) GEO_EXP_CASE(3) GEO_EXP_CASE(4) GEO_EXP_CASE(8) GEO_EXP_CASE(12) GEO_EXP_CASE(16) GEO_EXP_CASE(28) GEO_EXP_CASE(31)
     if (P <= 4 * GEO_T)
         hipLaunchKernelGGL(k_project_score<4>, grid, block, 0, ctx->stream, cubes, (int)P, K, k_per_object, cl,
                            ref_boxes, prior_mu, prior_sigma, rect_pts, out_corners, out_boxes, out_iou, out_dim,
-                           out_corner, out_combined, out_argmax, out_best);
+                           out_corner, out_combined, out_argmax, out_best, iou_boxes);
     else
         hipLaunchKernelGGL(k_project_score<16>, grid, block, 0, ctx->stream, cubes, (int)P, K, k_per_object, cl,
                            ref_boxes, prior_mu, prior_sigma, rect_pts, out_corners, out_boxes, out_iou, out_dim,
-                           out_corner, out_combined, out_argmax, out_best);
+                           out_corner, out_combined, out_argmax, out_best, iou_boxes);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

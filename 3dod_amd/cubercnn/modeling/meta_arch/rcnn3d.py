@@ -321,12 +321,18 @@ class BoxNet(RCNN3D):
     "masks" (N,H,W) per image (the reference reads depth/ground .npz files and runs SAM-HQ for the masks)."""
 
     def forward(self, batched_inputs, experiment_type=None, proposal_function='propose'):
-        assert not self.training, "BoxNet training (pseudo-GT generation) is driven by tools/eval_boxes.py: out of scope"
+        """rcnn3d.py:678-713.  Training mode generates pseudo ground truth on the GT boxes (experiment_type['pseudo_gt'] =
+        'learn' | 'pseudo'), eval mode is the AP path or, with experiment_type['output_recall_scores'], the MABO tuple."""
         experiment_type = experiment_type or {'use_pred_boxes': True}
-        return self.inference(batched_inputs, experiment_type=experiment_type, proposal_function=proposal_function)
+        if self.training:
+            experiment_type = dict(experiment_type, use_pred_boxes=False)
+        return self.inference(batched_inputs, experiment_type=experiment_type, proposal_function=proposal_function,
+                              do_postprocess=not (self.training or experiment_type.get('output_recall_scores', False)))
 
     def inference(self, batched_inputs, experiment_type=None, do_postprocess=True, generator=None, proposal_function='propose'):
         use_pred = (experiment_type or {}).get('use_pred_boxes', True)
+        if experiment_type and (self.training or experiment_type.get('output_recall_scores', False)):
+            do_postprocess = False                    # these branches return cubes / score tables, not detections to rescale
         if use_pred:
             images, x = self.preprocess_image(batched_inputs)
         else:
@@ -347,7 +353,8 @@ class BoxNet(RCNN3D):
             proposals = [b["instances"] if b["instances"].gt_boxes.device == self.device else b["instances"].to(self.device)
                          for b in batched_inputs]
         results, _ = self.roi_heads(images, features, proposals, depth, ground, Ks, im_scales_ratio, masks=masks,
-                                    use_pred_boxes=use_pred, generator=generator, proposal_function=proposal_function)
+                                    use_pred_boxes=use_pred, generator=generator, proposal_function=proposal_function,
+                                    experiment_type=experiment_type)
         if do_postprocess:
             return RCNN3D._postprocess(results, batched_inputs, images.image_sizes)
         return results

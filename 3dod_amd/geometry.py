@@ -31,9 +31,10 @@ def cuboid_corners(box6, R):
 
 
 def cubes_project_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_pts=None,
-                        want=("corners", "boxes", "iou", "dim", "corner", "combined")):
+                        want=("corners", "boxes", "iou", "dim", "corner", "combined"), iou_boxes=None):
     """Fused K17 (see cr_cubes_project_score).  Returns a dict with the requested
-    planes plus `argmax` (N,) int64 and `best` (N,)."""
+    planes plus `argmax` (N,) int64 and `best` (N,).  iou_boxes (N,4): the box of the IoU term when it is not
+    ref_boxes (the GT-box branches of ROIHeads_Boxer score IoU against the projected ground-truth cube)."""
     cubes = _f32c(cubes, "cubes", (None, None, 15))
     N, Pn = cubes.shape[:2]
     dev = cubes.device
@@ -49,6 +50,8 @@ def cubes_project_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_
     prior_sigma = _f32c(prior_sigma, "prior_sigma", (N, 3))
     if rect_pts is not None:
         rect_pts = _f32c(rect_pts, "rect_pts", (N, 4, 2))
+    if iou_boxes is not None:
+        iou_boxes = _f32c(iou_boxes, "iou_boxes", (N, 4))
     shapes = {"corners": (N, Pn, 8, 2), "boxes": (N, Pn, 4), "iou": (N, Pn), "dim": (N, Pn),
               "corner": (N, Pn), "combined": (N, Pn)}
     out = {k: (torch.empty(shapes[k], dtype=f32, device=dev) if k in want else None) for k in shapes}
@@ -61,7 +64,8 @@ def cubes_project_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_
         _lib.ctx_for(dev), _lib.ptr(cubes), N, Pn, _lib.ptr(K), kpo, float(im_wh[0]), float(im_wh[1]),
         _lib.ptr(ref_boxes), _lib.ptr(prior_mu), _lib.ptr(prior_sigma), _lib.ptr(rect_pts),
         _lib.ptr(out["corners"]), _lib.ptr(out["boxes"]), _lib.ptr(out["iou"]), _lib.ptr(out["dim"]),
-        _lib.ptr(out["corner"]), _lib.ptr(out["combined"]), _lib.ptr(out["argmax"]), _lib.ptr(out["best"]))
+        _lib.ptr(out["corner"]), _lib.ptr(out["combined"]), _lib.ptr(out["argmax"]), _lib.ptr(out["best"]),
+        _lib.ptr(iou_boxes))
     _lib.check(rc, "cr_cubes_project_score")
     return out
 

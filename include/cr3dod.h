@@ -68,13 +68,16 @@ int cr_cuboid_corners(cr_ctx* ctx, const float* box6, const float* R, int64_t n,
  *   out_corners (N,P,8,2) out_boxes (N,P,4) out_iou/out_dim/out_corner/
  *   out_combined (N,P); out_argmax (N) int64; out_best (N) = combined[argmax].
  * P <= 4096.  NaN/Inf are data (unguarded z<=0, 0/0 ratios) as in the reference;
- * argmax follows np.argmax (first maximal index, NaN maximal). */
+ * argmax follows np.argmax (first maximal index, NaN maximal).
+ * iou_boxes (N,4) or NULL: the box of the IoU term when it differs from ref_boxes (which then only gives the aspect ratio
+ * of score_dimensions) -- the GT-box branches score IoU against the projected ground-truth cube, roi_heads.py:459,530. */
 int cr_cubes_project_score(cr_ctx* ctx, const float* cubes, int64_t N, int64_t P,
                            const float* K, int k_per_object, float im_w, float im_h,
                            const float* ref_boxes, const float* prior_mu, const float* prior_sigma,
                            const float* rect_pts,
                            float* out_corners, float* out_boxes, float* out_iou, float* out_dim,
-                           float* out_corner, float* out_combined, int64_t* out_argmax, float* out_best);
+                           float* out_corner, float* out_combined, int64_t* out_argmax, float* out_best,
+                           const float* iou_boxes);
 
 /* K18: proposals.propose -- ProposalNetwork/proposals/proposals.py:338-424 with
  * the random variates supplied by the caller (RNG streams cannot be made

@@ -243,7 +243,7 @@ def argmax_numpy(x: np.ndarray) -> int:
     return int(np.argmax(np.asarray(x, dtype=F32)))
 
 
-def project_and_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_pts=None):
+def project_and_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_pts=None, iou_boxes=None):
     """The AP path of ROIHeads_Boxer._forward_cube, roi_heads.py:492-505, for N
     objects x P proposals, one object at a time like the reference's loop.
 
@@ -263,7 +263,8 @@ def project_and_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_pt
         c3 = cubes_corners(cubes[i])
         c2 = project_corners(c3, Ki, im_wh)
         bx = corners_to_boxes(c2)
-        iou = iou_one_to_many(ref_boxes[i], bx)
+        # (the GT-box branches score IoU against the projected ground-truth cube: roi_heads.py:459,530)
+        iou = iou_one_to_many(ref_boxes[i] if iou_boxes is None else iou_boxes[i], bx)
         dim, _, _, _ = score_dimensions(prior_mu[i], prior_sigma[i], cubes[i, :, 3:6], ref_boxes[i], bx)
         rect = fallback_rect(c2) if rect_pts is None else rect_pts[i]
         cor, _, _ = score_corners_from_rect(rect, c2)

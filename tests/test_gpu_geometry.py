@@ -118,6 +118,21 @@ def test_k_per_object_and_argmax_only():
     assert lean["corners"] is None
 
 
+def test_separate_iou_box_bitexact_vs_oracle():
+    """iou_boxes: the IoU term against another box than the aspect-ratio / corner terms (the GT-box branches of
+    ROIHeads_Boxer score IoU2D against the projected ground-truth cube, roi_heads.py:459,530)"""
+    cubes, K, im, ref, mu, sg, rect = random_case(5, 1000, seed=11)
+    rng = np.random.default_rng(4)
+    iou_ref = (ref + rng.normal(0, 12, ref.shape)).astype(np.float32)
+    out = geo.cubes_project_score(T(cubes), T(K), im, T(ref), T(mu), T(sg), T(rect), iou_boxes=T(iou_ref))
+    o = og.project_and_score(cubes, K, im, ref, mu, sg, rect, iou_boxes=iou_ref)
+    o0 = og.project_and_score(cubes, K, im, ref, mu, sg, rect)
+    for k in ("corners", "boxes", "iou", "dim", "corner", "combined"):
+        assert same_bits(out[k].cpu().numpy(), o[k]), k
+    assert (out["argmax"].cpu().numpy() == o["argmax"]).all()
+    assert same_bits(o["dim"], o0["dim"]) and not same_bits(o["iou"], o0["iou"])      # only the IoU term moved
+
+
 def test_nan_semantics():
     # zero-height projected boxes -> 0/0 ratio -> NaN dim score; np.argmax picks the first NaN
     cubes, K, im, ref, mu, sg, rect = random_case(2, 64, seed=5, nasty=False)
