@@ -62,6 +62,9 @@ SIGNATURES = {
     "cr_preprocess": [P, P, P, c_int, c_int, c_int, P, P, c_int],
     "cr_roi_align_fwd": [P, P, P, P, P, c_int, c_int, P, c_int64, c_int, c_int, P, c_int],
     "cr_roi_align_bwd": [P, P, P, P, P, c_int, c_int, P, c_int64, c_int, c_int, P, c_int],
+    "cr_conv2d_fwd_group": [P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int],
+    "cr_conv2d_bwd_data_group": [P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "cr_conv2d_bwd_weight_group": [P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int],
     "cr_roi_align_bwd_set": [P, P, P, P, P, c_int, c_int, c_int, P, c_int64, c_int, c_int, P, c_int],
     "cr_nms_grouped": [P, P, P, c_int, c_int, c_float, P, P],
     "cr_cube_loss_fwd": [P, P, c_int64, c_int, c_int, c_int, c_int, P, P],

@@ -514,8 +514,10 @@ __device__ __forceinline__ u32x4 lds_read16_asm(unsigned byte_addr) {
 // TFLOP/s on the 3x3 128->128 layers), without the slab traffic of more split-K.
 // BM = 64: half-height tiles for the f32 layers whose 128-pixel tiling gives fewer than one block per CU -- twice the
 // blocks without split-K slabs (a 64 x 128 tile moves 0.047 B/flop, 6 TB/s at the f32 peak: still under the L2 rate).
+// (the body is a device function of (parameters, block index, block count): k_conv_igemm_dma runs it on its own grid,
+// k_conv_igemm_dma_grp on one problem of a group)
 template <int BN, int KS, int MODE, typename T = u16, int KG = 1, int BM = 128>
-__global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm_dma(ConvP p) {
+__device__ __forceinline__ void conv_igemm_dma_body(const ConvP& p, const int blk_id, const int blk_count) {
     constexpr int ES = (int)sizeof(T), SUB = 64 / ES;                        // k per 64-B LDS row: 32 bf16 / 16 f32
     constexpr int BK = 2 * SUB, NBX = BM / 64;                               // pixel rows per thread (chunks of 64 rows)
     constexpr int WAVES_M = BN == 128 ? 2 : 4, WAVES_N = 4 / WAVES_M;      // as k_conv_igemm: same statistics order
@@ -530,8 +532,8 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm_dma(ConvP p) {
     static_assert(4 * 2 * BN * sizeof(float) <= 2 * STAGE * sizeof(u16), "sStat must fit");
     const int tid = threadIdx.x & (CONV_T - 1), lane = tid & 63, wave = tid >> 6;
     const int n_tiles = p.Cout / BN;
-    const int tiles_total = (int)gridDim.x / p.ksplit;                      // ksplit == 1: the whole grid
-    const int ks = (int)blockIdx.x / tiles_total, bt = (int)blockIdx.x - ks * tiles_total;
+    const int tiles_total = blk_count / p.ksplit;                           // ksplit == 1: the whole grid
+    const int ks = blk_id / tiles_total, bt = blk_id - ks * tiles_total;
     const int bid = (p.xcd && (p.ksplit == 1 || (tiles_total & 7) == 0)) ? xcd_swizzle(bt, tiles_total) : bt;
     const int nt = bid % n_tiles, mt = bid / n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -693,6 +695,29 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm_dma(ConvP p) {
         return;
     }
     conv_epilogue<BM, BN, TC, TP, T, T>(p, acc, reinterpret_cast<float*>(smem_all), m0, n0, mt, poff, coff, tid, lane, wave, grp == 0);
+}
+
+template <int BN, int KS, int MODE, typename T = u16, int KG = 1, int BM = 128>
+__global__ __launch_bounds__(CONV_T * KG) void k_conv_igemm_dma(ConvP p) {
+    conv_igemm_dma_body<BN, KS, MODE, T, KG, BM>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Grouped launch: up to CR_MAX_GROUP independent convolutions of one geometry class (same filter size, stride 1, Cin, Cout,
+// precision) in ONE grid of 128 x 128 tiles -- the five levels of the FPN output convolutions / the RPN head convolution.
+// Alone, the 32 x 32 ... 8 x 8 levels are a handful of tiles each: they take the split-K path (partial slabs + an epilogue
+// launch) and stay latency-bound at 28 ... 45 us for 0.3 ... 4.8 GFLOP; inside the group's grid their tiles run beside the
+// 128 x 128 level's at its rate.  Problem i owns blocks [start[i], start[i] + count[i]); starts are multiples of 8 so that
+// every problem's XCD-aware tile order sees the round-robin deal it assumes (the padding blocks exit at once).
+#define CR_MAX_GROUP 8
+struct ConvGroup { ConvP p[CR_MAX_GROUP]; int start[CR_MAX_GROUP], count[CR_MAX_GROUP]; int n; };
+
+template <int KS, int MODE, typename T>
+__global__ __launch_bounds__(CONV_T) void k_conv_igemm_dma_grp(ConvGroup g) {
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.start[i + 1]) ++i;
+    const int blk = (int)blockIdx.x - g.start[i];
+    if (blk >= g.count[i]) return;                                            // alignment padding (block-uniform)
+    conv_igemm_dma_body<128, KS, MODE, T, 1, 128>(g.p[i], blk, g.count[i]);
 }
 
 // k_conv_igemm_dma_s3: k_conv_igemm_dma in split mode (f32 activations and results, six bf16 MFMAs per tile pair and 32
@@ -1556,6 +1581,96 @@ extern "C" int cr_conv2d_bwd_data(cr_ctx* ctx, const void* dy, const void* wt, v
     return launch_igemm_ks<7, 1>(ctx, p, act_f32 ? 1 : 0);
 }
 
+// ---- grouped forward / backward-data (k_conv_igemm_dma_grp) ------------------------------------------------------------
+static int group_starts(int n, const int* counts, int* starts) {
+    int total = 0;
+    for (int i = 0; i < n; ++i) { starts[i] = total; total += (counts[i] + 7) & ~7; }
+    return total;
+}
+
+// n convolutions (stride 1, k in {1, 3}, Cin % 64 == 0 (f32: % 32), Cout % 128 == 0) in one launch.  Pointer tables are HOST
+// arrays of device pointers; biases / residuals (fwd) and accumulates (bwd-data) may be NULL or hold NULL entries.
+extern "C" int cr_conv2d_fwd_group(cr_ctx* ctx, int n, const void* const* xs, const void* const* ws, void* const* ys,
+                                   const int* Ns, const int* Hs, const int* Ws, int Cin, int Cout, int ks, int pad,
+                                   const float* const* biases, const void* const* residuals, int relu, int act_f32) {
+    CR_CHECK_ARG(ctx && xs && ws && ys && Ns && Hs && Ws, "cr_conv2d_fwd_group: NULL pointer");
+    CR_CHECK_ARG(n >= 1 && n <= CR_MAX_GROUP, "cr_conv2d_fwd_group: 1..%d problems", CR_MAX_GROUP);
+    CR_CHECK_ARG((ks == 1 || ks == 3) && act_f32 != 2 && Cout % 128 == 0 && (Cin & (act_f32 ? 31 : 63)) == 0,
+                 "cr_conv2d_fwd_group: k in {1,3}, Cout %% 128 == 0, Cin %% 64 (32 in f32) == 0, fp32 or bf16");
+    const size_t es = act_f32 ? 4 : 2;
+    ConvGroup g;
+    int counts[CR_MAX_GROUP];
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        CR_CHECK_ARG(xs[i] && ws[i] && ys[i], "cr_conv2d_fwd_group: NULL tensor %d", i);
+        int rc = conv_common_checks("cr_conv2d_fwd_group", Ns[i], Hs[i], Ws[i], Cin, Cout, ks, 1, pad, act_f32);
+        if (rc) return rc;
+        ConvP& p = g.p[i];
+        p.x = xs[i]; p.w = ws[i]; p.y = ys[i]; p.res = residuals ? residuals[i] : nullptr; p.bias = biases ? biases[i] : nullptr;
+        p.stats = nullptr;
+        p.N = Ns[i]; p.Hin = Hs[i]; p.Win = Ws[i]; p.Cin = Cin; p.Cout = Cout;
+        p.Hout = Hs[i] + 2 * pad - ks + 1; p.Wout = Ws[i] + 2 * pad - ks + 1;
+        p.stride = 1; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = p.N * p.Hout * p.Wout;
+        p.cshift = ks == 1 ? 0 : ilog2_exact(Cin); p.relu = relu; p.xcd = xcd_enabled(); p.f32 = act_f32 ? 1 : 0;
+        p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim; p.cls = 0; p.Hfull = p.Hout; p.Wfull = p.Wout; p.wstride = p.Kdim;
+        p.x_bytes = (unsigned)((size_t)p.N * p.Hin * p.Win * Cin * es); p.w_bytes = (unsigned)((size_t)Cout * p.Kdim * es);
+        p.w3 = nullptr; p.w3_bytes = 0;
+        counts[i] = (int)(cr_cdiv(p.M, 128) * (Cout / 128));
+    }
+    const int total = group_starts(n, counts, g.start);
+    for (int i = 0; i < n; ++i) g.count[i] = counts[i];
+    for (int i = n; i < CR_MAX_GROUP; ++i) { g.start[i] = total; g.count[i] = 0; }
+    const dim3 grid((unsigned)total), block(CONV_T);
+#define CR_GRP_CASE(K) if (ks == K) { \
+        if (act_f32) hipLaunchKernelGGL((k_conv_igemm_dma_grp<K, 0, float>), grid, block, 0, ctx->stream, g); \
+        else hipLaunchKernelGGL((k_conv_igemm_dma_grp<K, 0, u16>), grid, block, 0, ctx->stream, g); }
+    CR_GRP_CASE(1) CR_GRP_CASE(3)
+#undef CR_GRP_CASE
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// dX_i = conv^T(dY_i) (+ accumulate_i).  wts: the [Cin][k*k*Cout] layouts (cr_weight_transpose); Cin % 128 == 0 here.
+extern "C" int cr_conv2d_bwd_data_group(cr_ctx* ctx, int n, const void* const* dys, const void* const* wts, void* const* dxs,
+                                        const int* Ns, const int* Hs, const int* Ws, int Cin, int Cout, int ks, int pad,
+                                        int act_f32, const void* const* accumulates) {
+    CR_CHECK_ARG(ctx && dys && wts && dxs && Ns && Hs && Ws, "cr_conv2d_bwd_data_group: NULL pointer");
+    CR_CHECK_ARG(n >= 1 && n <= CR_MAX_GROUP, "cr_conv2d_bwd_data_group: 1..%d problems", CR_MAX_GROUP);
+    CR_CHECK_ARG((ks == 1 || ks == 3) && act_f32 != 2 && Cin % 128 == 0 && (Cout & (act_f32 ? 31 : 63)) == 0,
+                 "cr_conv2d_bwd_data_group: k in {1,3}, Cin %% 128 == 0, Cout %% 64 (32 in f32) == 0, fp32 or bf16");
+    const size_t es = act_f32 ? 4 : 2;
+    ConvGroup g;
+    int counts[CR_MAX_GROUP];
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        CR_CHECK_ARG(dys[i] && wts[i] && dxs[i], "cr_conv2d_bwd_data_group: NULL tensor %d", i);
+        int rc = conv_common_checks("cr_conv2d_bwd_data_group", Ns[i], Hs[i], Ws[i], Cout, Cin, ks, 1, pad, act_f32);
+        if (rc) return rc;
+        const int H = Hs[i], W = Ws[i], Ho = H + 2 * pad - ks + 1, Wo = W + 2 * pad - ks + 1;
+        ConvP& p = g.p[i];
+        p.x = dys[i]; p.w = wts[i]; p.y = dxs[i]; p.res = accumulates ? accumulates[i] : nullptr; p.bias = nullptr; p.stats = nullptr;
+        p.N = Ns[i]; p.Hin = Ho; p.Win = Wo; p.Cin = Cout;      // gather source = dY
+        p.Hout = H; p.Wout = W; p.Cout = Cin;                   // GEMM output = dX
+        p.stride = 1; p.pad = pad; p.Kdim = ks * ks * Cout; p.M = p.N * H * W;
+        p.cshift = ks == 1 ? 0 : ilog2_exact(Cout); p.relu = 0; p.xcd = xcd_enabled(); p.f32 = act_f32 ? 1 : 0;
+        p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim; p.cls = 0; p.Hfull = H; p.Wfull = W; p.wstride = p.Kdim;
+        p.x_bytes = (unsigned)((size_t)p.N * Ho * Wo * Cout * es); p.w_bytes = (unsigned)((size_t)Cin * p.Kdim * es);
+        p.w3 = nullptr; p.w3_bytes = 0;
+        counts[i] = (int)(cr_cdiv(p.M, 128) * (Cin / 128));
+    }
+    const int total = group_starts(n, counts, g.start);
+    for (int i = 0; i < n; ++i) g.count[i] = counts[i];
+    for (int i = n; i < CR_MAX_GROUP; ++i) { g.start[i] = total; g.count[i] = 0; }
+    const dim3 grid((unsigned)total), block(CONV_T);
+#define CR_GRP_CASE(K) if (ks == K) { \
+        if (act_f32) hipLaunchKernelGGL((k_conv_igemm_dma_grp<K, 1, float>), grid, block, 0, ctx->stream, g); \
+        else hipLaunchKernelGGL((k_conv_igemm_dma_grp<K, 1, u16>), grid, block, 0, ctx->stream, g); }
+    CR_GRP_CASE(1) CR_GRP_CASE(3)
+#undef CR_GRP_CASE
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
 // ---------------------------------------------------------------------------
 // backward-weight
 // ---------------------------------------------------------------------------
@@ -1798,7 +1913,7 @@ __global__ __launch_bounds__(CONV_T * KG) void k_conv_wgrad(WgP p) {
 // split-over-pixels scheme are hidden behind 16x more matrix time than in the bf16 kernel.
 // ---------------------------------------------------------------------------
 template <int TM, int KS>
-__global__ __launch_bounds__(CONV_T) void k_conv_wgrad_f32(WgP p) {
+__device__ __forceinline__ void conv_wgrad_f32_body(const WgP& p, const int blk_id, const int blk_count) {
     constexpr int TN = 128, KU = 2, PS = 16;             // k tile, sub-steps per stage, pixels per sub-step
     constexpr int WM = (TM == 128) ? 2 : 1, WN = 4 / WM;
     constexpr int WTM = TM / WM, WTN = TN / WN;          // wave tile
@@ -1813,7 +1928,7 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad_f32(WgP p) {
     (void)xg;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bid = p.xcd ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int bid = p.xcd ? xcd_swizzle(blk_id, blk_count) : blk_id;
     const int bx = bid % p.tm, by = (bid / p.tm) % p.tn, bz = bid / (p.tm * p.tn);
     const int c0 = bx * TM, q0 = by * TN;
     const int step0 = bz * p.steps_per_split;            // steps are PS pixels here
@@ -1948,6 +2063,25 @@ __global__ __launch_bounds__(CONV_T) void k_conv_wgrad_f32(WgP p) {
                 if (kk < p.Kdim && ch < p.Cout) atomicAdd(&p.dw[(size_t)ch * p.Kdim + kk], acc[i][j][e]);
             }
         }
+}
+
+template <int TM, int KS>
+__global__ __launch_bounds__(CONV_T) void k_conv_wgrad_f32(WgP p) {
+    conv_wgrad_f32_body<TM, KS>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// grouped launch (see k_conv_igemm_dma_grp): the weight gradients of up to CR_MAX_GROUP convolutions of one geometry class in
+// one grid; problems that share their weights (the RPN head over the five pyramid levels) name the same dW and their blocks
+// add into it like the pixel splits of one problem do
+struct WgGroup { WgP p[CR_MAX_GROUP]; int start[CR_MAX_GROUP], count[CR_MAX_GROUP]; int n; };
+
+template <int KS>
+__global__ __launch_bounds__(CONV_T) void k_conv_wgrad_f32_grp(WgGroup g) {
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.start[i + 1]) ++i;
+    const int blk = (int)blockIdx.x - g.start[i];
+    if (blk >= g.count[i]) return;
+    conv_wgrad_f32_body<128, KS>(g.p[i], blk, g.count[i]);
 }
 
 // ---------------------------------------------------------------------------
@@ -2788,6 +2922,54 @@ extern "C" int cr_conv2d_bwd_weight_bias(cr_ctx* ctx, const void* dy, const void
                                          int W, int Cin, int Cout, int ks, int stride, int pad, int accumulate, int act_f32) {
     CR_CHECK_ARG(dbias, "cr_conv2d_bwd_weight_bias: NULL dbias");
     return conv2d_bwd_weight_impl(ctx, dy, x, dw, dbias, N, H, W, Cin, Cout, ks, stride, pad, accumulate, act_f32);
+}
+
+// dW_i += dY_i^T X_i (f32 mode, k in {1, 3}, stride 1, Cout % 128 == 0) for n convolutions in one launch; dws may repeat a
+// pointer (shared weights: the contributions are summed); dbiases (or entries) may be NULL.  ALWAYS accumulates.
+extern "C" int cr_conv2d_bwd_weight_group(cr_ctx* ctx, int n, const void* const* dys, const void* const* xs, float* const* dws,
+                                          float* const* dbiases, const int* Ns, const int* Hs, const int* Ws, int Cin, int Cout,
+                                          int ks, int pad, int act_f32) {
+    CR_CHECK_ARG(ctx && dys && xs && dws && Ns && Hs && Ws, "cr_conv2d_bwd_weight_group: NULL pointer");
+    CR_CHECK_ARG(n >= 1 && n <= CR_MAX_GROUP, "cr_conv2d_bwd_weight_group: 1..%d problems", CR_MAX_GROUP);
+    CR_CHECK_ARG((ks == 1 || ks == 3) && act_f32 == 1 && Cout % 128 == 0, "cr_conv2d_bwd_weight_group: fp32, k in {1,3}, Cout %% 128 == 0");
+    WgGroup g;
+    int counts[CR_MAX_GROUP];
+    g.n = n;
+    constexpr int PS = 16;
+    int64_t steps_all = 0;
+    for (int i = 0; i < n; ++i) steps_all += cr_cdiv((int64_t)Ns[i] * (Hs[i] + 2 * pad - ks + 1) * (Ws[i] + 2 * pad - ks + 1), PS);
+    const int tm = Cout / 128, tn = (int)cr_cdiv((int64_t)ks * ks * Cin, 128), tiles = tm * tn;
+    // one resident round of blocks over the whole group (3 per CU, the single-problem rule of launch_wgrad_f32_ks), every
+    // block keeping >= 8 sub-steps; the same pixel count per block in every problem
+    int splits_all = 768 / tiles > 1 ? 768 / tiles : 1;
+    int sps = (int)cr_cdiv(steps_all, splits_all);
+    if (sps < 8) sps = 8;
+    sps = (sps + 1) & ~1;
+    for (int i = 0; i < n; ++i) {
+        CR_CHECK_ARG(dys[i] && xs[i] && dws[i], "cr_conv2d_bwd_weight_group: NULL tensor %d", i);
+        int rc = conv_common_checks("cr_conv2d_bwd_weight_group", Ns[i], Hs[i], Ws[i], Cin, Cout, ks, 1, pad, act_f32);
+        if (rc) return rc;
+        WgP& p = g.p[i];
+        p.dbg = 0; p.cshift_w = 0; p.cshift_hw = -1;
+        p.dy = dys[i]; p.x = xs[i]; p.dw = dws[i]; p.dbias = dbiases ? dbiases[i] : nullptr;
+        p.N = Ns[i]; p.Hin = Hs[i]; p.Win = Ws[i]; p.Cin = Cin; p.Cout = Cout;
+        p.Hout = Hs[i] + 2 * pad - ks + 1; p.Wout = Ws[i] + 2 * pad - ks + 1;
+        p.stride = 1; p.pad = pad; p.Kdim = ks * ks * Cin; p.M = p.N * p.Hout * p.Wout;
+        p.cshift = ks == 1 ? 0 : ilog2_exact(Cin);
+        p.x_bytes = (unsigned)((size_t)p.N * p.Hin * p.Win * Cin * 4); p.dy_bytes = (unsigned)((size_t)p.M * Cout * 4);
+        const int nsteps = (p.M + PS - 1) / PS;
+        p.steps_per_split = sps;
+        p.tm = tm; p.tn = tn; p.xcd = xcd_enabled();
+        counts[i] = tiles * (int)cr_cdiv(nsteps, sps);
+    }
+    const int total = group_starts(n, counts, g.start);
+    for (int i = 0; i < n; ++i) g.count[i] = counts[i];
+    for (int i = n; i < CR_MAX_GROUP; ++i) { g.start[i] = total; g.count[i] = 0; }
+    const dim3 grid((unsigned)total), block(CONV_T);
+    if (ks == 1) hipLaunchKernelGGL(k_conv_wgrad_f32_grp<1>, grid, block, 0, ctx->stream, g);
+    else hipLaunchKernelGGL(k_conv_wgrad_f32_grp<3>, grid, block, 0, ctx->stream, g);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -99,18 +99,22 @@ class FPN(Backbone):
     def forward(self, x):
         """x: NHWC bf16 image batch (channels padded to 8) -> dict name -> NHWC bf16 feature map."""
         bottom_up_features = self.bottom_up(x)
-        results = []
-        lat0, out0 = self.lateral_convs[0], self.output_convs[0]
+        # top-down pathway first (lateral 1x1 + nearest-2x sum, coarse to fine), then ALL output convolutions in one grouped
+        # launch per direction (ops.conv_bias_act_group): they are independent of each other, and alone the coarse levels
+        # are a handful of tiles each
+        lat0 = self.lateral_convs[0]
         prev = ops.conv_bias_act(bottom_up_features[self.in_features[-1]], lat0.weight, lat0.bias, 1, 0)
-        results.append(ops.conv_bias_act(prev, out0.weight, out0.bias, 1, 1))
-        for idx, (lateral_conv, output_conv) in enumerate(zip(self.lateral_convs, self.output_convs)):
+        inner = [prev]
+        for idx, lateral_conv in enumerate(self.lateral_convs):
             if idx > 0:
                 features = bottom_up_features[self.in_features[-idx - 1]]
                 lateral = ops.conv_bias_act(features, lateral_conv.weight, lateral_conv.bias, 1, 0)
                 prev = ops.upsample2x_add(lateral, prev)
                 if self._fuse_type == "avg":
                     prev = prev / 2
-                results.insert(0, ops.conv_bias_act(prev, output_conv.weight, output_conv.bias, 1, 1))
+                inner.append(prev)
+        outs = ops.conv_bias_act_group(inner, [c.weight for c in self.output_convs], [c.bias for c in self.output_convs], pad=1)
+        results = outs[::-1]                                   # fine -> coarse
         if self.top_block is not None:
             src = bottom_up_features[self.top_block.in_feature] if self.top_block.in_feature in bottom_up_features \
                 else results[self._out_features.index(self.top_block.in_feature)]

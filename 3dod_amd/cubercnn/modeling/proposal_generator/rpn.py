@@ -36,11 +36,11 @@ class StandardRPNHead(nn.Module):
         pad = (-n_out) % 16
         w = ops.cat_rows((self.objectness_logits.weight, self.anchor_deltas.weight), n_out + pad)
         b = ops.cat_rows((self.objectness_logits.bias, self.anchor_deltas.bias), n_out + pad)
-        ys = []
-        for x in features:
-            t = ops.conv_bias_act(x, self.conv.weight, self.conv.bias, 1, 1, relu=True)
-            ys.append(ops.conv_bias_act(t, w, b, 1, 0, relu=False, out_f32=True))
-        return ys
+        # the 3x3 convolution is ONE set of weights applied to every level: one grouped launch per direction, the weight
+        # gradient of all levels summed in one pass
+        n = len(features)
+        ts = ops.conv_bias_act_group(list(features), [self.conv.weight] * n, [self.conv.bias] * n, pad=1, relu=True)
+        return [ops.conv_bias_act(t, w, b, 1, 0, relu=False, out_f32=True) for t in ts]
 
     def forward(self, features: List[torch.Tensor]):
         A, D = self.num_anchors, self.box_dim

@@ -638,6 +638,132 @@ def conv_bias_act(x, weight, bias, stride=1, pad=0, relu=False, out_f32=False):
 
 
 # --------------------------------------------------------------------------
+# grouped convolutions: the five pyramid levels of an FPN output conv / the RPN head conv in ONE launch per direction
+# --------------------------------------------------------------------------
+_GROUP_ON = [os.environ.get("CR_CONV_GROUP", "1") == "1"]
+
+
+def _ptr_table(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
+
+
+def _int_table(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def group_supported(xs, weights, stride=1):
+    """shapes the grouped kernels take: stride 1, k in {1,3}, Cout % 128 == 0, Cin % 64 == 0, fp32 or bf16 (not the split mode)"""
+    w0 = weights[0]
+    Cout, Cin, k, _ = w0.shape
+    return (_GROUP_ON[0] and stride == 1 and 2 <= len(xs) <= 8 and k in (1, 3) and Cout % 128 == 0 and Cin % 128 == 0
+            and all(tuple(w.shape) == tuple(w0.shape) for w in weights) and all(x.is_cuda and x.dim() == 4 for x in xs)
+            and not (xs[0].dtype == f32 and _ACT[0][1] == 2))
+
+
+class _ConvBiasGroup(torch.autograd.Function):
+    """y_i = act(conv(x_i, W_i) + b_i) for n same-geometry problems: cr_conv2d_fwd_group forward, cr_conv2d_bwd_data_group and
+    (fp32) cr_conv2d_bwd_weight_group backward.  The W_i / b_i may be one parameter repeated (the RPN head)."""
+
+    @staticmethod
+    def forward(ctx, n, pad, relu, slots, *args):
+        xs, ws, bs = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        _p = _Args()
+        Cout, Cin, k, _ = ws[0].shape
+        dt = xs[0].dtype
+        xs = [x.contiguous() for x in xs]
+        wbs = [prepared_weights(w, False, dt)[0] for w in ws]
+        ys = [torch.empty((x.shape[0], x.shape[1] + 2 * pad - k + 1, x.shape[2] + 2 * pad - k + 1, Cout), dtype=dt, device=x.device)
+              for x in xs]
+        bd = [None if b is None else b.detach() for b in bs]
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        _chk(_lib.load().cr_conv2d_fwd_group(
+            _ctx(xs[0]), n, cast(_ptr_table(xs)), cast(_ptr_table(wbs)), cast(_ptr_table(ys)), cast(_int_table([x.shape[0] for x in xs])),
+            cast(_int_table([x.shape[1] for x in xs])), cast(_int_table([x.shape[2] for x in xs])), Cin, Cout, k, pad,
+            cast(_ptr_table(bd)), None, int(relu), _af(xs[0])), "cr_conv2d_fwd_group")
+        ctx.cfg = (n, k, pad, relu)
+        ctx.slots = slots
+        ctx.refs = (ws, bs)
+        ctx.save_for_backward(*xs, *(ys if relu else ()))
+        ctx.set_materialize_grads(False)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n, k, pad, relu = ctx.cfg
+        ws, bs = ctx.refs
+        saved = ctx.saved_tensors
+        xs, ys = saved[:n], (saved[n:] if relu else (None,) * n)
+        _p = _Args()
+        lib = _lib.load()
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        live = [i for i in range(n) if dys[i] is not None]            # an output nobody differentiated takes no part
+        gs = {}
+        for i in live:
+            g = dys[i].contiguous()
+            if relu:
+                g = relu_bwd(ys[i], g)
+            gs[i] = g.to(xs[i].dtype).contiguous()
+        dt = xs[0].dtype
+        Cout, Cin = ws[0].shape[0], ws[0].shape[1]
+        dxs = [None] * n
+        need_dx = [i for i in live if ctx.needs_input_grad[4 + i]]
+        for i in range(n):
+            if i not in need_dx and ctx.slots[i][0] is not None and i in live:
+                raise RuntimeError("gradient slot registered for an input that needs no gradient")
+        if need_dx:
+            wts = [prepared_weights(ws[i], True, dt)[1] for i in need_dx]
+            outs = [torch.empty_like(xs[i]) for i in need_dx]
+            accs = []
+            for i in need_dx:
+                slot, xi = ctx.slots[i]
+                a = _slot_take(slot) if (slot is not None and xi <= 1) else None
+                accs.append(None if a is None else a.to(dt).contiguous())
+            _chk(lib.cr_conv2d_bwd_data_group(
+                _ctx(xs[0]), len(need_dx), cast(_ptr_table([gs[i] for i in need_dx])), cast(_ptr_table(wts)), cast(_ptr_table(outs)),
+                cast(_int_table([xs[i].shape[0] for i in need_dx])), cast(_int_table([xs[i].shape[1] for i in need_dx])),
+                cast(_int_table([xs[i].shape[2] for i in need_dx])), Cin, Cout, k, pad, _af(xs[0]), cast(_ptr_table(accs))),
+                "cr_conv2d_bwd_data_group")
+            for i, o in zip(need_dx, outs):
+                slot, xi = ctx.slots[i]
+                if slot is not None and xi > 1:
+                    _slot_put(slot, o)
+                else:
+                    dxs[i] = o
+        # weight / bias gradients: one grouped launch in fp32 when every parameter has a sink to accumulate into; otherwise the
+        # per-problem kernels (bf16 mode, parameters without sinks)
+        dws, dbs = [None] * n, [None] * n
+        wl = [i for i in live if ctx.needs_input_grad[4 + n + i]]
+        sinks_ok = dt == f32 and all(grad_sink(ws[i]) is not None and (bs[i] is None or grad_sink(bs[i]) is not None) for i in wl)
+        if wl and sinks_ok and len(wl) > 1:
+            dwt = [grad_sink(ws[i]) for i in wl]
+            dbt = [None if bs[i] is None or not ctx.needs_input_grad[4 + 2 * n + i] else grad_sink(bs[i]) for i in wl]
+            _chk(lib.cr_conv2d_bwd_weight_group(
+                _ctx(xs[0]), len(wl), cast(_ptr_table([gs[i] for i in wl])), cast(_ptr_table([xs[i] for i in wl])), cast(_ptr_table(dwt)),
+                cast(_ptr_table(dbt)), cast(_int_table([xs[i].shape[0] for i in wl])), cast(_int_table([xs[i].shape[1] for i in wl])),
+                cast(_int_table([xs[i].shape[2] for i in wl])), Cin, Cout, k, pad, 1), "cr_conv2d_bwd_weight_group")
+        else:
+            for i in wl:
+                bsink = None if bs[i] is None else grad_sink(bs[i])
+                want_db = bs[i] is not None and ctx.needs_input_grad[4 + 2 * n + i]
+                acc = None
+                if want_db:
+                    acc = bsink if bsink is not None else torch.zeros((Cout,), dtype=f32, device=xs[i].device)
+                    if bsink is None:
+                        dbs[i] = acc if dbs[i] is None else dbs[i] + acc
+                dws[i] = conv_bwd_weight_raw(gs[i], xs[i], k, 1, pad, grad_sink(ws[i]), bias_acc=acc)
+        return (None, None, None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
+
+
+def conv_bias_act_group(xs, weights, biases, pad=0, relu=False):
+    """[act(conv(x_i, W_i) + b_i)] -- one launch per direction when the shapes allow (group_supported), else one conv each"""
+    xs, weights, biases = list(xs), [as_krsc(w) for w in weights], list(biases)
+    if not group_supported(xs, weights):
+        return [conv_bias_act(x, w, b, 1, pad, relu=relu) for x, w, b in zip(xs, weights, biases)]
+    slots = tuple(_slot_register(x, True) for x in xs)
+    return list(_ConvBiasGroup.apply(len(xs), pad, relu, slots, *xs, *weights, *biases))
+
+
+# --------------------------------------------------------------------------
 # pooling / FPN top-down
 # --------------------------------------------------------------------------
 class _Pool2x(torch.autograd.Function):

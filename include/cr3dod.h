@@ -283,6 +283,21 @@ int cr_fold_bn(cr_ctx* ctx, const float* w, const float* gamma, const float* bet
  * the same kernel from the dy tiles it stages anyway (dbias must be zeroed or hold the running gradient). */
 int cr_conv2d_bwd_weight_bias(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
                               int Cin, int Cout, int ks, int stride, int pad, int accumulate, int act_f32);
+/* Grouped launches: n <= 8 independent stride-1 convolutions of one geometry class (same k in {1,3}, pad, Cin, Cout, precision)
+ * in ONE grid of 128 x 128 tiles (csrc/conv.hip: k_conv_igemm_dma_grp, k_conv_wgrad_f32_grp) -- the five pyramid levels of
+ * detectron2's FPN output convolutions and of the RPN head's convolution (StandardRPNHead applies ONE conv to every level).
+ * xs / ws / ys ...: HOST arrays of n device pointers; Ns / Hs / Ws: HOST arrays of the input shapes.  Forward / backward-data:
+ * fp32 or bf16 (not the split mode); Cout (backward-data: Cin) % 128 == 0.  cr_conv2d_bwd_weight_group: fp32 only, always
+ * accumulates into dws[i] (entries may repeat: shared weights) and, when given, dbiases[i] += column sums of dys[i]. */
+int cr_conv2d_fwd_group(cr_ctx* ctx, int n, const void* const* xs, const void* const* ws, void* const* ys, const int* Ns,
+                        const int* Hs, const int* Ws, int Cin, int Cout, int ks, int pad, const float* const* biases,
+                        const void* const* residuals, int relu, int act_f32);
+int cr_conv2d_bwd_data_group(cr_ctx* ctx, int n, const void* const* dys, const void* const* wts, void* const* dxs,
+                             const int* Ns, const int* Hs, const int* Ws, int Cin, int Cout, int ks, int pad, int act_f32,
+                             const void* const* accumulates);
+int cr_conv2d_bwd_weight_group(cr_ctx* ctx, int n, const void* const* dys, const void* const* xs, float* const* dws,
+                               float* const* dbiases, const int* Ns, const int* Hs, const int* Ws, int Cin, int Cout, int ks,
+                               int pad, int act_f32);
 int cr_cast_f32_to_bf16(cr_ctx* ctx, const float* src, void* dst, int64_t n);
 /* bias gradient: out[c] += sum_m x[m][c]; x (M,C) bf16 or f32; ws = 1024*C floats; deterministic. */
 int cr_colsum_accum(cr_ctx* ctx, const void* x, int is_f32, int64_t M, int C, float* ws, float* out);

@@ -83,6 +83,11 @@ def conv_bias_act(x, weight, bias, stride=1, pad=0, relu=False, out_f32=False):
     return y if out_f32 else _q(y)
 
 
+def conv_bias_act_group(xs, weights, biases, pad=0, relu=False):
+    """hipops.conv_bias_act_group (one grouped launch per direction on the device): here simply one convolution per problem"""
+    return [conv_bias_act(x, w, b, 1, pad, relu=relu) for x, w, b in zip(xs, weights, biases)]
+
+
 def maxpool3x3s2(x):
     return _nhwc(_q(torch.nn.functional.max_pool2d(_nchw(x), 3, 2, 1)))
 
