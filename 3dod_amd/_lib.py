@@ -56,7 +56,7 @@ SIGNATURES = {
     "cr_bn_fwd": [P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, P, c_int],
     "cr_bn_bwd": [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int],
     "cr_pool2x_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int],
-    "cr_pool2x_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int],
+    "cr_pool2x_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "cr_upsample2x_add": [P, P, P, P, c_int, c_int, c_int, c_int, c_int],
     "cr_sum2x2": [P, P, P, c_int, c_int, c_int, c_int, c_int],
     "cr_preprocess": [P, P, P, c_int, c_int, c_int, P, P, c_int],

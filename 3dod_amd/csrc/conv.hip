@@ -3719,9 +3719,10 @@ __global__ void k_pool_fwd(const void* __restrict__ xv, void* __restrict__ yv, i
 // routes dy to the FIRST maximal element of each window in scan order (PyTorch's tie rule)
 template <typename T>
 __global__ void k_pool_bwd(const void* __restrict__ xv, const void* __restrict__ dyv, void* __restrict__ dxv, int N, int H,
-                           int W, int C, int window) {
+                           int W, int C, int window, const void* __restrict__ accv) {
     const T* __restrict__ x = (const T*)xv;
     const T* __restrict__ dy = (const T*)dyv;
+    const T* __restrict__ acc = (const T*)accv;          // optional: dx = routed dy + acc (gradient fan-in, hipops._GradSlot)
     T* __restrict__ dx = (T*)dxv;
     const int Ho = H / 2, Wo = W / 2, cg = C >> 3;
     const int64_t total = (int64_t)N * Ho * Wo * cg;
@@ -3737,9 +3738,19 @@ __global__ void k_pool_bwd(const void* __restrict__ xv, const void* __restrict__
     load8<T>(dy, (size_t)i * 8, g);
     const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (window == 1) {
-        store8<T>(dx, base, g);
 #pragma unroll
-        for (int q = 1; q < 4; ++q) store8<T>(dx, base + offs[q], z);
+        for (int q = 0; q < 4; ++q) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = q == 0 ? g[e] : z[e];
+            if (acc) {
+                float a8[8];
+                load8<T>(acc, base + offs[q], a8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += a8[e];
+            }
+            store8<T>(dx, base + offs[q], o);
+        }
         return;
     }
     float v[4][8];
@@ -3760,6 +3771,12 @@ __global__ void k_pool_bwd(const void* __restrict__ xv, const void* __restrict__
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = am[e] == q ? g[e] : 0.f;
+        if (acc) {
+            float a8[8];
+            load8<T>(acc, base + offs[q], a8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += a8[e];
+        }
         store8<T>(dx, base + offs[q], o);
     }
 }
@@ -3775,13 +3792,13 @@ extern "C" int cr_pool2x_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, 
 }
 
 extern "C" int cr_pool2x_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C,
-                             int window, int act_f32) {
+                             int window, int act_f32, const void* accumulate) {
     CR_CHECK_ARG(ctx && x && dy && dx, "cr_pool2x_bwd: NULL pointer");
     CR_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && (window == 1 || window == 2), "cr_pool2x_bwd: bad dims");
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
     if (total == 0) return CR_OK;
     CR_DISPATCH_T(act_f32, k_pool_bwd, dim3((unsigned)cr_cdiv(total, 256)), dim3(256), 0, ctx->stream, x, dy, dx, N, H, W, C,
-                  window);
+                  window, accumulate);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -52,6 +52,11 @@ class Root(nn.Module):
 
     def forward(self, *x):
         children = x
+        if not self.residual and self.bn.training and self.conv.kernel_size[0] == 1:
+            # training: the children's gradients come from per-child backward-data GEMMs (ops._RootConvBN), not from the
+            # gradient of the concatenation
+            return ops.root_conv_bn_act(children, self.conv.weight, self.bn.weight, self.bn.bias, self.bn.running_mean,
+                                        self.bn.running_var, relu=True, eps=self.bn.eps, momentum=self.bn.momentum, training=True)
         cat = torch.cat(x, 3)                                        # channel concat (NHWC)
         return _conv_bn(cat, self.conv, self.bn, relu=True, residual=children[0] if self.residual else None)
 

@@ -347,6 +347,13 @@ def _slot_put(slot, g):
     slot.n_arr += 1
 
 
+def _slot_fold(slot):
+    """a later consumer whose own kernel can add: takes what the slot holds so far (or None) and will put back the sum, so
+    that several contributions to one slot never meet in a torch add"""
+    buf, slot.buf = slot.buf, None
+    return buf
+
+
 def _slot_take(slot):
     """the first consumer (a convolution) collects what the others have contributed, in its backward.  A registered
     consumer whose output receives no gradient never contributes (e.g. a pooled level nobody uses): that is a zero, not an
@@ -431,9 +438,18 @@ class _ConvBN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        return _ConvBN._backward_impl(ctx, dout)
+
+    @staticmethod
+    def _backward_impl(ctx, dout, want_dx=None, want_dw=None):
+        """want_dx / want_dw: overrides of needs_input_grad[0] / [1] (_RootConvBN computes the input gradients itself and then
+        gets (dx_raw, dw, dgamma, dbeta) back instead of the argument-ordered tuple)"""
         _p = _Args()
         x, weight, gamma, y_raw, out, mi = ctx.saved_tensors
         k, stride, pad, relu, training, has_res = ctx.cfg
+        root = want_dx is not None
+        need_dx = ctx.needs_input_grad[0] if want_dx is None else want_dx
+        need_dw = ctx.needs_input_grad[1] if want_dw is None else want_dw
         if not training:
             raise _lib.CrError("backward through frozen BatchNorm is not implemented")
         Cout = weight.shape[0]
@@ -458,19 +474,77 @@ class _ConvBN(torch.autograd.Function):
             _slot_put(rslot, dres)
             dres = None
         dx = None
-        if ctx.needs_input_grad[0]:
+        if need_dx:
             _, wt = prepared_weights(weight, True, x.dtype)
             if xslot is not None and xi > 1:                # not the first consumer of x: leave the contribution in the slot
-                _slot_put(xslot, conv_bwd_data_raw(dx_raw, wt, x.shape, k, stride, pad))
+                _slot_put(xslot, conv_bwd_data_raw(dx_raw, wt, x.shape, k, stride, pad, accumulate=_slot_fold(xslot)))
             else:
                 acc = _slot_take(xslot) if xslot is not None else None
                 dx = conv_bwd_data_raw(dx_raw, wt, x.shape, k, stride, pad, accumulate=acc)
         elif xslot is not None:
             raise RuntimeError("gradient slot registered for an input that needs no gradient")
-        dw = conv_bwd_weight_raw(dx_raw, x, k, stride, pad, grad_sink(weight)) if ctx.needs_input_grad[1] else None
+        dw = conv_bwd_weight_raw(dx_raw, x, k, stride, pad, grad_sink(weight)) if need_dw else None
+        if root:
+            return dx_raw, dw, ret_g, ret_b
         return dx, dw, ret_g, ret_b, dres, None, None, None, None, None, None, None, None, None
 
 
+class _RootConvBN(torch.autograd.Function):
+    """DLA `Root` (dla.py:156-174): 1x1 convolution + BatchNorm (+ ReLU) over the channel concatenation of its children.
+    Forward: the concatenation is made inside (one cat kernel), then exactly _ConvBN.  Backward: the gradient of every child
+    is its OWN backward-data GEMM on the matching row slice of the transposed weights (rows = input channels: a slice is
+    contiguous) -- no gradient of the concatenation, no narrow / copy per child, and a child that another convolution
+    consumed first gets its share through that convolution's gradient slot instead of an autograd add."""
+
+    @staticmethod
+    def forward(ctx, weight, gamma, beta, running_mean, running_var, relu, eps, momentum, slots, *children):
+        with torch.no_grad():
+            x = torch.cat(children, 3)
+        out = _ConvBN.forward(ctx, x, weight, gamma, beta, None, running_mean, running_var, 1, 0, relu, eps, momentum, True)
+        ctx.child_slots = slots
+        ctx.child_ch = [c.shape[3] for c in children]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        nchild = len(ctx.child_ch)
+        need = ctx.needs_input_grad
+        # BatchNorm backward + weight gradient exactly as _ConvBN, without a gradient for the concatenated input
+        ctx.slots = ((None, 0), (None, 0))
+        res = _ConvBN._backward_impl(ctx, dout, want_dx=False, want_dw=need[0])
+        dx_raw, dw, ret_g, ret_b = res
+        _, wt = prepared_weights(weight, True, x.dtype)
+        outs, c0 = [], 0
+        N, H, W, _ = x.shape
+        for i, ci in enumerate(ctx.child_ch):
+            g = None
+            if need[9 + i]:
+                slot, idx = ctx.child_slots[i]
+                g = conv_bwd_data_raw(dx_raw, wt[c0:c0 + ci], (N, H, W, ci), 1, 1, 0,
+                                      accumulate=_slot_fold(slot) if slot is not None else None)
+                if slot is not None:
+                    _slot_put(slot, g)                       # the child's first consumer (a convolution / pooling) adds it
+                    g = None
+            elif ctx.child_slots[i][0] is not None:
+                raise RuntimeError("gradient slot registered for an input that needs no gradient")
+            outs.append(g)
+            c0 += ci
+        return (dw, ret_g, ret_b, None, None, None, None, None, None) + tuple(outs)
+
+
+def root_conv_bn_act(children, weight, gamma, beta, running_mean, running_var, relu=True, eps=1e-5, momentum=0.1, training=True):
+    """conv_bn_act(torch.cat(children, 3), 1x1 weight, ...) for DLA's Root nodes in training mode (see _RootConvBN)"""
+    children = list(children)
+    if not (training and torch.is_grad_enabled() and _ROOT_FUSED[0] and all(c.dim() == 4 for c in children)
+            and all(c.shape[3] % 16 == 0 for c in children) and weight.shape[2] == 1):
+        return conv_bn_act(torch.cat(children, 3), weight, gamma, beta, running_mean, running_var, 1, 0, relu, None, eps,
+                           momentum, training)
+    slots = tuple(_slot_register(c, False) for c in children)
+    return _RootConvBN.apply(as_krsc(weight), gamma, beta, running_mean, running_var, relu, eps, momentum, slots, *children)
+
+
+_ROOT_FUSED = [os.environ.get("CR_ROOT_FUSED", "1") == "1"]
 _STATS_EPOCH = [0]          # bumped by every eager train-mode BatchNorm forward (running statistics change through raw pointers)
 
 
@@ -569,7 +643,7 @@ class _ConvBias(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, wt = prepared_weights(weight, True, x.dtype)
             if xslot is not None and xi > 1:
-                _slot_put(xslot, conv_bwd_data_raw(g, wt, x.shape, k, stride, pad))
+                _slot_put(xslot, conv_bwd_data_raw(g, wt, x.shape, k, stride, pad, accumulate=_slot_fold(xslot)))
             else:
                 dx = conv_bwd_data_raw(g, wt, x.shape, k, stride, pad, accumulate=_slot_take(xslot) if xslot is not None else None)
         elif xslot is not None:
@@ -660,6 +734,31 @@ def group_supported(xs, weights, stride=1):
             and not (xs[0].dtype == f32 and _ACT[0][1] == 2))
 
 
+def conv_fwd_group_raw(xs, wbs, ys, Cin, Cout, k, pad, biases, relu):
+    """cr_conv2d_fwd_group on prepared operands (module-level so that bench.py can bracket the launch with events)"""
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    _chk(_lib.load().cr_conv2d_fwd_group(
+        _ctx(xs[0]), len(xs), cast(_ptr_table(xs)), cast(_ptr_table(wbs)), cast(_ptr_table(ys)), cast(_int_table([x.shape[0] for x in xs])),
+        cast(_int_table([x.shape[1] for x in xs])), cast(_int_table([x.shape[2] for x in xs])), Cin, Cout, k, pad,
+        cast(_ptr_table(biases)), None, int(relu), _af(xs[0])), "cr_conv2d_fwd_group")
+
+
+def conv_bwd_data_group_raw(gs, wts, outs, shapes, Cin, Cout, k, pad, accs):
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    _chk(_lib.load().cr_conv2d_bwd_data_group(
+        _ctx(gs[0]), len(gs), cast(_ptr_table(gs)), cast(_ptr_table(wts)), cast(_ptr_table(outs)),
+        cast(_int_table([s_[0] for s_ in shapes])), cast(_int_table([s_[1] for s_ in shapes])), cast(_int_table([s_[2] for s_ in shapes])),
+        Cin, Cout, k, pad, _af(gs[0]), cast(_ptr_table(accs))), "cr_conv2d_bwd_data_group")
+
+
+def conv_bwd_weight_group_raw(gs, xs, dws, dbs, Cin, Cout, k, pad):
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    _chk(_lib.load().cr_conv2d_bwd_weight_group(
+        _ctx(xs[0]), len(xs), cast(_ptr_table(gs)), cast(_ptr_table(xs)), cast(_ptr_table(dws)), cast(_ptr_table(dbs)),
+        cast(_int_table([x.shape[0] for x in xs])), cast(_int_table([x.shape[1] for x in xs])), cast(_int_table([x.shape[2] for x in xs])),
+        Cin, Cout, k, pad, 1), "cr_conv2d_bwd_weight_group")
+
+
 class _ConvBiasGroup(torch.autograd.Function):
     """y_i = act(conv(x_i, W_i) + b_i) for n same-geometry problems: cr_conv2d_fwd_group forward, cr_conv2d_bwd_data_group and
     (fp32) cr_conv2d_bwd_weight_group backward.  The W_i / b_i may be one parameter repeated (the RPN head)."""
@@ -675,11 +774,7 @@ class _ConvBiasGroup(torch.autograd.Function):
         ys = [torch.empty((x.shape[0], x.shape[1] + 2 * pad - k + 1, x.shape[2] + 2 * pad - k + 1, Cout), dtype=dt, device=x.device)
               for x in xs]
         bd = [None if b is None else b.detach() for b in bs]
-        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
-        _chk(_lib.load().cr_conv2d_fwd_group(
-            _ctx(xs[0]), n, cast(_ptr_table(xs)), cast(_ptr_table(wbs)), cast(_ptr_table(ys)), cast(_int_table([x.shape[0] for x in xs])),
-            cast(_int_table([x.shape[1] for x in xs])), cast(_int_table([x.shape[2] for x in xs])), Cin, Cout, k, pad,
-            cast(_ptr_table(bd)), None, int(relu), _af(xs[0])), "cr_conv2d_fwd_group")
+        conv_fwd_group_raw(xs, wbs, ys, Cin, Cout, k, pad, bd, relu)
         ctx.cfg = (n, k, pad, relu)
         ctx.slots = slots
         ctx.refs = (ws, bs)
@@ -716,13 +811,9 @@ class _ConvBiasGroup(torch.autograd.Function):
             accs = []
             for i in need_dx:
                 slot, xi = ctx.slots[i]
-                a = _slot_take(slot) if (slot is not None and xi <= 1) else None
+                a = None if slot is None else (_slot_take(slot) if xi <= 1 else _slot_fold(slot))
                 accs.append(None if a is None else a.to(dt).contiguous())
-            _chk(lib.cr_conv2d_bwd_data_group(
-                _ctx(xs[0]), len(need_dx), cast(_ptr_table([gs[i] for i in need_dx])), cast(_ptr_table(wts)), cast(_ptr_table(outs)),
-                cast(_int_table([xs[i].shape[0] for i in need_dx])), cast(_int_table([xs[i].shape[1] for i in need_dx])),
-                cast(_int_table([xs[i].shape[2] for i in need_dx])), Cin, Cout, k, pad, _af(xs[0]), cast(_ptr_table(accs))),
-                "cr_conv2d_bwd_data_group")
+            conv_bwd_data_group_raw([gs[i] for i in need_dx], wts, outs, [xs[i].shape for i in need_dx], Cin, Cout, k, pad, accs)
             for i, o in zip(need_dx, outs):
                 slot, xi = ctx.slots[i]
                 if slot is not None and xi > 1:
@@ -737,10 +828,7 @@ class _ConvBiasGroup(torch.autograd.Function):
         if wl and sinks_ok and len(wl) > 1:
             dwt = [grad_sink(ws[i]) for i in wl]
             dbt = [None if bs[i] is None or not ctx.needs_input_grad[4 + 2 * n + i] else grad_sink(bs[i]) for i in wl]
-            _chk(lib.cr_conv2d_bwd_weight_group(
-                _ctx(xs[0]), len(wl), cast(_ptr_table([gs[i] for i in wl])), cast(_ptr_table([xs[i] for i in wl])), cast(_ptr_table(dwt)),
-                cast(_ptr_table(dbt)), cast(_int_table([xs[i].shape[0] for i in wl])), cast(_int_table([xs[i].shape[1] for i in wl])),
-                cast(_int_table([xs[i].shape[2] for i in wl])), Cin, Cout, k, pad, 1), "cr_conv2d_bwd_weight_group")
+            conv_bwd_weight_group_raw([gs[i] for i in wl], [xs[i] for i in wl], dwt, dbt, Cin, Cout, k, pad)
         else:
             for i in wl:
                 bsink = None if bs[i] is None else grad_sink(bs[i])
@@ -788,9 +876,13 @@ class _Pool2x(torch.autograd.Function):
         dx = torch.empty_like(x)
         lib = _lib.load()
         dy = dy.to(x.dtype).contiguous()
-        _chk(lib.cr_pool2x_bwd(_ctx(x), _p(x), _p(dy), _p(dx), N, H, W, C, ctx.window, _af(x)), "cr_pool2x_bwd")
-        xslot, _ = ctx.slot
-        if xslot is not None:
+        xslot, xi = ctx.slot
+        # the FIRST registered consumer of x (DLA: a level's input is pooled before its first convolution sees it) collects
+        # what the others left in the slot, a later one folds the slot's content into its own result: added in the kernel
+        acc = None if xslot is None else (_slot_take(xslot) if xi <= 1 else _slot_fold(xslot))
+        acc = None if acc is None else acc.to(x.dtype).contiguous()
+        _chk(lib.cr_pool2x_bwd(_ctx(x), _p(x), _p(dy), _p(dx), N, H, W, C, ctx.window, _af(x), _p(acc)), "cr_pool2x_bwd")
+        if xslot is not None and xi > 1:
             _slot_put(xslot, dx)
             dx = None
         return dx, None, None
@@ -827,12 +919,12 @@ def maxpool3x3s2(x):
 
 def maxpool2x2(x):
     """nn.MaxPool2d(2, stride=2) -- dla.py:208."""
-    return _Pool2x.apply(x, 2, _slot_register(x, False))
+    return _Pool2x.apply(x, 2, _slot_register(x, True))
 
 
 def subsample2x(x):
     """F.max_pool2d(kernel_size=1, stride=2) -- dla.py:474."""
-    return _Pool2x.apply(x, 1, _slot_register(x, False))
+    return _Pool2x.apply(x, 1, _slot_register(x, True))
 
 
 class _UpsampleAdd(torch.autograd.Function):

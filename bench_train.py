@@ -195,18 +195,20 @@ def _bench_train_mode(args, rank, world, dev, prec, is_main=True):
     try:
         if ins_err:
             raise RuntimeError(ins_err)
-        # the roofline figure is the IN-STEP duration (HIP events around the launches of the dominant layer inside real
-        # train steps, caches in the state the step leaves them in); the back-to-back micro-benchmark stays beside it
-        worst = min(ins, key=lambda k: ins[k]["tflops"]) if ins else None
-        if worst is not None:
-            name = {"wgrad": [k for k in kern["all_directions"] if "wgrad" in k][0],
-                    "fwd": [k for k in kern["all_directions"] if "(fwd)" in k][0],
-                    "bwd-data": [k for k in kern["all_directions"] if "(bwd-data)" in k][0]}
+        # the roofline figure is the IN-STEP duration (HIP events around the dominant launches inside real train steps, caches
+        # in the state the step leaves them in); the back-to-back micro-benchmark stays beside it
+        if ins:
+            def kname(kind):
+                key = {"fwd": "(fwd", "bwd-data": "(bwd-data", "wgrad": "wgrad"}[kind.replace("-group", "")]
+                c = [k for k in kern["all_directions"] if key in k]
+                return c[0] if c else kind
+            worst = min(ins, key=lambda k: ins[k]["tflops"])
             kern["microbench"] = {"kernel": kern["kernel"], "achieved": kern["achieved"], "kernel_ms": kern["kernel_ms"]}
-            kern.update(kernel=name[worst], achieved=ins[worst]["tflops"], frac=ins[worst]["tflops"] / peak,
-                        kernel_ms=ins[worst]["ms"], measured="HIP events around the kernel's launches inside train steps "
-                        "(dense region run eagerly for this measurement), mean over %d launches" % ins[worst]["launches"])
-            kern["in_step"] = {name[k]: v for k, v in ins.items()}
+            kern.update(kernel=kname(worst), achieved=ins[worst]["tflops"], frac=ins[worst]["tflops"] / peak,
+                        kernel_ms=ins[worst]["ms"], algorithmic_flop_per_launch=ins[worst]["flop_per_launch"],
+                        measured="HIP events around the kernel's launches inside train steps (dense region run eagerly for "
+                                 "this measurement), mean over %d launches" % ins[worst]["launches"])
+            kern["in_step"] = {kname(k): v for k, v in ins.items()}
     except Exception as e:           # never lose the headline to the instrumentation
         kern["in_step_error"] = f"{type(e).__name__}: {e}"
     note("roofline done")
@@ -294,15 +296,27 @@ def bench_do_train(args, rank, world, dev):
                     "step, overlapped), per-shape dense-region graphs, WarmupMultiStepLR, host check every 20 iterations"}
 
 
+PYRAMID = ((128, 128), (64, 64), (32, 32), (16, 16), (8, 8))       # p2 ... p6 of a 512 x 512 image
+
+
+def pyramid_flop(n_img=IMS_PER_GPU, C=256, k=3):
+    """2 * M * Cout * k^2 * Cin summed over the five pyramid levels: one grouped launch of the FPN output convolutions or of
+    the RPN head's convolution (103.0 GFLOP at 4 images)"""
+    return sum(2.0 * n_img * h * w * C * k * k * C for h, w in PYRAMID)
+
+
 def dominant_kernel_in_step(model, step, batches, dev, n_steps=3):
-    """durations of the dominant layer's three kernels (3x3 256->256 on IMS_PER_GPU x 128 x 128: the FPN p2 output conv and
-    the RPN head conv on p2) INSIDE train steps: the raw launch wrappers are bracketed with HIP events on the stream they
-    launch on.  The captured dense region is switched off for these steps (a graph replay cannot be bracketed per kernel);
-    the kernels, their inputs and the cache state they find are those of the real step."""
+    """durations of the dominant launches INSIDE train steps: the grouped 3x3 256->256 convolutions over the five pyramid levels
+    (FPN output convolutions, RPN head convolution: cr_conv2d_*_group, 103 GFLOP per launch and direction) -- or, where a
+    direction is not grouped (bf16 weight gradients), the largest single layer (3x3 256->256 on IMS_PER_GPU x 128 x 128).
+    The raw launch wrappers are bracketed with HIP events on the stream they launch on.  The captured dense region is switched
+    off for these steps (a graph replay cannot be bracketed per kernel); the kernels, their inputs and the cache state they
+    find are those of the real step."""
     ops = importlib.import_module("3dod_amd.hipops")
     shape = (IMS_PER_GPU, 128, 128, 256)
-    recs = {"fwd": [], "bwd-data": [], "wgrad": []}
+    recs = {"fwd": [], "bwd-data": [], "wgrad": [], "fwd-group": [], "bwd-data-group": [], "wgrad-group": []}
     orig = (ops.conv_fwd_raw, ops.conv_bwd_data_raw, ops.conv_bwd_weight_raw)
+    orig_g = (ops.conv_fwd_group_raw, ops.conv_bwd_data_group_raw, ops.conv_bwd_weight_group_raw)
 
     def timed(kind, fn, *a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -327,22 +341,38 @@ def dominant_kernel_in_step(model, step, batches, dev, n_steps=3):
         hit = tuple(x.shape) == shape and dy.shape[3] == 256 and k == 3 and stride == 1
         f = lambda: orig[2](dy, x, k, stride, pad, sink, bias_acc)
         return timed("wgrad", lambda: f()) if hit else f()
-    graphed = getattr(model, "_graphed", None)
-    model._graphed = None
+    is_pyr = lambda ts, k: k == 3 and len(ts) == len(PYRAMID) and tuple(ts[0].shape) == shape
+
+    def gfwd(xs, wbs, ys, Cin, Cout, k, pad, biases, relu):
+        f = lambda: orig_g[0](xs, wbs, ys, Cin, Cout, k, pad, biases, relu)
+        return timed("fwd-group", f) if is_pyr(xs, k) else f()
+
+    def gbwd(gs, wts, outs, shapes, Cin, Cout, k, pad, accs):
+        f = lambda: orig_g[1](gs, wts, outs, shapes, Cin, Cout, k, pad, accs)
+        return timed("bwd-data-group", f) if is_pyr(outs, k) else f()
+
+    def gwg(gs, xs, dws, dbs, Cin, Cout, k, pad):
+        f = lambda: orig_g[2](gs, xs, dws, dbs, Cin, Cout, k, pad)
+        return timed("wgrad-group", f) if is_pyr(xs, k) else f()
+    saved = (model._graphed, model._graphed_cache, model._graphed_max)
+    model._graphed, model._graphed_cache, model._graphed_max = None, None, 0
     ops.conv_fwd_raw, ops.conv_bwd_data_raw, ops.conv_bwd_weight_raw = fwd, bwd, wg
+    ops.conv_fwd_group_raw, ops.conv_bwd_data_group_raw, ops.conv_bwd_weight_group_raw = gfwd, gbwd, gwg
     try:
         for i in range(n_steps):
             step(batches[i % len(batches)])
         torch.cuda.synchronize(dev)
     finally:
         ops.conv_fwd_raw, ops.conv_bwd_data_raw, ops.conv_bwd_weight_raw = orig
-        model._graphed = graphed
-    flop = 2.0 * IMS_PER_GPU * 128 * 128 * 256 * 9 * 256
+        ops.conv_fwd_group_raw, ops.conv_bwd_data_group_raw, ops.conv_bwd_weight_group_raw = orig_g
+        model._graphed, model._graphed_cache, model._graphed_max = saved
+    flop1, flopg = 2.0 * IMS_PER_GPU * 128 * 128 * 256 * 9 * 256, pyramid_flop()
     out = {}
     for kind, ev in recs.items():
         if ev:
             ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-            out[kind] = {"ms": ms, "tflops": flop / ms / 1e9, "launches": len(ev)}
+            fl = flopg if kind.endswith("-group") else flop1
+            out[kind] = {"ms": ms, "tflops": fl / ms / 1e9, "launches": len(ev), "flop_per_launch": fl}
     return out
 
 
@@ -374,26 +404,43 @@ def cpu_baseline_train(inference=False, steps=None):
 
 
 def dominant_kernel_roofline(dev, prec="fp32", reps=20):
-    """the dominant kernel family of the step (profiles/: the weight-gradient and forward / backward-data implicit GEMMs)
-    timed live with HIP events on the stream it is launched on, on its largest instance in the network: the FPN p2
-    output conv (3x3, 256->256, 4x128x128 pixels; 2*M*Cout*9*Cin = 77.3 GFLOP per launch and direction)."""
+    """the dominant launches of the step (profiles/: the implicit-GEMM convolutions) timed live with HIP events on the stream
+    they are launched on: the grouped 3x3 256->256 convolution over the five pyramid levels of IMS_PER_GPU 512 x 512 images
+    (FPN output convolutions / RPN head convolution; 103.0 GFLOP per launch and direction), warm, back to back; the directions
+    that are not grouped in this precision mode are timed on the largest single layer (4 x 128 x 128, 77.3 GFLOP)."""
     ops = importlib.import_module("3dod_amd.hipops")
     dt = torch.float32 if prec != "bf16" else torch.bfloat16
     peak = MFMA_PEAK[prec]
-    N, H, W, C = IMS_PER_GPU, 128, 128, 256
+    N, C = IMS_PER_GPU, 256
     g = torch.Generator(device="cpu").manual_seed(0)
-    x = torch.randn(N, H, W, C, generator=g).to(dev).to(dt)
-    dy = torch.randn(N, H, W, C, generator=g).to(dev).to(dt)
+    xs = [torch.randn(N, h, w, C, generator=g).to(dev).to(dt) for h, w in PYRAMID]
+    dys = [torch.randn(N, h, w, C, generator=g).to(dev).to(dt) for h, w in PYRAMID]
     w = (torch.randn(C, C, 3, 3, generator=g) * 0.02).to(dev).contiguous(memory_format=torch.channels_last)
     wb, wt = ops.prepared_weights(w, True, dt)
-    flop = 2.0 * N * H * W * C * 9 * C
+    flop1, flopg = 2.0 * N * 128 * 128 * C * 9 * C, pyramid_flop(N, C)
     out = {}
     sink = torch.zeros(C * C * 9, device=dev)           # accumulate target (the flat gradient in the train step)
-    wg = {"fp32": "k_conv_wgrad_f32<128,3>", "fp32x3": "k_conv_wgrad_s3_row", "bf16": "k_conv_wgrad<128,3>"}[prec]
-    ig = {"fp32": "k_conv_igemm_dma<128,3,%d,float>", "fp32x3": "k_conv_igemm_dma_s3<128,3,%d>", "bf16": "k_conv_igemm_dma<128,3,%d>"}[prec]
-    for name, fn in ((wg, lambda: ops.conv_bwd_weight_raw(dy, x, 3, 1, 1, sink=sink)),
-                     (ig % 0 + " (fwd)", lambda: ops.conv_fwd_raw(x, wb, C, 3, 1, 1)),
-                     (ig % 1 + " (bwd-data)", lambda: ops.conv_bwd_data_raw(dy, wt, x.shape, 3, 1, 1))):
+    grouped = prec != "fp32x3" and ops.group_supported(xs, [w] * len(xs))
+    wg1 = {"fp32": "k_conv_wgrad_f32<128,3>", "fp32x3": "k_conv_wgrad_s3_row", "bf16": "k_conv_wgrad<128,3>"}[prec]
+    ig1 = {"fp32": "k_conv_igemm_dma<128,3,%d,float>", "fp32x3": "k_conv_igemm_dma_s3<128,3,%d>", "bf16": "k_conv_igemm_dma<128,3,%d>"}[prec]
+    tname = "float" if prec == "fp32" else "u16"
+    cases = []
+    if grouped:
+        ys = [torch.empty_like(x) for x in xs]
+        dxs = [torch.empty_like(x) for x in xs]
+        cases.append(("k_conv_igemm_dma_grp<3,0,%s> (fwd, 5 levels)" % tname, flopg,
+                      lambda: ops.conv_fwd_group_raw(xs, [wb] * 5, ys, C, C, 3, 1, [None] * 5, False)))
+        cases.append(("k_conv_igemm_dma_grp<3,1,%s> (bwd-data, 5 levels)" % tname, flopg,
+                      lambda: ops.conv_bwd_data_group_raw(dys, [wt] * 5, dxs, [x.shape for x in xs], C, C, 3, 1, [None] * 5)))
+    else:
+        cases.append((ig1 % 0 + " (fwd)", flop1, lambda: ops.conv_fwd_raw(xs[0], wb, C, 3, 1, 1)))
+        cases.append((ig1 % 1 + " (bwd-data)", flop1, lambda: ops.conv_bwd_data_raw(dys[0], wt, xs[0].shape, 3, 1, 1)))
+    if grouped and prec == "fp32":
+        cases.append(("k_conv_wgrad_f32_grp<3> (wgrad, 5 levels)", flopg,
+                      lambda: ops.conv_bwd_weight_group_raw(dys, xs, [sink] * 5, [None] * 5, C, C, 3, 1)))
+    else:
+        cases.append((wg1, flop1, lambda: ops.conv_bwd_weight_raw(dys[0], xs[0], 3, 1, 1, sink=sink)))
+    for name, flop, fn in cases:
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -403,21 +450,23 @@ def dominant_kernel_roofline(dev, prec="fp32", reps=20):
         e1.record()
         torch.cuda.synchronize(dev)
         ms = e0.elapsed_time(e1) / reps
-        out[name] = {"ms": ms, "tflops": flop / ms / 1e9}
+        out[name] = {"ms": ms, "tflops": flop / ms / 1e9, "flop_per_launch": flop}
     worst = min(out, key=lambda k: out[k]["tflops"])
-    # memory-side traffic per launch from the committed PMC passes of the same kernel and shape (rocprofv3 --pmc
+    # memory-side traffic per launch from the committed PMC passes of the same kernel and shapes (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction applied: profiles/r0N_pmc_conv_traffic*.json)
     traffic = None
     try:
         here = os.path.dirname(os.path.abspath(__file__))
-        fn = {"fp32": "r02_pmc_conv_traffic_fp32.json", "fp32x3": "r02_pmc_conv_traffic_fp32x3.json"}.get(prec, "r01_pmc_conv_traffic.json")
+        fn = {"fp32": "r03_pmc_conv_traffic_fp32.json", "fp32x3": "r02_pmc_conv_traffic_fp32x3.json"}.get(prec, "r01_pmc_conv_traffic.json")
         pmc = json.load(open(os.path.join(here, "profiles", fn)))
         key = worst.split(" ")[0].replace(",", ", ").rstrip(">")
         traffic = [v["traffic_bytes"] for k, v in pmc["kernels"].items() if k.replace(" ", "").startswith(key.replace(" ", ""))][0]
     except Exception:
         pass
     return {"bound": "mfma", "kernel": worst,
-            "shape": "3x3 conv 256->256 on 4x128x128 (FPN p2 output), " + {"fp32": "f32 in / f32 acc", "fp32x3": "f32 in (3 x bf16 split, 6 MFMAs per term) / f32 acc", "bf16": "bf16 in / f32 acc"}[prec],
+            "shape": ("3x3 conv 256->256 on the five pyramid levels of 4 x 512 x 512 images (4x128x128 ... 4x8x8; FPN output convs / "
+                      "RPN head conv), one grouped launch, " if "levels" in worst else "3x3 conv 256->256 on 4x128x128 (FPN p2 output), ")
+                     + {"fp32": "f32 in / f32 acc", "fp32x3": "f32 in (3 x bf16 split, 6 MFMAs per term) / f32 acc", "bf16": "bf16 in / f32 acc"}[prec],
             "achieved": out[worst]["tflops"], "peak": peak, "unit": "TFLOP/s",
             "frac": out[worst]["tflops"] / peak, "traffic": traffic,
-            "algorithmic_flop_per_launch": flop, "kernel_ms": out[worst]["ms"], "all_directions": out}
+            "algorithmic_flop_per_launch": out[worst]["flop_per_launch"], "kernel_ms": out[worst]["ms"], "all_directions": out}

@@ -318,7 +318,9 @@ int cr_bn_bwd(cr_ctx* ctx, const void* dy, const void* out, const void* x, const
 
 /* window 2: MaxPool2d(2,2) (dla.py:208); window 1: max_pool2d(k=1,s=2) (dla.py:474). */
 int cr_pool2x_fwd(cr_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int window, int act_f32);
-int cr_pool2x_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int window, int act_f32);
+/* accumulate (or NULL): a tensor of dx's shape added in the same pass (gradient fan-in without an add kernel) */
+int cr_pool2x_bwd(cr_ctx* ctx, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int window, int act_f32,
+                  const void* accumulate);
 /* FPN top-down path (detectron2 FPN, fuse_type "sum"): y = lat + nearest_up2x(top); and d/dtop. */
 int cr_upsample2x_add(cr_ctx* ctx, const void* lat, const void* top, void* y, int N, int H, int W, int C, int act_f32);
 int cr_sum2x2(cr_ctx* ctx, const void* dy, void* dtop, int N, int H, int W, int C, int act_f32);

@@ -83,6 +83,12 @@ def conv_bias_act(x, weight, bias, stride=1, pad=0, relu=False, out_f32=False):
     return y if out_f32 else _q(y)
 
 
+def root_conv_bn_act(children, weight, gamma, beta, running_mean, running_var, relu=True, eps=1e-5, momentum=0.1, training=True):
+    """hipops.root_conv_bn_act: DLA's Root = 1x1 conv + BatchNorm + ReLU over the channel concatenation of the children"""
+    return conv_bn_act(torch.cat(list(children), 3), weight, gamma, beta, running_mean, running_var, 1, 0, relu, None, eps,
+                       momentum, training)
+
+
 def conv_bias_act_group(xs, weights, biases, pad=0, relu=False):
     """hipops.conv_bias_act_group (one grouped launch per direction on the device): here simply one convolution per problem"""
     return [conv_bias_act(x, w, b, 1, pad, relu=relu) for x, w, b in zip(xs, weights, biases)]

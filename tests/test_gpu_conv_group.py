@@ -135,3 +135,39 @@ def test_group_folds_a_gradient_slot_contribution():
     torch.autograd.backward(y2, [torch.ones_like(y) for y in y2])
     for x, x2, e in zip(xs, xs2, extra):
         assert _rel(x.grad, x2.grad + e) < 2e-6
+
+
+def test_root_conv_bn_children_gradients_equal_the_concatenation_path():
+    """ops.root_conv_bn_act (DLA Root): per-child backward-data GEMMs on row slices of the transposed weights give the
+    gradients autograd derives through torch.cat; a child that a convolution consumed first receives its share through that
+    convolution's gradient slot (no autograd add)"""
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 2, 24, 20
+    chans = (64, 64, 32)
+    kids = [torch.randn(N, H, W, c, generator=g).to(DEV) for c in chans]
+    wr = (torch.randn(64, sum(chans), 1, 1, generator=g) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last)
+    w3 = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last)
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(DEV), (torch.randn(64, generator=g) * 0.1).to(DEV)
+    dy = torch.randn(N, H, W, 64, generator=g).to(DEV)
+
+    def run(fused):
+        prev = ops._ROOT_FUSED[0]
+        ops._ROOT_FUSED[0] = fused
+        try:
+            ks = [k.clone().requires_grad_(True) for k in kids]
+            wr_, w3_, ga, be = wr.clone().requires_grad_(True), w3.clone().requires_grad_(True), gamma.clone().requires_grad_(True), \
+                beta.clone().requires_grad_(True)
+            rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+            # child 1 is consumed by a convolution FIRST (like x1 -> tree2.conv1 in DLA), then by the root
+            side = ops.conv_bias_act(ks[1], w3_, None, 1, 1)
+            y = ops.root_conv_bn_act(ks, wr_, ga, be, rm, rv, relu=True)
+            torch.autograd.backward([y, side], [dy, dy])
+            return y.detach(), [k.grad for k in ks], wr_.grad, ga.grad, be.grad
+        finally:
+            ops._ROOT_FUSED[0] = prev
+    ya, ga_, wa, gga, gba = run(True)
+    yb, gb_, wb, ggb, gbb = run(False)
+    assert torch.equal(ya, yb)
+    for a, b in zip(ga_, gb_):
+        assert _rel(a, b) < 2e-6
+    assert _rel(wa, wb) < 2e-5 and _rel(gga, ggb) < 2e-5 and _rel(gba, gbb) < 2e-5
