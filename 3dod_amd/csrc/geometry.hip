@@ -151,7 +151,7 @@ __device__ __forceinline__ bool arg_better(float va, int ia, float vb, int ib) {
 // registers across the two per-object reductions (max ratio difference, max
 // chamfer), outputs are written once.
 // ---------------------------------------------------------------------------
-template <int CPT, int EXP = 0>
+template <int CPT>
 __global__ __launch_bounds__(GEO_T) void k_project_score(
     const float* __restrict__ cubes, int P, const float* __restrict__ Kmat, int k_per_object, Clamp cl,
     const float* __restrict__ ref_boxes, const float* __restrict__ prior_mu,
@@ -244,31 +244,20 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
                 for (int j = 0; j < 15; ++j) cu[j] = s_cubes[tid * 15 + j];
                 float X[8], Y[8], Z[8], u[8], v[8];
                 cube_corners3d(cu, X, Y, Z);
-                if (EXP & 4) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float p0 = (K[0] * X[i] + K[1] * Y[i]) + K[2] * Z[i];
-                        const float p1 = (K[3] * X[i] + K[4] * Y[i]) + K[5] * Z[i];
-                        const float p2 = (K[6] * X[i] + K[7] * Y[i]) + K[8] * Z[i];
-                        const float r = __builtin_amdgcn_rcpf(p2);
-                        u[i] = clamp_keep_nan(p0 * r, cl.lo0, cl.hi0);
-                        v[i] = clamp_keep_nan(p1 * r, cl.lo1, cl.hi1);
-                    }
-                } else
                 project8(X, Y, Z, K, cl, u, v);
                 if (pass == 0) {
                     float b0, b1, b2, b3;
                     minmax8(u, b0, b2);
                     minmax8(v, b1, b3);
                     const size_t gi = (size_t)obj * P + p;
-                    if (out_corners && !(EXP & 2)) {
+                    if (out_corners) {
                         float4* oc = reinterpret_cast<float4*>(out_corners + gi * 16);
                         oc[0] = make_float4(u[0], v[0], u[1], v[1]);
                         oc[1] = make_float4(u[2], v[2], u[3], v[3]);
                         oc[2] = make_float4(u[4], v[4], u[5], v[5]);
                         oc[3] = make_float4(u[6], v[6], u[7], v[7]);
                     }
-                    if (out_boxes && !(EXP & 2)) reinterpret_cast<float4*>(out_boxes)[gi] = make_float4(b0, b1, b2, b3);
+                    if (out_boxes) reinterpret_cast<float4*>(out_boxes)[gi] = make_float4(b0, b1, b2, b3);
                     // IoU vs the object's 2D box (detectron2 pairwise_iou definition)
                     const float a2 = (b2 - b0) * (b3 - b1);
                     float w = nmin(r2, b2) - nmax(r0, b0);
@@ -283,28 +272,12 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
                     const float e0 = cr_exp_f32(-0.5f * (z0 * z0));
                     const float e1 = cr_exp_f32(-0.5f * (z1 * z1));
                     const float e2 = cr_exp_f32(-0.5f * (z2 * z2));
-                    VAT(v_gauss, c) = (EXP & 16) ? (z0 + z1 + z2) : ((e0 + e1) + e2) / 3.0f;
+                    VAT(v_gauss, c) = ((e0 + e1) + e2) / 3.0f;
                     const float pr = (b2 - b0) / (b3 - b1);
                     VAT(v_diff, c) = fabsf(gt_ratio - pr);
                     sum_mnx += b0; sum_mxx += b2; sum_mny += b1; sum_mxy += b3;
                 }
-                if (EXP & 1) { VAT(v_s, c) = u[0] + v[3]; }
-                else if (EXP & 8) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float rx = s_rect[q * 2], ry = s_rect[q * 2 + 1];
-                        float best = INFINITY;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const float dx = rx - u[i], dy = ry - v[i];
-                            best = fminf(best, __builtin_fmaf(dx, dx, dy * dy));
-                        }
-                        acc += __builtin_amdgcn_sqrtf(best);
-                    }
-                    VAT(v_s, c) = acc * 0.25f;
-                }
-                else if (have_rect || pass == 1) {
+                if (have_rect || pass == 1) {
                     // modified chamfer (scorefunction.py:51-56): float64 like scipy's cKDTree
                     double acc = 0.0;
 #pragma unroll
@@ -357,12 +330,10 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(
             const float cor = 1.0f - VAT(v_s, c) / maxs;
             const float comb = (VAT(v_iou, c) * dim) * cor;
             const size_t gi = (size_t)obj * P + p;
-            if (!(EXP & 2)) {
             if (out_iou) out_iou[gi] = VAT(v_iou, c);
             if (out_dim) out_dim[gi] = dim;
             if (out_corner) out_corner[gi] = cor;
             if (out_combined) out_combined[gi] = comb;
-            }
             if (arg_better(comb, p, bestv, besti)) { bestv = comb; besti = p; }
         }
     }
@@ -405,12 +376,6 @@ extern "C" int cr_cubes_project_score(cr_ctx* ctx, const float* cubes, int64_t N
     cl.lo1 = (float)(int)(-(double)im_h / 2 + 1);
     cl.hi1 = (float)(int)((double)im_h - 1 + (double)im_h);
     dim3 grid((unsigned)N), block(GEO_T);
-    static const int geo_exp = getenv("CR_GEO_EXP") ? atoi(getenv("CR_GEO_EXP")) : 0;       // experiment switches (timing only)
-#define GEO_EXP_CASE(E) if (geo_exp == E && P <= 4 * GEO_T) { \
-        hipLaunchKernelGGL((k_project_score<4, E>), grid, block, 0, ctx->stream, cubes, (int)P, K, k_per_object, cl, \
-                           ref_boxes, prior_mu, prior_sigma, rect_pts, out_corners, out_boxes, out_iou, out_dim, \
-                           out_corner, out_combined, out_argmax, out_best, iou_boxes); CR_LAUNCH_CHECK(); return CR_OK; }
-    GEO_EXP_CASE(1) GEO_EXP_CASE(2) GEO_EXP_CASE(3) GEO_EXP_CASE(4) GEO_EXP_CASE(8) GEO_EXP_CASE(12) GEO_EXP_CASE(16) GEO_EXP_CASE(28) GEO_EXP_CASE(31)
     if (P <= 4 * GEO_T)
         hipLaunchKernelGGL(k_project_score<4>, grid, block, 0, ctx->stream, cubes, (int)P, K, k_per_object, cl,
                            ref_boxes, prior_mu, prior_sigma, rect_pts, out_corners, out_boxes, out_iou, out_dim,

@@ -482,6 +482,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="train", choices=["train", "geometry", "inference", "weak", "depth", "boxnet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--argmax-only", action="store_true", help="geometry workload: the AP path (no output planes)")
     ap.add_argument("--train-only", action="store_true", help="train workload without the geometry / inference keys")
     ap.add_argument("--lean", action="store_true", help="headline measurement only (no eager / do_train / other-precision lines)")
     args = ap.parse_args()
@@ -492,7 +493,7 @@ def main():
     rank, world, local = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
     if args.workload == "geometry":
-        res = bench_geometry(args, rank, world, dev)
+        res = bench_geometry(args, rank, world, dev, argmax_only=args.argmax_only, cpu_baseline=not args.argmax_only)
     elif args.workload == "inference":
         res = bench_inference(args, rank, world, dev)
     elif args.workload == "weak":

@@ -17,7 +17,7 @@ for a in args:
         per = {}
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            if match not in name or len(name) > 200:
+            if match not in name or len(name) > 400:
                 continue
             short = name.replace("void ", "").split("(")[0]
             per.setdefault(short, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
