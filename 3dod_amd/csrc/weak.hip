@@ -48,17 +48,40 @@ __global__ __launch_bounds__(MED_T) void k_box_median(const float* __restrict__ 
         // bin changes removes the (otherwise fully serialised) same-address atomics
         int cur = -1;
         unsigned run = 0;
-        for (int r = tid >> 6; r < bh; r += MED_T / 64) {                 // one wave per row, lanes along the row
-            const float* row = base + (size_t)r * W;
-            for (int c = tid & 63; c < bw; c += 64) {
-                const unsigned key = f2ord(row[c]);
-                const int bin = (key & hi_mask) == prefix ? (int)((key >> shift) & 255u) : -1;
-                if (bin == cur) {
-                    ++run;
-                } else {
-                    if (cur >= 0) atomicAdd(&hist[cur], run);
-                    cur = bin;
-                    run = 1;
+        auto count = [&](float v) {
+            const unsigned key = f2ord(v);
+            const int bin = (key & hi_mask) == prefix ? (int)((key >> shift) & 255u) : -1;
+            if (bin == cur) {
+                ++run;
+            } else {
+                if (cur >= 0) atomicAdd(&hist[cur], run);
+                cur = bin;
+                run = 1;
+            }
+        };
+        // one wave per row pair, lanes along the rows; the eight loads of a step (2 rows x 4 column chunks) are issued before the
+        // first one is consumed -- the window comes out of L2 / HBM at ~1 us per dependent round trip otherwise
+        const int lane = tid & 63;
+        for (int r = (tid >> 6) * 2; r < bh; r += MED_T / 32) {
+            const float* row0 = base + (size_t)r * W;
+            const bool two = r + 1 < bh;
+            const float* row1 = two ? row0 + W : row0;
+            for (int c0 = lane; c0 < bw; c0 += 256) {
+                float v0[4], v1[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = c0 + 64 * k;
+                    const bool ok = c < bw;
+                    v0[k] = ok ? row0[c] : 0.f;
+                    v1[k] = ok && two ? row1[c] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c0 + 64 * k < bw) count(v0[k]);
+                if (two) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c0 + 64 * k < bw) count(v1[k]);
                 }
             }
         }
@@ -89,13 +112,136 @@ __global__ __launch_bounds__(MED_T) void k_box_median(const float* __restrict__ 
     if (tid == 0) out[b] = ord2f(s_prefix);
 }
 
+// ---- the same selection with every window spread over MED_SPLIT workgroups ----------------------------------------------------
+// A projected box clipped to the image is often most of the image (262k pixels at 512 x 512); one workgroup per window then
+// leaves the chip to the few largest windows.  Here pass p of the radix select is one launch over (windows x MED_SPLIT) workgroups
+// that histogram their rows in LDS and add the non-empty bins to the window's global histogram; the next launch starts by
+// scanning that histogram (every workgroup for itself, workgroup 0 of the window records the state), the fifth one writes the
+// result.  Workspace: hist [4][n][256] u32 (zeroed by k_med_zero) + state [5][n][2] u32.
+#define MED_SPLIT 16
+#define MED_PT 256
+__global__ void k_med_zero(unsigned* __restrict__ p, long count) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = 0u;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(MED_PT) void k_med_pass(const float* __restrict__ depth, int B, int H, int W, const int* __restrict__ boxes,
+                                                     const int* __restrict__ img, int n, unsigned* __restrict__ hist,
+                                                     unsigned* __restrict__ state, float* __restrict__ out) {
+    __shared__ unsigned sh[256];
+    __shared__ unsigned s_prefix, s_k;
+    const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    int x1 = boxes[4 * b + 0], y1 = boxes[4 * b + 1], x2 = boxes[4 * b + 2], y2 = boxes[4 * b + 3];
+    const int im = img[b];
+    x1 = min(max(x1, 0), W); x2 = min(max(x2, 0), W); y1 = min(max(y1, 0), H); y2 = min(max(y2, 0), H);
+    const int bw = max(x2 - x1, 0), bh = max(y2 - y1, 0);
+    const int cnt = bw * bh;
+    if (cnt == 0 || im < 0 || im >= B) {
+        if (PASS == 4 && tid == 0) out[b] = __uint_as_float(0x7fc00000u);       // empty window: NaN
+        return;
+    }
+    // ---- state before this pass: the previous state refined by the previous pass's histogram
+    unsigned prefix = 0u, k = (unsigned)((cnt - 1) >> 1);
+    if (PASS > 0) {
+        if (PASS > 1) { prefix = state[((size_t)(PASS - 1) * n + b) * 2]; k = state[((size_t)(PASS - 1) * n + b) * 2 + 1]; }
+        if (tid < 64) {
+            const unsigned* h = hist + ((size_t)(PASS - 1) * n + b) * 256;
+            const unsigned h0 = h[4 * tid], h1 = h[4 * tid + 1], h2 = h[4 * tid + 2], h3 = h[4 * tid + 3];
+            const unsigned mine = h0 + h1 + h2 + h3;
+            unsigned incl = mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned v = __shfl_up(incl, off, 64);
+                if (tid >= off) incl += v;
+            }
+            const unsigned excl = incl - mine;
+            if (k >= excl && k < incl) {                   // exactly one lane
+                unsigned run = excl, bin;
+                if (k < run + h0) bin = 0;
+                else if (k < (run += h0) + h1) bin = 1;
+                else if (k < (run += h1) + h2) bin = 2;
+                else { run += h2; bin = 3; }
+                s_prefix = prefix | ((4u * tid + bin) << (24 - 8 * (PASS - 1)));
+                s_k = k - run;
+            }
+        }
+        __syncthreads();
+        prefix = s_prefix; k = s_k;
+        if (part == 0 && tid == 0) { state[((size_t)PASS * n + b) * 2] = prefix; state[((size_t)PASS * n + b) * 2 + 1] = k; }
+    }
+    if (PASS == 4) {
+        if (tid == 0) out[b] = ord2f(prefix);
+        return;
+    }
+    // ---- histogram of this workgroup's rows
+    sh[tid] = 0u;
+    __syncthreads();
+    const int shift = 24 - 8 * (PASS < 4 ? PASS : 3);
+    const unsigned hi_mask = PASS == 0 ? 0u : (0xffffffffu << (shift + 8));
+    const float* base = depth + ((size_t)im * H + y1) * W + x1;
+    int cur = -1;
+    unsigned run = 0;
+    auto count = [&](float v) {
+        const unsigned key = f2ord(v);
+        const int bin = (key & hi_mask) == prefix ? (int)((key >> shift) & 255u) : -1;
+        if (bin == cur) {
+            ++run;
+        } else {
+            if (cur >= 0) atomicAdd(&sh[cur], run);
+            cur = bin;
+            run = 1;
+        }
+    };
+    const int lane = tid & 63;
+    for (int r = (part * (MED_PT / 64) + (tid >> 6)) * 2; r < bh; r += MED_SPLIT * (MED_PT / 64) * 2) {
+        const float* row0 = base + (size_t)r * W;
+        const bool two = r + 1 < bh;
+        const float* row1 = two ? row0 + W : row0;
+        for (int c0 = lane; c0 < bw; c0 += 256) {
+            float v0[4], v1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + 64 * q;
+                const bool ok = c < bw;
+                v0[q] = ok ? row0[c] : 0.f;
+                v1[q] = ok && two ? row1[c] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c0 + 64 * q < bw) count(v0[q]);
+            if (two) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c0 + 64 * q < bw) count(v1[q]);
+            }
+        }
+    }
+    if (cur >= 0) atomicAdd(&sh[cur], run);
+    __syncthreads();
+    if (sh[tid]) atomicAdd(&hist[((size_t)PASS * n + b) * 256 + tid], sh[tid]);
+}
+
 extern "C" int cr_box_median(cr_ctx* ctx, const float* depth, int B, int H, int W, const int32_t* boxes,
                              const int32_t* img, int n, float* out) {
     CR_CHECK_ARG(ctx && B >= 0 && H >= 0 && W >= 0 && n >= 0, "cr_box_median: bad args");
     if (n == 0) return CR_OK;
     CR_CHECK_ARG(depth && boxes && img && out, "cr_box_median: NULL pointer");
     CR_CHECK_ARG((int64_t)H * W < (1ll << 31), "cr_box_median: map too large");
-    hipLaunchKernelGGL(k_box_median, dim3(n), dim3(MED_T), 0, ctx->stream, depth, B, H, W, boxes, img, n, out);
+    const size_t hist_words = (size_t)4 * n * 256, state_words = (size_t)5 * n * 2;
+    if ((hist_words + state_words) * sizeof(unsigned) > ctx->ws_bytes || n > 65535) {       // one workgroup per window
+        hipLaunchKernelGGL(k_box_median, dim3(n), dim3(MED_T), 0, ctx->stream, depth, B, H, W, boxes, img, n, out);
+        CR_LAUNCH_CHECK();
+        return CR_OK;
+    }
+    unsigned* hist = (unsigned*)ctx->ws;
+    unsigned* state = hist + hist_words;
+    hipLaunchKernelGGL(k_med_zero, dim3((unsigned)cr_cdiv((int64_t)hist_words, 256)), dim3(256), 0, ctx->stream, hist, (long)hist_words);
+    const dim3 grid((unsigned)n, MED_SPLIT), blk(MED_PT);
+    hipLaunchKernelGGL((k_med_pass<0>), grid, blk, 0, ctx->stream, depth, B, H, W, boxes, img, n, hist, state, out);
+    hipLaunchKernelGGL((k_med_pass<1>), grid, blk, 0, ctx->stream, depth, B, H, W, boxes, img, n, hist, state, out);
+    hipLaunchKernelGGL((k_med_pass<2>), grid, blk, 0, ctx->stream, depth, B, H, W, boxes, img, n, hist, state, out);
+    hipLaunchKernelGGL((k_med_pass<3>), grid, blk, 0, ctx->stream, depth, B, H, W, boxes, img, n, hist, state, out);
+    hipLaunchKernelGGL((k_med_pass<4>), dim3((unsigned)n, 1), blk, 0, ctx->stream, depth, B, H, W, boxes, img, n, hist, state, out);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

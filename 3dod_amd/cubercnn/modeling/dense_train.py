@@ -371,12 +371,113 @@ def forward_train(model, image_sizes, features, head_outputs, gt: GTBatch, meta)
     return losses
 
 
+_WEAK_FUSED_LOSSES = {"dims", "pose_alignment", "pose_ground", "iou", "z", "z_pseudo_gt_patch", "z_pseudo_gt_center"}
+_WEAK_PRIOR_NAN = {}
+
+
+def weak_fusable(rh, kf, dev, masks=None):
+    """whether ops.weak_cube_loss covers this head's configuration: the loss set, uncertainty weighting on, 'exp' dimension
+    priors, at most ops.WEAK_MAX_SLOTS foreground slots per image, no test hook installed (the hooks are CPU restatements of
+    single kernels for the tensor composition); CR_WEAK_FUSED=0 selects the composition for comparisons."""
+    import os
+    if os.environ.get("CR_WEAK_FUSED", "1") == "0" or dev.type != "cuda":
+        return False
+    hooks = (rh._median_fn, rh._plane_cls, rh._ransac_triples, rh._hull_fn, rh._focal_fn)
+    return (set(rh.loss_functions) <= _WEAK_FUSED_LOSSES and rh.use_confidence > 0 and kf <= ops.WEAK_MAX_SLOTS
+            and (not rh.dims_priors_enabled or rh.dims_priors_func == "exp") and all(h is None for h in hooks))
+
+
+def _prior_std_has_nan(rh):
+    """dim_hinge_loss drops the three dims terms when a prior has a NaN standard deviation (roi_heads.py:1236-1237 looks at the
+    selected priors; here: at the whole table, read back once per version of the parameter)"""
+    p = rh.priors_dims_per_cat
+    key = (id(p), p._version)
+    if key not in _WEAK_PRIOR_NAN:
+        _WEAK_PRIOR_NAN.clear()
+        _WEAK_PRIOR_NAN[key] = bool(torch.isnan(p.detach()[0, :, 1, :]).any())
+    return _WEAK_PRIOR_NAN[key]
+
+
+def weak_cube_losses_fused(rh, samp, gt: GTBatch, cube_pooled, Ks, image_sizes, im_scales_ratio, ground_maps, depth_maps, generator=None,
+                           raw_layout=None, normals=None):
+    """ROIHeads3DScore._forward_cube in training (roi_heads.py:1366-1760) on the k_fg foreground slots of every image: the
+    ground normals of the batch (one RANSAC launch), then ops.weak_cube_loss (select, terms, window medians, reduce).  Empty
+    slots are excluded by their validity flag.  When every image holds exactly one foreground RoI the reference drops
+    Cube/loss_pose from the dictionary; here it is reported as 0 (same total).  raw_layout = (raw, layout): the fused predictor
+    output if the caller already has it; normals (B,3): ground normals computed elsewhere (both: tools and tests)."""
+    from .roi_heads import weak_losses as W
+    B, kf = samp["valid"].shape[0], samp["k_fg"]
+    K = rh.num_classes
+    n = B * kf
+    lf = set(rh.loss_functions)
+    raw, layout = raw_layout if raw_layout is not None else rh.cube_head.forward_fused(cube_pooled.flatten(1))
+    dev = raw.device
+    meta = camera_meta(rh, Ks, im_scales_ratio, image_sizes, dev)
+    table = W.weak_table(Ks, im_scales_ratio, image_sizes, ground_maps, depth_maps).to(dev, non_blocking=True)
+    prior_mean = prior_std = None
+    if rh.dims_priors_enabled:
+        pr = rh.priors_dims_per_cat.detach()[0]
+        prior_mean, prior_std = pr[:, 0, :].contiguous(), pr[:, 1, :].contiguous()
+    terms = 0
+    if "iou" in lf:
+        terms |= 1
+    if "pose_alignment" in lf:
+        terms |= 2
+    if "pose_ground" in lf:
+        terms |= 4
+    if "z" in lf:
+        terms |= 8
+    pgz = 1 if "z_pseudo_gt_patch" in lf else (2 if "z_pseudo_gt_center" in lf else 0)
+    if pgz:
+        terms |= 16
+    if "dims" in lf and not (rh.dims_priors_enabled and _prior_std_has_nan(rh)):
+        terms |= 32 | 64 | 128
+    if (terms & 4) and normals is None:
+        # the reference back-projects image i with the intrinsics of the i-th foreground RoI's image (:1612 passes the per-box K)
+        with torch.no_grad():
+            cls = samp["classes"][:, :kf]
+            vf = (samp["valid"][:, :kf] & (cls >= 0) & (cls < K)).reshape(-1)
+            rank = torch.cumsum(vf, 0)
+            hit = (rank.view(1, n) == torch.arange(1, B + 1, device=dev).view(B, 1)) & vf.view(1, n)
+            first = torch.argmax(hit.to(torch.uint8), dim=1)
+            own = torch.arange(B, device=dev)
+            kimg = torch.where(hit.any(1), torch.div(first, kf, rounding_mode="floor"), own)
+            normals = W.ground_normals_batched(ground_maps, depth_maps, table, kimg, generator=generator)
+    w_log = (rh.loss_w_iou, rh.loss_w_pose, 0.0, rh.loss_w_z, rh.loss_w_z, rh.loss_w_dims, rh.loss_w_dims, rh.loss_w_dims,
+             rh.loss_w_normal_vec)
+    red, stats, _, _, _ = ops.weak_cube_loss(
+        raw, layout, K, samp["classes"], samp["valid"], samp["gt_idx"], kf, gt.boxes, gt.boxes3D, gt.poses, prior_mean, prior_std,
+        meta, table, normals, samp["boxes"][:, :kf].reshape(n, 4), depth_maps.tensor if pgz else None, terms, pgz, w_log,
+        allocentric=rh.allocentric_pose)
+    w3 = rh.loss_w_3d
+    wkey = ("weak", float(rh.loss_w_iou * w3), float(rh.loss_w_pose * w3), float(rh.loss_w_normal_vec * w3), float(rh.loss_w_z * w3),
+            float(rh.loss_w_z * w3), float(rh.loss_w_dims * w3), float(rh.loss_w_dims * w3), float(rh.loss_w_dims * w3),
+            float(rh.use_confidence), str(dev))
+    wv = _WVEC.get(wkey)
+    if wv is None:
+        wv = _WVEC[wkey] = torch.tensor(wkey[1:10], dtype=torch.float32, device=dev)
+    scaled = (red * wv).unbind(0)
+    p = "Cube/"
+    losses = {p + "uncert": scaled[8]}
+    for k, name in enumerate(("loss_iou", "loss_pose", "loss_normal_vec", "loss_z", "loss_pseudo_gt_z", "loss_dims_w", "loss_dims_h",
+                              "loss_dims_l")):
+        if terms & (1 << k):
+            losses[p + name] = scaled[k]
+    storage = get_event_storage()
+    for k, name in enumerate(("z_error", "dims_error", "xy_error", "z_close", "2D IoU", "conf")):
+        storage.put_scalar(p + name, stats[k], smoothing_hint=False)
+    storage.put_scalar(p + "total_3D_loss", stats[6] * w3, smoothing_hint=False)
+    return losses
+
+
 def forward_train_weak(model, image_sizes, features, head_outputs, gt: GTBatch, Ks, im_scales_ratio, ground_maps, depth_maps,
                        masks=None, mask_keys=None):
     """RCNN3D_combined_features.forward in training mode (rcnn3d.py:362-414): RPN losses, proposals, RoI sampling and
-    the box head exactly as `forward_train` (fused, static shapes, no host sync); the weak cube losses of
-    ROIHeads3DScore then run on the COMPACTED foreground RoIs -- their number per image is the one value the host
-    waits for in this step."""
+    the box head exactly as `forward_train` (fused, static shapes, no host sync).  The weak cube losses of
+    ROIHeads3DScore run in the fused kernels of ops.weak_cube_loss on the (B, k_fg) foreground slots when the configured loss
+    set is one they cover (weak_fusable) -- no host sync in the step; otherwise (segmentation / depth losses on object masks,
+    pose_ground2) as the tensor composition of weak_losses.py on the COMPACTED foreground RoIs, whose number per image the host
+    then has to wait for."""
     rpn, rh = model.proposal_generator, model.roi_heads
     dev = features[rpn.in_features[0]].device
     feats = [features[f] for f in rpn.in_features]
@@ -396,6 +497,9 @@ def forward_train_weak(model, image_sizes, features, head_outputs, gt: GTBatch, 
     if rh.loss_w_3d <= 0:
         return losses
     B, kf = samp["valid"].shape[0], samp["k_fg"]
+    if weak_fusable(rh, kf, dev, masks):
+        losses.update(weak_cube_losses_fused(rh, samp, gt, cube_pooled, Ks, image_sizes, im_scales_ratio, ground_maps, depth_maps))
+        return losses
     cls = samp["classes"][:, :kf]
     fg = samp["valid"][:, :kf] & (cls >= 0) & (cls < rh.num_classes)
     counts = fg.sum(1).tolist()                                   # host sync

@@ -291,7 +291,12 @@ class RCNN3D_combined_features(RCNN3D):
         if self.only_2d:
             return None, None
         depth_maps = self._maps(batched_inputs, "depth_map")
-        filled = [dict(b, ground_map=torch.tensor([[1]])) if b.get("ground_map") is None else b for b in batched_inputs]
+        # the (1,1) dummy of an image without ground map lives on the device: a fresh host tensor would cost a blocking copy,
+        # i.e. a wait for the previous step's kernels, in every step
+        dummy = self.__dict__.get("_ground_dummy")
+        if dummy is None or dummy.device != self.device:
+            dummy = self.__dict__["_ground_dummy"] = torch.ones((1, 1), dtype=torch.int64, device=self.device)
+        filled = [dict(b, ground_map=dummy) if b.get("ground_map") is None else b for b in batched_inputs]
         return self._maps(filled, "ground_map"), depth_maps
 
     def _images_raw(self, batched_inputs):

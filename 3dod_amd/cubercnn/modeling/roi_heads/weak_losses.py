@@ -145,6 +145,71 @@ def ground_normals(ground_maps, depth_maps, Ks, use_nth=5, id_samples=None, gene
     return torch.stack(out)
 
 
+WEAK_TABLE_COLS = 20
+
+
+def weak_table(Ks, im_scales_ratio, im_dims, ground_maps, depth_maps, use_nth=5):
+    """per-image constants of the weak cube branch as ONE host-built (B,20) float32 tensor (pinned when CUDA is there):
+    K / ratio with K[2][2] = 1 (9) | clamp bounds of the projection (4: x with dims[0], y with dims[1], as the reference passes
+    them, roi_heads.py:1419-1423,1551) | ground-map confidence (0.1 for an image without ground map, :1600-1606) | height, width
+    of the depth map | strided height, width of `ground_normals` | 1 if the image has a ground map | 0."""
+    rows = []
+    for i in range(len(Ks)):
+        k = torch.as_tensor(Ks[i], dtype=torch.float32) / im_scales_ratio[i]
+        k[-1, -1] = 1
+        d = im_dims[i]
+        has_ground = ground_maps is not None and tuple(ground_maps.image_sizes[i]) != (1, 1)
+        dh, dw = tuple(depth_maps.image_sizes[i]) if depth_maps is not None else (d[0], d[1])
+        rows.append(k.flatten().tolist() + [float(v) for v in _int_clamp_bounds(d[0]) + _int_clamp_bounds(d[1])]
+                    + [1.0 if (ground_maps is None or has_ground) else 0.1, float(dh), float(dw), float(-(-int(dh) // use_nth)),
+                       float(-(-int(dw) // use_nth)), 1.0 if has_ground else 0.0, 0.0])
+    t = torch.tensor(rows, dtype=torch.float32)
+    return t.pin_memory() if torch.cuda.is_available() else t
+
+
+_GRID = {}
+
+
+def ground_normals_batched(ground_maps, depth_maps, table, kimg=None, use_nth=5, generator=None, n_iter=1000, thresh=0.05):
+    """`ground_normals` for every image at once and without a host sync (static shapes: usable on the dense training path):
+    the strided back-projection over the padded batch with a validity mask, triples sampled on the device among each image's
+    eligible points (Plane.sample_triples_batched), one cr_ransac_plane_batched launch, the axis fix-ups.  table: weak_table()
+    on the device; kimg (B) int64: the image whose intrinsics image i is back-projected with (the reference indexes the
+    per-BOX intrinsics with the image number, :1612) or None for its own.  An image whose ground map has fewer than three
+    pixels set falls back to all its points (the reference would fail there).  -> (B,3)"""
+    from .... import geometry as geo
+    from ....ProposalNetwork.utils.plane import Plane
+    from .boxer import fix_ground_normal
+    depth = depth_maps.tensor
+    dev, B = depth.device, depth.shape[0]
+    zs = depth[:, ::use_nth, ::use_nth]
+    Hs, Ws = zs.shape[1], zs.shape[2]
+    key = (Hs, Ws, str(dev))
+    if key not in _GRID:
+        _GRID[key] = (torch.arange(Ws, device=dev, dtype=torch.float32).view(1, 1, Ws),
+                      torch.arange(Hs, device=dev, dtype=torch.float32).view(1, Hs, 1))
+    u, v = _GRID[key]
+    K = table[:, :9] if kimg is None else table[kimg, :9]
+    fx, fy = torch.floor(K[:, 0] / use_nth).view(B, 1, 1), torch.floor(K[:, 4] / use_nth).view(B, 1, 1)
+    hh, ww = table[:, 16].view(B, 1, 1), table[:, 17].view(B, 1, 1)
+    x = (u - ww / 2) * zs / fx
+    y = (v - hh / 2) * zs / fy
+    inside = ((u < ww) & (v < hh)).reshape(B, -1)
+    pts = torch.stack((x, y, zs), dim=-1).reshape(B, -1, 3)
+    elig = inside
+    if ground_maps is not None:
+        g = ground_maps.tensor
+        if tuple(g.shape[-2:]) != tuple(depth.shape[-2:]):                  # the two lists are padded separately
+            g = torch.nn.functional.pad(g, (0, max(depth.shape[2] - g.shape[2], 0), 0, max(depth.shape[1] - g.shape[1], 0)))
+            g = g[:, :depth.shape[1], :depth.shape[2]]
+        on = (g[:, ::use_nth, ::use_nth] > 0).reshape(B, -1) | (table[:, 18] == 0).view(B, 1)
+        elig = inside & on
+        elig = elig | ((elig.sum(1, keepdim=True) < 3) & inside)
+    triples = Plane.sample_triples_batched(elig, B, pts.shape[1], n_iter, dev, generator)
+    neg_eq, _, _ = geo.ransac_plane_batched(pts, triples, elig, thresh=thresh)
+    return fix_ground_normal(neg_eq[:, :3].t()).t().contiguous()
+
+
 def normal_to_rotation(normal):
     """:1306-1317 (the normalisation by the norm of the WHOLE batch and the `.any() < 0.001` test are the reference's)"""
     n = normal.shape[0]

@@ -1737,6 +1737,113 @@ def cube_reduce(L, u_sel, buf, dec, validf, inverse_z=False):
 
 
 # --------------------------------------------------------------------------
+# weakly supervised 3D head on the static-shape path: class gather + fused decode / losses / reductions
+# --------------------------------------------------------------------------
+WEAK_TERMS = ("iou", "pose", "normal", "z", "pseudo_gt_z", "dims_w", "dims_h", "dims_l")      # bit k of `terms`
+WEAK_MAX_SLOTS = 256                                                                           # kf limit of k_weak_fwd / k_weak_bwd
+_WEAK_IMG = {}
+
+
+class _WeakCubeLoss(torch.autograd.Function):
+    """raw (n,13K) -> red (9) = safely reduced, uncertainty-weighted terms + the mean uncertainty; see include/cr3dod.h
+    (cr_weak_loss_fwd / _reduce / _bwd).  Five launches forward (select, terms, window medians, reduce), two backward."""
+
+    @staticmethod
+    def forward(ctx, raw, layout, K, cls, valid, gt_idx, kf, gt_boxes, gt3d, gtpose, prior_mean, prior_std, meta, table, normals,
+                boxes, depth, terms, pgz_mode, weights, allocentric):
+        _p = _Args()
+        _need_cuda(raw, "cube head output")
+        B, S = cls.shape
+        n, G = B * kf, gt3d.shape[1]
+        dev = raw.device
+        lib = _lib.load()
+        raw32 = raw.detach().float().contiguous()
+        buf = torch.empty((39 * n,), dtype=f32, device=dev)
+        validf = torch.empty((n,), dtype=torch.uint8, device=dev)
+        clsc = torch.empty((n,), dtype=torch.int32, device=dev)
+        lay = (_ct.c_int * 5)(*[int(v) for v in layout])
+        cls, gt_idx, gt_boxes, table = cls.contiguous(), gt_idx.contiguous(), gt_boxes.float().contiguous(), table.contiguous()
+        _chk(lib.cr_cube_select(_ctx(raw), _p(raw32), raw32.shape[1], lay, int(K), _p(cls), _p(valid.to(torch.uint8).contiguous()),
+                                _p(gt_idx), B, S, int(kf), G, _p(gt3d.contiguous()), _p(gtpose.contiguous()), _p(prior_mean),
+                                _p(meta.contiguous()), _p(buf), _p(validf), _p(clsc)), "cr_cube_select")
+        ch = _chunks(buf, n)
+        boxes = boxes.contiguous()
+        ins = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in (ch[0], ch[1], ch[2], ch[3], ch[4], ch[6], ch[7], boxes)])
+        out = torch.empty((n * (8 + 17 + 4 + 1 + 1) + 2 * B + 27,), dtype=f32, device=dev)
+        o = 0
+        def take(m):
+            nonlocal o
+            t = out[o:o + m]
+            o += m
+            return t
+        Lraw, dec, pbox, ztgt, med, pimg = take(8 * n), take(17 * n), take(4 * n), take(n), take(n), take(2 * B)
+        red, cnt, stats, aux = take(9), take(9), take(8), take(1)
+        ibox = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        common = (_ctx(raw), ctypes.cast(ins, ctypes.c_void_p), _p(validf), _p(clsc), _p(gt_idx), _p(gt_boxes), _p(prior_std), _p(table),
+                  _p(normals), B, int(kf), S, G, int(bool(allocentric)), int(terms))
+        _chk(lib.cr_weak_loss_fwd(*common, _p(Lraw), _p(dec), _p(pbox), _p(ibox), _p(pimg)), "cr_weak_loss_fwd")
+        H = W = 0
+        if pgz_mode:
+            depth = depth.float().contiguous()
+            H, W = depth.shape[1], depth.shape[2]
+        if pgz_mode == 1:
+            img = _WEAK_IMG.get((B, kf, str(dev)))
+            if img is None:
+                img = _WEAK_IMG[(B, kf, str(dev))] = (torch.arange(n, device=dev) // kf).to(torch.int32)
+            _chk(lib.cr_box_median(_ctx(raw), _p(depth), B, H, W, _p(ibox), _p(img), n, _p(med)), "cr_box_median")
+        rin = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in (ch[4], ch[8], ch[9], ch[10])])
+        wts = (_ct.c_float * 9)(*[float(w) for w in weights])
+        _chk(lib.cr_weak_loss_reduce(_ctx(raw), ctypes.cast(rin, ctypes.c_void_p), _p(validf), _p(table), _p(depth if pgz_mode else None),
+                                     H, W, _p(med if pgz_mode == 1 else None), _p(gt_boxes), _p(gt_idx), B, int(kf), S, G, int(terms),
+                                     int(pgz_mode), wts, _p(Lraw), _p(dec), _p(pbox), _p(ibox), _p(pimg), _p(ztgt), _p(red), _p(cnt),
+                                     _p(stats), _p(aux)), "cr_weak_loss_reduce")
+        ctx.keep = (raw32, buf, validf, clsc, boxes, tuple(layout), int(K), B, int(kf), S, G, raw.dtype, cls, gt_idx, gt_boxes, prior_std,
+                    table, normals, int(bool(allocentric)), int(terms), out)
+        dec2, pbox2 = dec.view(n, 17), pbox.view(n, 4)
+        ctx.mark_non_differentiable(stats, dec2, pbox2, validf)
+        return red, stats, dec2, pbox2, validf
+
+    @staticmethod
+    def backward(ctx, gred, *_unused):
+        _p = _Args()
+        (raw32, buf, validf, clsc, boxes, layout, K, B, kf, S, G, dt, cls, gt_idx, gt_boxes, prior_std, table, normals, allocentric, terms,
+         out) = ctx.keep
+        n = B * kf
+        dev = raw32.device
+        lib = _lib.load()
+        ch = _chunks(buf, n)
+        ins = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in (ch[0], ch[1], ch[2], ch[3], ch[4], ch[6], ch[7], boxes)])
+        Lraw, dec, ztgt, pimg = out[:8 * n], out[8 * n:25 * n], out[29 * n:30 * n], out[31 * n:31 * n + 2 * B]
+        tail = out[31 * n + 2 * B:]
+        cnt, aux = tail[9:18], tail[26:27]
+        g = torch.empty((17 * n,), dtype=f32, device=dev)
+        g_dxy, g_zr, g_dr, g_Ra, g_u, zero = g[:2 * n], g[2 * n:3 * n], g[3 * n:6 * n], g[6 * n:15 * n], g[15 * n:16 * n], g[16 * n:]
+        zero.zero_()
+        _chk(lib.cr_weak_loss_bwd(_ctx(raw32), ctypes.cast(ins, ctypes.c_void_p), _p(validf), _p(clsc), _p(gt_idx), _p(gt_boxes),
+                                  _p(prior_std), _p(table), _p(normals), B, kf, S, G, allocentric, terms, _p(gred.float().contiguous()),
+                                  _p(cnt), _p(aux), _p(Lraw), _p(dec), _p(ztgt), _p(pimg), _p(g_dxy), _p(g_zr), _p(g_dr), _p(g_Ra),
+                                  _p(g_u)), "cr_weak_loss_bwd")
+        g_raw = torch.empty_like(raw32)
+        lay = (_ct.c_int * 5)(*layout)
+        _chk(lib.cr_cube_select_bwd(_ctx(raw32), _p(raw32), raw32.shape[1], lay, K, B, kf, _p(validf), _p(clsc), _p(g_dxy), _p(g_zr),
+                                    _p(g_dr), _p(g_Ra), _p(g_u), _p(zero), _p(g_raw)), "cr_cube_select_bwd")
+        return (g_raw.to(dt),) + (None,) * 20
+
+
+def weak_cube_loss(raw, layout, K, cls, valid, gt_idx, kf, gt_boxes, gt3d, gtpose, prior_mean, prior_std, meta, table, normals, boxes,
+                   depth, terms, pgz_mode, weights, allocentric=True):
+    """Losses of the weakly supervised 3D head on the (B, kf) foreground slots (ROIHeads3DScore._forward_cube, training).
+    raw (n,13K) fused predictor output; cls / valid / gt_idx (B,S); gt_boxes (B,G,4); gt3d (B,G,9); gtpose (B,G,3,3);
+    prior_mean / prior_std (K,3) or None; meta (B,5) camera_meta(); table (B,20), normals (B,3) or None, depth (B,H,W) or
+    None: see cr_weak_loss_fwd in include/cr3dod.h; terms: bit mask over WEAK_TERMS; pgz_mode 0 / 1 (window median) / 2 (depth
+    under the centre); weights (9).  -> red (9), stats (8), dec (n,17), pbox (n,4), validf (n)."""
+    if kf > WEAK_MAX_SLOTS:
+        raise _lib.CrError(f"weak_cube_loss: {kf} foreground slots per image, the kernels take up to {WEAK_MAX_SLOTS}")
+    return _WeakCubeLoss.apply(raw, tuple(layout), K, cls, valid, gt_idx, kf, gt_boxes, gt3d, gtpose.reshape(gtpose.shape[0], -1, 9),
+                               prior_mean, prior_std, meta, table, normals, boxes, depth, terms, pgz_mode, tuple(weights), allocentric)
+
+
+# --------------------------------------------------------------------------
 # optimizer
 # --------------------------------------------------------------------------
 class _RPNUnpack(torch.autograd.Function):

@@ -477,6 +477,42 @@ int cr_cube_reduce(cr_ctx* ctx, const float* L, const float* buf39, const float*
 int cr_cube_reduce_bwd(cr_ctx* ctx, const float* L, const float* buf39, const unsigned char* validf, int n, int inverse_z,
                        const float* cnt6, const float* gred6, float* gL, float* gu);
 
+/* ---- fused losses of the weakly supervised 3D head on the static (B, kf) foreground slots --------------------------
+ * ROIHeads3DScore._forward_cube in training mode (cubercnn/modeling/roi_heads/roi_heads.py:1366-1760): decode, cuboid,
+ * projected + clamped corners and their hull, the per-RoI terms and their reduction.  Term index (bit of `terms`):
+ * 0 iou (GIoU :1585-1590) | 1 pose (pairwise alignment :1055-1074) | 2 normal (pose_ground :1610-1622) | 3 z (depth search
+ * :1151-1194) | 4 pseudo_gt_z (:1196-1232 window median, or :1256-1279 depth under the centre) | 5,6,7 dims_w/h/l (:1234-1254).
+ * inputs: HOST array of 8 device pointers [dxy, zr, dr, Ra, u, v2r, prior_mean (chunks of cr_cube_select's buf39), src_boxes
+ * (n,4)], n = B*kf; validf / clsc from cr_cube_select; gt_idx (B,S) int64, gt_boxes (B,G,4); prior_std (K,3) or NULL;
+ * table (B,20) = [K / ratio row-major with K[2][2] = 1 (9) | clamp x_lo x_hi y_lo y_hi of Cubes.get_bube_corners (spaces.py:
+ * 240-243) | ground-map confidence | image height, width | 4 columns the kernels do not read]; normals (B,3) or NULL (needed by term 2).  kf <= 256.
+ * Outputs: Lraw (n,8) unweighted terms (1 and 4 are filled by cr_weak_loss_reduce), dec (n,17) = [cube_x, cube_y, z, dims(3),
+ * R(9), x3d, y3d], pbox (n,4) projected hull, ibox (n,4) int32 window of the depth median (0,0,0,0 = none), pimg (B,2) =
+ * [pose alignment mean, valid slots] per image. */
+int cr_weak_loss_fwd(cr_ctx* ctx, const float* const* inputs, const unsigned char* validf, const int32_t* clsc,
+                     const int64_t* gt_idx, const float* gt_boxes, const float* prior_std, const float* table,
+                     const float* normals, int B, int kf, int S, int G, int allocentric, int terms, float* Lraw, float* dec,
+                     float* pbox, int32_t* ibox, float* pimg);
+/* uncertainty weighting (:1700-1712) and safely_reduce_losses (:2843-2851) of every term over the valid slots.
+ * red_inputs: HOST array of 4 device pointers [u, gt2d, gtz, gtdims] (buf39 chunks); depth (B,H,W) padded depth maps (needed
+ * when pgz_mode != 0); med (n) = cr_box_median of ibox (pgz_mode 1); pgz_mode 0 none / 1 window median, targets in the
+ * reference's [with area..., without area...] order per image / 2 depth under the predicted centre; weights (9) HOST = weights
+ * of the logged total (8 terms, then the extra ground-confidence factor of term 2).
+ * red (9) = mean of term x sqrt(2) exp(-u) over the valid finite entries, [8] = mean uncertainty; cnt (9); stats (8) = z_error,
+ * dims_error, xy_error, z_close, 2D IoU, conf, total_3D_loss / loss_w_3d, valid slots; aux (1) = images-with-one-slot + 1 (0 when
+ * every image has exactly one: the reference drops the pose term then, here it is 0); ztgt (n) pseudo depth targets. */
+int cr_weak_loss_reduce(cr_ctx* ctx, const float* const* red_inputs, const unsigned char* validf, const float* table,
+                        const float* depth, int H, int W, const float* med, const float* gt_boxes, const int64_t* gt_idx, int B,
+                        int kf, int S, int G, int terms, int pgz_mode, const float* weights, float* Lraw, const float* dec,
+                        const float* pbox, const int32_t* ibox, const float* pimg, float* ztgt, float* red, float* cnt,
+                        float* stats, float* aux);
+/* gradients of sum_k gred[k] * red[k] w.r.t. the selected head outputs, in the form cr_cube_select_bwd takes. */
+int cr_weak_loss_bwd(cr_ctx* ctx, const float* const* inputs, const unsigned char* validf, const int32_t* clsc,
+                     const int64_t* gt_idx, const float* gt_boxes, const float* prior_std, const float* table,
+                     const float* normals, int B, int kf, int S, int G, int allocentric, int terms, const float* gred,
+                     const float* cnt, const float* aux, const float* Lraw, const float* dec, const float* ztgt,
+                     const float* pimg, float* g_dxy, float* g_zr, float* g_dr, float* g_Ra, float* g_u);
+
 /* inference decode of the 3D head for n kept detections (roi_heads.py:2353-2436,2682-2735) from the fused predictor
  * output raw (n, ld) (layout as in cr_cube_select).  cls (n) int64, img (n) int32, boxes (n,4); meta6 (B,6) =
  * [fx,fy,cx,cy of K/ratio, virtual_to_real, ratio]; priors (K,3) or NULL.
