@@ -118,7 +118,7 @@ __global__ __launch_bounds__(MED_T) void k_box_median(const float* __restrict__ 
 // that histogram their rows in LDS and add the non-empty bins to the window's global histogram; the next launch starts by
 // scanning that histogram (every workgroup for itself, workgroup 0 of the window records the state), the fifth one writes the
 // result.  Workspace: hist [4][n][256] u32 (zeroed by k_med_zero) + state [5][n][2] u32.
-#define MED_SPLIT 16
+#define MED_SPLIT 64
 #define MED_PT 256
 __global__ void k_med_zero(unsigned* __restrict__ p, long count) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -165,9 +165,36 @@ __device__ __forceinline__ float z_step(int i) {
     return i < WK_STEPS / 2 ? step * (float)i : 4.9f - step * (float)(WK_STEPS - 1 - i);
 }
 
-// z_search_loss (:1151-1194) of one RoI, without the uncertainty weight
-__device__ __forceinline__ float z_search(const WeakRow& r, const float rl[8][3], const float* box) {
-    const float* gt = r.gtb;
+// z_search_loss (:1151-1194) without the uncertainty weight: 8 lanes per RoI walk the 50 depth steps (lane q takes steps q, q+8,
+// ...), the best step is the first minimum of |gt area - projected area| over all of them (torch.argmin: a NaN beats any number,
+// the first one wins).  Reads the decoded cuboid (dec) and its hull (pbox) written by k_weak_fwd.
+__device__ __forceinline__ bool z_better(float da, int sa, float db, int sb) {       // is (da, sa) the argmin over (db, sb)?
+    const bool na = da != da, nb = db != db;
+    if (na != nb) return na;
+    if (na) return sa < sb;
+    if (da != db) return da < db;
+    return sa < sb;
+}
+
+__global__ __launch_bounds__(256) void k_weak_zsearch(WeakIn in, const float* __restrict__ dec, const float* __restrict__ pbox,
+                                                      float* __restrict__ Lraw) {
+    const int t = blockIdx.x * 256 + threadIdx.x, n = in.B * in.kf;
+    const int i = min(t >> 3, n - 1), q = t & 7, b = i / in.kf;          // (whole waves stay active for the shuffles)
+    const float* d = dec + (size_t)i * 17;
+    const float* tab = in.table + (size_t)b * WK_TAB;
+    float K[9], bnd[4], rl[8][3], gt[4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) K[k] = tab[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bnd[k] = tab[9 + k];
+    corner_offsets(d + 3, d + 6, rl);
+    const bool valid = in.validf[i] != 0;
+    const int64_t gi = in.gt_idx[(size_t)b * in.S + (i - b * in.kf)];
+    const float* g = in.gt_boxes + ((size_t)b * in.G + (valid ? gi : 0)) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gt[k] = g[k];
+    const float* box = pbox + (size_t)i * 4;
+    const float z = d[2];
     const float gt_area = (gt[2] - gt[0]) * (gt[3] - gt[1]);
     const float pcx = (box[0] + box[2]) / 2.f, pcy = (box[1] + box[3]) / 2.f;
     const float pred_area = (box[2] - box[0]) * (box[3] - box[1]);
@@ -175,22 +202,27 @@ __device__ __forceinline__ float z_search(const WeakRow& r, const float rl[8][3]
     const float bx = (gt[0] - WK_STEPS <= pcx) ? 1.f : 0.f, by = (gt[1] - WK_STEPS <= pcy) ? 1.f : 0.f;
     const bool within = (bx <= gt[2] + WK_STEPS) && (by <= gt[3] + WK_STEPS);
     const float sign = gt_area < pred_area ? 1.f : -1.f;
-    float best = INFINITY, best_z = r.z;
-    bool first = true;
-    for (int s = 0; s < WK_STEPS; ++s) {
-        const float mz = r.z + sign * z_step(s);
-        const float c[3] = {r.x3d, r.y3d, mz};
+    float best = 0.f;
+    int best_s = -1;
+    for (int s = q; s < WK_STEPS; s += 8) {
+        const float c[3] = {d[15], d[16], z + sign * z_step(s)};
         float bb[4];
-        project_box(rl, c, r.K, r.bnd, bb, nullptr, nullptr, nullptr, nullptr);
+        project_box(rl, c, K, bnd, bb, nullptr, nullptr, nullptr, nullptr);
         float area = (bb[2] - bb[0]) * (bb[3] - bb[1]);
         area = area + (area == 0.f ? 10000000.f : 0.f);
-        const float d = fabsf(gt_area - area);
-        // torch.argmin: the first minimum; a NaN is smaller than everything (the first NaN wins)
-        const bool better = first || ((d != d) ? (best == best) : (best == best && d < best));
-        if (better) { best = d; best_z = mz; first = false; }
+        const float dd = fabsf(gt_area - area);
+        if (best_s < 0 || z_better(dd, s, best, best_s)) { best = dd; best_s = s; }
     }
-    const float found = fabsf(r.z - best_z);
-    return (within ? found : 0.1f * WK_STEPS) / 2.f;
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {
+        const float ob = __shfl_down(best, off, 64);
+        const int os = __shfl_down(best_s, off, 64);
+        if (z_better(ob, os, best, best_s)) { best = ob; best_s = os; }
+    }
+    if (q == 0 && (t >> 3) < n) {
+        const float found = fabsf(z - (z + sign * z_step(best_s)));
+        Lraw[(size_t)i * WK_NT + 3] = (within ? found : 0.1f * WK_STEPS) / 2.f;
+    }
 }
 
 // block-wide sum of one float per thread (result in every thread); scratch >= blockDim.x / 64 floats
@@ -240,7 +272,6 @@ __global__ __launch_bounds__(WK_MAXT) void k_weak_fwd(WeakIn in, float* __restri
         const float cs = ((r.nrm[0] * ix) * (y[0] * iy) + (r.nrm[1] * ix) * (y[1] * iy)) + (r.nrm[2] * ix) * (y[2] * iy);
         L[2] = (1.f - fabsf(cs)) * r.gconf;
     }
-    if (in.terms & 8) L[3] = z_search(r, rl, box);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
         if (in.terms & (32 << k)) L[5 + k] = fmaxf(fabsf(r.dims[k] - r.pm[k]) / r.ps[k] - 1.f, 0.f);
@@ -299,6 +330,7 @@ struct WeakRed {
 };
 
 #define WR_T 256
+#define WR_MAXN 8192          // slots of the whole batch (B * kf)
 __device__ __forceinline__ float depth_at(const WeakRed& p, int b, float x, float y, float ih, float iw) {
     // clamp 10 px inside the image (:1225-1229, 1262-1270); NaN coordinates go to the lower bound instead of faulting
     const float cx = fminf(fmaxf(x == x ? x : 10.f, 10.f), iw - 11.f), cy = fminf(fmaxf(y == y ? y : 10.f, 10.f), ih - 11.f);
@@ -313,6 +345,7 @@ __global__ __launch_bounds__(WR_T) void k_weak_reduce(WeakRed p, float* __restri
                                                       float* __restrict__ stats, float* __restrict__ aux) {
     __shared__ float s_acc[32][WR_T / 64];
     __shared__ float s_pose, s_fail1;
+    __shared__ unsigned char s_flag[WR_MAXN];
     const int tid = threadIdx.x, n = p.n, kf = p.kf;
     // ---- pose alignment over the images (:1055-1074): images with exactly one slot are skipped and counted
     if (tid == 0) {
@@ -326,6 +359,15 @@ __global__ __launch_bounds__(WR_T) void k_weak_reduce(WeakRed p, float* __restri
         s_pose = none ? 0.f : tot * 1.f / (float)(fail + 1);
         s_fail1 = none ? 0.f : (float)(fail + 1);
         aux[0] = s_fail1;
+    }
+    for (int i = tid; i < n; i += WR_T) {
+        const float* tab = p.table + (size_t)(i / kf) * WK_TAB;
+        const float ih = tab[14], iw = tab[15];
+        const float* bx = pbox + (size_t)i * 4;
+        const float q0 = fminf(fmaxf(bx[0], 0.f), iw), q1 = fminf(fmaxf(bx[1], 0.f), ih);
+        const float q2 = fminf(fmaxf(bx[2], 0.f), iw), q3 = fminf(fmaxf(bx[3], 0.f), ih);
+        const bool area = !(bx[0] != bx[0]) && (q2 - q0) * (q3 - q1) > 0.f;
+        s_flag[i] = (unsigned char)((p.validf[i] ? 1 : 0) | (area ? 2 : 0));
     }
     __syncthreads();
     const float pose = s_pose;
@@ -344,23 +386,19 @@ __global__ __launch_bounds__(WR_T) void k_weak_reduce(WeakRed p, float* __restri
             tz = depth_at(p, b, d[0], d[1], ih, iw);
         } else if (p.pgz_mode == 1 && valid) {
             // as in the reference the targets of an image are ordered [windows with area..., windows without...], i.e. permuted
-            // against the predictions when an image has both kinds: slot i with rank r among the valid slots takes entry r
+            // against the predictions when an image has both kinds: slot i with rank r among the valid slots takes entry r.
+            // s_flag: bit 0 valid, bit 1 the (float) window has area
             int rnk = 0, nin = 0;
-            for (int q = b * kf; q < i; ++q) rnk += p.validf[q] ? 1 : 0;
-            // inside flag of a slot = its float window has area (recomputed from the float box, like the forward kernel)
-            auto has_area = [&](int q) {
-                const float* bx = pbox + (size_t)q * 4;
-                if (bx[0] != bx[0]) return false;
-                const float q0 = fminf(fmaxf(bx[0], 0.f), iw), q1 = fminf(fmaxf(bx[1], 0.f), ih);
-                const float q2 = fminf(fmaxf(bx[2], 0.f), iw), q3 = fminf(fmaxf(bx[3], 0.f), ih);
-                return (q2 - q0) * (q3 - q1) > 0.f;
-            };
-            for (int q = b * kf; q < (b + 1) * kf; ++q) nin += (p.validf[q] && has_area(q)) ? 1 : 0;
-            int src = -1, seen = 0;
+            for (int q = b * kf; q < (b + 1) * kf; ++q) {
+                const int f = s_flag[q];
+                rnk += (q < i) & f & 1;
+                nin += f == 3 ? 1 : 0;
+            }
             const bool want_in = rnk < nin;
-            const int want = want_in ? rnk : rnk - nin;
+            const int want = want_in ? rnk : rnk - nin, wflag = want_in ? 3 : 1;
+            int src = -1, seen = 0;
             for (int q = b * kf; q < (b + 1) * kf && src < 0; ++q) {
-                if (!p.validf[q] || has_area(q) != want_in) continue;
+                if (s_flag[q] != wflag) continue;
                 if (seen == want) src = q;
                 ++seen;
             }
@@ -604,6 +642,9 @@ extern "C" int cr_weak_loss_fwd(cr_ctx* ctx, const float* const* inputs, const u
     const int T = (int)cr_cdiv(kf, 64) * 64;
     hipLaunchKernelGGL(k_weak_fwd, dim3((unsigned)B), dim3((unsigned)T), (size_t)kf * 10 * sizeof(float), ctx->stream, in, Lraw, dec,
                        pbox, ibox, pimg);
+    if (terms & 8)
+        hipLaunchKernelGGL(k_weak_zsearch, dim3((unsigned)cr_cdiv((int64_t)B * kf * 8, 256)), dim3(256), 0, ctx->stream, in, dec, pbox,
+                           Lraw);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -617,7 +658,7 @@ extern "C" int cr_weak_loss_reduce(cr_ctx* ctx, const float* const* red_inputs, 
                                    const float* pimg, float* ztgt, float* red, float* cnt, float* stats, float* aux) {
     CR_CHECK_ARG(ctx && red_inputs && validf && table && gt_boxes && gt_idx && weights && Lraw && dec && pbox && ibox && pimg && ztgt
                  && red && cnt && stats && aux, "cr_weak_loss_reduce: NULL pointer");
-    CR_CHECK_ARG(B > 0 && kf > 0 && kf <= S && G > 0, "cr_weak_loss_reduce: bad sizes");
+    CR_CHECK_ARG(B > 0 && kf > 0 && kf <= S && G > 0 && (int64_t)B * kf <= WR_MAXN, "cr_weak_loss_reduce: bad sizes");
     CR_CHECK_ARG(pgz_mode >= 0 && pgz_mode <= 2, "cr_weak_loss_reduce: pgz_mode %d", pgz_mode);
     CR_CHECK_ARG(pgz_mode == 0 || (depth && H > 0 && W > 0), "cr_weak_loss_reduce: the pseudo depth target needs the depth maps");
     CR_CHECK_ARG(pgz_mode != 1 || med, "cr_weak_loss_reduce: pgz_mode 1 needs the window medians");

@@ -390,6 +390,16 @@ def bench_weak(args, rank, world, dev):
         barrier(world)
         dt = max_over_ranks(time.perf_counter() - t0, world, dev)
         rep = step.report()
+    extra = {}
+    if rank == 0:
+        # the dominant launches of this step are the same grouped pyramid convolutions as in the supervised step, at 2 images
+        extra["roofline"] = bt.dominant_kernel_roofline(dev, importlib.import_module("3dod_amd.hipops").precision(), images=B)
+        if world == 1 and not args.no_cpu_baseline:
+            extra["cpu_baseline"] = bt.cpu_baseline_train(weak=True)
+    return {**_weak_line(args, world, dt, rep, live, cfg, B), **extra}
+
+
+def _weak_line(args, world, dt, rep, live, cfg, B):
     return {"metric": "images/sec weakly supervised Cube R-CNN train step (BASELINE configs[4], "
                       + ("live Depth-Anything-V2 depth maps)" if live else "precomputed depth maps)"),
             "value": B * world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,

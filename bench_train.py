@@ -376,9 +376,10 @@ def dominant_kernel_in_step(model, step, batches, dev, n_steps=3):
     return out
 
 
-def cpu_baseline_train(inference=False, steps=None):
+def cpu_baseline_train(inference=False, steps=None, weak=False):
     """the oracle's float32 torch-CPU train step (oracle/cpu_train_step.py) on the box's host cores, in a separate
-    process, on a bounded sample (1 warm-up + 4 timed steps of 4 images; inference: 1 + 3 batches of 8 images)."""
+    process, on a bounded sample (1 warm-up + 4 timed steps of 4 images; inference: 1 + 3 batches of 8 images; weak: 1 + 6
+    steps of 2 images of the weakly supervised model)."""
     import json
     import subprocess
     import sys
@@ -390,6 +391,8 @@ def cpu_baseline_train(inference=False, steps=None):
     threads = max(1, min(16, ncpu))          # a 1-GPU box gives this job a 16-core share
     cmd = [sys.executable, os.path.join(here, "oracle", "cpu_train_step.py"), "--images", "4", "--steps", str(steps or 4),
            "--warmup", "1", "--threads", str(threads)]
+    if weak:
+        cmd = cmd[:2] + ["--weak", "--images", "2", "--steps", str(steps or 6), "--warmup", "1", "--threads", str(threads)]
     if inference:
         cmd = cmd[:2] + ["--inference", "--images", "8", "--steps", str(steps or 3), "--warmup", "1", "--threads", str(threads)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads),
@@ -403,7 +406,7 @@ def cpu_baseline_train(inference=False, steps=None):
         return {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
 
-def dominant_kernel_roofline(dev, prec="fp32", reps=20):
+def dominant_kernel_roofline(dev, prec="fp32", reps=20, images=IMS_PER_GPU):
     """the dominant launches of the step (profiles/: the implicit-GEMM convolutions) timed live with HIP events on the stream
     they are launched on: the grouped 3x3 256->256 convolution over the five pyramid levels of IMS_PER_GPU 512 x 512 images
     (FPN output convolutions / RPN head convolution; 103.0 GFLOP per launch and direction), warm, back to back; the directions
@@ -411,7 +414,7 @@ def dominant_kernel_roofline(dev, prec="fp32", reps=20):
     ops = importlib.import_module("3dod_amd.hipops")
     dt = torch.float32 if prec != "bf16" else torch.bfloat16
     peak = MFMA_PEAK[prec]
-    N, C = IMS_PER_GPU, 256
+    N, C = images, 256
     g = torch.Generator(device="cpu").manual_seed(0)
     xs = [torch.randn(N, h, w, C, generator=g).to(dev).to(dt) for h, w in PYRAMID]
     dys = [torch.randn(N, h, w, C, generator=g).to(dev).to(dt) for h, w in PYRAMID]
@@ -456,6 +459,8 @@ def dominant_kernel_roofline(dev, prec="fp32", reps=20):
     # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction applied: profiles/r0N_pmc_conv_traffic*.json)
     traffic = None
     try:
+        if N != IMS_PER_GPU:
+            raise KeyError("the committed PMC passes are for 4 images")
         here = os.path.dirname(os.path.abspath(__file__))
         fn = {"fp32": "r03_pmc_conv_traffic_fp32.json", "fp32x3": "r02_pmc_conv_traffic_fp32x3.json"}.get(prec, "r01_pmc_conv_traffic.json")
         pmc = json.load(open(os.path.join(here, "profiles", fn)))
@@ -464,8 +469,8 @@ def dominant_kernel_roofline(dev, prec="fp32", reps=20):
     except Exception:
         pass
     return {"bound": "mfma", "kernel": worst,
-            "shape": ("3x3 conv 256->256 on the five pyramid levels of 4 x 512 x 512 images (4x128x128 ... 4x8x8; FPN output convs / "
-                      "RPN head conv), one grouped launch, " if "levels" in worst else "3x3 conv 256->256 on 4x128x128 (FPN p2 output), ")
+            "shape": ((f"3x3 conv 256->256 on the five pyramid levels of {N} x 512 x 512 images ({N}x128x128 ... {N}x8x8; FPN output convs / "
+                       "RPN head conv), one grouped launch, ") if "levels" in worst else f"3x3 conv 256->256 on {N}x128x128 (FPN p2 output), ")
                      + {"fp32": "f32 in / f32 acc", "fp32x3": "f32 in (3 x bf16 split, 6 MFMAs per term) / f32 acc", "bf16": "bf16 in / f32 acc"}[prec],
             "achieved": out[worst]["tflops"], "peak": peak, "unit": "TFLOP/s",
             "frac": out[worst]["tflops"] / peak, "traffic": traffic,

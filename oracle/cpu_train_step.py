@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--threads", type=int, default=os.cpu_count())
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--inference", action="store_true", help="time model.inference (eval mode) instead of the train step")
+    ap.add_argument("--weak", action="store_true", help="the weakly supervised model of configs/Omni_combined.yaml (depth / ground maps)")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     from oracle import cpu_backend
@@ -32,9 +33,14 @@ def main():
     modeling = importlib.import_module("3dod_amd.cubercnn.modeling")
     solver = importlib.import_module("3dod_amd.cubercnn.solver")
     d2 = importlib.import_module("3dod_amd.d2lite")
-    cfg = syn.make_cfg(overrides=["MODEL.DEVICE", "cpu", "VIS_PERIOD", 0, "log", False, "SOLVER.BASE_LR", 0.02])
+    cfg_file = os.path.join(ROOT, "configs", "Omni_combined.yaml") if args.weak else None
+    cfg = syn.make_cfg(cfg_file, overrides=["MODEL.DEVICE", "cpu", "VIS_PERIOD", 0, "log", False, "SOLVER.BASE_LR", 0.02])
     torch.manual_seed(0)
     model = cpu_backend.attach(modeling.build_model(cfg))
+    if args.weak:
+        # the two kernels of the tensor composition (window median, RANSAC plane) as their CPU restatements
+        from oracle import weak as ow
+        model.roi_heads._median_fn, model.roi_heads._plane_cls = ow.box_median, ow.Plane
     if args.inference:
         model.eval()
         batches = [syn.make_batch(args.images, 4321 + i, size=args.size, with_gt=False) for i in range(2)]
@@ -53,6 +59,8 @@ def main():
     opt = solver.build_optimizer(cfg, model)
     step = solver.TrainStep(cfg, model, opt, world_size=1)
     batches = [syn.make_batch(args.images, 1234 + i, size=args.size) for i in range(2)]
+    if args.weak:
+        batches = [syn.add_scene_maps(b, 99 + i, ground_every=2) for i, b in enumerate(batches)]
     with d2.EventStorage(0):
         for i in range(args.warmup):
             step(batches[i % 2])
@@ -62,8 +70,9 @@ def main():
         dt = time.perf_counter() - t0
         rep = step.report()
     print(json.dumps({"value": args.images * args.steps / dt, "unit": "images/s", "cores": args.threads, "kind": "port",
-                      "sample": f"{args.steps} train steps of {args.images} images {args.size}x{args.size}, torch "
-                                f"float32 eager on the host, {dt:.1f} s", "final_loss": rep["total_loss"]}))
+                      "sample": f"{args.steps} {'weakly supervised ' if args.weak else ''}train steps of {args.images} images "
+                                f"{args.size}x{args.size}, torch float32 eager on the host, {dt:.1f} s",
+                      "final_loss": rep["total_loss"]}))
 
 
 if __name__ == "__main__":
