@@ -302,9 +302,17 @@ class GraphedDenseEval(GraphOwner):
         torch.cuda.synchronize(dev)
         ops.bump_weight_epoch()          # the bf16 weight copies are made inside the graph (cheap; weights may change)
         self.graph = torch.cuda.CUDAGraph()
-        with capture_guard() as self._keep, torch.no_grad(), torch.cuda.graph(self.graph):
-            self.static_outs = dense()
+        # the BatchNorm folds are NOT part of the graph: it reads persistent folded weights / biases that refresh_folds()
+        # rewrites before a replay when a parameter, a running statistic or the weight epoch has moved (serving: never)
+        self.folds = []
+        ops._FOLD_REG[0] = self.folds
+        try:
+            with capture_guard() as self._keep, torch.no_grad(), torch.cuda.graph(self.graph):
+                self.static_outs = dense()
+        finally:
+            ops._FOLD_REG[0] = None
         torch.cuda.synchronize(dev)
+        ops.refresh_folds(self.folds)
 
     def matches(self, images_u8):
         return (tuple(images_u8.shape) == self.shape and images_u8.device == self.static_img.device
@@ -312,6 +320,7 @@ class GraphedDenseEval(GraphOwner):
 
     def __call__(self, images_u8):
         self.static_img.copy_(images_u8)
+        ops.refresh_folds(self.folds)
         self.graph.replay()
         outs = self.static_outs
         nf, nl = len(self.feat_names), self.n_levels

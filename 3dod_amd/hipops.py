@@ -548,6 +548,24 @@ _ROOT_FUSED = [os.environ.get("CR_ROOT_FUSED", "1") == "1"]
 _STATS_EPOCH = [0]          # bumped by every eager train-mode BatchNorm forward (running statistics change through raw pointers)
 
 
+_FOLD_REG = [None]          # a list while graphed.GraphedDenseEval captures: the folds the graph reads (see refresh_folds)
+
+
+def refresh_folds(reg):
+    """re-fold (cr_fold_bn, in place) every registered BatchNorm whose inputs changed since its buffers were written; the
+    check is host-side (version counters, weight / statistics epochs, storage addresses)"""
+    lib = None
+    for e in reg:
+        w, g, b, m, v = e["t"]
+        tag = (w._version, g._version, b._version, m._version, v._version, _WEIGHT_EPOCH[0], _STATS_EPOCH[0], w.data_ptr(), m.data_ptr())
+        if tag == e["tag"]:
+            continue
+        lib = lib or _lib.load()
+        _chk(lib.cr_fold_bn(_ctx(e["wf"]), _p(w.detach()), _p(g.detach()), _p(b.detach()), _p(m), _p(v), e["eps"], _p(e["wf"]),
+                            _p(e["b"]), e["Cout"], e["K"], e["af"]), "cr_fold_bn")
+        e["tag"] = tag
+
+
 def conv_bn_folded(x, weight, gamma, beta, running_mean, running_var, stride=1, pad=0, relu=True, residual=None, eps=1e-5):
     """inference: frozen BatchNorm folded into the convolution's weights and bias (cr_fold_bn), residual and ReLU in the
     conv epilogue -- one kernel per layer instead of conv + scale/shift arithmetic + a second pass over the output.
@@ -560,10 +578,24 @@ def conv_bn_folded(x, weight, gamma, beta, running_mean, running_var, stride=1, 
     Cout, _, k, _ = weight.shape
     K_ = weight.numel() // Cout
     capturing = torch.cuda.is_current_stream_capturing()
+    attr = "_cr_fold" if x.dtype == bf16 else "_cr_fold32"
+    warm = getattr(weight, attr, None)
+    if capturing and _FOLD_REG[0] is not None and warm is not None:
+        # eval-mode graph with externally refreshed folds: the graph only READS the folded copies; refresh_folds() rewrites
+        # them (eagerly, before a replay) when one of the five tensors or the weight / statistics epoch has moved.  The
+        # buffers are the ones the warm-up pass allocated OUTSIDE the capture: a tensor allocated during the capture may share
+        # its block with an earlier intermediate of the graph, which every replay rewrites.
+        _, wf, bias_f = warm
+        _FOLD_REG[0].append({"t": (weight, gamma, beta, running_mean, running_var), "eps": float(eps), "wf": wf, "b": bias_f,
+                             "tag": None, "af": _af(x), "K": K_, "Cout": Cout})
+        try:
+            delattr(weight, attr)           # the graph owns these buffers now: eager calls make their own
+        except Exception:
+            pass
+        return conv_fwd_raw(x, wf, Cout, k, stride, pad, bias=bias_f, residual=residual, relu=relu)
     tag = None if capturing else (weight._version, gamma._version, beta._version, running_mean._version, running_var._version,
                                   _WEIGHT_EPOCH[0], _STATS_EPOCH[0], weight.data_ptr(), running_mean.data_ptr(), float(eps))
-    attr = "_cr_fold" if x.dtype == bf16 else "_cr_fold32"
-    ent = None if capturing else getattr(weight, attr, None)
+    ent = None if capturing else warm
     if ent is None or ent[0] != tag:
         wf = torch.empty((Cout, K_), dtype=x.dtype, device=x.device)
         bias_f = torch.empty((Cout,), dtype=f32, device=x.device)

@@ -540,6 +540,25 @@ def test_eval_graph_matches_eager_inference(built):
             assert torch.allclose(ia.scores, ib.scores, atol=1e-4) and torch.equal(ia.pred_classes, ib.pred_classes)
             assert torch.allclose(ia.pred_bbox3D, ib.pred_bbox3D, atol=1e-3)
         assert len(graphed2) == 2 and not torch.equal(graphed2[0]["instances"].scores, graphed[0]["instances"].scores)
+        # the BatchNorm folds live outside the graph (ops.refresh_folds): a running statistic / a scale changed after the
+        # capture must reach the next replay
+        ge = model._graphed_eval
+        assert len(ge.folds) >= 30 and all(e["tag"] is not None for e in ge.folds)
+        bn = model.backbone.bottom_up.level2.tree1.bn1
+        old_var, old_w = bn.running_var.clone(), bn.weight.data.clone()
+        with torch.no_grad():
+            bn.running_var.mul_(1.7)
+            bn.weight.data.mul_(0.8)
+            changed = model(batch)
+            cache, model._graphed_eval_cache = model._graphed_eval_cache, None
+            eager_changed = model(batch)
+            model._graphed_eval_cache = cache
+            bn.running_var.copy_(old_var)
+            bn.weight.data.copy_(old_w)
+            back = model(batch)
+        assert not torch.equal(changed[0]["instances"].scores, graphed[0]["instances"].scores)
+        assert torch.allclose(changed[0]["instances"].scores, eager_changed[0]["instances"].scores, atol=1e-4)
+        assert torch.equal(back[0]["instances"].scores, graphed[0]["instances"].scores)
         # per-shape cache: a second resolution is captured on first sight, the least recently used shape is dropped
         with torch.no_grad():
             model.enable_graphs_eval(max_shapes=2)
