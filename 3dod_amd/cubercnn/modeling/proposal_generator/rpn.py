@@ -174,7 +174,7 @@ class RPN(nn.Module):
             # training runs on the static-shape path (modeling/dense_train.py: rpn_label_and_sample / rpn_losses on fused
             # kernels).  The per-image list formulation (label_and_sample_anchors / losses, rpn.py:41-354 of the reference)
             # is test infrastructure: oracle/list_path.py attaches it (oracle.list_path.install).
-            if not hasattr(self, "label_and_sample_anchors"):
+            if not hasattr(self, "losses"):
                 raise RuntimeError("RPN.forward(training) on instance lists: use the static-shape path (model.dense_train "
                                    "= True); the list formulation is oracle/list_path.py")
             gt_labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances)
@@ -235,6 +235,18 @@ class RPNWithIgnore(RPN):
         ret["ignore_thresh"] = cfg.MODEL.RPN.IGNORE_THRESHOLD
         ret["objectness_uncertainty"] = cfg.MODEL.RPN.OBJECTNESS_UNCERTAINTY
         return ret
+
+    @torch.no_grad()
+    def label_and_sample_anchors(self, anchors: List[Boxes], gt_instances: List[Instances]):
+        """rpn.py:41-110 under its reference name and signature, computed by the fused kernels of the static-shape path
+        (dense_train.rpn_label_and_sample: IoU matching with the forced best anchor per object, IoU-weighted sampling without
+        replacement, ignore regions by IoA): -> (list of (A,) int8 labels in {-1, 0, 1}, list of (A,4) matched gt boxes)."""
+        from ..dense_train import GTBatch, rpn_label_and_sample, matched_boxes
+        A = Boxes.cat(anchors).tensor
+        gt = GTBatch(gt_instances, A.device)
+        labels, midx, _ = rpn_label_and_sample(self, A, gt)
+        boxes = matched_boxes(gt, midx)
+        return [l.to(torch.int8) for l in labels], [b for b in boxes]
 
 def _construct(cls, cfg, *args, **kwargs):
     return cls(**cls.from_config(cfg, *args, **kwargs))

@@ -183,6 +183,37 @@ class ROIHeads3D(StandardROIHeads):
             self.priors_z_scales = nn.Parameter(torch.ones(self.num_classes, self.cluster_bins))
 
     # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]) -> List[Instances]:
+        """roi_heads.py:2773-2840 under its reference name and signature, computed by the fused kernels of the static-shape
+        path (dense_train.roi_label_and_sample: ground truth appended, IoU matching, ignore rule, IoU-weighted sampling of
+        <= 25 % foreground up to BATCH_SIZE_PER_IMAGE): per image an Instances with `proposal_boxes`, `gt_classes`
+        (num_classes = background) and, for images with objects, every `gt_*` field of the matched target.  Foreground
+        rows come first.  `objectness_logits` is not carried (nothing downstream reads it)."""
+        from ..dense_train import GTBatch, roi_label_and_sample
+        dev = proposals[0].proposal_boxes.tensor.device
+        B, P = len(proposals), max(1, max(len(p) for p in proposals))
+        boxes = torch.zeros((B, P, 4), device=dev)
+        scores = torch.full((B, P), float("-inf"), device=dev)
+        for i, p in enumerate(proposals):
+            boxes[i, :len(p)] = p.proposal_boxes.tensor
+            scores[i, :len(p)] = p.objectness_logits.clamp(min=-3.0e38) if p.has("objectness_logits") else 0.0
+        gt = GTBatch(targets, dev)
+        samp = roi_label_and_sample(self, boxes, scores, gt)
+        out = []
+        for i, t in enumerate(targets):
+            keep = samp["valid"][i]
+            inst = Instances(proposals[i].image_size)
+            inst.proposal_boxes = Boxes(samp["boxes"][i][keep])
+            inst.gt_classes = samp["classes"][i][keep]
+            if int((t.gt_classes >= 0).sum()) > 0:
+                gi = samp["gt_idx"][i][keep].long()       # GTBatch keeps the target order (ignore rows stay addressable)
+                for name, value in t.get_fields().items():
+                    if name.startswith("gt_") and not inst.has(name):
+                        inst.set(name, value[gi])
+            out.append(inst)
+        return out
+
     def forward(self, images, features, proposals, Ks, im_scales_ratio, targets=None):
         """roi_heads.py:2116-2157.  images: ImageList (only sizes are used)."""
         im_dims = [tuple(s) for s in images.image_sizes]
@@ -191,7 +222,7 @@ class ROIHeads3D(StandardROIHeads):
             # rule and IoU-weighted sampling are fused kernels there.  The per-image Instances-list formulation of
             # label_and_sample_proposals (roi_heads.py:2737-2840 of the reference) is test infrastructure: it lives in
             # oracle/list_path.py and is attached by oracle.list_path.install(roi_heads) (tests only).
-            if not hasattr(self, "label_and_sample_proposals"):
+            if not hasattr(self, "_forward_cube_list") and self.loss_w_3d > 0 and type(self)._forward_cube is ROIHeads3D._forward_cube:
                 raise RuntimeError("ROIHeads3D.forward(training) on proposal lists: use the static-shape path "
                                    "(model.dense_train = True); the list formulation is oracle/list_path.py")
             proposals = self.label_and_sample_proposals(proposals, targets)
