@@ -1588,6 +1588,58 @@ static int group_starts(int n, const int* counts, int* starts) {
     return total;
 }
 
+// Tile quantisation of a grouped launch: T tiles of equal duration over 2 x 256 resident slots run as ceil(T / 512) rounds (the
+// pyramid at 4 images: 1 364 tiles = 2.66 rounds, paid as 3).  The problems that do not fit into the full rounds (the tail:
+// the smaller levels) are split S ways along k (the split-K mode of the body: partial slabs in the ctx workspace, finished by
+// k_splitk_epilogue in a fixed order), so the last round is made of 1/S-duration blocks: 1 024 + 3 x 340 blocks = 2 + 2/3 rounds.
+// f32 only (bf16 tiles are 6 x shorter: the epilogue launches would cost more than the partial round).  Returns the number of
+// problems that were split; their indices are the trailing ones of `split[]`.
+static int group_tail_split(cr_ctx* ctx, ConvGroup& g, int* counts, int n, bool* split) {
+    static const int S_env = env_int("CR_GRP_KSPLIT", 3);
+    for (int i = 0; i < n; ++i) split[i] = false;
+    if (S_env < 2 || !ctx->ws) return 0;
+    const int slots = 512;
+    int total = 0;
+    for (int i = 0; i < n; ++i) total += counts[i];
+    const int full = (total / slots) * slots, rem = total - full;
+    if (full == 0 || rem < slots / 16 || rem > (slots * 7) / 8) return 0;        // nothing to win / the last round is nearly full anyway
+    int bulk = 0, nsplit = 0;
+    size_t need = 0;
+    for (int i = 0; i < n; ++i) {                                                 // problems arrive largest first
+        if (bulk + counts[i] <= full) { bulk += counts[i]; continue; }
+        split[i] = true;
+        need += (size_t)g.p[i].M * g.p[i].Cout * sizeof(float);
+        ++nsplit;
+    }
+    int S = S_env;
+    while (S >= 2 && need * S > ctx->ws_bytes) --S;
+    if (S < 2) { for (int i = 0; i < n; ++i) split[i] = false; return 0; }
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!split[i]) continue;
+        ConvP& p = g.p[i];
+        const int nstage_all = p.Kdim / 32;
+        int s = S;
+        if (s > nstage_all / 4) s = nstage_all / 4;                              // >= 4 stages per block
+        if (s < 2) { split[i] = false; --nsplit; continue; }
+        p.kstages = (int)cr_cdiv(nstage_all, s);
+        p.ksplit = (int)cr_cdiv(nstage_all, p.kstages);
+        p.part = (float*)((char*)ctx->ws + off);
+        off += (size_t)p.M * p.Cout * sizeof(float) * p.ksplit;
+        counts[i] *= p.ksplit;
+    }
+    return nsplit;
+}
+
+static void group_tail_epilogues(cr_ctx* ctx, const ConvGroup& g, int n, const bool* split) {
+    for (int i = 0; i < n; ++i) {
+        if (!split[i]) continue;
+        const ConvP& p = g.p[i];
+        const dim3 g2((unsigned)cr_cdiv(p.M, 64), (unsigned)(p.Cout / 64));
+        hipLaunchKernelGGL(k_splitk_epilogue<float>, g2, dim3(256), 0, ctx->stream, p);
+    }
+}
+
 // n convolutions (stride 1, k in {1, 3}, Cin % 64 == 0 (f32: % 32), Cout % 128 == 0) in one launch.  Pointer tables are HOST
 // arrays of device pointers; biases / residuals (fwd) and accumulates (bwd-data) may be NULL or hold NULL entries.
 extern "C" int cr_conv2d_fwd_group(cr_ctx* ctx, int n, const void* const* xs, const void* const* ws, void* const* ys,
@@ -1617,6 +1669,8 @@ extern "C" int cr_conv2d_fwd_group(cr_ctx* ctx, int n, const void* const* xs, co
         p.w3 = nullptr; p.w3_bytes = 0;
         counts[i] = (int)(cr_cdiv(p.M, 128) * (Cout / 128));
     }
+    bool split[CR_MAX_GROUP];
+    const int nsplit = act_f32 == 1 ? group_tail_split(ctx, g, counts, n, split) : 0;
     const int total = group_starts(n, counts, g.start);
     for (int i = 0; i < n; ++i) g.count[i] = counts[i];
     for (int i = n; i < CR_MAX_GROUP; ++i) { g.start[i] = total; g.count[i] = 0; }
@@ -1626,6 +1680,7 @@ extern "C" int cr_conv2d_fwd_group(cr_ctx* ctx, int n, const void* const* xs, co
         else hipLaunchKernelGGL((k_conv_igemm_dma_grp<K, 0, u16>), grid, block, 0, ctx->stream, g); }
     CR_GRP_CASE(1) CR_GRP_CASE(3)
 #undef CR_GRP_CASE
+    if (nsplit) group_tail_epilogues(ctx, g, n, split);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -1658,6 +1713,8 @@ extern "C" int cr_conv2d_bwd_data_group(cr_ctx* ctx, int n, const void* const* d
         p.w3 = nullptr; p.w3_bytes = 0;
         counts[i] = (int)(cr_cdiv(p.M, 128) * (Cin / 128));
     }
+    bool split[CR_MAX_GROUP];
+    const int nsplit = act_f32 == 1 ? group_tail_split(ctx, g, counts, n, split) : 0;
     const int total = group_starts(n, counts, g.start);
     for (int i = 0; i < n; ++i) g.count[i] = counts[i];
     for (int i = n; i < CR_MAX_GROUP; ++i) { g.start[i] = total; g.count[i] = 0; }
@@ -1667,6 +1724,7 @@ extern "C" int cr_conv2d_bwd_data_group(cr_ctx* ctx, int n, const void* const* d
         else hipLaunchKernelGGL((k_conv_igemm_dma_grp<K, 1, u16>), grid, block, 0, ctx->stream, g); }
     CR_GRP_CASE(1) CR_GRP_CASE(3)
 #undef CR_GRP_CASE
+    if (nsplit) group_tail_epilogues(ctx, g, n, split);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

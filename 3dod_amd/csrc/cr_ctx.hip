@@ -22,7 +22,7 @@ extern "C" int cr_ctx_create(int device, void* hip_stream, cr_ctx** out) {
     if (!c) { cr_set_error("cr_ctx_create: host alloc failed"); return CR_ENOMEM; }
     c->device = device;
     c->stream = (hipStream_t)hip_stream;
-    c->ws_bytes = 64u << 20;
+    c->ws_bytes = 128u << 20;
     hipError_t e = hipMalloc(&c->ws, c->ws_bytes);
     if (e != hipSuccess) {
         cr_set_error("cr_ctx_create: hipMalloc workspace failed: %s", hipGetErrorString(e));

@@ -171,3 +171,40 @@ def test_root_conv_bn_children_gradients_equal_the_concatenation_path():
     for a, b in zip(ga_, gb_):
         assert _rel(a, b) < 2e-6
     assert _rel(wa, wb) < 2e-5 and _rel(gga, ggb) < 2e-5 and _rel(gba, gbb) < 2e-5
+
+
+def test_group_tail_split_matches_single_convs():
+    """a group whose tiles do not fill whole rounds of the 512 resident slots (the pyramid of 2 x 512 x 512 images: 682 tiles)
+    runs its smaller problems split three ways along k (partial slabs + k_splitk_epilogue): same results as the single
+    convolutions up to the summation order, bias / the gradient-slot contribution applied by the epilogue (no ReLU here: a
+    pre-activation within rounding of zero may fall on either side of it under a different summation order)"""
+    g = torch.Generator().manual_seed(77)
+    sizes = ((128, 128), (64, 64), (32, 32), (16, 16), (8, 8))
+    xs = _levels(g, N=2, C=256, sizes=sizes)
+    ws, bs = _weights(g, len(xs), 256, 3, True)
+    dys = [torch.randn(x.shape, generator=g).to(DEV) for x in xs]
+
+    def run(grouped):
+        prev = ops._GROUP_ON[0]
+        ops._GROUP_ON[0] = grouped
+        try:
+            xin = [x.clone().requires_grad_(True) for x in xs]
+            params = _with_sinks(ws, bs)
+            ys = ops.conv_bias_act_group(xin, ws, bs, pad=1, relu=False)
+            torch.autograd.backward(ys, dys)
+            return [y.detach() for y in ys], [x.grad for x in xin], [p._cr_grad.clone() for p in params]
+        finally:
+            ops._GROUP_ON[0] = prev
+            for t in list(ws) + list(bs):
+                t.requires_grad_(False)
+    ya, dxa, dpa = run(True)
+    yb, dxb, dpb = run(False)
+    for a, b in zip(ya, yb):
+        assert _rel(a, b) < 3e-6
+    for a, b in zip(dxa, dxb):
+        assert _rel(a, b) < 3e-6
+    for a, b in zip(dpa, dpb):
+        assert _rel(a, b) < 2e-5
+    relu_a = ops.conv_bias_act_group([x.clone() for x in xs], ws, bs, pad=1, relu=True)
+    for a, b in zip(relu_a, yb):
+        assert float((a - b.clamp(min=0)).abs().max()) < 1e-4 and float(a.min()) >= 0.0
