@@ -898,6 +898,7 @@ class _Pool2x(torch.autograd.Function):
         _chk(lib.cr_pool2x_fwd(_ctx(x), _p(x), _p(y), N, H, W, C, window, _af(x)), "cr_pool2x_fwd")
         ctx.window = window
         ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)
         return y
 
     @staticmethod
@@ -905,10 +906,18 @@ class _Pool2x(torch.autograd.Function):
         _p = _Args()
         (x,) = ctx.saved_tensors
         N, H, W, C = x.shape
+        xslot, xi = ctx.slot
+        if dy is None:
+            # every consumer of the pooled map handed its gradient on through gradient slots: nothing arrives here
+            if xslot is None:
+                return None, None, None
+            if xi > 1:
+                return None, None, None                      # what the slot holds stays for the accumulating consumer
+            acc = _slot_take(xslot)
+            return (None if acc is None else acc.to(x.dtype)), None, None
         dx = torch.empty_like(x)
         lib = _lib.load()
         dy = dy.to(x.dtype).contiguous()
-        xslot, xi = ctx.slot
         # the FIRST registered consumer of x (DLA: a level's input is pooled before its first convolution sees it) collects
         # what the others left in the slot, a later one folds the slot's content into its own result: added in the kernel
         acc = None if xslot is None else (_slot_take(xslot) if xi <= 1 else _slot_fold(xslot))
@@ -1147,6 +1156,7 @@ class _CubeLoss(torch.autograd.Function):
         _chk(lib.cr_cube_loss_fwd(_ctx(dxy), ctypes.cast(arr, ctypes.c_void_p), n, *flags, _p(losses), _p(dec)),
              "cr_cube_loss_fwd")
         ctx.ins, ctx.flags = ins, flags
+        ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None, not as zero fills
         ctx.mark_non_differentiable(dec)
         return losses, dec
 
@@ -1565,13 +1575,14 @@ class _RPNLoss(torch.autograd.Function):
                              _p(gt_boxes.contiguous()), B, A, G, _f4(weights), _p(ws), _p(sums), _p(dl), _p(dd)),
              "cr_rpn_loss")
         ctx.save_for_backward(dl, dd)
+        ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None, not as zero fills
         ctx.mark_non_differentiable(sums)
         return sums[0], sums[1], sums
 
     @staticmethod
     def backward(ctx, g_cls, g_loc, _gs):
         dl, dd = ctx.saved_tensors
-        return dl * g_cls, dd * g_loc, None, None, None, None, None
+        return (None if g_cls is None else dl * g_cls), (None if g_loc is None else dd * g_loc), None, None, None, None, None
 
 
 def rpn_loss(logits, deltas, anchors, labels, midx, gt_boxes, weights):
@@ -1631,13 +1642,15 @@ class _BoxLoss(torch.autograd.Function):
                              float(scale_clamp), _p(ws), _p(sums), _p(ds), _p(dd), _p(pred)), "cr_box_loss")
         ctx.save_for_backward(ds, dd)
         ctx.dt = (scores.dtype, deltas.dtype)
+        ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None, not as zero fills
         ctx.mark_non_differentiable(sums, pred)
         return sums[0], sums[1], sums, pred
 
     @staticmethod
     def backward(ctx, g_ce, g_l1, _gs, _gp):
         ds, dd = ctx.saved_tensors
-        return (ds * g_ce).to(ctx.dt[0]), (dd * g_l1).to(ctx.dt[1]), None, None, None, None, None, None, None
+        return (None if g_ce is None else (ds * g_ce).to(ctx.dt[0])), (None if g_l1 is None else (dd * g_l1).to(ctx.dt[1])), \
+            None, None, None, None, None, None, None
 
 
 def box_loss(scores, deltas, valid, cls, pboxes, gt_idx, gt_boxes, weights, scale_clamp):
@@ -1685,6 +1698,7 @@ class _CubeHeadLoss(torch.autograd.Function):
         _chk(lib.cr_cube_loss_fwd(_ctx(raw), ctypes.cast(arr, ctypes.c_void_p), n, *flags, _p(losses), _p(dec)),
              "cr_cube_loss_fwd")
         ctx.keep = (raw32, buf, validf, clsc, boxes, tuple(layout), int(K), B, int(kf), flags, raw.dtype)
+        ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None, not as zero fills
         ctx.mark_non_differentiable(dec, buf, validf)
         return losses, ch[4].clone(), dec, buf, validf
 
@@ -1747,6 +1761,7 @@ class _CubeReduce(torch.autograd.Function):
         _chk(lib.cr_cube_reduce(_ctx(L), _p(Lc), _p(buf), _p(dec), _p(validf), n, int(inverse_z), _p(red), _p(cnt),
                                 _p(stats)), "cr_cube_reduce")
         ctx.keep = (Lc, buf, validf, cnt, int(inverse_z))
+        ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None, not as zero fills
         ctx.mark_non_differentiable(stats)
         return red, stats
 
@@ -1832,6 +1847,7 @@ class _WeakCubeLoss(torch.autograd.Function):
         ctx.keep = (raw32, buf, validf, clsc, boxes, tuple(layout), int(K), B, int(kf), S, G, raw.dtype, cls, gt_idx, gt_boxes, prior_std,
                     table, normals, int(bool(allocentric)), int(terms), out)
         dec2, pbox2 = dec.view(n, 17), pbox.view(n, 4)
+        ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None, not as zero fills
         ctx.mark_non_differentiable(stats, dec2, pbox2, validf)
         return red, stats, dec2, pbox2, validf
 
@@ -1895,6 +1911,7 @@ class _RPNUnpack(torch.autograd.Function):
         _chk(_lib.load().cr_rpn_unpack(_ctx(ys[0]), yp, ca, L, B, A, C, _lib.ptr(logits), _lib.ptr(deltas), _lib.ptr(padded)),
              "cr_rpn_unpack")
         ctx.cfg = (A, C, B, cells, [tuple(y.shape) for y in ys])
+        ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None, not as zero fills
         ctx.mark_non_differentiable(padded)
         return logits, deltas, padded
 

@@ -21,6 +21,7 @@ SKIP = ("view", "reshape", "as_strided", "detach", "alias", "expand", "permute",
         "_local_scalar_dense", "lift_fresh", "new_empty", "chunk", "flatten", "result_type", "set_", "record_stream")
 agg = collections.defaultdict(lambda: [0, 0])
 shapes = collections.Counter()
+zshapes = collections.Counter()
 
 
 class Count(TorchDispatchMode):
@@ -42,6 +43,8 @@ class Count(TorchDispatchMode):
                 break
         if where == 'autograd engine' and short.startswith('add.Tensor'):
             shapes[tuple(out.shape)] += 1
+        if where == 'autograd engine' and short.startswith('zeros'):
+            zshapes[tuple(out.shape)] += 1
         a = agg[(short, where)]
         a[0] += 1
         a[1] += max((t.numel() for t in ts), default=0)
@@ -64,4 +67,8 @@ for (name, where), (n, el) in rows[:150]:
 
 print('autograd-engine fan-in adds by shape (per step):')
 for sh, n in sorted(shapes.items(), key=lambda kv: -kv[1] * torch.Size(kv[0]).numel()):
+    print(f'  {n / NSTEP:4.1f} x {sh}')
+
+print('autograd-engine zero fills by shape (per step): materialised gradients of unused outputs')
+for sh, n in sorted(zshapes.items(), key=lambda kv: -kv[1] * torch.Size(kv[0]).numel()):
     print(f'  {n / NSTEP:4.1f} x {sh}')
