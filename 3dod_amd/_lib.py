@@ -77,6 +77,10 @@ SIGNATURES = {
     "cr_roi_label": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, P, P, P],
     "cr_roi_compact": [P, P, P, c_int, P, P, c_int, c_int, P, P, P, c_int, c_int, P, P, P, P, P],
     "cr_box_loss": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_float, P, P, P, P, P],
+    "cr_det_scores": [P, P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P, P],
+    "cr_det_gather": [P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, c_float, P, P, P, P],
+    "cr_nms_grouped_cls": [P, P, P, P, c_int, c_int, c_float, P, P],
+    "cr_det_pick": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P],
     "cr_weak_loss_fwd": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],
     "cr_weak_loss_reduce": [P, P, P, P, P, c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
                             P, P, P],

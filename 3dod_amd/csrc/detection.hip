@@ -698,27 +698,32 @@ extern "C" int cr_roi_align_bwd_set(cr_ctx* ctx, float* const* grads, const int*
 // parallel, pass 2 is one wave per group walking the rows in order (rows prefetched).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ counts,
-                                                 int maxn, float thresh, unsigned long long* __restrict__ mask) {
+                                                 int maxn, float thresh, unsigned long long* __restrict__ mask,
+                                                 const int* __restrict__ cls = nullptr) {
     const int g = blockIdx.z, n = counts[g];
     const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
     if (row0 >= n || col0 >= n) return;
     if (col0 + 63 < row0) return;                       // only j > i matters
     __shared__ float sb[64 * 4];
+    __shared__ int sc[64];
     const float* gb = boxes + (size_t)g * maxn * 4;
+    const int* gc = cls ? cls + (size_t)g * maxn : nullptr;     // class of every box: only same-class pairs suppress
     const int t = threadIdx.x;
     if (col0 + t < n) {
         sb[t * 4 + 0] = gb[(col0 + t) * 4 + 0]; sb[t * 4 + 1] = gb[(col0 + t) * 4 + 1];
         sb[t * 4 + 2] = gb[(col0 + t) * 4 + 2]; sb[t * 4 + 3] = gb[(col0 + t) * 4 + 3];
+        sc[t] = gc ? gc[col0 + t] : 0;
     }
     __syncthreads();
     const int i = row0 + t;
     if (i >= n) return;
     const float ax1 = gb[i * 4], ay1 = gb[i * 4 + 1], ax2 = gb[i * 4 + 2], ay2 = gb[i * 4 + 3];
     const float aa = (ax2 - ax1) * (ay2 - ay1);
+    const int ci = gc ? gc[i] : 0;
     unsigned long long bits = 0;
     const int jn = min(64, n - col0);
     for (int j = 0; j < jn; ++j) {
-        if (col0 + j <= i) continue;
+        if (col0 + j <= i || sc[j] != ci) continue;
         const float bx1 = sb[j * 4], by1 = sb[j * 4 + 1], bx2 = sb[j * 4 + 2], by2 = sb[j * 4 + 3];
         const float w = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f), h = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
         const float inter = w * h, ba = (bx2 - bx1) * (by2 - by1);
@@ -818,8 +823,21 @@ __global__ void k_fill_zero_u64(unsigned long long* __restrict__ p, int64_t n) {
 }
 
 // mask_ws: workspace of G*maxn*ceil(maxn/64) u64.
+static int nms_grouped_impl(cr_ctx* ctx, const float* boxes, const int* counts, int G, int maxn, float thresh, void* mask_ws,
+                            unsigned char* keep, const int* cls);
 extern "C" int cr_nms_grouped(cr_ctx* ctx, const float* boxes, const int* counts, int G, int maxn, float thresh,
                               void* mask_ws, unsigned char* keep) {
+    return nms_grouped_impl(ctx, boxes, counts, G, maxn, thresh, mask_ws, keep, nullptr);
+}
+// the same with a class per box (cls (G,maxn) int32): a box is only suppressed by a kept box of its own class -- torchvision
+// batched_nms over the detections of an image (fast_rcnn.py:105) without regrouping them by class
+extern "C" int cr_nms_grouped_cls(cr_ctx* ctx, const float* boxes, const int32_t* cls, const int* counts, int G, int maxn,
+                                  float thresh, void* mask_ws, unsigned char* keep) {
+    CR_CHECK_ARG(cls != nullptr, "cr_nms_grouped_cls: cls is NULL");
+    return nms_grouped_impl(ctx, boxes, counts, G, maxn, thresh, mask_ws, keep, cls);
+}
+static int nms_grouped_impl(cr_ctx* ctx, const float* boxes, const int* counts, int G, int maxn, float thresh, void* mask_ws,
+                            unsigned char* keep, const int* cls) {
     CR_CHECK_ARG(ctx, "cr_nms_grouped: ctx is NULL");
     if (G == 0 || maxn == 0) return CR_OK;
     CR_CHECK_ARG(boxes && counts && mask_ws && keep && G > 0 && maxn > 0 && maxn <= 65536, "cr_nms_grouped: bad args");
@@ -832,7 +850,7 @@ extern "C" int cr_nms_grouped(cr_ctx* ctx, const float* boxes, const int* counts
         CR_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_nms_mask, dim3(words, words, G), dim3(64), 0, ctx->stream, boxes, counts, maxn, thresh,
-                       (unsigned long long*)mask_ws);
+                       (unsigned long long*)mask_ws, cls);
     CR_LAUNCH_CHECK();
     if (words <= 32)
         hipLaunchKernelGGL(k_nms_scan32, dim3(G), dim3(256), 0, ctx->stream, counts, maxn,
@@ -840,6 +858,199 @@ extern "C" int cr_nms_grouped(cr_ctx* ctx, const float* boxes, const int* counts
     else
         hipLaunchKernelGGL(k_nms_scan, dim3(G), dim3(64), words * 8, ctx->stream, counts, maxn,
                            (const unsigned long long*)mask_ws, keep);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Test-time filter of the box head on padded proposals, without a host round trip (FastRCNNOutputs.inference ->
+// fast_rcnn_inference_single_image, cubercnn/modeling/roi_heads/fast_rcnn.py:57-116 of the reference):
+//   k_det_scores   softmax over the K+1 logits of every proposal; entry (row, class) of the masked score matrix S (B, P*K) is the
+//                  class probability if it exceeds the threshold and the row is a real, finite prediction, else -inf; the
+//                  number of candidates of every image is counted
+//   (cr_topk)      the Kc best candidates of every image in descending order
+//   k_det_gather   their boxes: Box2BoxTransform.apply_deltas of the (row, class) deltas, clipped to the image
+//   (cr_nms_grouped_cls)  class-wise NMS over the sorted candidates
+//   k_det_pick     the first `topk` survivors of every image, with the full score row of their proposal
+// If an image has more candidates than Kc AND fewer than `topk` survivors among the first Kc, a box beyond the first Kc could
+// still be a detection: the image is flagged (overflow) and the caller repeats it on the exact, unbounded path.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_det_scores(const float* __restrict__ logits, int ldl, const float* __restrict__ deltas,
+                                                    int ldd, const float* __restrict__ prop, const float* __restrict__ objectness,
+                                                    int B, int P, int K, int nreg, float thresh, float* __restrict__ S,
+                                                    int* __restrict__ ncand) {
+    // one wave per proposal row
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= B * P) return;
+    const int b = r / P;
+    const float* lg = logits + (size_t)r * ldl;
+    float mx = -INFINITY;
+    bool fin = true;
+    for (int c = lane; c <= K; c += 64) { const float v = lg[c]; mx = fmaxf(mx, v); fin &= isfinite(v); }
+    for (int c = lane; c < nreg * 4; c += 64) fin &= isfinite(deltas[(size_t)r * ldd + c]);
+    if (lane < 4) fin &= isfinite(prop[(size_t)r * 4 + lane]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    fin = __all(fin) && (objectness == nullptr || isfinite(objectness[r]));
+    float sum = 0.f;
+    for (int c = lane; c <= K; c += 64) sum += expf(lg[c] - mx);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    int mine = 0;
+    for (int c = lane; c < K; c += 64) {
+        const float pr = expf(lg[c] - mx) / sum;
+        const bool ok = fin && pr > thresh;
+        S[(size_t)r * K + c] = ok ? pr : -INFINITY;
+        mine += ok ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if (lane == 0 && mine) atomicAdd(&ncand[b], mine);
+}
+
+__global__ __launch_bounds__(256) void k_det_gather(const float* __restrict__ val, const int64_t* __restrict__ idx,
+                                                    const float* __restrict__ deltas, int ldd, const float* __restrict__ prop,
+                                                    const float* __restrict__ img_hw, int B, int P, int K, int nreg, int Kc, float wx,
+                                                    float wy, float ww, float wh, float scale_clamp, float* __restrict__ boxes,
+                                                    int* __restrict__ cls, int* __restrict__ row, int* __restrict__ counts) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * Kc) return;
+    const int b = t / Kc;
+    const float v = val[t];
+    const bool ok = v > -INFINITY;
+    const int64_t id = ok ? idx[t] : 0;
+    const int rr = (int)(id / K), c = (int)(id - (int64_t)rr * K);
+    const int r = b * P + rr;
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        const float* d = deltas + (size_t)r * ldd + (nreg == 1 ? 0 : c * 4);
+        const float* pb = prop + (size_t)r * 4;
+        const float w = pb[2] - pb[0], h = pb[3] - pb[1], cx = pb[0] + 0.5f * w, cy = pb[1] + 0.5f * h;
+        const float dx = d[0] / wx, dy = d[1] / wy, dw = fminf(d[2] / ww, scale_clamp), dh = fminf(d[3] / wh, scale_clamp);
+        const float pcx = dx * w + cx, pcy = dy * h + cy, pw = expf(dw) * w, ph = expf(dh) * h;
+        const float H = img_hw[b * 2], W = img_hw[b * 2 + 1];
+        bx.x = fminf(fmaxf(pcx - 0.5f * pw, 0.f), W); bx.y = fminf(fmaxf(pcy - 0.5f * ph, 0.f), H);       // Boxes.clip
+        bx.z = fminf(fmaxf(pcx + 0.5f * pw, 0.f), W); bx.w = fminf(fmaxf(pcy + 0.5f * ph, 0.f), H);
+    }
+    reinterpret_cast<float4*>(boxes)[t] = bx;
+    cls[t] = ok ? c : -1;
+    row[t] = ok ? rr : -1;
+    // the candidates are sorted: the count of an image is the position of its first empty slot
+    const float nxt = (t % Kc) + 1 < Kc ? val[t + 1] : -INFINITY;
+    if (ok && !(nxt > -INFINITY)) counts[b] = (t % Kc) + 1;
+    if (!ok && (t % Kc) == 0) counts[b] = 0;
+}
+
+#define DET_MAX_TOPK 512
+__global__ __launch_bounds__(256) void k_det_pick(const unsigned char* __restrict__ keep, const int* __restrict__ counts,
+                                                  const int* __restrict__ ncand, const float* __restrict__ val,
+                                                  const float* __restrict__ boxes, const int* __restrict__ cls,
+                                                  const int* __restrict__ row, const float* __restrict__ logits, int ldl, int P,
+                                                  int K, int Kc, int topk, float* __restrict__ out_boxes,
+                                                  float* __restrict__ out_scores, int64_t* __restrict__ out_cls,
+                                                  int64_t* __restrict__ out_row, float* __restrict__ out_full,
+                                                  int* __restrict__ out_count) {
+    // one workgroup per image: ranks of the survivors by a block-wide prefix sum over chunks of 256 candidates
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    __shared__ int s_row[DET_MAX_TOPK];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = counts[b];
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + t;
+        const bool k = i < n && keep[(size_t)b * Kc + i];
+        const unsigned long long bal = __ballot(k);
+        const int before = __popcll(bal & ((1ULL << lane) - 1ULL));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        const int rank = off + before;
+        if (k && rank < topk) {
+            const size_t src = (size_t)b * Kc + i, dst = (size_t)b * topk + rank;
+            reinterpret_cast<float4*>(out_boxes)[dst] = reinterpret_cast<const float4*>(boxes)[src];
+            out_scores[dst] = val[src];
+            out_cls[dst] = cls[src];
+            out_row[dst] = row[src];
+            s_row[rank] = row[src];
+        }
+        __syncthreads();
+        if (t == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+        if (s_base >= topk) break;                            // block-uniform
+    }
+    const int kept = min(s_base, topk);
+    if (t == 0) {
+        out_count[b * 2] = kept;
+        out_count[b * 2 + 1] = (ncand[b] > Kc && kept < topk) ? 1 : 0;       // overflow: repeat on the exact path
+    }
+    // scores_full of every detection: the softmax row of its proposal without the background column (fast_rcnn.py:96,110)
+    for (int d = wave; d < topk; d += 4) {
+        float* of = out_full + ((size_t)b * topk + d) * K;
+        if (d >= kept) {
+            for (int c = lane; c < K; c += 64) of[c] = 0.f;
+            if (lane == 0) {
+                const size_t dst = (size_t)b * topk + d;
+                reinterpret_cast<float4*>(out_boxes)[dst] = make_float4(0.f, 0.f, 0.f, 0.f);
+                out_scores[dst] = 0.f; out_cls[dst] = 0; out_row[dst] = 0;
+            }
+            continue;
+        }
+        const int rr = s_row[d];
+        const float* lg = logits + ((size_t)b * P + rr) * ldl;
+        float mx = -INFINITY;
+        for (int c = lane; c <= K; c += 64) mx = fmaxf(mx, lg[c]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        float sum = 0.f;
+        for (int c = lane; c <= K; c += 64) sum += expf(lg[c] - mx);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        for (int c = lane; c < K; c += 64) of[c] = expf(lg[c] - mx) / sum;
+    }
+}
+
+extern "C" int cr_det_scores(cr_ctx* ctx, const float* logits, int ldl, const float* deltas, int ldd, const float* prop_boxes,
+                             const float* objectness, int B, int P, int K, int nreg, float thresh, float* S, int32_t* ncand) {
+    CR_CHECK_ARG(ctx && logits && deltas && prop_boxes && S && ncand, "cr_det_scores: NULL pointer");
+    CR_CHECK_ARG(B > 0 && P > 0 && K > 0 && ldl >= K + 1 && (nreg == 1 || nreg == K) && ldd >= nreg * 4, "cr_det_scores: bad sizes");
+    hipLaunchKernelGGL(k_fill_zero_u64, dim3(1), dim3(256), 0, ctx->stream, (unsigned long long*)ncand, (int64_t)((B + 1) / 2));
+    hipLaunchKernelGGL(k_det_scores, dim3((unsigned)cr_cdiv((int64_t)B * P, 4)), dim3(256), 0, ctx->stream, logits, ldl, deltas, ldd,
+                       prop_boxes, objectness, B, P, K, nreg, thresh, S, ncand);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// val / idx (B,Kc): cr_topk of S viewed as (B, P*K), descending.  boxes (B,Kc,4), cls / row (B,Kc) int32 (-1 = empty slot),
+// counts (B) int32 candidates per image among the Kc.
+extern "C" int cr_det_gather(cr_ctx* ctx, const float* val, const int64_t* idx, const float* deltas, int ldd,
+                             const float* prop_boxes, const float* img_hw, int B, int P, int K, int nreg, int Kc,
+                             const float* weights4, float scale_clamp, float* boxes, int32_t* cls, int32_t* row, int32_t* counts) {
+    CR_CHECK_ARG(ctx && val && idx && deltas && prop_boxes && img_hw && weights4 && boxes && cls && row && counts,
+                 "cr_det_gather: NULL pointer");
+    CR_CHECK_ARG(B > 0 && P > 0 && K > 0 && Kc > 0 && (nreg == 1 || nreg == K), "cr_det_gather: bad sizes");
+    hipLaunchKernelGGL(k_det_gather, dim3((unsigned)cr_cdiv((int64_t)B * Kc, 256)), dim3(256), 0, ctx->stream, val, idx, deltas, ldd,
+                       prop_boxes, img_hw, B, P, K, nreg, Kc, weights4[0], weights4[1], weights4[2], weights4[3], scale_clamp, boxes,
+                       cls, row, counts);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// keep (B,Kc) from cr_nms_grouped_cls.  out_* (B,topk,...): boxes f32 x4, scores f32, classes / rows int64, scores_full (B,topk,K);
+// out_count (B,2) int32 = [detections, overflow flag].  Empty slots are zero.
+extern "C" int cr_det_pick(cr_ctx* ctx, const unsigned char* keep, const int32_t* counts, const int32_t* ncand, const float* val,
+                           const float* boxes, const int32_t* cls, const int32_t* row, const float* logits, int ldl, int B, int P,
+                           int K, int Kc, int topk, float* out_boxes, float* out_scores, int64_t* out_cls, int64_t* out_row,
+                           float* out_full, int32_t* out_count) {
+    CR_CHECK_ARG(ctx && keep && counts && ncand && val && boxes && cls && row && logits && out_boxes && out_scores && out_cls &&
+                 out_row && out_full && out_count, "cr_det_pick: NULL pointer");
+    CR_CHECK_ARG(B > 0 && P > 0 && K > 0 && Kc > 0 && topk > 0 && topk <= DET_MAX_TOPK && ldl >= K + 1, "cr_det_pick: bad sizes");
+    hipLaunchKernelGGL(k_det_pick, dim3((unsigned)B), dim3(256), 0, ctx->stream, keep, counts, ncand, val, boxes, cls, row, logits, ldl,
+                       P, K, Kc, topk, out_boxes, out_scores, out_cls, out_row, out_full, out_count);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -242,10 +242,82 @@ class ROIHeads3D(StandardROIHeads):
                 pred_instances_i.scores = torch.ones_like(proposal['gt_classes']).float()
                 pred_instances.append(pred_instances_i)
         else:
+            fused = self._infer_padded(features, proposals, Ks, im_dims, im_scales_ratio)
+            if fused is not None:
+                return fused, {}
             pred_instances = self._forward_box(features, proposals)
         if self.loss_w_3d > 0:
             pred_instances = self._forward_cube(features, pred_instances, Ks, im_dims, im_scales_ratio)
         return pred_instances, {}
+
+    def _infer_padded(self, features, proposals, Ks, im_dims, im_scales_ratio):
+        """inference on the RPN's padded proposal slots (every image P slots, empty ones with objectness -inf) with ONE host wait
+        at the end: box head -> ops.det_select (softmax, threshold, decode + clip, class-wise NMS, top detections: fast_rcnn.py:
+        57-116 as five launches) -> the 3D head on the (B, D) padded detections (_forward_cube's inference branch, roi_heads.py:
+        2353-2436, 2682-2735) -> the counts come to the host and the Instances are cut from the padded arrays.  Returns None
+        when the inputs are not of that form, or when an image has more candidates than the selection looks at and too few
+        survivors among them (ops.det_select's overflow flag): the caller then takes the per-image path."""
+        import os
+        bp = self.box_predictor
+        if (os.environ.get("CR_INFER_FUSED", "1") == "0" or not proposals or getattr(self, "_forward_cube_list", None) is not None
+                or not all(isinstance(p, Instances) and p.has("objectness_logits") for p in proposals)):
+            return None
+        B, P = len(proposals), len(proposals[0])
+        D = int(bp.test_topk_per_image)
+        pb = torch.cat([p.proposal_boxes.tensor for p in proposals])
+        if P == 0 or not pb.is_cuda or any(len(p) != P for p in proposals) or not (0 < D <= 512):
+            return None
+        dev = pb.device
+        K = self.num_classes
+        feats = [features[f] for f in self.box_in_features]
+        predictions = bp(self.box_head(self.box_pooler(feats, [x.proposal_boxes for x in proposals])))
+        obj = torch.cat([p.objectness_logits for p in proposals]).float()
+        hw = torch.tensor([[float(s[0]), float(s[1])] for s in im_dims], dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
+        t = bp.box2box_transform
+        ob, osc, ocls, orow, ofull, ocnt = ops.det_select(predictions[0], predictions[1], pb, obj, hw, B, P, K, t.weights, t.scale_clamp,
+                                                          bp.test_score_thresh, bp.test_nms_thresh, D)
+        out = None
+        if self.loss_w_3d > 0:
+            flat = Boxes(ob.view(B * D, 4))
+            scaled = self.scale_proposals([flat])[0].tensor
+            idx = torch.arange(B, device=dev).repeat_interleave(D)
+            rois = torch.cat([idx[:, None].float(), scaled], 1)
+            cube_features = ops.roi_align_pyramid([features[f] for f in self.in_features], rois, self.cube_pooler.scales,
+                                                  self.cube_pooler.output_size).flatten(1)
+            raw, layout = self.cube_head.forward_fused(cube_features)
+            rows = []
+            for k, r, d in zip(Ks, im_scales_ratio, im_dims):
+                k = torch.as_tensor(k, dtype=torch.float32)
+                v2r = util.compute_virtual_scale_from_focal_spaces(float(k[1, 1]), float(d[0]) * float(r), self.virtual_focal,
+                                                                   float(d[0])) if self.virtual_depth else 1.0
+                rows.append([float(k[0, 0]) / r, float(k[1, 1]) / r, float(k[0, 2]) / r, float(k[1, 2]) / r, float(v2r), float(r)])
+            meta6 = torch.tensor(rows, dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
+            priors = self.priors_dims_per_cat.detach()[0, :, 0, :].contiguous() if self.dims_priors_enabled else None
+            out = ops.cube_decode_infer(raw, layout, K, ocls.reshape(-1), idx, flat.tensor, meta6, priors,
+                                        allocentric=self.allocentric_pose).view(B, D, 42)
+            score3 = (osc * out[:, :, 8]) ** (1 / 2)
+        counts = ocnt.tolist()                                   # the one host wait of the step
+        if any(c[1] for c in counts):
+            return None
+        results = []
+        for b in range(B):
+            n = counts[b][0]
+            inst = Instances(im_dims[b])
+            inst.pred_boxes = Boxes(ob[b, :n])
+            inst.scores_full = ofull[b, :n]
+            inst.pred_classes = ocls[b, :n]
+            if out is None:
+                inst.scores = osc[b, :n]
+            else:
+                o = out[b, :n]
+                inst.scores = score3[b, :n]
+                inst.pred_bbox3D = o[:, 18:42].reshape(n, 8, 3)
+                inst.pred_center_cam = o[:, 0:3]
+                inst.pred_center_2D = o[:, 6:8]
+                inst.pred_dimensions = o[:, 3:6]
+                inst.pred_pose = o[:, 9:18].reshape(n, 3, 3)
+            results.append(inst)
+        return results
 
     def _forward_box(self, features, proposals):
         """roi_heads.py:2160-2204."""

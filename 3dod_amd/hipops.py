@@ -1482,6 +1482,52 @@ def nms_grouped(boxes, counts, thresh):
     return keep.bool()
 
 
+def det_select(logits, deltas, prop_boxes, objectness, img_hw, B, P, K, weights, scale_clamp, score_thresh, nms_thresh, detections,
+               max_candidates=2048):
+    """Test-time filter of the box head on B x P padded proposal slots, no host round trip (fast_rcnn.py:57-116): logits
+    (B*P, >= K+1), deltas (B*P, 4K or 4), prop_boxes (B*P,4), objectness (B*P) or None, img_hw (B,2) float.
+    -> boxes (B,D,4), scores (B,D), classes (B,D) int64, rows (B,D) int64 (proposal slot inside the image),
+    scores_full (B,D,K), count (B,2) int32 = [detections, overflow flag]."""
+    _p = _Args()
+    _need_cuda(logits, "box head logits")
+    lib = _lib.load()
+    dev = logits.device
+    # column slices of the predictor GEMM's output are taken as they are (row stride = its width): no copies
+    rows_ok = lambda t: t.dtype == f32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]
+    lg = logits.detach() if rows_ok(logits) else logits.detach().float().contiguous()
+    dl = deltas.detach() if rows_ok(deltas) else deltas.detach().float().contiguous()
+    ldl, ldd = lg.stride(0), dl.stride(0)
+    pb = prop_boxes.detach().float().contiguous()
+    nreg = 1 if dl.shape[1] < 4 * K else K
+    S = torch.empty((B, P * K), dtype=f32, device=dev)
+    ncand = torch.empty((B + 2,), dtype=torch.int32, device=dev)
+    _chk(lib.cr_det_scores(_ctx(lg), _lib.P(lg.data_ptr()), ldl, _lib.P(dl.data_ptr()), ldd, _p(pb), _p(objectness), B, P, K, nreg, float(score_thresh),
+                           _p(S), _p(ncand)), "cr_det_scores")
+    Kc = min(int(max_candidates), P * K)
+    val, idx = topk(S, Kc)
+    boxes = torch.empty((B, Kc, 4), dtype=f32, device=dev)
+    meta = torch.empty((3, B, Kc), dtype=torch.int32, device=dev)
+    cls, row = meta[0], meta[1]
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    w4 = (_ct.c_float * 4)(*[float(w) for w in weights])
+    val, idx = val.contiguous(), idx.contiguous()
+    _chk(lib.cr_det_gather(_ctx(lg), _p(val), _p(idx), _lib.P(dl.data_ptr()), ldd, _p(pb), _p(img_hw.float().contiguous()), B, P, K, nreg, Kc,
+                           w4, float(scale_clamp), _p(boxes), _p(cls), _p(row), _p(counts)), "cr_det_gather")
+    words = (Kc + 63) // 64
+    ws = torch.empty((B * Kc * words,), dtype=torch.int64, device=dev)
+    keep = torch.empty((B, Kc), dtype=torch.uint8, device=dev)
+    _chk(lib.cr_nms_grouped_cls(_ctx(lg), _p(boxes), _p(cls), _p(counts), B, Kc, float(nms_thresh), _p(ws), _p(keep)), "cr_nms_grouped_cls")
+    D = int(detections)
+    ob = torch.empty((B, D, 4), dtype=f32, device=dev)
+    osc = torch.empty((B, D), dtype=f32, device=dev)
+    oi = torch.empty((2, B, D), dtype=torch.int64, device=dev)
+    ofull = torch.empty((B, D, K), dtype=f32, device=dev)
+    ocnt = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    _chk(lib.cr_det_pick(_ctx(lg), _p(keep), _p(counts), _p(ncand), _p(val), _p(boxes), _p(cls), _p(row), _lib.P(lg.data_ptr()), ldl, B, P, K, Kc,
+                         D, _p(ob), _p(osc), _p(oi[0]), _p(oi[1]), _p(ofull), _p(ocnt)), "cr_det_pick")
+    return ob, osc, oi[0], oi[1], ofull, ocnt
+
+
 # --------------------------------------------------------------------------
 # static-shape RPN training glue (csrc/dense_train.hip)
 # --------------------------------------------------------------------------

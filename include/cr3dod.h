@@ -477,6 +477,31 @@ int cr_cube_reduce(cr_ctx* ctx, const float* L, const float* buf39, const float*
 int cr_cube_reduce_bwd(cr_ctx* ctx, const float* L, const float* buf39, const unsigned char* validf, int n, int inverse_z,
                        const float* cnt6, const float* gred6, float* gL, float* gu);
 
+/* ---- test-time filter of the box head on padded proposals, without a host round trip -----------------------------------
+ * FastRCNNOutputs.inference -> fast_rcnn_inference_single_image (cubercnn/modeling/roi_heads/fast_rcnn.py:57-116): softmax,
+ * score threshold, Box2BoxTransform.apply_deltas + Boxes.clip, class-wise NMS (torchvision batched_nms), the best `topk`
+ * detections per image with the full score row of their proposal.  B images x P proposal slots; logits (B*P, ldl >= K+1),
+ * deltas (B*P, ldd >= 4*nreg), nreg = K (class-specific regression) or 1; objectness (B*P) or NULL: slots whose objectness is
+ * not finite are padding; rows with a non-finite logit / delta / proposal coordinate are dropped (fast_rcnn.py:75-78).
+ * cr_det_scores: S (B, P*K) = class probability where it exceeds `thresh`, else -inf; ncand (B+2) int32 candidates per image.
+ * (cr_topk of S viewed as (B, P*K) gives val / idx (B,Kc), descending.)
+ * cr_det_gather: boxes (B,Kc,4), cls / row (B,Kc) int32 (-1 = empty slot), counts (B) int32.
+ * cr_nms_grouped_cls: cr_nms_grouped where a box is only suppressed by a kept box of its own class (cls (G,maxn) int32).
+ * cr_det_pick: out_boxes (B,topk,4), out_scores (B,topk), out_cls / out_row (B,topk) int64, out_full (B,topk,K) =
+ * scores_full (:96,110), out_count (B,2) int32 = [detections, overflow]; overflow = 1 when the image has more candidates
+ * than Kc and fewer than topk survivors among them: repeat it on an unbounded path.  topk <= 512. */
+int cr_det_scores(cr_ctx* ctx, const float* logits, int ldl, const float* deltas, int ldd, const float* prop_boxes,
+                  const float* objectness, int B, int P, int K, int nreg, float thresh, float* S, int32_t* ncand);
+int cr_det_gather(cr_ctx* ctx, const float* val, const int64_t* idx, const float* deltas, int ldd, const float* prop_boxes,
+                  const float* img_hw, int B, int P, int K, int nreg, int Kc, const float* weights4, float scale_clamp,
+                  float* boxes, int32_t* cls, int32_t* row, int32_t* counts);
+int cr_nms_grouped_cls(cr_ctx* ctx, const float* boxes, const int32_t* cls, const int* counts, int G, int maxn, float thresh,
+                       void* mask_ws, unsigned char* keep);
+int cr_det_pick(cr_ctx* ctx, const unsigned char* keep, const int32_t* counts, const int32_t* ncand, const float* val,
+                const float* boxes, const int32_t* cls, const int32_t* row, const float* logits, int ldl, int B, int P, int K,
+                int Kc, int topk, float* out_boxes, float* out_scores, int64_t* out_cls, int64_t* out_row, float* out_full,
+                int32_t* out_count);
+
 /* ---- fused losses of the weakly supervised 3D head on the static (B, kf) foreground slots --------------------------
  * ROIHeads3DScore._forward_cube in training mode (cubercnn/modeling/roi_heads/roi_heads.py:1366-1760): decode, cuboid,
  * projected + clamped corners and their hull, the per-RoI terms and their reduction.  Term index (bit of `terms`):
