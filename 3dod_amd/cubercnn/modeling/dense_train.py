@@ -161,6 +161,10 @@ def rpn_tensors(rpn, feats, head_outputs):
     A = rpn.rpn_head.num_anchors
     if head_outputs is None or isinstance(head_outputs, RawRPNOutputs):
         ys = head_outputs.ys if head_outputs is not None else rpn.rpn_head.forward_raw(feats)
+        if len(ys) == 1 and len(feats) > 1:                           # the levels stacked in one map (StandardRPNHead.forward_raw)
+            cells = [int(f.shape[1] * f.shape[2]) for f in feats]
+            logits, deltas, padded = ops.rpn_unpack_stacked(ys[0], cells, feats[0].shape[0], A)
+            return logits, deltas, padded, [c * A for c in cells]
         logits, deltas, padded = ops.rpn_unpack(ys, A)               # one launch each way
         return logits, deltas, padded, [int(y.shape[1] * y.shape[2] * A) for y in ys]
     logits_lv, deltas_lv = head_outputs

@@ -193,9 +193,11 @@ class RCNN3D(nn.Module):
         if self.dense_train and gt_instances is not None:
             return self._forward_dense(images, features, head_outputs, gt_instances, Ks, im_scales_ratio, batched_inputs)
         if head_outputs is not None:                       # instance-list path (tests): the lists of RPN.forward
-            A, D = self.proposal_generator.rpn_head.num_anchors, self.proposal_generator.rpn_head.box_dim
-            head_outputs = ([y[..., :A].reshape(y.shape[0], -1) for y in head_outputs.ys],
-                            [y[..., A:A + A * D].reshape(y.shape[0], -1, D) for y in head_outputs.ys])
+            pg = self.proposal_generator
+            A, D = pg.rpn_head.num_anchors, pg.rpn_head.box_dim
+            ys = pg.rpn_head.level_views(head_outputs.ys, [features[f] for f in pg.in_features])
+            head_outputs = ([y[..., :A].reshape(y.shape[0], -1) for y in ys],
+                            [y[..., A:A + A * D].reshape(y.shape[0], -1, D) for y in ys])
         proposals, proposal_losses = self.proposal_generator(images, features, gt_instances, head_outputs=head_outputs)
         instances, detector_losses = self._run_roi_heads(images, features, proposals, Ks, im_scales_ratio, gt_instances,
                                                          batched_inputs)

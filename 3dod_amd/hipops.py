@@ -797,39 +797,66 @@ class _ConvBiasGroup(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, n, pad, relu, slots, *args):
+        """slots[-1] == "stacked" (conv_bias_act_group(stacked=True)): the n outputs are the consecutive row blocks of ONE
+        (1, 1, sum of pixels, Cout) tensor -- what a following 1x1 convolution treats as a single map (the RPN predictors
+        over all pyramid levels at once); one gradient comes back and one ReLU backward covers all levels."""
+        stacked = len(slots) == n + 1
         xs, ws, bs = args[:n], args[n:2 * n], args[2 * n:3 * n]
         _p = _Args()
         Cout, Cin, k, _ = ws[0].shape
         dt = xs[0].dtype
         xs = [x.contiguous() for x in xs]
         wbs = [prepared_weights(w, False, dt)[0] for w in ws]
-        ys = [torch.empty((x.shape[0], x.shape[1] + 2 * pad - k + 1, x.shape[2] + 2 * pad - k + 1, Cout), dtype=dt, device=x.device)
-              for x in xs]
+        shapes = [(x.shape[0], x.shape[1] + 2 * pad - k + 1, x.shape[2] + 2 * pad - k + 1, Cout) for x in xs]
+        if stacked:
+            rows = [s[0] * s[1] * s[2] for s in shapes]
+            Y = torch.empty((1, 1, sum(rows), Cout), dtype=dt, device=xs[0].device)
+            flat, off, ys = Y.view(-1, Cout), 0, []
+            for s, m in zip(shapes, rows):
+                ys.append(flat[off:off + m].view(s))
+                off += m
+        else:
+            ys = [torch.empty(s, dtype=dt, device=x.device) for s, x in zip(shapes, xs)]
         bd = [None if b is None else b.detach() for b in bs]
         conv_fwd_group_raw(xs, wbs, ys, Cin, Cout, k, pad, bd, relu)
         ctx.cfg = (n, k, pad, relu)
         ctx.slots = slots
         ctx.refs = (ws, bs)
-        ctx.save_for_backward(*xs, *(ys if relu else ()))
+        ctx.stacked = shapes if stacked else None
+        ctx.save_for_backward(*xs, *((Y,) if stacked and relu else (ys if relu else ())))
         ctx.set_materialize_grads(False)
-        return tuple(ys)
+        return Y if stacked else tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
         n, k, pad, relu = ctx.cfg
         ws, bs = ctx.refs
         saved = ctx.saved_tensors
-        xs, ys = saved[:n], (saved[n:] if relu else (None,) * n)
+        xs = saved[:n]
         _p = _Args()
         lib = _lib.load()
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
-        live = [i for i in range(n) if dys[i] is not None]            # an output nobody differentiated takes no part
         gs = {}
-        for i in live:
-            g = dys[i].contiguous()
-            if relu:
-                g = relu_bwd(ys[i], g)
-            gs[i] = g.to(xs[i].dtype).contiguous()
+        if ctx.stacked is not None:
+            live = list(range(n)) if dys[0] is not None else []
+            if live:
+                g = dys[0].contiguous()
+                if relu:
+                    g = relu_bwd(saved[n], g)
+                g = g.to(xs[0].dtype).contiguous().view(-1, g.shape[-1])
+                off = 0
+                for i, s in enumerate(ctx.stacked):
+                    m = s[0] * s[1] * s[2]
+                    gs[i] = g[off:off + m].view(s)
+                    off += m
+        else:
+            ys = saved[n:] if relu else (None,) * n
+            live = [i for i in range(n) if dys[i] is not None]            # an output nobody differentiated takes no part
+            for i in live:
+                g = dys[i].contiguous()
+                if relu:
+                    g = relu_bwd(ys[i], g)
+                gs[i] = g.to(xs[i].dtype).contiguous()
         dt = xs[0].dtype
         Cout, Cin = ws[0].shape[0], ws[0].shape[1]
         dxs = [None] * n
@@ -874,12 +901,17 @@ class _ConvBiasGroup(torch.autograd.Function):
         return (None, None, None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
 
 
-def conv_bias_act_group(xs, weights, biases, pad=0, relu=False):
-    """[act(conv(x_i, W_i) + b_i)] -- one launch per direction when the shapes allow (group_supported), else one conv each"""
+def conv_bias_act_group(xs, weights, biases, pad=0, relu=False, stacked=False):
+    """[act(conv(x_i, W_i) + b_i)] -- one launch per direction when the shapes allow (group_supported), else one conv each.
+    stacked=True (only when group_supported): ONE tensor (1, 1, sum_i N_i H_i W_i, Cout) whose row blocks are the outputs."""
     xs, weights, biases = list(xs), [as_krsc(w) for w in weights], list(biases)
     if not group_supported(xs, weights):
+        if stacked:
+            raise _lib.CrError("conv_bias_act_group(stacked=True): the problems do not form a group (see group_supported)")
         return [conv_bias_act(x, w, b, 1, pad, relu=relu) for x, w, b in zip(xs, weights, biases)]
     slots = tuple(_slot_register(x, True) for x in xs)
+    if stacked:
+        return _ConvBiasGroup.apply(len(xs), pad, relu, slots + ("stacked",), *xs, *weights, *biases)
     return list(_ConvBiasGroup.apply(len(xs), pad, relu, slots, *xs, *weights, *biases))
 
 
@@ -1973,6 +2005,52 @@ class _RPNUnpack(torch.autograd.Function):
         dp, ca = (_ct.c_void_p * L)(*[d.data_ptr() for d in dys]), (_ct.c_int * L)(*cells)
         _chk(_lib.load().cr_rpn_pack_grad(_ctx(ref), _p(dl), _p(dd), dp, ca, L, B, A, C), "cr_rpn_pack_grad")
         return (None,) + tuple(dys)
+
+
+class _RPNUnpackStacked(torch.autograd.Function):
+    """_RPNUnpack on ONE tensor Y (1,1,sum_l B H_l W_l,C) whose row blocks are the levels (conv_bias_act_group(stacked=True)
+    followed by the 1x1 predictor convolution): same two kernels, level pointers = offsets into Y, one gradient tensor back"""
+
+    @staticmethod
+    def forward(ctx, A, cells, B, Y):
+        _p = _Args()
+        Y = Y.contiguous()
+        L, C = len(cells), Y.shape[-1]
+        assert Y.numel() == B * sum(cells) * C, "stacked RPN output does not match the level sizes"
+        atot, amax = sum(cells) * A, max(cells) * A
+        dev = Y.device
+        logits = torch.empty((B, atot), dtype=f32, device=dev)
+        deltas = torch.empty((B, atot, 4), dtype=f32, device=dev)
+        padded = torch.empty((B, L, amax), dtype=f32, device=dev)
+        offs = [0]
+        for c in cells:
+            offs.append(offs[-1] + B * c * C * 4)
+        yp, ca = (_ct.c_void_p * L)(*[Y.data_ptr() + o for o in offs[:-1]]), (_ct.c_int * L)(*cells)
+        _p.keep.append(Y)
+        _chk(_lib.load().cr_rpn_unpack(_ctx(Y), yp, ca, L, B, A, C, _lib.ptr(logits), _lib.ptr(deltas), _lib.ptr(padded)),
+             "cr_rpn_unpack")
+        ctx.cfg = (A, C, B, tuple(cells), tuple(Y.shape), offs)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(padded)
+        return logits, deltas, padded
+
+    @staticmethod
+    def backward(ctx, dlogits, ddeltas, _dpad):
+        _p = _Args()
+        A, C, B, cells, shape, offs = ctx.cfg
+        L = len(cells)
+        ref = dlogits if dlogits is not None else ddeltas
+        dY = torch.empty(shape, dtype=f32, device=ref.device)
+        dl = None if dlogits is None else dlogits.contiguous()
+        dd = None if ddeltas is None else ddeltas.contiguous()
+        dp, ca = (_ct.c_void_p * L)(*[dY.data_ptr() + o for o in offs[:-1]]), (_ct.c_int * L)(*cells)
+        _chk(_lib.load().cr_rpn_pack_grad(_ctx(ref), _p(dl), _p(dd), dp, ca, L, B, A, C), "cr_rpn_pack_grad")
+        return None, None, None, dY
+
+
+def rpn_unpack_stacked(Y, cells, B, A):
+    """rpn_unpack for the stacked head output: Y (1,1,B*sum(cells),C), cells = H_l*W_l per level"""
+    return _RPNUnpackStacked.apply(int(A), tuple(int(c) for c in cells), int(B), Y)
 
 
 def rpn_unpack(ys, A):

@@ -89,6 +89,15 @@ def root_conv_bn_act(children, weight, gamma, beta, running_mean, running_var, r
                        momentum, training)
 
 
+def group_supported(xs, weights, stride=1):
+    """the oracle evaluates every convolution on its own: no grouped / stacked launches"""
+    return False
+
+
+def as_krsc(weight):
+    return weight
+
+
 def conv_bias_act_group(xs, weights, biases, pad=0, relu=False):
     """hipops.conv_bias_act_group (one grouped launch per direction on the device): here simply one convolution per problem"""
     return [conv_bias_act(x, w, b, 1, pad, relu=relu) for x, w, b in zip(xs, weights, biases)]

@@ -192,6 +192,7 @@ def test_graphed_dense_region_equals_eager(built):
         images, u8 = model._stack_images(batch)
         feats2, ys2 = runner(u8)                          # the RPN head's raw per-level outputs (B,H,W,16): [A logits | 4A deltas | pad]
         A = pg.rpn_head.num_anchors
+        ys2 = pg.rpn_head.level_views(ys2, [feats2[f] for f in pg.in_features])      # (the levels arrive stacked in one map)
         logits2 = [y[..., :A].reshape(y.shape[0], -1) for y in ys2]
         deltas2 = [y[..., A:5 * A].reshape(y.shape[0], -1, 4) for y in ys2]
         loss2 = sum((f.float() ** 2).mean() for f in feats2.values()) + sum(l.mean() for l in logits2) + sum((d ** 2).mean() for d in deltas2)
