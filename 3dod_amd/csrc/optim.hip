@@ -71,6 +71,62 @@ extern "C" int cr_sgd_step(cr_ctx* ctx, float* p, const float* g, float* m, int6
     return CR_OK;
 }
 
+// torch.optim.Adam / AdamW (cubercnn/solver/build.py:57-64 selects them with eps = 1e-2, optionally amsgrad), one launch per
+// hyper-parameter segment like k_sgd:
+//   Adam   g' = g * gscale + wd * p                       AdamW   p *= 1 - lr * wd ;  g' = g * gscale
+//   m = b1 m + (1 - b1) g' ;  v = b2 v + (1 - b2) g'^2 ;  amsgrad: vmax = max(vmax, v), used in place of v
+//   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// t is the number of updates actually applied: it lives on the device (`step`, advanced by k_adam_tick unless the step is
+// skipped), so a skipped step leaves the optimizer state untouched exactly like the host-side `continue` of train_net.py:246.
+__global__ void k_adam_tick(float* __restrict__ step, const int* __restrict__ skip) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !(skip && *skip)) *step += 1.f;
+}
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, float* __restrict__ vmax, int64_t n, float lr_base,
+                                              const float* __restrict__ lr_scale, float b1, float b2, float eps, float wd,
+                                              float gscale, int decoupled, const float* __restrict__ step,
+                                              const int* __restrict__ skip) {
+    if (skip && *skip) return;
+    const float lr = lr_scale ? lr_base * *lr_scale : lr_base;
+    const float t = *step;
+    const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float pv = p[i];
+        float gv = g[i] * gscale;
+        if (decoupled) pv *= 1.f - lr * wd; else gv += wd * pv;
+        const float mv = b1 * m[i] + (1.f - b1) * gv;
+        float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        if (vmax) { vv = fmaxf(vmax[i], vv); vmax[i] = vv; }
+        p[i] = pv - step_size * (mv / (sqrtf(vv) / bc2s + eps));
+    }
+}
+
+// step: device float, the number of applied updates (advance it once per optimizer step with cr_adam_tick BEFORE the segments)
+extern "C" int cr_adam_tick(cr_ctx* ctx, float* step, const int* skip_flag) {
+    CR_CHECK_ARG(ctx && step, "cr_adam_tick: NULL pointer");
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, ctx->stream, step, skip_flag);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+extern "C" int cr_adam_step(cr_ctx* ctx, float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                            int64_t n, float lr, const float* lr_scale_dev, float beta1, float beta2, float eps,
+                            float weight_decay, float grad_scale, int decoupled, const float* step, const int* skip_flag) {
+    CR_CHECK_ARG(ctx && n >= 0, "cr_adam_step: bad args");
+    if (n == 0) return CR_OK;
+    CR_CHECK_ARG(p && g && exp_avg && exp_avg_sq && step, "cr_adam_step: NULL pointer");
+    int64_t nb = cr_cdiv(n, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)nb), dim3(256), 0, ctx->stream, p, g, exp_avg, exp_avg_sq, max_exp_avg_sq, n, lr,
+                       lr_scale_dev, beta1, beta2, eps, weight_decay, grad_scale, decoupled, step, skip_flag);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
 // Multi-segment copy / accumulate: segment d moves n floats from src to dst (mode 0: dst = src, 1: dst += src); one thread
 // per float, the segment found by binary search over the running item count.  Used to stack the predictor weights of a
 // head into one GEMM operand (and to route the stacked gradient back into the flat gradient) with ONE launch instead of

@@ -174,11 +174,54 @@ class FlatSGD:
         self.refresh_lr()
 
 
+class FlatAdam(FlatSGD):
+    """torch.optim.Adam / AdamW (optionally amsgrad) on the flat buffers of FlatSGD: `flat_m` is exp_avg, `flat_v` exp_avg_sq,
+    `flat_vmax` the amsgrad maximum; betas (0.9, 0.999) are torch's defaults, eps is the caller's (the reference passes 1e-2,
+    solver/build.py:57-64).  The count of applied updates lives on the device (a skipped step does not advance it)."""
+
+    def __init__(self, groups, eps=1e-2, betas=(0.9, 0.999), decoupled=False, amsgrad=False):
+        super().__init__(groups, momentum=0.0)
+        self.eps, self.betas, self.decoupled, self.amsgrad = float(eps), (float(betas[0]), float(betas[1])), bool(decoupled), bool(amsgrad)
+        self.flat_v = torch.zeros_like(self.flat_m)
+        self.flat_vmax = torch.zeros_like(self.flat_m) if amsgrad else None
+        self.step_dev = torch.zeros(1, dtype=torch.float32, device=self.flat_p.device)
+
+    def step(self, skip_flag=None, grad_scale=1.0):
+        self.refresh_lr()
+        ops.adam_tick(self.step_dev, skip_flag)
+        for (a, b, lr, wd) in self.segments:
+            ops.adam_step(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b],
+                          None if self.flat_vmax is None else self.flat_vmax[a:b], lr, self.betas[0], self.betas[1], self.eps, wd,
+                          self.step_dev, grad_scale, skip_flag, lr_scale_dev=self._lr_dev, decoupled=self.decoupled)
+        ops.bump_weight_epoch()
+
+    def state_dict(self):
+        sd = {"exp_avg": self.flat_m, "exp_avg_sq": self.flat_v, "step": self.step_dev, "lr_scale": self.lr_scale}
+        if self.flat_vmax is not None:
+            sd["max_exp_avg_sq"] = self.flat_vmax
+        return sd
+
+    def load_state_dict(self, sd):
+        self.flat_m.copy_(sd["exp_avg"])
+        self.flat_v.copy_(sd["exp_avg_sq"])
+        self.step_dev.copy_(sd["step"])
+        if self.flat_vmax is not None:
+            self.flat_vmax.copy_(sd["max_exp_avg_sq"])
+        self.lr_scale = sd.get("lr_scale", 1.0)
+        self.refresh_lr()
+
+
 def build_optimizer(cfg, model):
-    """solver/build.py:6-69; only the SGD type is built (the reference's default and BASELINE config)."""
-    if cfg.SOLVER.TYPE != 'sgd':
-        raise ValueError('{} is not supported as an optimizer.'.format(cfg.SOLVER.TYPE))
-    return FlatSGD(_param_groups(cfg, model), cfg.SOLVER.MOMENTUM, cfg.SOLVER.NESTEROV)
+    """solver/build.py:6-69: 'sgd' (the reference's default and every shipped config), 'adam', 'adam+amsgrad', 'adamw',
+    'adamw+amsgrad' (eps 1e-2 as there); anything else raises like the reference.  SOLVER.CLIP_GRADIENTS (detectron2
+    maybe_add_gradient_clipping [third-party]) is off in every shipped config and not built."""
+    groups = _param_groups(cfg, model)
+    t = cfg.SOLVER.TYPE
+    if t == 'sgd':
+        return FlatSGD(groups, cfg.SOLVER.MOMENTUM, cfg.SOLVER.NESTEROV)
+    if t in ('adam', 'adam+amsgrad', 'adamw', 'adamw+amsgrad'):
+        return FlatAdam(groups, eps=1e-02, decoupled=t.startswith('adamw'), amsgrad=t.endswith('+amsgrad'))
+    raise ValueError('{} is not supported as an optimizer.'.format(t))
 
 
 def early_allreduce_ranges(model, optimizer):

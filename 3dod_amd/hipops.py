@@ -2136,6 +2136,22 @@ def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None
                          float(weight_decay), float(grad_scale), _p(skip_flag)), "cr_sgd_step")
 
 
+def adam_tick(step, skip_flag=None):
+    """advance the device-side count of applied Adam updates unless the step is skipped (cr_adam_tick)"""
+    _p = _Args()
+    _chk(_lib.load().cr_adam_tick(_ctx(step), _p(step), _p(skip_flag)), "cr_adam_tick")
+
+
+def adam_step(p, g, exp_avg, exp_avg_sq, max_exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, skip_flag=None,
+              lr_scale_dev=None, decoupled=False):
+    """torch.optim.Adam (decoupled=False) / AdamW (True) on one hyper-parameter segment of the flat buffers; max_exp_avg_sq:
+    the amsgrad state or None; step: device float advanced by adam_tick"""
+    _p = _Args()
+    _chk(_lib.load().cr_adam_step(_ctx(p), _p(p), _p(g), _p(exp_avg), _p(exp_avg_sq), _p(max_exp_avg_sq), p.numel(), float(lr),
+                                  _p(lr_scale_dev), float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale),
+                                  int(bool(decoupled)), _p(step), _p(skip_flag)), "cr_adam_step")
+
+
 # --------------------------------------------------------------------------
 # Depth-Anything-V2 forward ops (inference only: no autograd)
 # --------------------------------------------------------------------------

@@ -559,6 +559,14 @@ int cr_nonfinite_flag(cr_ctx* ctx, const float* g, int64_t n, int* flag);
  * tools/train_net.py:410-414) is given, so a launch captured in a HIP graph follows the schedule. */
 int cr_sgd_step(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, const float* lr_scale_dev,
                 float momentum, float weight_decay, float grad_scale, const int* skip_flag);
+/* torch.optim.Adam / AdamW with the reference's eps (cubercnn/solver/build.py:57-64: 'adam', 'adam+amsgrad', 'adamw',
+ * 'adamw+amsgrad'), fused like cr_sgd_step: one launch per hyper-parameter segment of the flat buffers; decoupled = 1: AdamW.
+ * max_exp_avg_sq: amsgrad state or NULL.  step: device float = number of applied updates, advanced by cr_adam_tick once per
+ * optimizer step before the segments; both kernels do nothing when *skip_flag != 0 (train_net.py:246). */
+int cr_adam_tick(cr_ctx* ctx, float* step, const int* skip_flag);
+int cr_adam_step(cr_ctx* ctx, float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n,
+                 float lr, const float* lr_scale_dev, float beta1, float beta2, float eps, float weight_decay,
+                 float grad_scale, int decoupled, const float* step, const int* skip_flag);
 
 #ifdef __cplusplus
 }
