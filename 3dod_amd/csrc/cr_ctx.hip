@@ -13,7 +13,7 @@ void cr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cr_last_error(void) { return g_err; }
-extern "C" int cr_abi_version(void) { return 4; }   // 2: act_f32 argument on the activation entry points; 3: split mode (act_f32 = 2, w_split); 4: cr_roi_align_bwd_set, iou_boxes of cr_cubes_project_score
+extern "C" int cr_abi_version(void) { return 5; }   // 5: z_type of cr_cube_select(_bwd) / cr_cube_decode_infer; 2: act_f32 argument on the activation entry points; 3: split mode (act_f32 = 2, w_split); 4: cr_roi_align_bwd_set, iou_boxes of cr_cubes_project_score
 
 extern "C" int cr_ctx_create(int device, void* hip_stream, cr_ctx** out) {
     CR_CHECK_ARG(out != nullptr, "cr_ctx_create: out is NULL");

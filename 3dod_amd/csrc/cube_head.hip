@@ -267,7 +267,16 @@ struct CubeSel {
     const int64_t* cls; const unsigned char* valid; const int64_t* gt_idx;   // (B,S) rows, first kf columns used
     int S, kf, G, n;
     const float* gt3d; const float* gtpose; const float* priors; const float* meta;
+    int z_type;          // 0 direct | 1 sigmoid: z = 100 sigmoid(raw) | 2 log: z = exp(raw)   (roi_heads.py:2404-2410)
 };
+
+// depth parametrisation of MODEL.ROI_CUBE_HEAD.Z_TYPE (before the virtual-depth factor) and its derivative
+__device__ __forceinline__ float z_decode(float raw, int z_type, float* dz) {
+    if (z_type == 1) { const float sg = 1.f / (1.f + expf(-raw)); if (dz) *dz = 100.f * sg * (1.f - sg); return 100.f * sg; }
+    if (z_type == 2) { const float e = expf(raw); if (dz) *dz = e; return e; }
+    if (dz) *dz = 1.f;
+    return raw;
+}
 __device__ __constant__ int CUBE_OFF[12] = {0, 2, 3, 6, 15, 16, 20, 21, 24, 26, 27, 30};   // chunk starts (x n)
 
 __device__ __forceinline__ void rot6d(const float* a, float* R, float* n1, float* nu) {
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(64) void k_cube_select(CubeSel p, float* __restrict
     const size_t n = p.n;
     float* o = buf;
     o[CUBE_OFF[0] * n + i * 2] = r[p.o_d2 + c * 2]; o[CUBE_OFF[0] * n + i * 2 + 1] = r[p.o_d2 + c * 2 + 1];
-    o[CUBE_OFF[1] * n + i] = r[p.o_z + c];
+    o[CUBE_OFF[1] * n + i] = z_decode(r[p.o_z + c], p.z_type, nullptr);
 #pragma unroll
     for (int k = 0; k < 3; ++k) o[CUBE_OFF[2] * n + i * 3 + k] = r[p.o_dims + c * 3 + k];
     float a[6], R[9], l1, lu;
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(64) void k_cube_select_bwd(CubeSel p, const unsigne
             // b1 = a1 / |a1|
             const float dot1 = gb1[0] * b1[0] + gb1[1] * b1[1] + gb1[2] * b1[2];
             for (int k = 0; k < 3; ++k) { s[5 + k] = (gb1[k] - dot1 * b1[k]) / l1; s[8 + k] = ga2[k]; }
-            s[11] = g_zr[i];
+            { float dz; z_decode(r[p.o_z + c], p.z_type, &dz); s[11] = g_zr[i] * dz; }
             s[12] = r[p.o_unc + c] >= 0.01f ? g_u[i] + g_usel[i] : 0.f;      // clip(0.01) passes the gradient where raw >= 0.01
         }
     }
@@ -383,22 +392,23 @@ __global__ __launch_bounds__(64) void k_cube_select_bwd(CubeSel p, const unsigne
 
 static int cube_sel_args(CubeSel& p, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
                          const unsigned char* valid, const int64_t* gt_idx, int B, int S, int kf, int G, const float* gt3d,
-                         const float* gtpose, const float* priors, const float* meta) {
+                         const float* gtpose, const float* priors, const float* meta, int z_type) {
     CR_CHECK_ARG(raw && layout5 && cls && valid && gt_idx && gt3d && gtpose && meta, "cube_select: NULL pointer");
     CR_CHECK_ARG(B > 0 && kf > 0 && kf <= S && G > 0 && K > 0 && ld >= 13 * K, "cube_select: bad sizes");
     p.raw = raw; p.ld = ld; p.o_d2 = layout5[0]; p.o_dims = layout5[1]; p.o_pose = layout5[2]; p.o_z = layout5[3];
     p.o_unc = layout5[4]; p.K = K; p.cls = cls; p.valid = valid; p.gt_idx = gt_idx; p.S = S; p.kf = kf; p.G = G; p.n = B * kf;
-    p.gt3d = gt3d; p.gtpose = gtpose; p.priors = priors; p.meta = meta;
+    p.gt3d = gt3d; p.gtpose = gtpose; p.priors = priors; p.meta = meta; p.z_type = z_type;
+    CR_CHECK_ARG(z_type >= 0 && z_type <= 2, "cube_select: z_type %d (0 direct, 1 sigmoid, 2 log)", z_type);
     return CR_OK;
 }
 
 extern "C" int cr_cube_select(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
                               const unsigned char* valid, const int64_t* gt_idx, int B, int S, int kf, int G,
                               const float* gt3d, const float* gtpose, const float* priors, const float* meta, float* buf39,
-                              unsigned char* validf, int* clsc) {
+                              unsigned char* validf, int* clsc, int z_type) {
     CR_CHECK_ARG(ctx && buf39 && validf && clsc, "cr_cube_select: NULL pointer");
     CubeSel p;
-    int rc = cube_sel_args(p, raw, ld, layout5, K, cls, valid, gt_idx, B, S, kf, G, gt3d, gtpose, priors, meta);
+    int rc = cube_sel_args(p, raw, ld, layout5, K, cls, valid, gt_idx, B, S, kf, G, gt3d, gtpose, priors, meta, z_type);
     if (rc) return rc;
     hipLaunchKernelGGL(k_cube_select, dim3((unsigned)cr_cdiv(p.n, 64)), dim3(64), 0, ctx->stream, p, buf39, validf, clsc);
     CR_LAUNCH_CHECK();
@@ -407,10 +417,13 @@ extern "C" int cr_cube_select(cr_ctx* ctx, const float* raw, int ld, const int* 
 
 extern "C" int cr_cube_select_bwd(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, int B, int kf,
                                   const unsigned char* validf, const int* clsc, const float* g_dxy, const float* g_zr,
-                                  const float* g_dr, const float* g_Ra, const float* g_u, const float* g_usel, float* g_raw) {
+                                  const float* g_dr, const float* g_Ra, const float* g_u, const float* g_usel, float* g_raw,
+                                  int z_type) {
     CR_CHECK_ARG(ctx && raw && layout5 && validf && clsc && g_dxy && g_zr && g_dr && g_Ra && g_u && g_usel && g_raw,
                  "cr_cube_select_bwd: NULL pointer");
+    CR_CHECK_ARG(z_type >= 0 && z_type <= 2, "cr_cube_select_bwd: z_type %d", z_type);
     CubeSel p = {};
+    p.z_type = z_type;
     p.raw = raw; p.ld = ld; p.o_d2 = layout5[0]; p.o_dims = layout5[1]; p.o_pose = layout5[2]; p.o_z = layout5[3];
     p.o_unc = layout5[4]; p.K = K; p.kf = kf; p.n = B * kf;
     if (p.n == 0) return CR_OK;
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(64) void k_cube_decode_infer(const float* __restric
                                                           int o_z, int o_unc, int K, const int64_t* __restrict__ cls,
                                                           const int* __restrict__ img, const float* __restrict__ boxes,
                                                           const float* __restrict__ meta, const float* __restrict__ priors,
-                                                          int n, int allocentric, float* __restrict__ out) {
+                                                          int n, int allocentric, float* __restrict__ out, int z_type) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const int64_t c0 = cls[i];
@@ -542,7 +555,7 @@ __global__ __launch_bounds__(64) void k_cube_decode_infer(const float* __restric
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             R[p * 3 + q] = rot ? (M[p * 3] * Ra[q] + M[p * 3 + 1] * Ra[3 + q]) + M[p * 3 + 2] * Ra[6 + q] : Ra[p * 3 + q];
-    const float z = r[o_z + c] * m[4];
+    const float z = z_decode(r[o_z + c], z_type, nullptr) * m[4];
     const float ctr[3] = {z * (cux - K4[2]) / K4[0], z * (cuy - K4[3]) / K4[1], z};
     float* o = out + (size_t)i * 42;
     o[0] = ctr[0]; o[1] = ctr[1]; o[2] = ctr[2];
@@ -559,12 +572,12 @@ __global__ __launch_bounds__(64) void k_cube_decode_infer(const float* __restric
 
 extern "C" int cr_cube_decode_infer(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
                                     const int* img, const float* boxes, const float* meta6, const float* priors, int n,
-                                    int allocentric, float* out42) {
-    CR_CHECK_ARG(ctx && n >= 0, "cr_cube_decode_infer: bad args");
+                                    int allocentric, float* out42, int z_type) {
+    CR_CHECK_ARG(ctx && n >= 0 && z_type >= 0 && z_type <= 2, "cr_cube_decode_infer: bad args");
     if (n == 0) return CR_OK;
     CR_CHECK_ARG(raw && layout5 && cls && img && boxes && meta6 && out42 && K > 0 && ld >= 13 * K, "cr_cube_decode_infer: bad args");
     hipLaunchKernelGGL(k_cube_decode_infer, dim3((unsigned)cr_cdiv(n, 64)), dim3(64), 0, ctx->stream, raw, ld, layout5[0],
-                       layout5[1], layout5[2], layout5[3], layout5[4], K, cls, img, boxes, meta6, priors, n, allocentric, out42);
+                       layout5[1], layout5[2], layout5[3], layout5[4], K, cls, img, boxes, meta6, priors, n, allocentric, out42, z_type);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

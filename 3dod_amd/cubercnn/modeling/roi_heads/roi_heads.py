@@ -162,8 +162,10 @@ class ROIHeads3D(StandardROIHeads):
         self.cluster_bins = c.CLUSTER_BINS
         self.dims_priors_enabled = c.DIMS_PRIORS_ENABLED
         self.dims_priors_func = c.DIMS_PRIORS_FUNC
-        if self.z_type != "direct" or self.cluster_bins > 1 or not self.disentangled_loss:
-            raise ValueError("only Z_TYPE 'direct', CLUSTER_BINS 1 and the disentangled loss of configs/Base.yaml are built")
+        if self.z_type not in ('direct', 'sigmoid', 'log') or self.cluster_bins > 1 or not self.disentangled_loss:
+            raise ValueError("built: Z_TYPE 'direct' / 'sigmoid' / 'log', CLUSTER_BINS 1, the disentangled loss (configs/Base.yaml); "
+                             "got Z_TYPE '{}', CLUSTER_BINS {}, DISENTANGLED_LOSS {}".format(self.z_type, self.cluster_bins,
+                                                                                           self.disentangled_loss))
         if self.loss_w_3d > 0 and (self.use_confidence <= 0 or (self.dims_priors_enabled and self.dims_priors_func != 'exp')):
             raise ValueError("the fused 3D-head kernels are built for USE_CONFIDENCE > 0 and DIMS_PRIORS_FUNC 'exp' "
                              "(configs/Base.yaml); got USE_CONFIDENCE {} / DIMS_PRIORS_FUNC '{}'".format(
@@ -294,7 +296,7 @@ class ROIHeads3D(StandardROIHeads):
             meta6 = torch.tensor(rows, dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
             priors = self.priors_dims_per_cat.detach()[0, :, 0, :].contiguous() if self.dims_priors_enabled else None
             out = ops.cube_decode_infer(raw, layout, K, ocls.reshape(-1), idx, flat.tensor, meta6, priors,
-                                        allocentric=self.allocentric_pose).view(B, D, 42)
+                                        allocentric=self.allocentric_pose, z_type=self.z_type).view(B, D, 42)
             score3 = (osc * out[:, :, 8]) ** (1 / 2)
         counts = ocnt.tolist()                                   # the one host wait of the step
         if any(c[1] for c in counts):
@@ -402,7 +404,7 @@ class ROIHeads3D(StandardROIHeads):
         meta6 = torch.tensor(rows, dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
         priors = self.priors_dims_per_cat.detach()[0, :, 0, :].contiguous() if self.dims_priors_enabled else None
         out = ops.cube_decode_infer(raw, layout, self.num_classes, box_classes, idx, torch.cat([b.tensor for b in boxes]),
-                                    meta6, priors, allocentric=self.allocentric_pose)
+                                    meta6, priors, allocentric=self.allocentric_pose, z_type=self.z_type)
         for inst, o, cls_i in zip(instances, out.split(counts), box_classes.split(counts)):
             m = o.shape[0]
             inst.scores = (inst.scores * o[:, 8]) ** (1 / 2) if inst.has('scores') else o[:, 8]

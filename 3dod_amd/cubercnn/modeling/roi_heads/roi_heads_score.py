@@ -213,6 +213,10 @@ class ROIHeads3DScore(ROIHeads3D):
         if self.allocentric_pose:
             cube_pose = util.R_from_allocentric(Ks_scaled_per_box, cube_pose, u=cube_x.detach(), v=cube_y.detach())
         cube_z = cube_z.squeeze(1)
+        if self.z_type == 'sigmoid':                        # roi_heads.py:1495-1501
+            cube_z = torch.sigmoid(cube_z) * 100
+        elif self.z_type == 'log':
+            cube_z = torch.exp(cube_z)
         if self.virtual_depth:
             cube_z = cube_z * virtual_to_real
 

@@ -1740,6 +1740,13 @@ def box_loss(scores, deltas, valid, cls, pboxes, gt_idx, gt_boxes, weights, scal
 # 3D head on the static-shape path: class gather + fused decode/loss + reductions
 # --------------------------------------------------------------------------
 CUBE_OFF = (0, 2, 3, 6, 15, 16, 20, 21, 24, 26, 27, 30)      # chunk starts of buf39 (x n), see include/cr3dod.h
+Z_TYPES = {"direct": 0, "sigmoid": 1, "log": 2}           # MODEL.ROI_CUBE_HEAD.Z_TYPE values the kernels decode (roi_heads.py:2404-2410)
+
+
+def z_type_code(z_type):
+    if z_type not in Z_TYPES:
+        raise ValueError(f"Z_TYPE '{z_type}' is not built (built: {sorted(Z_TYPES)})")
+    return Z_TYPES[z_type]
 CUBE_DIM = (2, 1, 3, 9, 1, 4, 1, 3, 2, 1, 3, 9)
 
 
@@ -1766,14 +1773,14 @@ class _CubeHeadLoss(torch.autograd.Function):
         _chk(lib.cr_cube_select(_ctx(raw), _p(raw32), raw32.shape[1], lay, int(K), _p(cls.contiguous()),
                                 _p(valid.to(torch.uint8).contiguous()), _p(gt_idx.contiguous()), B, S, int(kf), gt3d.shape[1],
                                 _p(gt3d.contiguous()), _p(gtpose.contiguous()), _p(priors), _p(meta.contiguous()), _p(buf),
-                                _p(validf), _p(clsc)), "cr_cube_select")
+                                _p(validf), _p(clsc), int(flags[4])), "cr_cube_select")
         ch = _chunks(buf, n)
         boxes = boxes.contiguous()
         ins = ch[:5] + [boxes] + ch[5:]
         arr = (ctypes.c_void_p * 13)(*[t.data_ptr() for t in ins])
         losses = torch.empty((n, 5), dtype=f32, device=dev)
         dec = torch.empty((n, 17), dtype=f32, device=dev)
-        _chk(lib.cr_cube_loss_fwd(_ctx(raw), ctypes.cast(arr, ctypes.c_void_p), n, *flags, _p(losses), _p(dec)),
+        _chk(lib.cr_cube_loss_fwd(_ctx(raw), ctypes.cast(arr, ctypes.c_void_p), n, *flags[:4], _p(losses), _p(dec)),
              "cr_cube_loss_fwd")
         ctx.keep = (raw32, buf, validf, clsc, boxes, tuple(layout), int(K), B, int(kf), flags, raw.dtype)
         ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None, not as zero fills
@@ -1792,26 +1799,26 @@ class _CubeHeadLoss(torch.autograd.Function):
         g = torch.empty((16 * n,), dtype=f32, device=dev)
         g_dxy, g_zr, g_dr, g_Ra, g_u = g[:2 * n], g[2 * n:3 * n], g[3 * n:6 * n], g[6 * n:15 * n], g[15 * n:]
         lib = _lib.load()
-        _chk(lib.cr_cube_loss_bwd(_ctx(raw32), ctypes.cast(arr, ctypes.c_void_p), n, *flags, _p(gl.contiguous()),
+        _chk(lib.cr_cube_loss_bwd(_ctx(raw32), ctypes.cast(arr, ctypes.c_void_p), n, *flags[:4], _p(gl.contiguous()),
                                   _p(g_dxy), _p(g_zr), _p(g_dr), _p(g_Ra), _p(g_u)), "cr_cube_loss_bwd")
         g_raw = torch.empty_like(raw32)
         lay = (_ct.c_int * 5)(*layout)
         _chk(lib.cr_cube_select_bwd(_ctx(raw32), _p(raw32), raw32.shape[1], lay, K, B, kf, _p(validf), _p(clsc), _p(g_dxy),
-                                    _p(g_zr), _p(g_dr), _p(g_Ra), _p(g_u), _p(g_usel.contiguous()), _p(g_raw)),
+                                    _p(g_zr), _p(g_dr), _p(g_Ra), _p(g_u), _p(g_usel.contiguous()), _p(g_raw), int(flags[4])),
              "cr_cube_select_bwd")
         return (g_raw.to(dt),) + (None,) * 12
 
 
 def cube_head_loss(raw, layout, K, cls, valid, gt_idx, kf, gt3d, gtpose, priors, meta, boxes, allocentric=True,
-                   chamfer_pose=True, use_conf=True, joint=True):
+                   chamfer_pose=True, use_conf=True, joint=True, z_type="direct"):
     """raw (n,13K) fused predictor output; cls/valid/gt_idx (B,S); gt3d (B,G,9); gtpose (B,G,3,3); priors (K,3) or None;
     meta (B,5); boxes (n,4).  -> losses (n,5), u_sel (n), dec (n,17), buf39, validf (n) uint8."""
-    flags = (int(bool(allocentric)), int(bool(chamfer_pose)), int(bool(use_conf)), int(bool(joint)))
+    flags = (int(bool(allocentric)), int(bool(chamfer_pose)), int(bool(use_conf)), int(bool(joint)), z_type_code(z_type))
     return _CubeHeadLoss.apply(raw, tuple(layout), K, cls, valid, gt_idx, kf, gt3d, gtpose.reshape(gtpose.shape[0], -1, 9),
                                priors, meta, boxes, flags)
 
 
-def cube_decode_infer(raw, layout, K, cls, img, boxes, meta6, priors, allocentric=True):
+def cube_decode_infer(raw, layout, K, cls, img, boxes, meta6, priors, allocentric=True, z_type="direct"):
     """inference decode of the 3D head (no autograd) -> (n,42), see cr_cube_decode_infer."""
     _p = _Args()
     _need_cuda(raw, "cube head output")
@@ -1822,7 +1829,7 @@ def cube_decode_infer(raw, layout, K, cls, img, boxes, meta6, priors, allocentri
     lib = _lib.load()
     _chk(lib.cr_cube_decode_infer(_ctx(raw), _p(raw32), raw32.shape[1], lay, int(K), _p(cls.contiguous()),
                                   _p(img.to(torch.int32).contiguous()), _p(boxes.float().contiguous()), _p(meta6.contiguous()),
-                                  _p(priors), n, int(bool(allocentric)), _p(out)), "cr_cube_decode_infer")
+                                  _p(priors), n, int(bool(allocentric)), _p(out), z_type_code(z_type)), "cr_cube_decode_infer")
     return out
 
 
@@ -1875,7 +1882,7 @@ class _WeakCubeLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, layout, K, cls, valid, gt_idx, kf, gt_boxes, gt3d, gtpose, prior_mean, prior_std, meta, table, normals,
-                boxes, depth, terms, pgz_mode, weights, allocentric):
+                boxes, depth, terms, pgz_mode, weights, allocentric, zt):
         _p = _Args()
         _need_cuda(raw, "cube head output")
         B, S = cls.shape
@@ -1890,7 +1897,7 @@ class _WeakCubeLoss(torch.autograd.Function):
         cls, gt_idx, gt_boxes, table = cls.contiguous(), gt_idx.contiguous(), gt_boxes.float().contiguous(), table.contiguous()
         _chk(lib.cr_cube_select(_ctx(raw), _p(raw32), raw32.shape[1], lay, int(K), _p(cls), _p(valid.to(torch.uint8).contiguous()),
                                 _p(gt_idx), B, S, int(kf), G, _p(gt3d.contiguous()), _p(gtpose.contiguous()), _p(prior_mean),
-                                _p(meta.contiguous()), _p(buf), _p(validf), _p(clsc)), "cr_cube_select")
+                                _p(meta.contiguous()), _p(buf), _p(validf), _p(clsc), int(zt)), "cr_cube_select")
         ch = _chunks(buf, n)
         boxes = boxes.contiguous()
         ins = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in (ch[0], ch[1], ch[2], ch[3], ch[4], ch[6], ch[7], boxes)])
@@ -1923,7 +1930,7 @@ class _WeakCubeLoss(torch.autograd.Function):
                                      int(pgz_mode), wts, _p(Lraw), _p(dec), _p(pbox), _p(ibox), _p(pimg), _p(ztgt), _p(red), _p(cnt),
                                      _p(stats), _p(aux)), "cr_weak_loss_reduce")
         ctx.keep = (raw32, buf, validf, clsc, boxes, tuple(layout), int(K), B, int(kf), S, G, raw.dtype, cls, gt_idx, gt_boxes, prior_std,
-                    table, normals, int(bool(allocentric)), int(terms), out)
+                    table, normals, int(bool(allocentric)), int(terms), out, int(zt))
         dec2, pbox2 = dec.view(n, 17), pbox.view(n, 4)
         ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None, not as zero fills
         ctx.mark_non_differentiable(stats, dec2, pbox2, validf)
@@ -1933,7 +1940,7 @@ class _WeakCubeLoss(torch.autograd.Function):
     def backward(ctx, gred, *_unused):
         _p = _Args()
         (raw32, buf, validf, clsc, boxes, layout, K, B, kf, S, G, dt, cls, gt_idx, gt_boxes, prior_std, table, normals, allocentric, terms,
-         out) = ctx.keep
+         out, zt) = ctx.keep
         n = B * kf
         dev = raw32.device
         lib = _lib.load()
@@ -1952,12 +1959,12 @@ class _WeakCubeLoss(torch.autograd.Function):
         g_raw = torch.empty_like(raw32)
         lay = (_ct.c_int * 5)(*layout)
         _chk(lib.cr_cube_select_bwd(_ctx(raw32), _p(raw32), raw32.shape[1], lay, K, B, kf, _p(validf), _p(clsc), _p(g_dxy), _p(g_zr),
-                                    _p(g_dr), _p(g_Ra), _p(g_u), _p(zero), _p(g_raw)), "cr_cube_select_bwd")
-        return (g_raw.to(dt),) + (None,) * 20
+                                    _p(g_dr), _p(g_Ra), _p(g_u), _p(zero), _p(g_raw), zt), "cr_cube_select_bwd")
+        return (g_raw.to(dt),) + (None,) * 21
 
 
 def weak_cube_loss(raw, layout, K, cls, valid, gt_idx, kf, gt_boxes, gt3d, gtpose, prior_mean, prior_std, meta, table, normals, boxes,
-                   depth, terms, pgz_mode, weights, allocentric=True):
+                   depth, terms, pgz_mode, weights, allocentric=True, z_type="direct"):
     """Losses of the weakly supervised 3D head on the (B, kf) foreground slots (ROIHeads3DScore._forward_cube, training).
     raw (n,13K) fused predictor output; cls / valid / gt_idx (B,S); gt_boxes (B,G,4); gt3d (B,G,9); gtpose (B,G,3,3);
     prior_mean / prior_std (K,3) or None; meta (B,5) camera_meta(); table (B,20), normals (B,3) or None, depth (B,H,W) or
@@ -1966,7 +1973,8 @@ def weak_cube_loss(raw, layout, K, cls, valid, gt_idx, kf, gt_boxes, gt3d, gtpos
     if kf > WEAK_MAX_SLOTS:
         raise _lib.CrError(f"weak_cube_loss: {kf} foreground slots per image, the kernels take up to {WEAK_MAX_SLOTS}")
     return _WeakCubeLoss.apply(raw, tuple(layout), K, cls, valid, gt_idx, kf, gt_boxes, gt3d, gtpose.reshape(gtpose.shape[0], -1, 9),
-                               prior_mean, prior_std, meta, table, normals, boxes, depth, terms, pgz_mode, tuple(weights), allocentric)
+                               prior_mean, prior_std, meta, table, normals, boxes, depth, terms, pgz_mode, tuple(weights), allocentric,
+                               z_type_code(z_type))
 
 
 # --------------------------------------------------------------------------

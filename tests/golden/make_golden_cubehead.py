@@ -75,15 +75,19 @@ def make_case(seed, training, K_classes=50):
     return instances, Ks, ratios, head, priors
 
 
-def run(seed, training):
+def run(seed, training, z_type="direct"):
     instances, Ks, ratios, head, priors = make_case(seed, training)
+    if z_type == "log":
+        head["z"] = head["z"] - 1.5                      # exp(1.5 +- 0.5): a few metres
+    elif z_type == "sigmoid":
+        head["z"] = head["z"] - 6.0                      # 100 sigmoid(-3 +- 0.5): a few metres
     leaves = {k: v.clone().requires_grad_(training) for k, v in head.items()}
     pose = my_util.rotation_6d_to_matrix(leaves["pose6"].view(-1, 6)).view(leaves["pose6"].shape[0], -1, 3, 3)
     n = leaves["z"].shape[0]
     self = types.SimpleNamespace()
     cfgv = dict(in_features=["p2"], training=training, num_classes=50, scale_roi_boxes=0.0, virtual_depth=True,
                 virtual_focal=512.0, cluster_bins=1, use_confidence=1.0, dims_priors_enabled=True,
-                dims_priors_func="exp", allocentric_pose=True, z_type="direct", disentangled_loss=True,
+                dims_priors_func="exp", allocentric_pose=True, z_type=z_type, disentangled_loss=True,
                 chamfer_pose=True, loss_w_3d=1.0, loss_w_xy=1.0, loss_w_z=1.0, loss_w_dims=20.0, loss_w_pose=7.0,
                 loss_w_joint=1.0, inverse_z_weight=False)
     for k, v in cfgv.items():
@@ -137,6 +141,13 @@ if __name__ == "__main__":
     ev["scores_2d"] = torch.cat([i.scores for i in make_case(12, False)[0]]).numpy()
     np.savez_compressed(os.path.join(HERE, "cubehead_train.npz"), **tr)
     np.savez_compressed(os.path.join(HERE, "cubehead_eval.npz"), **ev)
+    for zt in ("sigmoid", "log"):                        # MODEL.ROI_CUBE_HEAD.Z_TYPE variants (roi_heads.py:2404-2410)
+        t2 = run(13, True, zt)
+        e2 = run(14, False, zt)
+        e2["scores_2d"] = torch.cat([i.scores for i in make_case(14, False)[0]]).numpy()
+        np.savez_compressed(os.path.join(HERE, "cubehead_train_z%s.npz" % zt), **t2)
+        np.savez_compressed(os.path.join(HERE, "cubehead_eval_z%s.npz" % zt), **e2)
+        print(zt, {k: float(v) for k, v in t2.items() if k.startswith("loss_")})
     for k in sorted(tr):
         if k.startswith("loss_"):
             print(k, float(tr[k]))

@@ -27,7 +27,7 @@ def test_header_symbols_exported():
     # and the python binding covers every declared entry point
     bound = set(lib_mod.SIGNATURES) | {"cr_last_error"}
     assert declared <= bound, f"unbound: {declared - bound}"
-    assert lib.cr_abi_version() == 4
+    assert lib.cr_abi_version() == 5
 
 
 def test_fails_loudly_without_gpu():

@@ -57,8 +57,13 @@ def _setup(heads, g, training):
     return insts, leaves, Ks, [float(r) for r in g["ratios"]]
 
 
-def test_forward_cube_training_matches_reference(heads, golden_dir):
-    g = np.load(os.path.join(golden_dir, "cubehead_train.npz"), allow_pickle=False)
+ZT = [("direct", ""), ("sigmoid", "_zsigmoid"), ("log", "_zlog")]      # MODEL.ROI_CUBE_HEAD.Z_TYPE (roi_heads.py:2404-2410)
+
+
+@pytest.mark.parametrize("z_type,suffix", ZT)
+def test_forward_cube_training_matches_reference(heads, golden_dir, z_type, suffix):
+    g = np.load(os.path.join(golden_dir, "cubehead_train%s.npz" % suffix), allow_pickle=False)
+    heads.z_type = z_type
     heads.train()
     insts, leaves, Ks, ratios = _setup(heads, g, True)
     with d2.EventStorage(0):
@@ -73,15 +78,19 @@ def test_forward_cube_training_matches_reference(heads, golden_dir):
     for f in ("pred_bbox3D", "pred_center_cam", "pred_center_2D", "pred_dimensions", "pred_pose", "scores"):
         got = torch.cat([i.get(f) for i in pred]).detach().numpy()
         np.testing.assert_allclose(got, g["out_" + f], rtol=1e-4, atol=1e-5, err_msg=f)
+    heads.z_type = "direct"
 
 
-def test_forward_cube_eval_matches_reference(heads, golden_dir):
-    g = np.load(os.path.join(golden_dir, "cubehead_eval.npz"), allow_pickle=False)
+@pytest.mark.parametrize("z_type,suffix", ZT)
+def test_forward_cube_eval_matches_reference(heads, golden_dir, z_type, suffix):
+    g = np.load(os.path.join(golden_dir, "cubehead_eval%s.npz" % suffix), allow_pickle=False)
+    heads.z_type = z_type
     heads.eval()
     insts, leaves, Ks, ratios = _setup(heads, g, False)
     with torch.no_grad():
         pred = heads._forward_cube({f: None for f in heads.in_features}, insts, Ks, [(512, 512)] * 3, ratios)
     heads.train()
+    heads.z_type = "direct"
     for f in ("pred_bbox3D", "pred_center_cam", "pred_center_2D", "pred_dimensions", "pred_pose", "scores"):
         got = torch.cat([i.get(f) for i in pred]).numpy()
         np.testing.assert_allclose(got, g["out_" + f], rtol=1e-4, atol=1e-5, err_msg=f)   # north_star: corners 1e-4 rel
