@@ -33,20 +33,35 @@ class CubeHead(nn.Module):
         self.pose_type = cfg.MODEL.ROI_CUBE_HEAD.POSE_TYPE
         self.cluster_bins = cfg.MODEL.ROI_CUBE_HEAD.CLUSTER_BINS
         self.shared_fc = cfg.MODEL.ROI_CUBE_HEAD.SHARED_FC
-        if not self.shared_fc or self.cluster_bins > 1 or cfg.MODEL.ROI_CUBE_HEAD.NUM_CONV > 0:
-            raise ValueError("only the shared-FC, single-bin cube head of configs/Base.yaml is built")
+        if self.cluster_bins > 1 or cfg.MODEL.ROI_CUBE_HEAD.NUM_CONV > 0:
+            raise ValueError("built: the single-bin cube head without convolutions (configs/Base.yaml), shared or per-predictor FC "
+                             "trunks; got CLUSTER_BINS {} / NUM_CONV {}".format(self.cluster_bins, cfg.MODEL.ROI_CUBE_HEAD.NUM_CONV))
         num_fc = cfg.MODEL.ROI_CUBE_HEAD.NUM_FC
         fc_dim = cfg.MODEL.ROI_CUBE_HEAD.FC_DIM
         self._in_chw = (input_shape.channels, input_shape.height, input_shape.width)
         self._output_size = self._in_chw
-        self.feature_generator = nn.Sequential()
+        # SHARED_FC = False (cube_head.py:56-111): one FC trunk per predictor, created in the reference's order (dims, XY, pose,
+        # Z, confidence per layer) so that a seeded initialisation matches
+        if self.shared_fc:
+            self.feature_generator = nn.Sequential()
+            trunks = [self.feature_generator]
+        else:
+            self.feature_generator_XY = nn.Sequential()
+            self.feature_generator_dims = nn.Sequential()
+            self.feature_generator_pose = nn.Sequential()
+            self.feature_generator_Z = nn.Sequential()
+            trunks = [self.feature_generator_dims, self.feature_generator_XY, self.feature_generator_pose, self.feature_generator_Z]
+            if self.use_conf:
+                self.feature_generator_conf = nn.Sequential()
+                trunks.append(self.feature_generator_conf)
         for k in range(num_fc):
             fc_dim_in = int(np.prod(self._output_size))
             self._output_size = fc_dim
-            fc = nn.Linear(fc_dim_in, fc_dim)
-            c2_xavier_fill(fc)
-            self.feature_generator.add_module("fc{}".format(k + 1), fc)
-            self.feature_generator.add_module("fc_relu{}".format(k + 1), nn.ReLU())
+            for gen in trunks:
+                fc = nn.Linear(fc_dim_in, fc_dim)
+                c2_xavier_fill(fc)
+                gen.add_module("fc{}".format(k + 1), fc)
+                gen.add_module("fc_relu{}".format(k + 1), nn.ReLU())
         self.bbox_3D_dims = nn.Linear(self._output_size, self.num_classes * 3)
         nn.init.normal_(self.bbox_3D_dims.weight, std=0.001)
         nn.init.constant_(self.bbox_3D_dims.bias, 0)
@@ -67,18 +82,37 @@ class CubeHead(nn.Module):
             nn.init.normal_(self.bbox_3D_uncertainty.weight, std=0.001)
             nn.init.constant_(self.bbox_3D_uncertainty.bias, 5)
 
-    def forward(self, x):
-        """x (n, H*W*C) bf16 in (h,w,c) order -> (deltas (n,K,2), z (n,K,1), dims (n,K,3), pose (n,K,3,3), uncert (n,K))."""
-        n = x.shape[0]
-        fcs = [m for m in self.feature_generator if isinstance(m, nn.Linear)]
+    def _trunk(self, gen, x):
+        fcs = [m for m in gen if isinstance(m, nn.Linear)]
         h = fc_nhwc(x, fcs[0], self._in_chw, relu=True)
         for fc in fcs[1:]:
             h = ops.linear(h, fc.weight, fc.bias, relu=True)
-        preds = [self.bbox_3D_center_deltas, self.bbox_3D_dims, self.bbox_3D_pose, self.bbox_3D_center_depth]
+        return h
+
+    def _separate(self, x):
+        """SHARED_FC = False (cube_head.py:170-178): every predictor on its own trunk -> [deltas, dims, pose6, z, (uncert)]"""
+        pairs = [(self.feature_generator_XY, self.bbox_3D_center_deltas), (self.feature_generator_dims, self.bbox_3D_dims),
+                 (self.feature_generator_pose, self.bbox_3D_pose), (self.feature_generator_Z, self.bbox_3D_center_depth)]
         if self.use_conf:
-            preds.append(self.bbox_3D_uncertainty)
-        y, offs = ops.linear_cat(h, [m.weight for m in preds], [m.bias for m in preds])      # the predictors as one GEMM
-        outs = [y[:, offs[i]:offs[i + 1]].float().contiguous() for i in range(len(preds))]
+            pairs.append((self.feature_generator_conf, self.bbox_3D_uncertainty))
+        outs = []
+        for gen, m in pairs:                  # (linear_cat pads the predictor's rows to the GEMM tile)
+            y, offs = ops.linear_cat(self._trunk(gen, x), [m.weight], [m.bias])
+            outs.append(y[:, offs[0]:offs[1]].float())
+        return outs
+
+    def forward(self, x):
+        """x (n, H*W*C) bf16 in (h,w,c) order -> (deltas (n,K,2), z (n,K,1), dims (n,K,3), pose (n,K,3,3), uncert (n,K))."""
+        n = x.shape[0]
+        if self.shared_fc:
+            h = self._trunk(self.feature_generator, x)
+            preds = [self.bbox_3D_center_deltas, self.bbox_3D_dims, self.bbox_3D_pose, self.bbox_3D_center_depth]
+            if self.use_conf:
+                preds.append(self.bbox_3D_uncertainty)
+            y, offs = ops.linear_cat(h, [m.weight for m in preds], [m.bias for m in preds])      # the predictors as one GEMM
+            outs = [y[:, offs[i]:offs[i + 1]].float().contiguous() for i in range(len(preds))]
+        else:
+            outs = [t.contiguous() for t in self._separate(x)]
         box_2d_deltas, box_dims, box_pose, box_z = outs[:4]
         box_uncert = outs[4].clip(0.01) if self.use_conf else None
         box_pose = rotation_6d_to_matrix(box_pose.view(-1, 6))
@@ -93,14 +127,14 @@ def _forward_fused(self, x):
     """training form for the static-shape path: the five predictors as ONE GEMM.  Returns (raw (n, 13K) f32, layout) with
     layout = column offsets of [deltas 2K, dims 3K, pose6d 6K, z K, uncert K]; the per-class gather, the 6D -> matrix
     conversion and the uncertainty clip happen in ops.cube_head_loss (only for each RoI's own class)."""
-    fcs = [m for m in self.feature_generator if isinstance(m, nn.Linear)]
-    h = fc_nhwc(x, fcs[0], self._in_chw, relu=True)
-    for fc in fcs[1:]:
-        h = ops.linear(h, fc.weight, fc.bias, relu=True)
     assert self.use_conf
+    K = self.num_classes
+    if not self.shared_fc:
+        # per-predictor trunks: five GEMM chains, their outputs laid side by side in the fused layout
+        return torch.cat(self._separate(x), 1), (0, 2 * K, 5 * K, 11 * K, 12 * K)
+    h = self._trunk(self.feature_generator, x)
     preds = [self.bbox_3D_center_deltas, self.bbox_3D_dims, self.bbox_3D_pose, self.bbox_3D_center_depth,
              self.bbox_3D_uncertainty]
-    K = self.num_classes
     y, offs = ops.linear_cat(h, [m.weight for m in preds], [m.bias for m in preds])
     assert tuple(offs[:5]) == (0, 2 * K, 5 * K, 11 * K, 12 * K)
     return y, tuple(offs[:5])                            # y (n, 13K rounded up to 16) f32; consumers take its row stride

@@ -183,7 +183,8 @@ ref_rh.Instances = d2.Instances
 ref_rh.Boxes = d2.Boxes
 ref_rh.pairwise_iou = structures.pairwise_iou
 ref_rh.pairwise_ioa = structures.pairwise_ioa
-ref_rh.add_ground_truth_to_proposals = my_rh.add_ground_truth_to_proposals
+from oracle import list_path as _lp   # noqa: E402  (detectron2 add_ground_truth_to_proposals [third-party], restated there)
+ref_rh.add_ground_truth_to_proposals = _lp.add_ground_truth_to_proposals
 ref_rh.get_event_storage = lambda: storage
 ref_rh.subsample_labels = _recording_subsample
 

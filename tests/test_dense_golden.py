@@ -53,3 +53,13 @@ def test_cube_head_forward_matches_reference(G, oracle_backend):
     syn = importlib.import_module("3dod_amd.synthetic")
     d2 = importlib.import_module("3dod_amd.d2lite")
     C.check_cube_head(ch, syn.make_cfg, d2, DEV, G)
+
+
+def test_cube_head_with_per_predictor_trunks_matches_reference(oracle_backend, golden_dir):
+    """MODEL.ROI_CUBE_HEAD.SHARED_FC = False (cube_head.py:56-111,170-178): the reference's own CubeHead with one FC trunk per
+    predictor (tests/golden/make_golden_cubehead_variants.py): state-dict names, seeded initialisation, the five outputs"""
+    import os
+    ch = importlib.import_module("3dod_amd.cubercnn.modeling.roi_heads.cube_head")
+    syn = importlib.import_module("3dod_amd.synthetic")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    C.check_cube_head(ch, syn.make_cfg, d2, DEV, C.load(os.path.join(golden_dir, "cubehead_nonshared.npz")), shared_fc=False)

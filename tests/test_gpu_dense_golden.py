@@ -41,6 +41,24 @@ def test_cube_head_forward_matches_reference(G, precision):
     C.check_cube_head(ch, syn.make_cfg, d2, DEV, G, tol=1e-5 if precision != "bf16" else 3e-2)
 
 
+def test_cube_head_with_per_predictor_trunks_matches_reference(golden_dir):
+    """SHARED_FC = False on the GPU kernels (five FC chains, outputs side by side in the fused layout) against the reference's
+    own CubeHead; and one train step of the model under that setting"""
+    import os
+    ch = importlib.import_module("3dod_amd.cubercnn.modeling.roi_heads.cube_head")
+    syn = importlib.import_module("3dod_amd.synthetic")
+    d2 = importlib.import_module("3dod_amd.d2lite")
+    C.check_cube_head(ch, syn.make_cfg, d2, DEV, C.load(os.path.join(golden_dir, "cubehead_nonshared.npz")), shared_fc=False)
+    bt = importlib.import_module("bench_train")
+    cfg, model, opt, syn2, solver = bt.build(DEV, extra=["MODEL.ROI_CUBE_HEAD.SHARED_FC", False])
+    assert hasattr(model.roi_heads.cube_head, "feature_generator_Z") and not hasattr(model.roi_heads.cube_head, "feature_generator")
+    step = solver.TrainStep(cfg, model, opt, world_size=1)
+    with d2.EventStorage(0):
+        step(syn2.make_batch(2, 3))
+        rep = step.report()
+    assert rep["iterations_explode"] == 0 and rep["total_loss"] == rep["total_loss"]
+
+
 @pytest.mark.parametrize("z_type,suffix", [("direct", ""), ("sigmoid", "_zsigmoid"), ("log", "_zlog")])
 def test_cube_decode_infer_kernel_matches_reference_eval_golden(golden_dir, z_type, suffix):
     """cr_cube_decode_infer (the fused inference decode of the 3D head, roi_heads.py:2353-2436,2682-2735) against
