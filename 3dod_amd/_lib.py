@@ -85,8 +85,8 @@ SIGNATURES = {
     "cr_weak_loss_reduce": [P, P, P, P, P, c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
                             P, P, P],
     "cr_weak_loss_bwd": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P],
-    "cr_cube_select": [P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int],
-    "cr_cube_select_bwd": [P, P, c_int, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int],
+    "cr_cube_select": [P, P, c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, c_int, P, P, P],
+    "cr_cube_select_bwd": [P, P, c_int, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P],
     "cr_cube_reduce": [P, P, P, P, P, c_int, c_int, P, P, P],
     "cr_cube_reduce_bwd": [P, P, P, P, c_int, c_int, P, P, P, P],
     "cr_weights_prepare": [P, P, P, P, P, P, c_int, c_int],
@@ -98,7 +98,7 @@ SIGNATURES = {
     "cr_transpose2d": [P, P, P, c_int, c_int, c_int],
     "cr_maxpool3x3s2_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int],
     "cr_maxpool3x3s2_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int],
-    "cr_cube_decode_infer": [P, P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, P, c_int],
+    "cr_cube_decode_infer": [P, P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, P, c_int, c_int, P, P],
     "cr_box3d_overlap": [P, P, P, c_int, c_int, P, P],
     "cr_nonfinite_flag": [P, P, c_int64, P],
     "cr_sgd_step": [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, P],

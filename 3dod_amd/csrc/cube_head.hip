@@ -267,15 +267,51 @@ struct CubeSel {
     const int64_t* cls; const unsigned char* valid; const int64_t* gt_idx;   // (B,S) rows, first kf columns used
     int S, kf, G, n;
     const float* gt3d; const float* gtpose; const float* priors; const float* meta;
-    int z_type;          // 0 direct | 1 sigmoid: z = 100 sigmoid(raw) | 2 log: z = exp(raw)   (roi_heads.py:2404-2410)
+    int z_type;          // 0 direct | 1 sigmoid: z = 100 sigmoid(raw) | 2 log: z = exp(raw) | 3 clusters: scaled sigmoid between
+                         // mean -+ 3 std of the RoI's depth cluster   (roi_heads.py:2404-2436)
+    int bins;            // MODEL.ROI_CUBE_HEAD.CLUSTER_BINS: the depth predictor has K * bins columns laid out [bin][class]
+    const float* z_scales;   // (K, bins) 2D-scale centre of every (class, bin)  (priors_z_scales)   -- bins > 1
+    const float* z_stats;    // (K, bins, 2) depth mean / std of every (class, bin) (priors_z_stats) -- z_type 3
+    const float* boxes;      // (n, 4) proposal boxes: the bin of a RoI is the one whose scale is closest to the box diagonal
 };
 
 // depth parametrisation of MODEL.ROI_CUBE_HEAD.Z_TYPE (before the virtual-depth factor) and its derivative
-__device__ __forceinline__ float z_decode(float raw, int z_type, float* dz) {
+__device__ __forceinline__ float z_decode(float raw, int z_type, float* dz, float mu = 0.f, float sd = 0.f) {
     if (z_type == 1) { const float sg = 1.f / (1.f + expf(-raw)); if (dz) *dz = 100.f * sg * (1.f - sg); return 100.f * sg; }
     if (z_type == 2) { const float e = expf(raw); if (dz) *dz = e; return e; }
+    if (z_type == 3) {
+        const float mn = fmaxf(mu - 3.f * sd, 0.f), mx = mu + 3.f * sd, sg = 1.f / (1.f + expf(-raw));
+        if (dz) *dz = (mx - mn) * sg * (1.f - sg);
+        return mn + (mx - mn) * sg;
+    }
     if (dz) *dz = 1.f;
     return raw;
+}
+
+// cluster bin of RoI i with class c (roi_heads.py:2343-2356): argmin over the bins of |scale[c][b] - box diagonal|, first minimum
+__device__ __forceinline__ int z_bin(const float* z_scales, const float* boxes, int bins, int i, int c) {
+    if (bins <= 1) return 0;
+    const float* b = boxes + (size_t)i * 4;
+    const float w = b[2] - b[0], h = b[3] - b[1];
+    const float diag = sqrtf(h * h + w * w);
+    int best = 0;
+    float bd = fabsf(z_scales[c * bins] - diag);
+    for (int k = 1; k < bins; ++k) {
+        const float d = fabsf(z_scales[c * bins + k] - diag);
+        if (d < bd) { bd = d; best = k; }
+    }
+    return best;
+}
+
+// the RoI's depth: column o_z + bin * K + c of the predictor output, decoded
+__device__ __forceinline__ float z_of(const float* r, int o_z, int K, int c, int i, int z_type, int bins, const float* z_scales,
+                                      const float* z_stats, const float* boxes, float* dz, int* col) {
+    const int bin = z_bin(z_scales, boxes, bins, i, c);
+    const int cz = o_z + bin * K + c;
+    if (col) *col = cz;
+    float mu = 0.f, sd = 0.f;
+    if (z_type == 3) { mu = z_stats[(c * bins + bin) * 2]; sd = z_stats[(c * bins + bin) * 2 + 1]; }
+    return z_decode(r[cz], z_type, dz, mu, sd);
 }
 __device__ __constant__ int CUBE_OFF[12] = {0, 2, 3, 6, 15, 16, 20, 21, 24, 26, 27, 30};   // chunk starts (x n)
 
@@ -307,7 +343,7 @@ __global__ __launch_bounds__(64) void k_cube_select(CubeSel p, float* __restrict
     const size_t n = p.n;
     float* o = buf;
     o[CUBE_OFF[0] * n + i * 2] = r[p.o_d2 + c * 2]; o[CUBE_OFF[0] * n + i * 2 + 1] = r[p.o_d2 + c * 2 + 1];
-    o[CUBE_OFF[1] * n + i] = z_decode(r[p.o_z + c], p.z_type, nullptr);
+    o[CUBE_OFF[1] * n + i] = z_of(r, p.o_z, p.K, c, i, p.z_type, p.bins, p.z_scales, p.z_stats, p.boxes, nullptr, nullptr);
 #pragma unroll
     for (int k = 0; k < 3; ++k) o[CUBE_OFF[2] * n + i * 3 + k] = r[p.o_dims + c * 3 + k];
     float a[6], R[9], l1, lu;
@@ -372,11 +408,12 @@ __global__ __launch_bounds__(64) void k_cube_select_bwd(CubeSel p, const unsigne
             // b1 = a1 / |a1|
             const float dot1 = gb1[0] * b1[0] + gb1[1] * b1[1] + gb1[2] * b1[2];
             for (int k = 0; k < 3; ++k) { s[5 + k] = (gb1[k] - dot1 * b1[k]) / l1; s[8 + k] = ga2[k]; }
-            { float dz; z_decode(r[p.o_z + c], p.z_type, &dz); s[11] = g_zr[i] * dz; }
+            { float dz; z_of(r, p.o_z, p.K, c, i, p.z_type, p.bins, p.z_scales, p.z_stats, p.boxes, &dz, nullptr); s[11] = g_zr[i] * dz; }
             s[12] = r[p.o_unc + c] >= 0.01f ? g_u[i] + g_usel[i] : 0.f;      // clip(0.01) passes the gradient where raw >= 0.01
         }
     }
     __syncthreads();
+    const int zcol = p.o_z + z_bin(p.z_scales, p.boxes, p.bins, i, c) * p.K + c;
     float* g = g_raw + (size_t)i * p.ld;
     for (int col = lane; col < p.ld; col += 64) {
         float val = 0.f;
@@ -384,7 +421,7 @@ __global__ __launch_bounds__(64) void k_cube_select_bwd(CubeSel p, const unsigne
         if ((e = col - (p.o_d2 + c * 2)) >= 0 && e < 2) val = s[e];
         else if ((e = col - (p.o_dims + c * 3)) >= 0 && e < 3) val = s[2 + e];
         else if ((e = col - (p.o_pose + c * 6)) >= 0 && e < 6) val = s[5 + e];
-        else if (col == p.o_z + c) val = s[11];
+        else if (col == zcol) val = s[11];
         else if (col == p.o_unc + c) val = s[12];
         g[col] = val;
     }
@@ -392,23 +429,29 @@ __global__ __launch_bounds__(64) void k_cube_select_bwd(CubeSel p, const unsigne
 
 static int cube_sel_args(CubeSel& p, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
                          const unsigned char* valid, const int64_t* gt_idx, int B, int S, int kf, int G, const float* gt3d,
-                         const float* gtpose, const float* priors, const float* meta, int z_type) {
+                         const float* gtpose, const float* priors, const float* meta, int z_type, int bins,
+                         const float* z_scales, const float* z_stats, const float* boxes) {
     CR_CHECK_ARG(raw && layout5 && cls && valid && gt_idx && gt3d && gtpose && meta, "cube_select: NULL pointer");
-    CR_CHECK_ARG(B > 0 && kf > 0 && kf <= S && G > 0 && K > 0 && ld >= 13 * K, "cube_select: bad sizes");
+    CR_CHECK_ARG(bins >= 1 && B > 0 && kf > 0 && kf <= S && G > 0 && K > 0 && ld >= (12 + bins) * K, "cube_select: bad sizes");
+    CR_CHECK_ARG(bins == 1 || (z_scales && boxes), "cube_select: CLUSTER_BINS > 1 needs the scale centres and the RoI boxes");
+    CR_CHECK_ARG(z_type != 3 || (bins > 1 && z_stats), "cube_select: Z_TYPE 'clusters' needs CLUSTER_BINS > 1 and the depth statistics");
     p.raw = raw; p.ld = ld; p.o_d2 = layout5[0]; p.o_dims = layout5[1]; p.o_pose = layout5[2]; p.o_z = layout5[3];
     p.o_unc = layout5[4]; p.K = K; p.cls = cls; p.valid = valid; p.gt_idx = gt_idx; p.S = S; p.kf = kf; p.G = G; p.n = B * kf;
     p.gt3d = gt3d; p.gtpose = gtpose; p.priors = priors; p.meta = meta; p.z_type = z_type;
-    CR_CHECK_ARG(z_type >= 0 && z_type <= 2, "cube_select: z_type %d (0 direct, 1 sigmoid, 2 log)", z_type);
+    p.bins = bins; p.z_scales = z_scales; p.z_stats = z_stats; p.boxes = boxes;
+    CR_CHECK_ARG(z_type >= 0 && z_type <= 3, "cube_select: z_type %d (0 direct, 1 sigmoid, 2 log, 3 clusters)", z_type);
     return CR_OK;
 }
 
 extern "C" int cr_cube_select(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
                               const unsigned char* valid, const int64_t* gt_idx, int B, int S, int kf, int G,
                               const float* gt3d, const float* gtpose, const float* priors, const float* meta, float* buf39,
-                              unsigned char* validf, int* clsc, int z_type) {
+                              unsigned char* validf, int* clsc, int z_type, int bins, const float* z_scales,
+                              const float* z_stats, const float* boxes) {
     CR_CHECK_ARG(ctx && buf39 && validf && clsc, "cr_cube_select: NULL pointer");
     CubeSel p;
-    int rc = cube_sel_args(p, raw, ld, layout5, K, cls, valid, gt_idx, B, S, kf, G, gt3d, gtpose, priors, meta, z_type);
+    int rc = cube_sel_args(p, raw, ld, layout5, K, cls, valid, gt_idx, B, S, kf, G, gt3d, gtpose, priors, meta, z_type, bins, z_scales,
+                           z_stats, boxes);
     if (rc) return rc;
     hipLaunchKernelGGL(k_cube_select, dim3((unsigned)cr_cdiv(p.n, 64)), dim3(64), 0, ctx->stream, p, buf39, validf, clsc);
     CR_LAUNCH_CHECK();
@@ -418,12 +461,13 @@ extern "C" int cr_cube_select(cr_ctx* ctx, const float* raw, int ld, const int* 
 extern "C" int cr_cube_select_bwd(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, int B, int kf,
                                   const unsigned char* validf, const int* clsc, const float* g_dxy, const float* g_zr,
                                   const float* g_dr, const float* g_Ra, const float* g_u, const float* g_usel, float* g_raw,
-                                  int z_type) {
+                                  int z_type, int bins, const float* z_scales, const float* z_stats, const float* boxes) {
     CR_CHECK_ARG(ctx && raw && layout5 && validf && clsc && g_dxy && g_zr && g_dr && g_Ra && g_u && g_usel && g_raw,
                  "cr_cube_select_bwd: NULL pointer");
-    CR_CHECK_ARG(z_type >= 0 && z_type <= 2, "cr_cube_select_bwd: z_type %d", z_type);
+    CR_CHECK_ARG(z_type >= 0 && z_type <= 3 && bins >= 1 && (bins == 1 || (z_scales && boxes)) && (z_type != 3 || z_stats),
+                 "cr_cube_select_bwd: z_type %d / bins %d", z_type, bins);
     CubeSel p = {};
-    p.z_type = z_type;
+    p.z_type = z_type; p.bins = bins; p.z_scales = z_scales; p.z_stats = z_stats; p.boxes = boxes;
     p.raw = raw; p.ld = ld; p.o_d2 = layout5[0]; p.o_dims = layout5[1]; p.o_pose = layout5[2]; p.o_z = layout5[3];
     p.o_unc = layout5[4]; p.K = K; p.kf = kf; p.n = B * kf;
     if (p.n == 0) return CR_OK;
@@ -531,7 +575,8 @@ __global__ __launch_bounds__(64) void k_cube_decode_infer(const float* __restric
                                                           int o_z, int o_unc, int K, const int64_t* __restrict__ cls,
                                                           const int* __restrict__ img, const float* __restrict__ boxes,
                                                           const float* __restrict__ meta, const float* __restrict__ priors,
-                                                          int n, int allocentric, float* __restrict__ out, int z_type) {
+                                                          int n, int allocentric, float* __restrict__ out, int z_type, int bins,
+                                                          const float* __restrict__ z_scales, const float* __restrict__ z_stats) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const int64_t c0 = cls[i];
@@ -555,7 +600,7 @@ __global__ __launch_bounds__(64) void k_cube_decode_infer(const float* __restric
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             R[p * 3 + q] = rot ? (M[p * 3] * Ra[q] + M[p * 3 + 1] * Ra[3 + q]) + M[p * 3 + 2] * Ra[6 + q] : Ra[p * 3 + q];
-    const float z = z_decode(r[o_z + c], z_type, nullptr) * m[4];
+    const float z = z_of(r, o_z, K, c, i, z_type, bins, z_scales, z_stats, boxes, nullptr, nullptr) * m[4];
     const float ctr[3] = {z * (cux - K4[2]) / K4[0], z * (cuy - K4[3]) / K4[1], z};
     float* o = out + (size_t)i * 42;
     o[0] = ctr[0]; o[1] = ctr[1]; o[2] = ctr[2];
@@ -572,12 +617,14 @@ __global__ __launch_bounds__(64) void k_cube_decode_infer(const float* __restric
 
 extern "C" int cr_cube_decode_infer(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
                                     const int* img, const float* boxes, const float* meta6, const float* priors, int n,
-                                    int allocentric, float* out42, int z_type) {
-    CR_CHECK_ARG(ctx && n >= 0 && z_type >= 0 && z_type <= 2, "cr_cube_decode_infer: bad args");
+                                    int allocentric, float* out42, int z_type, int bins, const float* z_scales,
+                                    const float* z_stats) {
+    CR_CHECK_ARG(ctx && n >= 0 && z_type >= 0 && z_type <= 3 && bins >= 1, "cr_cube_decode_infer: bad args");
+    CR_CHECK_ARG((bins == 1 || z_scales) && (z_type != 3 || (bins > 1 && z_stats)), "cr_cube_decode_infer: cluster tables missing");
     if (n == 0) return CR_OK;
-    CR_CHECK_ARG(raw && layout5 && cls && img && boxes && meta6 && out42 && K > 0 && ld >= 13 * K, "cr_cube_decode_infer: bad args");
+    CR_CHECK_ARG(raw && layout5 && cls && img && boxes && meta6 && out42 && K > 0 && ld >= (12 + bins) * K, "cr_cube_decode_infer: bad args");
     hipLaunchKernelGGL(k_cube_decode_infer, dim3((unsigned)cr_cdiv(n, 64)), dim3(64), 0, ctx->stream, raw, ld, layout5[0],
-                       layout5[1], layout5[2], layout5[3], layout5[4], K, cls, img, boxes, meta6, priors, n, allocentric, out42, z_type);
+                       layout5[1], layout5[2], layout5[3], layout5[4], K, cls, img, boxes, meta6, priors, n, allocentric, out42, z_type, bins, z_scales, z_stats);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

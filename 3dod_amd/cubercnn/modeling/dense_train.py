@@ -327,7 +327,7 @@ def cube_head_losses(rh, features, samp, pred_boxes, gt: GTBatch, meta, pooled=N
     L, u_sel, dec, buf, validf = ops.cube_head_loss(raw, layout, K, samp["classes"], samp["valid"], samp["gt_idx"], kf,
                                                     gt.boxes3D, gt.poses, priors, meta, boxes.reshape(n, 4),
                                                     allocentric=rh.allocentric_pose, chamfer_pose=rh.chamfer_pose,
-                                                    use_conf=True, joint=rh.loss_w_joint > 0, z_type=rh.z_type)
+                                                    use_conf=True, joint=rh.loss_w_joint > 0, z_cfg=rh.z_cfg())
     red, stats = ops.cube_reduce(L, u_sel, buf, dec, validf, inverse_z=bool(rh.inverse_z_weight))
     p = "Cube/"
     w3 = rh.loss_w_3d
@@ -452,7 +452,7 @@ def weak_cube_losses_fused(rh, samp, gt: GTBatch, cube_pooled, Ks, image_sizes, 
     red, stats, _, _, _ = ops.weak_cube_loss(
         raw, layout, K, samp["classes"], samp["valid"], samp["gt_idx"], kf, gt.boxes, gt.boxes3D, gt.poses, prior_mean, prior_std,
         meta, table, normals, samp["boxes"][:, :kf].reshape(n, 4), depth_maps.tensor if pgz else None, terms, pgz, w_log,
-        allocentric=rh.allocentric_pose, z_type=rh.z_type)
+        allocentric=rh.allocentric_pose, z_cfg=rh.z_cfg())
     w3 = rh.loss_w_3d
     wkey = ("weak", float(rh.loss_w_iou * w3), float(rh.loss_w_pose * w3), float(rh.loss_w_normal_vec * w3), float(rh.loss_w_z * w3),
             float(rh.loss_w_z * w3), float(rh.loss_w_dims * w3), float(rh.loss_w_dims * w3), float(rh.loss_w_dims * w3),

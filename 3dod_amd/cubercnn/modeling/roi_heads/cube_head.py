@@ -33,9 +33,9 @@ class CubeHead(nn.Module):
         self.pose_type = cfg.MODEL.ROI_CUBE_HEAD.POSE_TYPE
         self.cluster_bins = cfg.MODEL.ROI_CUBE_HEAD.CLUSTER_BINS
         self.shared_fc = cfg.MODEL.ROI_CUBE_HEAD.SHARED_FC
-        if self.cluster_bins > 1 or cfg.MODEL.ROI_CUBE_HEAD.NUM_CONV > 0:
-            raise ValueError("built: the single-bin cube head without convolutions (configs/Base.yaml), shared or per-predictor FC "
-                             "trunks; got CLUSTER_BINS {} / NUM_CONV {}".format(self.cluster_bins, cfg.MODEL.ROI_CUBE_HEAD.NUM_CONV))
+        if cfg.MODEL.ROI_CUBE_HEAD.NUM_CONV > 0:
+            raise ValueError("built: the cube head without convolutions (configs/Base.yaml); got NUM_CONV {}".format(
+                cfg.MODEL.ROI_CUBE_HEAD.NUM_CONV))
         num_fc = cfg.MODEL.ROI_CUBE_HEAD.NUM_FC
         fc_dim = cfg.MODEL.ROI_CUBE_HEAD.FC_DIM
         self._in_chw = (input_shape.channels, input_shape.height, input_shape.width)
@@ -74,7 +74,7 @@ class CubeHead(nn.Module):
             raise ValueError('Cuboid pose type {} is not recognized'.format(self.pose_type))
         nn.init.normal_(self.bbox_3D_pose.weight, std=0.001)
         nn.init.constant_(self.bbox_3D_pose.bias, 0)
-        self.bbox_3D_center_depth = nn.Linear(self._output_size, self.num_classes * 1)
+        self.bbox_3D_center_depth = nn.Linear(self._output_size, self.num_classes * max(1, self.cluster_bins))    # [bin][class] (cube_head.py:141,196-197)
         nn.init.normal_(self.bbox_3D_center_depth.weight, std=0.001)
         nn.init.constant_(self.bbox_3D_center_depth.bias, 1)
         if self.use_conf:
@@ -119,7 +119,7 @@ class CubeHead(nn.Module):
         box_2d_deltas = box_2d_deltas.view(n, self.num_classes, 2)
         box_dims = box_dims.view(n, self.num_classes, 3)
         box_pose = box_pose.view(n, self.num_classes, 3, 3)
-        box_z = box_z.view(n, self.num_classes, -1)
+        box_z = box_z.view(n, self.cluster_bins, self.num_classes, -1) if self.cluster_bins > 1 else box_z.view(n, self.num_classes, -1)
         return box_2d_deltas, box_z, box_dims, box_pose, box_uncert
 
 
@@ -131,12 +131,12 @@ def _forward_fused(self, x):
     K = self.num_classes
     if not self.shared_fc:
         # per-predictor trunks: five GEMM chains, their outputs laid side by side in the fused layout
-        return torch.cat(self._separate(x), 1), (0, 2 * K, 5 * K, 11 * K, 12 * K)
+        return torch.cat(self._separate(x), 1), (0, 2 * K, 5 * K, 11 * K, (11 + max(1, self.cluster_bins)) * K)
     h = self._trunk(self.feature_generator, x)
     preds = [self.bbox_3D_center_deltas, self.bbox_3D_dims, self.bbox_3D_pose, self.bbox_3D_center_depth,
              self.bbox_3D_uncertainty]
     y, offs = ops.linear_cat(h, [m.weight for m in preds], [m.bias for m in preds])
-    assert tuple(offs[:5]) == (0, 2 * K, 5 * K, 11 * K, 12 * K)
+    assert tuple(offs[:5]) == (0, 2 * K, 5 * K, 11 * K, (11 + max(1, self.cluster_bins)) * K)
     return y, tuple(offs[:5])                            # y (n, 13K rounded up to 16) f32; consumers take its row stride
 
 

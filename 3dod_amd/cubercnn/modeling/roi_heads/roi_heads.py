@@ -162,10 +162,11 @@ class ROIHeads3D(StandardROIHeads):
         self.cluster_bins = c.CLUSTER_BINS
         self.dims_priors_enabled = c.DIMS_PRIORS_ENABLED
         self.dims_priors_func = c.DIMS_PRIORS_FUNC
-        if self.z_type not in ('direct', 'sigmoid', 'log') or self.cluster_bins > 1 or not self.disentangled_loss:
-            raise ValueError("built: Z_TYPE 'direct' / 'sigmoid' / 'log', CLUSTER_BINS 1, the disentangled loss (configs/Base.yaml); "
-                             "got Z_TYPE '{}', CLUSTER_BINS {}, DISENTANGLED_LOSS {}".format(self.z_type, self.cluster_bins,
-                                                                                           self.disentangled_loss))
+        if self.z_type not in ('direct', 'sigmoid', 'log', 'clusters') or not self.disentangled_loss:
+            raise ValueError("built: Z_TYPE 'direct' / 'sigmoid' / 'log' / 'clusters' with the disentangled loss (configs/Base.yaml); "
+                             "got Z_TYPE '{}', DISENTANGLED_LOSS {}".format(self.z_type, self.disentangled_loss))
+        if self.z_type == 'clusters' and self.cluster_bins <= 1:
+            raise ValueError('To use z_type of priors, there must be more than 1 cluster bin')       # roi_heads.py:2044
         if self.loss_w_3d > 0 and (self.use_confidence <= 0 or (self.dims_priors_enabled and self.dims_priors_func != 'exp')):
             raise ValueError("the fused 3D-head kernels are built for USE_CONFIDENCE > 0 and DIMS_PRIORS_FUNC 'exp' "
                              "(configs/Base.yaml); got USE_CONFIDENCE {} / DIMS_PRIORS_FUNC '{}'".format(
@@ -182,7 +183,23 @@ class ROIHeads3D(StandardROIHeads):
                 self.priors_dims_per_cat = nn.Parameter(torch.FloatTensor(priors['priors_dims_per_cat']).unsqueeze(0))
             else:
                 self.priors_dims_per_cat = nn.Parameter(torch.ones(1, self.num_classes, 2, 3))
-            self.priors_z_scales = nn.Parameter(torch.ones(self.num_classes, self.cluster_bins))
+            # the depth can be clustered by the 2D scale of the box (roi_heads.py:2032-2051): scale centres per (class, bin) and,
+            # for Z_TYPE 'clusters', the depth mean / std of every cluster
+            bins = priors.get('priors_bins') if (priors is not None and self.cluster_bins > 1) else None
+            if bins is not None:
+                self.priors_z_scales = nn.Parameter(torch.stack([torch.FloatTensor(prior[1]) for prior in bins]))
+            else:
+                self.priors_z_scales = nn.Parameter(torch.ones(self.num_classes, self.cluster_bins))
+            if self.z_type == 'clusters':
+                if bins is None:
+                    self.priors_z_stats = nn.Parameter(torch.ones(self.num_classes, self.cluster_bins, 2).float())
+                else:
+                    self.priors_z_stats = nn.Parameter(torch.cat([torch.FloatTensor(prior[2]).unsqueeze(0) for prior in bins]))
+
+    def z_cfg(self):
+        """how a RoI's depth is read from the predictor output (ops.z_config): Z_TYPE, CLUSTER_BINS and the cluster tables"""
+        return ops.z_config(self.z_type, self.cluster_bins, self.priors_z_scales if self.cluster_bins > 1 else None,
+                            getattr(self, "priors_z_stats", None))
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -296,7 +313,7 @@ class ROIHeads3D(StandardROIHeads):
             meta6 = torch.tensor(rows, dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
             priors = self.priors_dims_per_cat.detach()[0, :, 0, :].contiguous() if self.dims_priors_enabled else None
             out = ops.cube_decode_infer(raw, layout, K, ocls.reshape(-1), idx, flat.tensor, meta6, priors,
-                                        allocentric=self.allocentric_pose, z_type=self.z_type).view(B, D, 42)
+                                        allocentric=self.allocentric_pose, z_cfg=self.z_cfg()).view(B, D, 42)
             score3 = (osc * out[:, :, 8]) ** (1 / 2)
         counts = ocnt.tolist()                                   # the one host wait of the step
         if any(c[1] for c in counts):
@@ -404,7 +421,7 @@ class ROIHeads3D(StandardROIHeads):
         meta6 = torch.tensor(rows, dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
         priors = self.priors_dims_per_cat.detach()[0, :, 0, :].contiguous() if self.dims_priors_enabled else None
         out = ops.cube_decode_infer(raw, layout, self.num_classes, box_classes, idx, torch.cat([b.tensor for b in boxes]),
-                                    meta6, priors, allocentric=self.allocentric_pose, z_type=self.z_type)
+                                    meta6, priors, allocentric=self.allocentric_pose, z_cfg=self.z_cfg())
         for inst, o, cls_i in zip(instances, out.split(counts), box_classes.split(counts)):
             m = o.shape[0]
             inst.scores = (inst.scores * o[:, 8]) ** (1 / 2) if inst.has('scores') else o[:, 8]

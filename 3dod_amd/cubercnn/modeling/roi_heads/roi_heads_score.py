@@ -188,7 +188,8 @@ class ROIHeads3DScore(ROIHeads3D):
         cube_2d_deltas, cube_z, cube_dims, cube_pose, cube_uncert = (
             t[:n] if t is not None else None for t in self.cube_head(head_in))
         fg_inds = torch.arange(n, device=device)
-        cube_z = cube_z[fg_inds, box_classes, :]
+        cube_z = util.cluster_depth(cube_z, box_classes, src_boxes, getattr(self, "priors_z_scales", None),
+                                    getattr(self, "z_type", "direct"), getattr(self, "priors_z_stats", None)).unsqueeze(1)
         cube_dims = cube_dims[fg_inds, box_classes, :]
         cube_pose = cube_pose[fg_inds, box_classes, :, :]
         if self.use_confidence:
@@ -213,10 +214,6 @@ class ROIHeads3DScore(ROIHeads3D):
         if self.allocentric_pose:
             cube_pose = util.R_from_allocentric(Ks_scaled_per_box, cube_pose, u=cube_x.detach(), v=cube_y.detach())
         cube_z = cube_z.squeeze(1)
-        if self.z_type == 'sigmoid':                        # roi_heads.py:1495-1501
-            cube_z = torch.sigmoid(cube_z) * 100
-        elif self.z_type == 'log':
-            cube_z = torch.exp(cube_z)
         if self.virtual_depth:
             cube_z = cube_z * virtual_to_real
 

@@ -142,6 +142,33 @@ def scaled_sigmoid(vals, min=0.0, max=1.0):
     return min + (max - min) * torch.sigmoid(vals)
 
 
+def cluster_depth(cube_z, box_classes, src_boxes, priors_z_scales, z_type="direct", priors_z_stats=None):
+    """the RoI's raw depth out of the (n, bins, K, 1) predictor output and its decode (roi_heads.py:2343-2356, 2404-2436; the
+    weak head has the same lines at :1436-1449, :1495-1530): the bin of a RoI is the one whose 2D-scale centre is closest to
+    the diagonal of its proposal box, per category; Z_TYPE 'sigmoid' / 'log' / 'clusters' before the virtual-depth factor.
+    cube_z (n,bins,K,1) for bins > 1 or (n,K,1); -> (n,)"""
+    n = cube_z.shape[0]
+    fg = torch.arange(n, device=cube_z.device)
+    assign = None
+    if cube_z.dim() == 4:
+        scales = ((src_boxes[:, 3] - src_boxes[:, 1]) ** 2 + (src_boxes[:, 2] - src_boxes[:, 0]) ** 2).sqrt()
+        diff = (priors_z_scales.detach().T.unsqueeze(0) - scales.unsqueeze(1).unsqueeze(2)).abs()        # (n, bins, K)
+        assign = diff.argmin(1)[fg, box_classes]
+        z = cube_z[fg, assign, box_classes, 0]
+    else:
+        z = cube_z[fg, box_classes, 0]
+    if z_type == 'sigmoid':
+        z = torch.sigmoid(z) * 100
+    elif z_type == 'log':
+        z = torch.exp(z)
+    elif z_type == 'clusters':
+        st = priors_z_stats.detach()[box_classes, assign]                                             # (n, 2)
+        z = scaled_sigmoid(z, min=(st[:, 0] - 3 * st[:, 1]).clip(0), max=st[:, 0] + 3 * st[:, 1])
+    elif z_type != 'direct':
+        raise ValueError(f"Z_TYPE '{z_type}'")
+    return z
+
+
 def approx_eval_resolution(h, w, scale_min=0, scale_max=1e10):
     """math_util.py:288-316: resolution an h x w image is evaluated at (shortest edge -> scale_min, then capped so the
     longest edge <= scale_max); returns (h, w, factor original -> network)."""

@@ -1743,10 +1743,25 @@ CUBE_OFF = (0, 2, 3, 6, 15, 16, 20, 21, 24, 26, 27, 30)      # chunk starts of b
 Z_TYPES = {"direct": 0, "sigmoid": 1, "log": 2}           # MODEL.ROI_CUBE_HEAD.Z_TYPE values the kernels decode (roi_heads.py:2404-2410)
 
 
+Z_TYPES["clusters"] = 3
+
+
 def z_type_code(z_type):
     if z_type not in Z_TYPES:
         raise ValueError(f"Z_TYPE '{z_type}' is not built (built: {sorted(Z_TYPES)})")
     return Z_TYPES[z_type]
+
+
+def z_config(z_type="direct", bins=1, z_scales=None, z_stats=None):
+    """(code, bins, z_scales (K,bins) f32 or None, z_stats (K,bins,2) f32 or None): how a RoI's depth is read from the predictor
+    output -- MODEL.ROI_CUBE_HEAD.Z_TYPE / CLUSTER_BINS with the head's priors_z_scales / priors_z_stats (roi_heads.py:2343-2436)"""
+    code, bins = z_type_code(z_type), int(bins)
+    if bins > 1 and z_scales is None:
+        raise ValueError("CLUSTER_BINS > 1 needs priors_z_scales")
+    if code == 3 and (bins <= 1 or z_stats is None):
+        raise ValueError("Z_TYPE 'clusters' needs CLUSTER_BINS > 1 and priors_z_stats")
+    f = lambda t: None if t is None else t.detach().float().contiguous()
+    return (code, bins, f(z_scales) if bins > 1 else None, f(z_stats) if code == 3 else None)
 CUBE_DIM = (2, 1, 3, 9, 1, 4, 1, 3, 2, 1, 3, 9)
 
 
@@ -1770,12 +1785,13 @@ class _CubeHeadLoss(torch.autograd.Function):
         clsc = torch.empty((n,), dtype=torch.int32, device=dev)
         lay = (_ct.c_int * 5)(*[int(v) for v in layout])
         lib = _lib.load()
+        boxes = boxes.float().contiguous()
         _chk(lib.cr_cube_select(_ctx(raw), _p(raw32), raw32.shape[1], lay, int(K), _p(cls.contiguous()),
                                 _p(valid.to(torch.uint8).contiguous()), _p(gt_idx.contiguous()), B, S, int(kf), gt3d.shape[1],
                                 _p(gt3d.contiguous()), _p(gtpose.contiguous()), _p(priors), _p(meta.contiguous()), _p(buf),
-                                _p(validf), _p(clsc), int(flags[4])), "cr_cube_select")
+                                _p(validf), _p(clsc), flags[4][0], flags[4][1], _p(flags[4][2]), _p(flags[4][3]), _p(boxes)),
+             "cr_cube_select")
         ch = _chunks(buf, n)
-        boxes = boxes.contiguous()
         ins = ch[:5] + [boxes] + ch[5:]
         arr = (ctypes.c_void_p * 13)(*[t.data_ptr() for t in ins])
         losses = torch.empty((n, 5), dtype=f32, device=dev)
@@ -1804,21 +1820,21 @@ class _CubeHeadLoss(torch.autograd.Function):
         g_raw = torch.empty_like(raw32)
         lay = (_ct.c_int * 5)(*layout)
         _chk(lib.cr_cube_select_bwd(_ctx(raw32), _p(raw32), raw32.shape[1], lay, K, B, kf, _p(validf), _p(clsc), _p(g_dxy),
-                                    _p(g_zr), _p(g_dr), _p(g_Ra), _p(g_u), _p(g_usel.contiguous()), _p(g_raw), int(flags[4])),
-             "cr_cube_select_bwd")
+                                    _p(g_zr), _p(g_dr), _p(g_Ra), _p(g_u), _p(g_usel.contiguous()), _p(g_raw), flags[4][0], flags[4][1],
+                                    _p(flags[4][2]), _p(flags[4][3]), _p(boxes)), "cr_cube_select_bwd")
         return (g_raw.to(dt),) + (None,) * 12
 
 
 def cube_head_loss(raw, layout, K, cls, valid, gt_idx, kf, gt3d, gtpose, priors, meta, boxes, allocentric=True,
-                   chamfer_pose=True, use_conf=True, joint=True, z_type="direct"):
+                   chamfer_pose=True, use_conf=True, joint=True, z_type="direct", z_cfg=None):
     """raw (n,13K) fused predictor output; cls/valid/gt_idx (B,S); gt3d (B,G,9); gtpose (B,G,3,3); priors (K,3) or None;
     meta (B,5); boxes (n,4).  -> losses (n,5), u_sel (n), dec (n,17), buf39, validf (n) uint8."""
-    flags = (int(bool(allocentric)), int(bool(chamfer_pose)), int(bool(use_conf)), int(bool(joint)), z_type_code(z_type))
+    flags = (int(bool(allocentric)), int(bool(chamfer_pose)), int(bool(use_conf)), int(bool(joint)), z_cfg or z_config(z_type))
     return _CubeHeadLoss.apply(raw, tuple(layout), K, cls, valid, gt_idx, kf, gt3d, gtpose.reshape(gtpose.shape[0], -1, 9),
                                priors, meta, boxes, flags)
 
 
-def cube_decode_infer(raw, layout, K, cls, img, boxes, meta6, priors, allocentric=True, z_type="direct"):
+def cube_decode_infer(raw, layout, K, cls, img, boxes, meta6, priors, allocentric=True, z_type="direct", z_cfg=None):
     """inference decode of the 3D head (no autograd) -> (n,42), see cr_cube_decode_infer."""
     _p = _Args()
     _need_cuda(raw, "cube head output")
@@ -1827,9 +1843,10 @@ def cube_decode_infer(raw, layout, K, cls, img, boxes, meta6, priors, allocentri
     raw32 = raw.detach().float().contiguous()
     lay = (_ct.c_int * 5)(*[int(v) for v in layout])
     lib = _lib.load()
+    zc = z_cfg or z_config(z_type)
     _chk(lib.cr_cube_decode_infer(_ctx(raw), _p(raw32), raw32.shape[1], lay, int(K), _p(cls.contiguous()),
                                   _p(img.to(torch.int32).contiguous()), _p(boxes.float().contiguous()), _p(meta6.contiguous()),
-                                  _p(priors), n, int(bool(allocentric)), _p(out), z_type_code(z_type)), "cr_cube_decode_infer")
+                                  _p(priors), n, int(bool(allocentric)), _p(out), zc[0], zc[1], _p(zc[2]), _p(zc[3])), "cr_cube_decode_infer")
     return out
 
 
@@ -1895,11 +1912,11 @@ class _WeakCubeLoss(torch.autograd.Function):
         clsc = torch.empty((n,), dtype=torch.int32, device=dev)
         lay = (_ct.c_int * 5)(*[int(v) for v in layout])
         cls, gt_idx, gt_boxes, table = cls.contiguous(), gt_idx.contiguous(), gt_boxes.float().contiguous(), table.contiguous()
+        boxes = boxes.float().contiguous()
         _chk(lib.cr_cube_select(_ctx(raw), _p(raw32), raw32.shape[1], lay, int(K), _p(cls), _p(valid.to(torch.uint8).contiguous()),
                                 _p(gt_idx), B, S, int(kf), G, _p(gt3d.contiguous()), _p(gtpose.contiguous()), _p(prior_mean),
-                                _p(meta.contiguous()), _p(buf), _p(validf), _p(clsc), int(zt)), "cr_cube_select")
+                                _p(meta.contiguous()), _p(buf), _p(validf), _p(clsc), zt[0], zt[1], _p(zt[2]), _p(zt[3]), _p(boxes)), "cr_cube_select")
         ch = _chunks(buf, n)
-        boxes = boxes.contiguous()
         ins = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in (ch[0], ch[1], ch[2], ch[3], ch[4], ch[6], ch[7], boxes)])
         out = torch.empty((n * (8 + 17 + 4 + 1 + 1) + 2 * B + 27,), dtype=f32, device=dev)
         o = 0
@@ -1930,7 +1947,7 @@ class _WeakCubeLoss(torch.autograd.Function):
                                      int(pgz_mode), wts, _p(Lraw), _p(dec), _p(pbox), _p(ibox), _p(pimg), _p(ztgt), _p(red), _p(cnt),
                                      _p(stats), _p(aux)), "cr_weak_loss_reduce")
         ctx.keep = (raw32, buf, validf, clsc, boxes, tuple(layout), int(K), B, int(kf), S, G, raw.dtype, cls, gt_idx, gt_boxes, prior_std,
-                    table, normals, int(bool(allocentric)), int(terms), out, int(zt))
+                    table, normals, int(bool(allocentric)), int(terms), out, zt)
         dec2, pbox2 = dec.view(n, 17), pbox.view(n, 4)
         ctx.set_materialize_grads(False)       # outputs nobody differentiates arrive as None, not as zero fills
         ctx.mark_non_differentiable(stats, dec2, pbox2, validf)
@@ -1959,12 +1976,12 @@ class _WeakCubeLoss(torch.autograd.Function):
         g_raw = torch.empty_like(raw32)
         lay = (_ct.c_int * 5)(*layout)
         _chk(lib.cr_cube_select_bwd(_ctx(raw32), _p(raw32), raw32.shape[1], lay, K, B, kf, _p(validf), _p(clsc), _p(g_dxy), _p(g_zr),
-                                    _p(g_dr), _p(g_Ra), _p(g_u), _p(zero), _p(g_raw), zt), "cr_cube_select_bwd")
+                                    _p(g_dr), _p(g_Ra), _p(g_u), _p(zero), _p(g_raw), zt[0], zt[1], _p(zt[2]), _p(zt[3]), _p(boxes)), "cr_cube_select_bwd")
         return (g_raw.to(dt),) + (None,) * 21
 
 
 def weak_cube_loss(raw, layout, K, cls, valid, gt_idx, kf, gt_boxes, gt3d, gtpose, prior_mean, prior_std, meta, table, normals, boxes,
-                   depth, terms, pgz_mode, weights, allocentric=True, z_type="direct"):
+                   depth, terms, pgz_mode, weights, allocentric=True, z_type="direct", z_cfg=None):
     """Losses of the weakly supervised 3D head on the (B, kf) foreground slots (ROIHeads3DScore._forward_cube, training).
     raw (n,13K) fused predictor output; cls / valid / gt_idx (B,S); gt_boxes (B,G,4); gt3d (B,G,9); gtpose (B,G,3,3);
     prior_mean / prior_std (K,3) or None; meta (B,5) camera_meta(); table (B,20), normals (B,3) or None, depth (B,H,W) or
@@ -1974,7 +1991,7 @@ def weak_cube_loss(raw, layout, K, cls, valid, gt_idx, kf, gt_boxes, gt3d, gtpos
         raise _lib.CrError(f"weak_cube_loss: {kf} foreground slots per image, the kernels take up to {WEAK_MAX_SLOTS}")
     return _WeakCubeLoss.apply(raw, tuple(layout), K, cls, valid, gt_idx, kf, gt_boxes, gt3d, gtpose.reshape(gtpose.shape[0], -1, 9),
                                prior_mean, prior_std, meta, table, normals, boxes, depth, terms, pgz_mode, tuple(weights), allocentric,
-                               z_type_code(z_type))
+                               z_cfg or z_config(z_type))
 
 
 # --------------------------------------------------------------------------

@@ -462,17 +462,21 @@ int cr_box_loss(cr_ctx* ctx, const float* scores, const float* deltas, const uns
  * buf39 (39*n f32): chunks dxy 2|zr 1|dr 3|Ra 9|u 1|K4 4|v2r 1|prior 3|gt2d 2|gtz 1|gtdims 3|gtR 9, each (n,d):
  * the 12 pointers cr_cube_loss_fwd takes besides the RoI boxes.  validf (n) u8, clsc (n) i32 (clamped class).
  * z_type (ABI 5): MODEL.ROI_CUBE_HEAD.Z_TYPE -- 0 'direct', 1 'sigmoid' (z = 100 sigmoid(raw)), 2 'log' (z = exp(raw)),
- * roi_heads.py:2404-2410; the `zr` chunk holds the DECODED depth (before the virtual-depth factor), cr_cube_select_bwd and
- * cr_cube_decode_infer take the same value. */
+ * 3 'clusters' (scaled sigmoid between mean -+ 3 std of the RoI's depth cluster), roi_heads.py:2404-2436; the `zr` chunk holds
+ * the DECODED depth (before the virtual-depth factor).  bins = MODEL.ROI_CUBE_HEAD.CLUSTER_BINS: the depth predictor has
+ * K * bins columns [bin][class] (layout5[4] = layout5[3] + K * bins) and a RoI reads the bin whose 2D-scale centre z_scales
+ * (K, bins) is closest to the diagonal of its proposal box boxes (n,4) (roi_heads.py:2343-2356); z_stats (K, bins, 2) = depth
+ * mean / std per (class, bin) for z_type 3; both NULL when bins = 1.  cr_cube_select_bwd / cr_cube_decode_infer take the same. */
 int cr_cube_select(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
                    const unsigned char* valid, const int64_t* gt_idx, int B, int S, int kf, int G, const float* gt3d,
                    const float* gtpose, const float* priors, const float* meta, float* buf39, unsigned char* validf,
-                   int* clsc, int z_type);
+                   int* clsc, int z_type, int bins, const float* z_scales, const float* z_stats, const float* boxes);
 /* transpose of the gather: g_raw (n, ld) dense (zeros off each RoI's class), 6D rotation and clip(0.01) back-propagated;
  * g_usel (n) = extra gradient on the selected uncertainty (from the uncertainty loss term). */
 int cr_cube_select_bwd(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, int B, int kf,
                        const unsigned char* validf, const int* clsc, const float* g_dxy, const float* g_zr, const float* g_dr,
-                       const float* g_Ra, const float* g_u, const float* g_usel, float* g_raw, int z_type);
+                       const float* g_Ra, const float* g_u, const float* g_usel, float* g_raw, int z_type,
+                       int bins, const float* z_scales, const float* z_stats, const float* boxes);
 /* red6 = safely_reduce_losses of [dims, xy, z, pose, joint] (losses (n,5) from cr_cube_loss_fwd) and of the uncertainty
  * over the valid RoIs; cnt6 = entries averaged; stats4 = mean |z|, |dims|, |xy| errors, mean exp(-u) (dec from the fwd). */
 int cr_cube_reduce(cr_ctx* ctx, const float* L, const float* buf39, const float* dec, const unsigned char* validf, int n,
@@ -547,7 +551,7 @@ int cr_weak_loss_bwd(cr_ctx* ctx, const float* const* inputs, const unsigned cha
  * out42 (n,42) = [x3d,y3d,z | w,h,l | 2D centre x ratio | exp(-uncert) | R (9) | corners (8,3)]. */
 int cr_cube_decode_infer(cr_ctx* ctx, const float* raw, int ld, const int* layout5, int K, const int64_t* cls,
                          const int* img, const float* boxes, const float* meta6, const float* priors, int n,
-                         int allocentric, float* out42, int z_type);
+                         int allocentric, float* out42, int z_type, int bins, const float* z_scales, const float* z_stats);
 
 /* ---- exact IoU of oriented 3D boxes -----------------------------------------------------------
  * replaces pytorch3d box3d_overlap / _C.iou_box3d [third-party] at ProposalNetwork/utils/utils.py:194-210,

@@ -495,8 +495,12 @@ CUBE_OFF = (0, 2, 3, 6, 15, 16, 20, 21, 24, 26, 27, 30)
 CUBE_DIM = (2, 1, 3, 9, 1, 4, 1, 3, 2, 1, 3, 9)
 
 
+def z_config(z_type="direct", bins=1, z_scales=None, z_stats=None):
+    return (z_type, int(bins), z_scales, z_stats)
+
+
 def cube_head_loss(raw, layout, K, cls, valid, gt_idx, kf, gt3d, gtpose, priors, meta, boxes, allocentric=True,
-                   chamfer_pose=True, use_conf=True, joint=True, z_type="direct"):
+                   chamfer_pose=True, use_conf=True, joint=True, z_type="direct", z_cfg=None):
     """tensor-op restatement of cr_cube_select + cr_cube_loss_fwd (autograd provides both backward kernels):
     per-RoI class gather of the fused predictor output, rotation_6d_to_matrix, clip(0.01), matched ground truth."""
     util = importlib.import_module("3dod_amd.cubercnn.util.math_util")
@@ -510,13 +514,10 @@ def cube_head_loss(raw, layout, K, cls, valid, gt_idx, kf, gt3d, gtpose, priors,
     o_d2, o_dims, o_pose, o_z, o_unc = layout
     seg = lambda o, d: raw[:, o:o + K * d].view(n, K, d)[ar, c]
     dxy, dr, a6 = seg(o_d2, 2), seg(o_dims, 3), seg(o_pose, 6)
-    zr, u = seg(o_z, 1)[:, 0], seg(o_unc, 1)[:, 0].clip(0.01)
-    if z_type == "sigmoid":                               # MODEL.ROI_CUBE_HEAD.Z_TYPE (roi_heads.py:2404-2410)
-        zr = torch.sigmoid(zr) * 100
-    elif z_type == "log":
-        zr = torch.exp(zr)
-    elif z_type != "direct":
-        raise ValueError(f"Z_TYPE '{z_type}'")
+    u = seg(o_unc, 1)[:, 0].clip(0.01)
+    zt, bins, zsc, zst = z_cfg or z_config(z_type)
+    zall = raw[:, o_z:o_z + K * bins]
+    zr = util.cluster_depth(zall.view(n, bins, K, 1) if bins > 1 else zall.view(n, K, 1), c, boxes, zsc, zt, zst)
     Ra = util.rotation_6d_to_matrix(a6)
     gi = gt_idx[:, :kf]
     g3 = torch.gather(gt3d, 1, gi[:, :, None].expand(-1, -1, 9)).reshape(n, 9)

@@ -74,12 +74,9 @@ def forward_cube_list(self, features, instances, Ks, im_current_dims, im_scales_
 
     cube_2d_deltas, cube_z, cube_dims, cube_pose, cube_uncert = self.cube_head(cube_features)
     fg_inds = torch.arange(n, device=device)
-    cube_z = cube_z[fg_inds, box_classes, :]
-    z_type = getattr(self, "z_type", "direct")
-    if z_type == 'sigmoid':                                 # roi_heads.py:2404-2410 (before the virtual-depth factor)
-        cube_z = torch.sigmoid(cube_z) * 100
-    elif z_type == 'log':
-        cube_z = torch.exp(cube_z)
+    # cluster bin (CLUSTER_BINS > 1) and Z_TYPE decode, before the virtual-depth factor (roi_heads.py:2343-2356, 2404-2436)
+    cube_z = util.cluster_depth(cube_z, box_classes, src_boxes, getattr(self, "priors_z_scales", None), getattr(self, "z_type", "direct"),
+                                getattr(self, "priors_z_stats", None)).unsqueeze(1)
     cube_dims = cube_dims[fg_inds, box_classes, :]
     cube_pose = cube_pose[fg_inds, box_classes, :, :]
     if self.use_confidence:

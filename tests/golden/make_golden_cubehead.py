@@ -75,8 +75,19 @@ def make_case(seed, training, K_classes=50):
     return instances, Ks, ratios, head, priors
 
 
-def run(seed, training, z_type="direct"):
+def run(seed, training, z_type="direct", cluster_bins=1):
     instances, Ks, ratios, head, priors = make_case(seed, training)
+    K_classes = head["z"].shape[1]
+    z_scales = z_stats = None
+    if cluster_bins > 1:
+        # the depth predictor has one output per (bin, class): (n, bins, K, 1) (cube_head.py:196-197); scale centres / depth
+        # statistics per (class, bin) like priors['priors_bins'] (roi_heads.py:2032-2051)
+        g2 = torch.Generator().manual_seed(seed + 100)
+        n = head["z"].shape[0]
+        head["z"] = torch.randn(n, cluster_bins, K_classes, 1, generator=g2) * 0.5 + (0.0 if z_type == "clusters" else 3.0)
+        z_scales = torch.sort(torch.rand(K_classes, cluster_bins, generator=g2) * 250 + 20, dim=1).values
+        z_stats = torch.stack((torch.rand(K_classes, cluster_bins, generator=g2) * 8 + 2,
+                               torch.rand(K_classes, cluster_bins, generator=g2) * 1.5 + 0.3), dim=-1)
     if z_type == "log":
         head["z"] = head["z"] - 1.5                      # exp(1.5 +- 0.5): a few metres
     elif z_type == "sigmoid":
@@ -86,13 +97,16 @@ def run(seed, training, z_type="direct"):
     n = leaves["z"].shape[0]
     self = types.SimpleNamespace()
     cfgv = dict(in_features=["p2"], training=training, num_classes=50, scale_roi_boxes=0.0, virtual_depth=True,
-                virtual_focal=512.0, cluster_bins=1, use_confidence=1.0, dims_priors_enabled=True,
+                virtual_focal=512.0, cluster_bins=cluster_bins, use_confidence=1.0, dims_priors_enabled=True,
                 dims_priors_func="exp", allocentric_pose=True, z_type=z_type, disentangled_loss=True,
                 chamfer_pose=True, loss_w_3d=1.0, loss_w_xy=1.0, loss_w_z=1.0, loss_w_dims=20.0, loss_w_pose=7.0,
                 loss_w_joint=1.0, inverse_z_weight=False)
     for k, v in cfgv.items():
         setattr(self, k, v)
     self.priors_dims_per_cat = priors
+    if cluster_bins > 1:
+        self.priors_z_scales = z_scales
+        self.priors_z_stats = z_stats
     self.cube_pooler = lambda feats, boxes: torch.zeros(n, 4)
     self.cube_head = lambda x: (leaves["deltas"], leaves["z"], leaves["dims"], pose, leaves["uncert"])
     C = ref_rh.ROIHeads3D
@@ -104,6 +118,8 @@ def run(seed, training, z_type="direct"):
     for k, v in head.items():
         rec["in_" + k] = v.numpy()
     rec["priors"] = priors.numpy()
+    if cluster_bins > 1:
+        rec["priors_z_scales"], rec["priors_z_stats"] = z_scales.numpy(), z_stats.numpy()
     rec["ratios"] = np.array(ratios, np.float32)
     rec["Ks"] = torch.stack(Ks).numpy()
     rec["n_per"] = np.array([len(i) for i in instances])
@@ -148,6 +164,13 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "cubehead_train_z%s.npz" % zt), **t2)
         np.savez_compressed(os.path.join(HERE, "cubehead_eval_z%s.npz" % zt), **e2)
         print(zt, {k: float(v) for k, v in t2.items() if k.startswith("loss_")})
+    for zt in ("direct", "clusters"):                    # CLUSTER_BINS = 3 (roi_heads.py:2343-2356), with and without cluster depth priors
+        t3 = run(15, True, zt, cluster_bins=3)
+        e3 = run(16, False, zt, cluster_bins=3)
+        e3["scores_2d"] = torch.cat([i.scores for i in make_case(16, False)[0]]).numpy()
+        np.savez_compressed(os.path.join(HERE, "cubehead_train_bins3_%s.npz" % zt), **t3)
+        np.savez_compressed(os.path.join(HERE, "cubehead_eval_bins3_%s.npz" % zt), **e3)
+        print("bins3", zt, {k: float(v) for k, v in t3.items() if k.startswith("loss_")})
     for k in sorted(tr):
         if k.startswith("loss_"):
             print(k, float(tr[k]))

@@ -23,6 +23,16 @@ def heads():
     return list_path.install_heads(modeling.build_roi_heads(cfg, shapes))
 
 
+def _clusters(heads, g):
+    """CLUSTER_BINS and the cluster tables of a fixture (priors_z_scales (K,bins), priors_z_stats (K,bins,2)), or back to one bin"""
+    if "priors_z_scales" in g.files:
+        heads.cluster_bins = int(g["priors_z_scales"].shape[1])
+        heads.priors_z_scales = torch.nn.Parameter(torch.tensor(g["priors_z_scales"]))
+        heads.priors_z_stats = torch.nn.Parameter(torch.tensor(g["priors_z_stats"]))
+    else:
+        heads.cluster_bins = 1
+
+
 def _setup(heads, g, training):
     n_per = g["n_per"].tolist()
     T = lambda k: torch.tensor(g[k])
@@ -57,13 +67,15 @@ def _setup(heads, g, training):
     return insts, leaves, Ks, [float(r) for r in g["ratios"]]
 
 
-ZT = [("direct", ""), ("sigmoid", "_zsigmoid"), ("log", "_zlog")]      # MODEL.ROI_CUBE_HEAD.Z_TYPE (roi_heads.py:2404-2410)
+# MODEL.ROI_CUBE_HEAD.Z_TYPE (roi_heads.py:2404-2436) and CLUSTER_BINS = 3 (:2343-2356)
+ZT = [("direct", ""), ("sigmoid", "_zsigmoid"), ("log", "_zlog"), ("direct", "_bins3_direct"), ("clusters", "_bins3_clusters")]
 
 
 @pytest.mark.parametrize("z_type,suffix", ZT)
 def test_forward_cube_training_matches_reference(heads, golden_dir, z_type, suffix):
     g = np.load(os.path.join(golden_dir, "cubehead_train%s.npz" % suffix), allow_pickle=False)
     heads.z_type = z_type
+    _clusters(heads, g)
     heads.train()
     insts, leaves, Ks, ratios = _setup(heads, g, True)
     with d2.EventStorage(0):
@@ -78,19 +90,20 @@ def test_forward_cube_training_matches_reference(heads, golden_dir, z_type, suff
     for f in ("pred_bbox3D", "pred_center_cam", "pred_center_2D", "pred_dimensions", "pred_pose", "scores"):
         got = torch.cat([i.get(f) for i in pred]).detach().numpy()
         np.testing.assert_allclose(got, g["out_" + f], rtol=1e-4, atol=1e-5, err_msg=f)
-    heads.z_type = "direct"
+    heads.z_type, heads.cluster_bins = "direct", 1
 
 
 @pytest.mark.parametrize("z_type,suffix", ZT)
 def test_forward_cube_eval_matches_reference(heads, golden_dir, z_type, suffix):
     g = np.load(os.path.join(golden_dir, "cubehead_eval%s.npz" % suffix), allow_pickle=False)
     heads.z_type = z_type
+    _clusters(heads, g)
     heads.eval()
     insts, leaves, Ks, ratios = _setup(heads, g, False)
     with torch.no_grad():
         pred = heads._forward_cube({f: None for f in heads.in_features}, insts, Ks, [(512, 512)] * 3, ratios)
     heads.train()
-    heads.z_type = "direct"
+    heads.z_type, heads.cluster_bins = "direct", 1
     for f in ("pred_bbox3D", "pred_center_cam", "pred_center_2D", "pred_dimensions", "pred_pose", "scores"):
         got = torch.cat([i.get(f) for i in pred]).numpy()
         np.testing.assert_allclose(got, g["out_" + f], rtol=1e-4, atol=1e-5, err_msg=f)   # north_star: corners 1e-4 rel
