@@ -1744,7 +1744,48 @@ struct WgP {
     int dbg;                // tuning only (CR_S3_DBG): 1 = no MFMAs, 2 = no LDS fragment reads either, 4 = no atomics
     int cshift_w;           // log2(Wout) (k_conv_wgrad_s3_row)
     int cshift_hw;          // log2(Hout * Wout) or -1
+    // deterministic mode (CR_DETERMINISTIC=1, f32 kernels): pixel split s writes ITS sum of every dW / bias element to
+    // slab[s][...] with a plain store (one writer per element and split) and k_wgrad_reduce adds the splits in a fixed order
+    float* slab;            // [splits][slab_stride] or NULL (atomics into dw)
+    float* bslab;           // [splits][Cout] or NULL
+    long slab_stride;
 };
+
+// out[i] += sum_s slab[s][i], s ascending: the fixed-order second pass of the deterministic weight gradient
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, int splits, long stride, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int s2 = 0; s2 < splits; ++s2) a += slab[(size_t)s2 * stride + i];
+    out[i] += a;
+}
+
+static bool deterministic_on() {
+    static const int v = getenv("CR_DETERMINISTIC") ? atoi(getenv("CR_DETERMINISTIC")) : 0;
+    return v != 0;
+}
+
+// points p at slabs in the ctx workspace (at byte offset `off`, advanced) for `splits` pixel splits; false = does not fit
+static bool wgrad_use_slabs(cr_ctx* ctx, WgP& p, int splits, size_t* off) {
+    p.slab = nullptr; p.bslab = nullptr; p.slab_stride = 0;
+    if (!deterministic_on() || !ctx->ws) return false;
+    const size_t nw = ((size_t)p.Cout * p.Kdim + 3) & ~(size_t)3, nb = p.dbias ? (((size_t)p.Cout + 3) & ~(size_t)3) : 0;
+    const size_t need = (size_t)splits * (nw + nb) * sizeof(float);
+    if (*off + need > ctx->ws_bytes) return false;
+    p.slab = (float*)((char*)ctx->ws + *off);
+    p.slab_stride = (long)nw;
+    if (nb) p.bslab = p.slab + (size_t)splits * nw;
+    *off += need;
+    return true;
+}
+
+static void wgrad_reduce_slabs(cr_ctx* ctx, const WgP& p, int splits) {
+    const long n = (long)p.Cout * p.Kdim;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cr_cdiv(n, 256)), dim3(256), 0, ctx->stream, p.slab, splits, p.slab_stride, n, p.dw);
+    if (p.bslab)
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cr_cdiv(p.Cout, 256)), dim3(256), 0, ctx->stream, p.bslab, splits,
+                           (long)(((size_t)p.Cout + 3) & ~(size_t)3), (long)p.Cout, p.dbias);
+}
 
 // transposing LDS read: 16-lane group reads a 4(row) x 16(col) block of 16-bit elements and
 // returns it column-major: lane i gets column i, rows 0..3 (cdna_hip_programming.md T10).
@@ -2108,7 +2149,11 @@ __device__ __forceinline__ void conv_wgrad_f32_body(const WgP& p, const int blk_
             __syncthreads();
         }
     }
-    if (do_bias && c0 + tid < p.Cout) atomicAdd(&p.dbias[c0 + tid], bsum);
+    float* const dwo = p.slab ? p.slab + (size_t)bz * p.slab_stride : p.dw;
+    if (do_bias && c0 + tid < p.Cout) {
+        if (p.bslab) p.bslab[(size_t)bz * (((size_t)p.Cout + 3) & ~(size_t)3) + c0 + tid] = bsum;
+        else atomicAdd(&p.dbias[c0 + tid], bsum);
+    }
     // D: col (lane&15) = k index, row 4(lane>>4)+reg = channel
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -2118,7 +2163,10 @@ __device__ __forceinline__ void conv_wgrad_f32_body(const WgP& p, const int blk_
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ch = c0 + moff + i * 16 + 4 * g + e;
-                if (kk < p.Kdim && ch < p.Cout) atomicAdd(&p.dw[(size_t)ch * p.Kdim + kk], acc[i][j][e]);
+                if (kk < p.Kdim && ch < p.Cout) {
+                    if (p.slab) dwo[(size_t)ch * p.Kdim + kk] = acc[i][j][e];
+                    else atomicAdd(&dwo[(size_t)ch * p.Kdim + kk], acc[i][j][e]);
+                }
             }
         }
 }
@@ -2291,12 +2339,14 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_patch_f32(WgP p, int tiles_x
             const int co = f / (TAPS * CIN), k = f - co * (TAPS * CIN);
             const int i = (k >> 4) * 256 + co * 16 + (k & 15);   // accumulator tile k / 16 (one tap x 16 ci, or four taps x 4 ci)
             const float v = (sRed[i] + sRed[NT * 256 + i]) + (sRed[2 * NT * 256 + i] + sRed[3 * NT * 256 + i]);
-            atomicAdd(&p.dw[f], v);
+            if (p.slab) p.slab[(size_t)blockIdx.x * p.slab_stride + f] = v;
+            else atomicAdd(&p.dw[f], v);
         }
     }
     if (p.dbias != nullptr) {
 #pragma unroll
         for (int off = 16; off < 64; off <<= 1) bsum += __shfl_xor(bsum, off, 64);   // the wave's four pixel groups
+        // (the bias of these two layers does not exist in the model: BatchNorm follows; kept on atomics)
         if (lane < 16) atomicAdd(&p.dbias[lane], bsum);
     }
 }
@@ -2310,8 +2360,13 @@ static bool try_launch_wgrad_patch_f32(cr_ctx* ctx, WgP& p, int ks, int* rc) {
     const int tiles_x = p.Wout / 16, tiles_per_img = tiles_x * (p.Hout / 16), tiles_total = tiles_per_img * p.N;
     static const int per_cu = env_int("CR_WG_PATCH_BLOCKS", 2);       // few long blocks: the prologue / epilogue of all blocks coincide
     const dim3 grid((unsigned)std::min(tiles_total, 256 * per_cu));   // block b: tiles b, b + grid, ...
+    size_t ws_off = 0;
+    float* const db = p.dbias;
+    if (deterministic_on() && db) return false;                       // (bias on this kernel stays on atomics: generic kernel instead)
+    const bool slabs = wgrad_use_slabs(ctx, p, (int)grid.x, &ws_off);
     if (ks == 3) hipLaunchKernelGGL((k_conv_wgrad_patch_f32<3, 16>), grid, dim3(256), 0, ctx->stream, p, tiles_x, tiles_per_img, tiles_total);
     else hipLaunchKernelGGL((k_conv_wgrad_patch_f32<7, 4>), grid, dim3(256), 0, ctx->stream, p, tiles_x, tiles_per_img, tiles_total);
+    if (slabs) wgrad_reduce_slabs(ctx, p, (int)grid.x);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cr_set_error("k_conv_wgrad_patch_f32 launch failed: %s", hipGetErrorString(e)); *rc = CR_EHIP; }
     else *rc = CR_OK;
@@ -2353,11 +2408,14 @@ static int launch_wgrad_f32_ks(cr_ctx* ctx, WgP& p) {
     splits = (nsteps + p.steps_per_split - 1) / p.steps_per_split;
     dim3 grid(tm * tn * splits);
     p.tm = tm; p.tn = tn; p.xcd = xcd_enabled();
+    size_t ws_off = 0;
+    const bool slabs = wgrad_use_slabs(ctx, p, splits, &ws_off);
     static const int lds_pad = env_int("CR_WG_F32_LDS_PAD", 0);     // extra dynamic LDS per block: caps the blocks per CU (tuning)
     if (TM == 128) hipLaunchKernelGGL((k_conv_wgrad_f32<128, KS>), grid, dim3(CONV_T), lds_pad, ctx->stream, p);
     else if (TM == 64) hipLaunchKernelGGL((k_conv_wgrad_f32<64, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
     else if (TM == 32) hipLaunchKernelGGL((k_conv_wgrad_f32<32, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
     else hipLaunchKernelGGL((k_conv_wgrad_f32<16, KS>), grid, dim3(CONV_T), 0, ctx->stream, p);
+    if (slabs) wgrad_reduce_slabs(ctx, p, splits);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -2935,7 +2993,7 @@ static int conv2d_bwd_weight_impl(cr_ctx* ctx, const void* dy, const void* x, fl
     if (rc) return rc;
     const size_t es = act_f32 ? 4 : 2;
     WgP p;
-    p.dbg = 0; p.cshift_w = 0; p.cshift_hw = -1;
+    p.dbg = 0; p.cshift_w = 0; p.cshift_hw = -1; p.slab = nullptr; p.bslab = nullptr; p.slab_stride = 0;
     p.dy = dy; p.x = x; p.dw = dw; p.dbias = dbias;
     p.N = N; p.Hin = H; p.Win = W; p.Cin = Cin; p.Cout = Cout;
     p.Hout = (H + 2 * pad - ks) / stride + 1;
@@ -3008,7 +3066,7 @@ extern "C" int cr_conv2d_bwd_weight_group(cr_ctx* ctx, int n, const void* const*
         int rc = conv_common_checks("cr_conv2d_bwd_weight_group", Ns[i], Hs[i], Ws[i], Cin, Cout, ks, 1, pad, act_f32);
         if (rc) return rc;
         WgP& p = g.p[i];
-        p.dbg = 0; p.cshift_w = 0; p.cshift_hw = -1;
+        p.dbg = 0; p.cshift_w = 0; p.cshift_hw = -1; p.slab = nullptr; p.bslab = nullptr; p.slab_stride = 0;
         p.dy = dys[i]; p.x = xs[i]; p.dw = dws[i]; p.dbias = dbiases ? dbiases[i] : nullptr;
         p.N = Ns[i]; p.Hin = Hs[i]; p.Win = Ws[i]; p.Cin = Cin; p.Cout = Cout;
         p.Hout = Hs[i] + 2 * pad - ks + 1; p.Wout = Ws[i] + 2 * pad - ks + 1;
@@ -3020,12 +3078,20 @@ extern "C" int cr_conv2d_bwd_weight_group(cr_ctx* ctx, int n, const void* const*
         p.tm = tm; p.tn = tn; p.xcd = xcd_enabled();
         counts[i] = tiles * (int)cr_cdiv(nsteps, sps);
     }
+    // deterministic mode: every problem gets its own slabs (all of them, or none: shared parameters must not mix the two forms)
+    size_t ws_off = 0;
+    bool slabs = deterministic_on();
+    for (int i = 0; i < n && slabs; ++i) slabs = wgrad_use_slabs(ctx, g.p[i], counts[i] / tiles, &ws_off);
+    if (!slabs)
+        for (int i = 0; i < n; ++i) { g.p[i].slab = nullptr; g.p[i].bslab = nullptr; g.p[i].slab_stride = 0; }
     const int total = group_starts(n, counts, g.start);
     for (int i = 0; i < n; ++i) g.count[i] = counts[i];
     for (int i = n; i < CR_MAX_GROUP; ++i) { g.start[i] = total; g.count[i] = 0; }
     const dim3 grid((unsigned)total), block(CONV_T);
     if (ks == 1) hipLaunchKernelGGL(k_conv_wgrad_f32_grp<1>, grid, block, 0, ctx->stream, g);
     else hipLaunchKernelGGL(k_conv_wgrad_f32_grp<3>, grid, block, 0, ctx->stream, g);
+    if (slabs)
+        for (int i = 0; i < n; ++i) wgrad_reduce_slabs(ctx, g.p[i], counts[i] / tiles);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
