@@ -19,6 +19,8 @@ SIGNATURES = {
     "cr_cuboid_corners": [P, P, P, c_int64, P],
     "cr_cubes_project_score": [P, P, c_int64, c_int64, P, c_int, c_float, c_float, P, P, P, P,
                                P, P, P, P, P, P, P, P, P],
+    "cr_cubes_project_score_fast": [P, P, c_int64, c_int64, P, c_int, c_float, c_float, P, P, P, P,
+                                    P, P, P, P, P, P, P, P, P, P],
     "cr_propose": [P, P, c_int64, P, c_int, c_int, P, P, P, c_int64, P, c_int, P, P, P, P, P],
     "cr_ransac_plane": [P, P, c_int64, P, c_int64, c_float, P, P, P],
     "cr_ransac_plane_batched": [P, P, P, c_int, c_int64, P, c_int64, c_float, P, P, P],

@@ -2222,8 +2222,6 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_patch_f32(WgP p, int tiles_x
     float* sRed = smem;                                              // after the last tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const float* __restrict__ dy = reinterpret_cast<const float*>(p.dy);
-    const float* __restrict__ x = reinterpret_cast<const float*>(p.x);
     const int H = p.Hout, W = p.Wout;
     f32x4 acc[NT];
 #pragma unroll

@@ -1,5 +1,7 @@
 """Python entry points of the geometry kernels (thin: argument checking, output
 allocation, one C-ABI call each).  Semantics documented in include/cr3dod.h."""
+import os
+
 import torch
 
 from . import _lib
@@ -31,10 +33,15 @@ def cuboid_corners(box6, R):
 
 
 def cubes_project_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_pts=None,
-                        want=("corners", "boxes", "iou", "dim", "corner", "combined"), iou_boxes=None):
+                        want=("corners", "boxes", "iou", "dim", "corner", "combined"), iou_boxes=None, fast=None, stats=None):
     """Fused K17 (see cr_cubes_project_score).  Returns a dict with the requested
     planes plus `argmax` (N,) int64 and `best` (N,).  iou_boxes (N,4): the box of the IoU term when it is not
-    ref_boxes (the GT-box branches of ROIHeads_Boxer score IoU against the projected ground-truth cube)."""
+    ref_boxes (the GT-box branches of ROIHeads_Boxer score IoU against the projected ground-truth cube).
+    fast: cr_cubes_project_score_fast (argmax / best bit-equal, planes to 1e-4).  None = fast exactly when no plane is
+    requested -- then nothing that leaves the kernel differs (CR_GEO_EXACT=1: always the exact kernel).  stats: int64 (2,)
+    device tensor, fast kernel only: [0] += objects that took the exact sequence, [1] += re-evaluated candidates."""
+    if fast is None:
+        fast = len(want) == 0 and os.environ.get("CR_GEO_EXACT", "0") != "1"
     cubes = _f32c(cubes, "cubes", (None, None, 15))
     N, Pn = cubes.shape[:2]
     dev = cubes.device
@@ -60,12 +67,18 @@ def cubes_project_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_
     if N == 0:
         return out
     lib = _lib.load()
-    rc = lib.cr_cubes_project_score(
+    extra = ()
+    if fast:
+        if stats is not None and (stats.dtype != torch.int64 or stats.numel() != 2 or not stats.is_cuda):
+            raise ValueError("stats must be an int64 device tensor of 2 elements")
+        extra = (_lib.ptr(stats),)
+    fn = lib.cr_cubes_project_score_fast if fast else lib.cr_cubes_project_score
+    rc = fn(
         _lib.ctx_for(dev), _lib.ptr(cubes), N, Pn, _lib.ptr(K), kpo, float(im_wh[0]), float(im_wh[1]),
         _lib.ptr(ref_boxes), _lib.ptr(prior_mu), _lib.ptr(prior_sigma), _lib.ptr(rect_pts),
         _lib.ptr(out["corners"]), _lib.ptr(out["boxes"]), _lib.ptr(out["iou"]), _lib.ptr(out["dim"]),
         _lib.ptr(out["corner"]), _lib.ptr(out["combined"]), _lib.ptr(out["argmax"]), _lib.ptr(out["best"]),
-        _lib.ptr(iou_boxes))
+        _lib.ptr(iou_boxes), *extra)
     _lib.check(rc, "cr_cubes_project_score")
     return out
 

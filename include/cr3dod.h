@@ -79,6 +79,22 @@ int cr_cubes_project_score(cr_ctx* ctx, const float* cubes, int64_t N, int64_t P
                            float* out_corner, float* out_combined, int64_t* out_argmax, float* out_best,
                            const float* iou_boxes);
 
+/* Same arguments and contract on out_argmax / out_best (bit-equal to cr_cubes_project_score: the product + np.argmax of
+ * roi_heads.py:492-505); the six optional planes are written from reciprocal / native-exp / float32-chamfer arithmetic and
+ * agree with the exact planes to 1e-4 (relative, + 1e-5 absolute on the scores in [0, 1]) instead of bit for bit.  Per object the kernel keeps the
+ * cubes whose fast ratio difference, chamfer term or combined score lies within a four-fold error interval of the object's
+ * maximum, re-evaluates those with the exact sequence (exact normalisers, exact product) and takes the argmax among them.
+ * Objects with anything non-finite, a zero normaliser, a best score below 1e-6, more than 256 candidates or without a
+ * rectangle (the fallback rectangle is a float64 mean over the exact boxes) run the exact sequence as a whole.
+ * stats (2) int64 device counters or NULL: [0] += objects that took the exact sequence, [1] += re-evaluated candidates. */
+int cr_cubes_project_score_fast(cr_ctx* ctx, const float* cubes, int64_t N, int64_t P,
+                                const float* K, int k_per_object, float im_w, float im_h,
+                                const float* ref_boxes, const float* prior_mu, const float* prior_sigma,
+                                const float* rect_pts,
+                                float* out_corners, float* out_boxes, float* out_iou, float* out_dim,
+                                float* out_corner, float* out_combined, int64_t* out_argmax, float* out_best,
+                                const float* iou_boxes, int64_t* stats);
+
 /* K18: proposals.propose -- ProposalNetwork/proposals/proposals.py:338-424 with
  * the random variates supplied by the caller (RNG streams cannot be made
  * identical across back-ends; parity = same outputs for the same draws):

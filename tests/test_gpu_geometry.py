@@ -229,3 +229,126 @@ def test_ransac_golden(golden_dir):
     assert_close(neg_eq.cpu().numpy(), g["neg_equation"], atol=1e-6)
     with pytest.raises(ValueError):
         geo.ransac_plane(T(g["pts"]), T(np.array([[0, 1, 10**6]]), torch.int32))
+
+
+# ---------------------------------------------------------------------------
+# cr_cubes_project_score_fast: argmax / best bit-equal to the exact kernel (and so to the oracle), planes to 1e-4
+# ---------------------------------------------------------------------------
+PLANES = ("corners", "boxes", "iou", "dim", "corner", "combined")
+
+
+def both(case, want=PLANES, **kw):
+    cubes, K, im, ref, mu, sg, rect = case
+    args = (T(cubes), T(K), im, T(ref), T(mu), T(sg), None if rect is None else T(rect))
+    st = torch.zeros(2, dtype=torch.int64, device=DEV)
+    ex = geo.cubes_project_score(*args, want=want, fast=False, **kw)
+    fa = geo.cubes_project_score(*args, want=want, fast=True, stats=st, **kw)
+    torch.cuda.synchronize()
+    n = lambda d: {k: v.cpu().numpy() for k, v in d.items() if v is not None}
+    return n(ex), n(fa), st.cpu().numpy()
+
+
+def check_fast(ex, fa):
+    assert (fa["argmax"] == ex["argmax"]).all()
+    assert same_bits(fa["best"], ex["best"])
+    for k in PLANES:
+        if k in ex:
+            assert_close(fa[k], ex[k], rtol=1e-4, atol=2e-4 if k in ("corners", "boxes") else 1e-5)
+
+
+@pytest.mark.parametrize("N,P", [(1, 1), (2, 7), (3, 255), (3, 256), (2, 257), (64, 1000), (2, 1024), (2, 1025), (1, 4096)])
+def test_fast_clean_inputs(N, P):
+    """no cube near the camera plane: the objects go through the fast planes + candidate re-evaluation"""
+    case = random_case(N, P, seed=N * 313 + P, nasty=False)
+    ex, fa, st = both(case)
+    check_fast(ex, fa)
+    o = og.project_and_score(*case)
+    assert (fa["argmax"] == o["argmax"]).all() and same_bits(fa["best"], o["best"])
+    if P >= 255:
+        assert st[0] < N, "every object fell back to the exact sequence"
+        assert st[1] <= 64 * N
+
+
+def test_fast_error_is_far_inside_the_candidate_intervals():
+    """the measured fast-vs-exact differences on BASELINE configs[2]-shaped input against the interval half-widths the
+    kernel uses (4x the analytic bound): chamfer 4*delta px, combined 4e-3 relative"""
+    case = random_case(256, 1000, seed=99, nasty=False)
+    ex, fa, st = both(case)
+    check_fast(ex, fa)
+    delta = 1023.0 / 4194304.0
+    m = ex["combined"].max(axis=1, keepdims=True)
+    rel = np.abs(fa["combined"] - ex["combined"]) / np.maximum(m, 1e-6)
+    assert rel.max() < 4e-3 / 8, rel.max()
+    assert np.abs(fa["boxes"] - ex["boxes"]).max() <= delta
+    assert np.abs(fa["corner"] - ex["corner"]).max() < 1e-5
+
+
+def test_fast_nasty_inputs():
+    """cubes almost at / behind the camera and far off-screen (finite values: fast path), and cubes with a corner exactly
+    on the camera plane (p2 = 0: inf / NaN coordinates -> those objects run the exact sequence, planes bit-equal)"""
+    case = random_case(6, 1000, seed=5, nasty=True)
+    ex, fa, st = both(case)
+    check_fast(ex, fa)
+    o = og.project_and_score(*case)
+    assert (fa["argmax"] == o["argmax"]).all() and same_bits(fa["best"], o["best"])
+    cubes = case[0].copy()
+    for n in (1, 4):
+        cubes[n, 7, :3] = [0.3, -0.2, 0.5]                   # centre z 0.5, extent 1.0 along z, identity pose:
+        cubes[n, 7, 3:6] = [1.0, 0.6, 0.8]                   # four corners at z = 0 exactly
+        cubes[n, 7, 6:] = np.eye(3, dtype=np.float32).ravel()
+    case = (cubes,) + case[1:]
+    ex, fa, st = both(case)
+    assert st[0] == 2
+    for k in PLANES:
+        assert same_bits(fa[k][[1, 4]], ex[k][[1, 4]]), k
+    check_fast(ex, fa)
+    o = og.project_and_score(*case)
+    assert (fa["argmax"] == o["argmax"]).all() and same_bits(fa["best"], o["best"])
+
+
+def test_fast_ties_empty_overlap_no_rect_and_iou_boxes():
+    cubes, K, im, ref, mu, sg, rect = random_case(8, 1000, seed=21, nasty=False)
+    cubes[:, 500:] = cubes[:, :500]                          # every cube has a twin: first index wins
+    ref[3] = [-2000.0, -2000.0, -1990.0, -1985.0]            # outside the clamp range: every combined score is 0 -> index 0
+    rect[5] = np.nan                                         # empty mask: the fallback rectangle
+    case = (cubes, K, im, ref, mu, sg, rect)
+    ex, fa, st = both(case)
+    check_fast(ex, fa)
+    assert (fa["argmax"] < 500).all() and fa["argmax"][3] == 0
+    assert st[0] >= 2
+    o = og.project_and_score(*case)
+    keep = np.arange(8) != 5                                 # (a NaN row means "fallback rectangle" to the kernels only)
+    assert (fa["argmax"][keep] == o["argmax"][keep]).all() and same_bits(fa["best"][keep], o["best"][keep])
+    o5 = og.project_and_score(cubes[5:6], K, im, ref[5:6], mu[5:6], sg[5:6], None)
+    assert fa["argmax"][5] == o5["argmax"][0] and same_bits(fa["best"][5:6], o5["best"])
+    rng = np.random.default_rng(8)
+    iou_ref = (ref + rng.normal(0, 12, ref.shape)).astype(np.float32)
+    ex, fa, st = both(case, iou_boxes=T(iou_ref))
+    check_fast(ex, fa)
+    ex, fa, st = both((cubes, K, im, ref, mu, sg, None))      # no rectangle at all
+    assert st[0] == 8
+    check_fast(ex, fa)
+
+
+def test_fast_is_the_default_of_the_argmax_only_launch():
+    case = random_case(32, 1000, seed=77, nasty=False)
+    cubes, K, im, ref, mu, sg, rect = case
+    lean = geo.cubes_project_score(T(cubes), T(K), im, T(ref), T(mu), T(sg), T(rect), want=())
+    o = og.project_and_score(*case)
+    assert (lean["argmax"].cpu().numpy() == o["argmax"]).all()
+    assert same_bits(lean["best"].cpu().numpy(), o["best"])
+
+
+def test_fast_full_size_matches_exact_kernel():
+    """BASELINE configs[2] size: 1024 objects x 1000 cubes, the bench's own inputs"""
+    import bench
+    inp = bench.geometry_inputs(1024, 1000, 1234, DEV)
+    a = (inp["cubes"], inp["K"], inp["im_wh"], inp["ref"], inp["mu"], inp["sg"], inp["rect"])
+    st = torch.zeros(2, dtype=torch.int64, device=DEV)
+    ex = geo.cubes_project_score(*a, fast=False)
+    fa = geo.cubes_project_score(*a, fast=True, stats=st)
+    assert torch.equal(ex["argmax"], fa["argmax"])
+    assert torch.equal(ex["best"].view(torch.int32), fa["best"].view(torch.int32))
+    for k in PLANES:
+        assert_close(fa[k].cpu().numpy(), ex[k].cpu().numpy(), rtol=1e-4, atol=2e-4 if k in ("corners", "boxes") else 1e-5)
+    assert st[0].item() < 64, st
