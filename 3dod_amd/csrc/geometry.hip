@@ -267,6 +267,35 @@ __device__ __forceinline__ void stage_cubes(const float* src, int cnt, float* s_
     }
 }
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// The 64 cubes of a wave own 4 KB of contiguous corner output (64 B per lane).  Stored lane by lane that is four store
+// instructions that each touch a quarter of 32 cache lines (39 -> 32.5 us for the fast kernel with whole lines instead).
+// Transposed through LDS in four rounds of 16 cubes: the 16 lanes of round k park their four float4 in four 256-byte
+// pieces `tw + piece * piece_stride` (the wave's still unused score slots of the chunk it is working on), then lane l
+// picks float4 l of that 1 KB and the wave stores 1 KB contiguous.  Inline asm: the compiler would put
+// `s_waitcnt vmcnt(0)` in front of LDS writes it can see while an LDS-DMA is in flight; one wave's LDS operations
+// complete in order, so no wait between the writes and the read.  All 64 lanes of the wave must be active.
+__device__ __forceinline__ void store_corners_transposed(const float* u, const float* v, float* wave_out, float* tw,
+                                                         int piece_stride) {
+    const int lane = threadIdx.x & 63;
+    const unsigned wr_a = (unsigned)(size_t)(lds_ptr_t)(tw + ((lane & 15) >> 2) * piece_stride + (lane & 3) * 16);
+    const unsigned rd_a = (unsigned)(size_t)(lds_ptr_t)(tw + (lane >> 4) * piece_stride + (lane & 15) * 4);
+    f32x4_t* const og = reinterpret_cast<f32x4_t*>(wave_out) + lane;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if ((lane >> 4) == k)
+            asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\t"
+                         "ds_write_b128 %0, %3 offset:32\n\tds_write_b128 %0, %4 offset:48"
+                         :: "v"(wr_a), "v"((f32x4_t){u[0], v[0], u[1], v[1]}), "v"((f32x4_t){u[2], v[2], u[3], v[3]}),
+                            "v"((f32x4_t){u[4], v[4], u[5], v[5]}), "v"((f32x4_t){u[6], v[6], u[7], v[7]}) : "memory");
+        f32x4_t t;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(rd_a) : "memory");
+        og[k * 64] = t;
+    }
+}
+
 #define VAT(arr, c) arr[(c) * GEO_T]
 
 // the whole object with the exact sequence (body of k_project_score; the fast kernel's fallback)
@@ -423,9 +452,7 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(const ScoreArgs a) {
 // sigma ...) sends the whole object through the exact sequence: NaN / inf ordering is the reference's business.
 #define GEO_CAND 256
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // one LDS-DMA: 64 lanes x 16 B from base + voff[lane] (0 past the descriptor's extent) to dst + 16 lane.  A plain function:
 // the target builtin inside an instantiation-dependent call is re-checked per template instantiation.
 __device__ __forceinline__ void dma16_f(__amdgpu_buffer_rsrc_t r, float* dst, unsigned voff) {
@@ -653,29 +680,8 @@ __global__ __launch_bounds__(GEO_T, (CPT <= 4 ? 4 : 1)) void k_project_score_fas
             const float b3 = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
             const size_t gi = (size_t)obj * P + base + tid;
             if (a.out_corners && (tid | 63) < cnt) {              // whole wave active
-                // a lane's 64 B of corners straight to memory would be four store instructions that each touch a quarter
-                // of 32 cache lines (39 -> 32.5 us with whole lines).  Transposed through LDS in four rounds of 16 cubes:
-                // the 16 lanes of round k park their four float4 in the wave's still unused s_v slots of THIS chunk
-                // (5 pieces of 256 B, 4 used), then lane l picks float4 l of the 1 KB and the wave stores 1 KB contiguous.
-                const int lane = tid & 63;
-                float* const tw = s_v + c * GEO_T + (tid & ~63);             // + piece * CPT * GEO_T
-                float* const rd = tw + (lane >> 4) * (CPT * GEO_T) + (lane & 15) * 4;
-                float4* const og = reinterpret_cast<float4*>(a.out_corners + ((size_t)obj * P + base + (tid & ~63)) * 16) + lane;
-                // (inline asm: the compiler would put `s_waitcnt vmcnt(0)` in front of LDS writes it can see while the next
-                // chunk's LDS-DMA is in flight; one wave's LDS operations complete in order, so no wait between write and read)
-                const unsigned wr_a = (unsigned)(size_t)(lds_ptr_t)(tw + ((lane & 15) >> 2) * (CPT * GEO_T) + (lane & 3) * 16);
-                const unsigned rd_a = (unsigned)(size_t)(lds_ptr_t)rd;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if ((lane >> 4) == k)
-                        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\t"
-                                     "ds_write_b128 %0, %3 offset:32\n\tds_write_b128 %0, %4 offset:48"
-                                     :: "v"(wr_a), "v"((f32x4_t){u[0], v[0], u[1], v[1]}), "v"((f32x4_t){u[2], v[2], u[3], v[3]}),
-                                        "v"((f32x4_t){u[4], v[4], u[5], v[5]}), "v"((f32x4_t){u[6], v[6], u[7], v[7]}) : "memory");
-                    f32x4_t t;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(rd_a) : "memory");
-                    *reinterpret_cast<f32x4_t*>(og + k * 64) = t;
-                }
+                store_corners_transposed(u, v, a.out_corners + ((size_t)obj * P + base + (tid & ~63)) * 16,
+                                         s_v + c * GEO_T + (tid & ~63), CPT * GEO_T);
             } else if (a.out_corners) {
                 float4* oc = reinterpret_cast<float4*>(a.out_corners + gi * 16);
                 oc[0] = make_float4(u[0], v[0], u[1], v[1]);

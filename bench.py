@@ -103,9 +103,11 @@ def pmc_traffic(fname, kernel_prefix):
         return None
 
 
-def bench_geometry(args, rank, world, dev, argmax_only=False, inp=None, cpu_baseline=True):
+def bench_geometry(args, rank, world, dev, argmax_only=False, inp=None, cpu_baseline=True, exact=False):
     """argmax_only: the AP path of roi_heads.py:501-505 -- only the best cube's index and score leave the kernel
-    (60 B/cube read, O(1) per object written); default: corners, boxes and the four score planes are written too (156 B/cube)"""
+    (60 B/cube read, O(1) per object written); default: corners, boxes and the four score planes are written too (156 B/cube).
+    exact=False: cr_cubes_project_score_fast (argmax and best score bit-equal to the oracle, planes to 1e-4: north_star's
+    contract); exact=True: cr_cubes_project_score (every plane bit-equal to the oracle)."""
     geo = importlib.import_module("3dod_amd.geometry")
     n_img, n_obj_img, P = 64, 16, 1000
     n_obj = n_img * n_obj_img
@@ -115,7 +117,7 @@ def bench_geometry(args, rank, world, dev, argmax_only=False, inp=None, cpu_base
 
     def step():
         return geo.cubes_project_score(inp["cubes"], inp["K"], inp["im_wh"], inp["ref"], inp["mu"], inp["sg"],
-                                       inp["rect"], want=want)
+                                       inp["rect"], want=want, fast=not exact)
     for _ in range(args.warmup):
         step()
     barrier(world)
@@ -135,16 +137,18 @@ def bench_geometry(args, rank, world, dev, argmax_only=False, inp=None, cpu_base
     achieved = bytes_per_cube * n_obj * P / (kern_ms * 1e-3) / 1e9
     res = {
         "metric": "cubes/sec ProposalNetwork 1000-cube project+score+argmax (BASELINE configs[2])"
-                  + (", argmax-only outputs" if argmax_only else ""),
+                  + (", argmax-only outputs" if argmax_only else "") + (", bit-exact planes" if exact else ""),
         "value": value, "unit": "cubes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "geometry: 64 images x 16 objects x 1000 cubes per GPU, "
-                               + ("argmax + best score only (60 B/cube)" if argmax_only else "full outputs (156 B/cube)") + ", one launch",
+                               + ("argmax + best score only (60 B/cube)" if argmax_only else "full outputs (156 B/cube)") + ", one launch; "
+                               + ("every plane bit-equal to the oracle" if exact else
+                                  "argmax / best score bit-equal to the oracle, planes to 1e-4 (cr_cubes_project_score_fast)"),
                    "objects_per_gpu": n_obj, "proposals": P, "parallelism": f"objects sharded x{world}, no collective"},
-        "roofline": {"bound": "hbm", "kernel": GEOMETRY_KERNEL[argmax_only], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(GEOMETRY_PMC[argmax_only], "k_project_score"),
+        "roofline": {"bound": "hbm", "kernel": GEOMETRY_KERNEL[exact] + (" (no output planes)" if argmax_only else ""),
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic(GEOMETRY_PMC[(exact, argmax_only)], "k_project_score"),
                      "algorithmic_bytes_per_launch": bytes_per_cube * n_obj * P, "kernel_ms": kern_ms},
     }
     if rank == 0 and world == 1 and cpu_baseline and not args.no_cpu_baseline:
@@ -152,8 +156,9 @@ def bench_geometry(args, rank, world, dev, argmax_only=False, inp=None, cpu_base
     return res
 
 
-GEOMETRY_KERNEL = {False: "k_project_score<4>", True: "k_project_score<4> (no output planes)"}
-GEOMETRY_PMC = {False: "r02_pmc_geometry_traffic.json", True: "r03_pmc_geometry_argmax_traffic.json"}
+GEOMETRY_KERNEL = {False: "k_project_score_fast<4>", True: "k_project_score<4>"}
+GEOMETRY_PMC = {(True, False): "r02_pmc_geometry_traffic.json", (True, True): "r03_pmc_geometry_argmax_traffic.json",
+                (False, False): "r03_pmc_geometry_fast_traffic.json", (False, True): "r03_pmc_geometry_fast_argmax_traffic.json"}
 
 
 def cpu_baseline_geometry(inp, P):
@@ -493,6 +498,7 @@ def main():
     ap.add_argument("--workload", default="train", choices=["train", "geometry", "inference", "weak", "depth", "boxnet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--argmax-only", action="store_true", help="geometry workload: the AP path (no output planes)")
+    ap.add_argument("--exact-planes", action="store_true", help="geometry workload: cr_cubes_project_score (bit-exact planes)")
     ap.add_argument("--train-only", action="store_true", help="train workload without the geometry / inference keys")
     ap.add_argument("--lean", action="store_true", help="headline measurement only (no eager / do_train / other-precision lines)")
     args = ap.parse_args()
@@ -503,7 +509,8 @@ def main():
     rank, world, local = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
     if args.workload == "geometry":
-        res = bench_geometry(args, rank, world, dev, argmax_only=args.argmax_only, cpu_baseline=not args.argmax_only)
+        res = bench_geometry(args, rank, world, dev, argmax_only=args.argmax_only, cpu_baseline=not args.argmax_only,
+                             exact=args.exact_planes)
     elif args.workload == "inference":
         res = bench_inference(args, rank, world, dev)
     elif args.workload == "weak":
@@ -525,6 +532,7 @@ def main():
             keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "cpu_baseline")
             for key, fn, st, wu, kw in (("geometry", bench_geometry, 200, 20, {}),
                                         ("geometry_argmax_only", bench_geometry, 200, 20, {"argmax_only": True, "cpu_baseline": False}),
+                                        ("geometry_exact_planes", bench_geometry, 200, 20, {"exact": True, "cpu_baseline": False}),
                                         ("inference", bench_inference, 20, 5, {})):
                 sub.steps, sub.warmup, sub.cpu_steps = st, wu, 1
                 try:

@@ -4,7 +4,6 @@ import torch, ctypes
 import bench
 import numpy as np
 _lib = importlib.import_module("3dod_amd._lib")
-geo = importlib.import_module("3dod_amd.geometry")
 dev = "cuda:0"
 inp = bench.geometry_inputs(1024, 1000, 1234, dev)
 a = (inp["cubes"], inp["K"], inp["im_wh"], inp["ref"], inp["mu"], inp["sg"], inp["rect"])
@@ -24,8 +23,20 @@ for want in (ALL, ()):
     torch.cuda.synchronize()
     t = tl.cpu().numpy().reshape(1024, 16).astype(np.int64)
     t0 = t[:, 0].min()
-    names = ["start", "chunk0 ready", "chunk1 ready", "chunk2 ready", "chunk3 ready", "passA done", "maxc", "flags", "cand done", "argmax", "end"]
-    print("want =", "all" if want else "none", "(10 ns ticks relative to first block start; mean / min / max over blocks)")
-    for i, n in enumerate(names):
-        c = t[:, i] - t0
-        print(f"  {n:14s} {c.mean() / 100:7.2f} us  {c.min() / 100:7.2f}  {c.max() / 100:7.2f}")
+    print("want =", "all" if want else "none")
+    for i, n in enumerate(["start", "passA done", "end"]):
+        c = (t[:, i] - t0) / 100
+        print(f"  {n:12s} mean {c.mean():6.2f} min {c.min():6.2f} max {c.max():6.2f}  p90 {np.percentile(c, 90):6.2f}")
+    end = (t[:, 2] - t0) / 100
+    xcc = t[:, 14] & 0xf
+    hw = t[:, 15]
+    cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
+    print("  XCC_ID of block b for b<16:", xcc[:16].tolist())
+    for x in range(8):
+        m = xcc == x
+        print(f"  xcc {x}: {m.sum():4d} blocks, end mean {end[m].mean():6.2f} max {end[m].max():6.2f}")
+    key = xcc * 1000 + se * 100 + sh * 20 + cu
+    uniq, cnt = np.unique(key, return_counts=True)
+    print("  distinct CUs used:", len(uniq), "blocks per CU histogram:", np.bincount(cnt).tolist())
+    slow = np.argsort(end)[-12:]
+    print("  slowest blocks:", [(int(b), float(end[b]), int(key[b])) for b in slow])
