@@ -17,6 +17,7 @@ for v, fname, out_b in (("all", "r03_pmc_geometry_fast_traffic.json", 96), ("non
                          "hbm_write_bytes": wr, "traffic_bytes": rd + wr, "algorithmic_bytes": alg,
                          "traffic_over_algorithmic": (rd + wr) / alg, "duration_us_under_pmc": g[k]["duration_ns_under_pmc"] / 1e3}}}
     json.dump(d, open(os.path.join(ROOT, "profiles", fname), "w"), indent=1)
+    json.dump(d, open(os.path.join(ROOT, "gpurun_out", fname), "w"), indent=1)       # (profiles/ does not travel back from the box)
     print(v, k, "traffic %.1f MB (x%.3f algorithmic)" % ((rd + wr) / 1e6, (rd + wr) / alg))
 dur = {}
 for n in ("fast_all", "fast_none", "exact_all", "exact_none"):
@@ -26,4 +27,4 @@ for n in ("fast_all", "fast_none", "exact_all", "exact_none"):
     dur[n] = {"kernel": rows[0]["Kernel_Name"], "launches": len(t), "mean_us": sum(t) / len(t), "min_us": min(t), "max_us": max(t)}
     print(n, "%.1f us mean, %.1f min" % (dur[n]["mean_us"], dur[n]["min_us"]))
 json.dump({"method": "rocprofv3 --kernel-trace over scripts/geo_one.py (220 launches, first 20 dropped), no counters", "variants": dur},
-          open(os.path.join(ROOT, "profiles", "r03_geometry_kernel_durations.json"), "w"), indent=1)
+          open(os.path.join(ROOT, "gpurun_out", "r03_geometry_kernel_durations.json"), "w"), indent=1)
