@@ -125,7 +125,8 @@ def bench_geometry(args, rank, world, dev, argmax_only=False, inp=None, cpu_base
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
-        out = step()
+        step()            # (the result is dropped before the next launch, like a consumer that is done with it: holding it
+                          # across the next call would keep two sets of output planes alive and alternate between them)
     ev1.record()
     barrier(world)
     dt = time.perf_counter() - t0
