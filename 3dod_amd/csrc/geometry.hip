@@ -695,6 +695,10 @@ __global__ __launch_bounds__(GEO_T, (CPT <= 4 ? 4 : 1)) void k_project_score_fas
             const float h = fmaxf(fminf(o.r3, b3) - fmaxf(o.r1, b1), 0.0f);
             const float inter = w * h;
             const float iou = inter > 0.0f ? inter * __builtin_amdgcn_rcpf((o.a1 + bw * bh) - inter) : 0.0f;
+            // a box thinner than a pixel that overlaps the reference box: its IoU is only good to delta / width, which the
+            // 4e-3 interval of the combined score does not cover -> the exact sequence for this object (rare: off-screen
+            // cubes have no overlap, cubes in view project to several pixels)
+            if (fminf(bw, bh) < 1.0f && inter > 0.0f) poison = nan_f();
             const float z0 = (cu[3] - o.mu0) * is0, z1 = (cu[4] - o.mu1) * is1, z2 = (cu[5] - o.mu2) * is2;
             const float kE = -0.5f * 1.4426950408889634f;
             const float gauss = ((__builtin_amdgcn_exp2f(kE * (z0 * z0)) + __builtin_amdgcn_exp2f(kE * (z1 * z1)))

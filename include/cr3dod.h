@@ -84,7 +84,8 @@ int cr_cubes_project_score(cr_ctx* ctx, const float* cubes, int64_t N, int64_t P
  * agree with the exact planes to 1e-4 (relative, + 1e-5 absolute on the scores in [0, 1]) instead of bit for bit.  Per object the kernel keeps the
  * cubes whose fast ratio difference, chamfer term or combined score lies within a four-fold error interval of the object's
  * maximum, re-evaluates those with the exact sequence (exact normalisers, exact product) and takes the argmax among them.
- * Objects with anything non-finite, a zero normaliser, a best score below 1e-6, more than 256 candidates or without a
+ * Objects with anything non-finite, a zero normaliser, a best score below 1e-6, a projected box thinner than one pixel that
+ * still overlaps the reference box, more than 256 candidates or without a
  * rectangle (the fallback rectangle is a float64 mean over the exact boxes) run the exact sequence as a whole.
  * stats (2) int64 device counters or NULL: [0] += objects that took the exact sequence, [1] += re-evaluated candidates. */
 int cr_cubes_project_score_fast(cr_ctx* ctx, const float* cubes, int64_t N, int64_t P,
