@@ -104,6 +104,9 @@ SIGNATURES = {
     "cr_box3d_overlap": [P, P, P, c_int, c_int, P, P],
     "cr_nonfinite_flag": [P, P, c_int64, P],
     "cr_sgd_step": [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, P],
+    "cr_sgd_step_nesterov": [P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, P],
+    "cr_grad_clip_value": [P, P, c_int64, c_float, c_float],
+    "cr_grad_clip_norm": [P, P, P, P, c_int, c_float, c_float, c_float, P],
     "cr_adam_tick": [P, P, P],
     "cr_adam_step": [P, P, P, P, P, P, c_int64, c_float, P, c_float, c_float, c_float, c_float, c_float, c_int, P, P],
 }

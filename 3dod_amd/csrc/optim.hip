@@ -28,45 +28,142 @@ extern "C" int cr_nonfinite_flag(cr_ctx* ctx, const float* g, int64_t n, int* fl
     return CR_OK;
 }
 
-// torch.optim.SGD(momentum, dampening 0, no nesterov): g' = g*gscale + wd*p ; m = mom*m + g' ; p -= lr*m
+// torch.optim.SGD(momentum, dampening 0): g' = g*gscale + wd*p ; m = mom*m + g' ; p -= lr*m   (nesterov: p -= lr*(g' + mom*m))
 // lr = lr_base * (*lr_scale): the schedule's factor is read on the device, so a captured launch (HIP graph) follows the
 // warm-up / multi-step schedule without being re-captured
+template <bool NESTEROV>
 __global__ __launch_bounds__(256) void k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                              int64_t n, float lr_base, const float* __restrict__ lr_scale, float mom, float wd,
                                              float gscale, const int* __restrict__ skip) {
     if (skip && *skip) return;
     const float lr = lr_scale ? lr_base * *lr_scale : lr_base;
+    auto upd = [&](float& pv, float gv, float& mv) {
+        const float gg = gv * gscale + wd * pv;
+        mv = mom * mv + gg;
+        pv -= lr * (NESTEROV ? gg + mom * mv : mv);
+    };
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
         if (i + 3 < n) {
             float4 pv = *reinterpret_cast<float4*>(p + i);
             const float4 gv = *reinterpret_cast<const float4*>(g + i);
             float4 mv = *reinterpret_cast<float4*>(m + i);
-            mv.x = mom * mv.x + (gv.x * gscale + wd * pv.x); pv.x -= lr * mv.x;
-            mv.y = mom * mv.y + (gv.y * gscale + wd * pv.y); pv.y -= lr * mv.y;
-            mv.z = mom * mv.z + (gv.z * gscale + wd * pv.z); pv.z -= lr * mv.z;
-            mv.w = mom * mv.w + (gv.w * gscale + wd * pv.w); pv.w -= lr * mv.w;
+            upd(pv.x, gv.x, mv.x); upd(pv.y, gv.y, mv.y); upd(pv.z, gv.z, mv.z); upd(pv.w, gv.w, mv.w);
             *reinterpret_cast<float4*>(p + i) = pv;
             *reinterpret_cast<float4*>(m + i) = mv;
         } else {
             for (int64_t j = i; j < n; ++j) {
-                const float mm = mom * m[j] + (g[j] * gscale + wd * p[j]);
-                m[j] = mm;
-                p[j] -= lr * mm;
+                float pv = p[j], mv = m[j];
+                upd(pv, g[j], mv);
+                m[j] = mv;
+                p[j] = pv;
             }
         }
     }
 }
 
-extern "C" int cr_sgd_step(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, const float* lr_scale_dev,
-                           float momentum, float weight_decay, float grad_scale, const int* skip_flag) {
-    CR_CHECK_ARG(ctx && n >= 0, "cr_sgd_step: bad args");
+static int sgd_launch(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, const float* lr_scale_dev,
+                      float momentum, float weight_decay, float grad_scale, const int* skip_flag, bool nesterov, const char* who) {
+    CR_CHECK_ARG(ctx && n >= 0, "%s: bad args", who);
     if (n == 0) return CR_OK;
-    CR_CHECK_ARG(p && g && m, "cr_sgd_step: NULL pointer");
-    CR_CHECK_ARG(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m)) & 15) == 0, "cr_sgd_step: misaligned buffers");
+    CR_CHECK_ARG(p && g && m, "%s: NULL pointer", who);
+    CR_CHECK_ARG(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m)) & 15) == 0, "%s: misaligned buffers", who);
     int64_t nb = cr_cdiv(cr_cdiv(n, 4), 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(k_sgd, dim3((unsigned)nb), dim3(256), 0, ctx->stream, p, g, m, n, lr, lr_scale_dev, momentum,
-                       weight_decay, grad_scale, skip_flag);
+    if (nesterov)
+        hipLaunchKernelGGL(k_sgd<true>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, p, g, m, n, lr, lr_scale_dev, momentum,
+                           weight_decay, grad_scale, skip_flag);
+    else
+        hipLaunchKernelGGL(k_sgd<false>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, p, g, m, n, lr, lr_scale_dev, momentum,
+                           weight_decay, grad_scale, skip_flag);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+extern "C" int cr_sgd_step(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, const float* lr_scale_dev,
+                           float momentum, float weight_decay, float grad_scale, const int* skip_flag) {
+    return sgd_launch(ctx, p, g, m, n, lr, lr_scale_dev, momentum, weight_decay, grad_scale, skip_flag, false, "cr_sgd_step");
+}
+
+extern "C" int cr_sgd_step_nesterov(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, const float* lr_scale_dev,
+                                    float momentum, float weight_decay, float grad_scale, const int* skip_flag) {
+    return sgd_launch(ctx, p, g, m, n, lr, lr_scale_dev, momentum, weight_decay, grad_scale, skip_flag, true, "cr_sgd_step_nesterov");
+}
+
+// SOLVER.CLIP_GRADIENTS (detectron2 maybe_add_gradient_clipping, called from cubercnn/solver/build.py:68), applied to the flat
+// gradient in place before the update.  `gscale` (1 / world size after the all-reduce) is folded in, so the update that follows
+// runs with grad_scale 1.
+//   value:  g = clamp(g * gscale, -clip, clip)                                   (torch.nn.utils.clip_grad_value_)
+//   norm:   per PARAMETER (detectron2 clips each parameter on its own): norm = || g * gscale ||_type,
+//           g = g * gscale * min(1, max_norm / (norm + 1e-6))                    (torch.nn.utils.clip_grad_norm_)
+__global__ __launch_bounds__(256) void k_clip_value(float* __restrict__ g, int64_t n, float clip, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        g[i] = fminf(fmaxf(g[i] * gscale, -clip), clip);
+}
+
+#define CLIP_SPLIT 16
+// partial[param][split]: sum |g|^type over the split's slice (type 2: squares; other finite types: powf) or its maximum (inf)
+__global__ __launch_bounds__(256) void k_clip_norm_partial(const float* __restrict__ g, const int64_t* __restrict__ starts,
+                                                           const int64_t* __restrict__ counts, float type, float gscale,
+                                                           float* __restrict__ partial) {
+    __shared__ float s[4];
+    const int prm = blockIdx.x, sp = blockIdx.y;
+    const int64_t n = counts[prm], per = (n + CLIP_SPLIT - 1) / CLIP_SPLIT;
+    const int64_t a = starts[prm] + sp * per, b = starts[prm] + min(n, (sp + 1) * per);
+    const bool inf = isinf(type);
+    float acc = 0.f;
+    for (int64_t i = a + threadIdx.x; i < b; i += 256) {
+        const float v = fabsf(g[i] * gscale);
+        acc = inf ? fmaxf(acc, v) : acc + (type == 2.f ? v * v : (type == 1.f ? v : powf(v, type)));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_down(acc, off, 64);
+        acc = inf ? fmaxf(acc, o) : acc + o;
+    }
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[prm * CLIP_SPLIT + sp] = inf ? fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])) : ((s[0] + s[1]) + (s[2] + s[3]));
+}
+
+__global__ __launch_bounds__(256) void k_clip_norm_apply(float* __restrict__ g, const int64_t* __restrict__ starts,
+                                                         const int64_t* __restrict__ counts, float type, float max_norm,
+                                                         float gscale, const float* __restrict__ partial) {
+    const int prm = blockIdx.x, sp = blockIdx.y;
+    const bool inf = isinf(type);
+    float tot = 0.f;
+    for (int k = 0; k < CLIP_SPLIT; ++k) {                      // fixed order: every block of a parameter gets the same bits
+        const float v = partial[prm * CLIP_SPLIT + k];
+        tot = inf ? fmaxf(tot, v) : tot + v;
+    }
+    const float norm = inf ? tot : (type == 2.f ? sqrtf(tot) : (type == 1.f ? tot : powf(tot, 1.f / type)));
+    const float coef = fminf(max_norm / (norm + 1e-6f), 1.f) * gscale;
+    const int64_t n = counts[prm], per = (n + CLIP_SPLIT - 1) / CLIP_SPLIT;
+    const int64_t a = starts[prm] + sp * per, b = starts[prm] + min(n, (sp + 1) * per);
+    for (int64_t i = a + threadIdx.x; i < b; i += 256) g[i] *= coef;
+}
+
+extern "C" int cr_grad_clip_value(cr_ctx* ctx, float* g, int64_t n, float clip_value, float grad_scale) {
+    CR_CHECK_ARG(ctx && n >= 0 && clip_value >= 0.f, "cr_grad_clip_value: bad args");
+    if (n == 0) return CR_OK;
+    CR_CHECK_ARG(g != nullptr, "cr_grad_clip_value: NULL gradient");
+    int64_t nb = cr_cdiv(n, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_clip_value, dim3((unsigned)nb), dim3(256), 0, ctx->stream, g, n, clip_value, grad_scale);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// starts / counts (nparam) int64 on the device: offset and element count of every parameter inside g; partial: nparam * 16 floats
+extern "C" int cr_grad_clip_norm(cr_ctx* ctx, float* g, const int64_t* starts, const int64_t* counts, int nparam, float max_norm,
+                                 float norm_type, float grad_scale, float* partial) {
+    CR_CHECK_ARG(ctx && nparam >= 0 && max_norm >= 0.f && norm_type > 0.f, "cr_grad_clip_norm: bad args");
+    if (nparam == 0) return CR_OK;
+    CR_CHECK_ARG(g && starts && counts && partial, "cr_grad_clip_norm: NULL pointer");
+    CR_CHECK_ARG(nparam <= 65535 * 16, "cr_grad_clip_norm: too many parameters");
+    const dim3 grid((unsigned)nparam, CLIP_SPLIT);
+    hipLaunchKernelGGL(k_clip_norm_partial, grid, dim3(256), 0, ctx->stream, g, starts, counts, norm_type, grad_scale, partial);
+    hipLaunchKernelGGL(k_clip_norm_apply, grid, dim3(256), 0, ctx->stream, g, starts, counts, norm_type, max_norm, grad_scale, partial);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -58,8 +58,9 @@ class FlatSGD:
     """torch.optim.SGD(momentum) semantics on flat buffers + fused kernels (cr_sgd_step)."""
 
     def __init__(self, groups, momentum, nesterov=False):
-        assert not nesterov, "nesterov is not built"
         self.momentum = float(momentum)
+        self.nesterov = bool(nesterov)
+        self.clip = None                                        # set_gradient_clipping
         # order by (lr, wd) so that equal-hyperparameter parameters are contiguous
         keys = sorted({(lr, wd) for _, lr, wd in groups})
         ordered = [(p, lr, wd) for k in keys for (p, lr, wd) in groups if (lr, wd) == k]
@@ -158,11 +159,38 @@ class FlatSGD:
         for p in self.params:
             p.grad = None
 
+    def set_gradient_clipping(self, clip_type, clip_value, norm_type=2.0):
+        """SOLVER.CLIP_GRADIENTS (detectron2 maybe_add_gradient_clipping, solver/build.py:68): 'value' clamps every gradient
+        element, 'norm' rescales every PARAMETER's gradient on its own to at most clip_value in the norm_type norm -- applied
+        to the flat gradient right before the update (after the all-reduce), one / two launches for the whole model"""
+        if clip_type not in ("value", "norm"):
+            raise ValueError(f"SOLVER.CLIP_GRADIENTS.CLIP_TYPE must be 'value' or 'norm', got {clip_type!r}")
+        self.clip = (clip_type, float(clip_value), float(norm_type))
+        if clip_type == "norm" and not hasattr(self, "_clip_starts"):
+            dev = self.flat_g.device
+            base = self.flat_g.data_ptr()
+            st = [(p._cr_grad.data_ptr() - base) // 4 for p in self.params]
+            self._clip_starts = torch.tensor(st, dtype=torch.int64, device=dev)
+            self._clip_counts = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
+            self._clip_partial = torch.empty(len(st) * 16, dtype=torch.float32, device=dev)
+
+    def clip_gradients(self, grad_scale=1.0):
+        """returns the grad_scale the update has to use afterwards (1.0 when clipping folded it in)"""
+        if self.clip is None:
+            return grad_scale
+        kind, value, norm_type = self.clip
+        if kind == "value":
+            ops.grad_clip_value(self.flat_g, value, grad_scale)
+        else:
+            ops.grad_clip_norm(self.flat_g, self._clip_starts, self._clip_counts, value, norm_type, grad_scale, self._clip_partial)
+        return 1.0
+
     def step(self, skip_flag=None, grad_scale=1.0):
         self.refresh_lr()
+        grad_scale = self.clip_gradients(grad_scale)
         for (a, b, lr, wd) in self.segments:
             ops.sgd_step(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], lr, self.momentum, wd,
-                         grad_scale, skip_flag, lr_scale_dev=self._lr_dev)
+                         grad_scale, skip_flag, lr_scale_dev=self._lr_dev, nesterov=self.nesterov)
         ops.bump_weight_epoch()
 
     def state_dict(self):
@@ -188,6 +216,7 @@ class FlatAdam(FlatSGD):
 
     def step(self, skip_flag=None, grad_scale=1.0):
         self.refresh_lr()
+        grad_scale = self.clip_gradients(grad_scale)
         ops.adam_tick(self.step_dev, skip_flag)
         for (a, b, lr, wd) in self.segments:
             ops.adam_step(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b],
@@ -212,16 +241,22 @@ class FlatAdam(FlatSGD):
 
 
 def build_optimizer(cfg, model):
-    """solver/build.py:6-69: 'sgd' (the reference's default and every shipped config), 'adam', 'adam+amsgrad', 'adamw',
-    'adamw+amsgrad' (eps 1e-2 as there); anything else raises like the reference.  SOLVER.CLIP_GRADIENTS (detectron2
-    maybe_add_gradient_clipping [third-party]) is off in every shipped config and not built."""
+    """solver/build.py:6-69: 'sgd' (the reference's default and every shipped config; SOLVER.NESTEROV honoured), 'adam',
+    'adam+amsgrad', 'adamw', 'adamw+amsgrad' (eps 1e-2 as there); anything else raises like the reference.
+    SOLVER.CLIP_GRADIENTS (detectron2 maybe_add_gradient_clipping [third-party], :68; off in every shipped config): 'value' and
+    per-parameter 'norm' clipping on the flat gradient (cr_grad_clip_value / cr_grad_clip_norm)."""
     groups = _param_groups(cfg, model)
     t = cfg.SOLVER.TYPE
     if t == 'sgd':
-        return FlatSGD(groups, cfg.SOLVER.MOMENTUM, cfg.SOLVER.NESTEROV)
-    if t in ('adam', 'adam+amsgrad', 'adamw', 'adamw+amsgrad'):
-        return FlatAdam(groups, eps=1e-02, decoupled=t.startswith('adamw'), amsgrad=t.endswith('+amsgrad'))
-    raise ValueError('{} is not supported as an optimizer.'.format(t))
+        opt = FlatSGD(groups, cfg.SOLVER.MOMENTUM, cfg.SOLVER.NESTEROV)
+    elif t in ('adam', 'adam+amsgrad', 'adamw', 'adamw+amsgrad'):
+        opt = FlatAdam(groups, eps=1e-02, decoupled=t.startswith('adamw'), amsgrad=t.endswith('+amsgrad'))
+    else:
+        raise ValueError('{} is not supported as an optimizer.'.format(t))
+    cg = cfg.SOLVER.get("CLIP_GRADIENTS", None)
+    if cg is not None and cg.ENABLED:
+        opt.set_gradient_clipping(str(cg.CLIP_TYPE).lower(), cg.CLIP_VALUE, cg.NORM_TYPE)
+    return opt
 
 
 def early_allreduce_ranges(model, optimizer):

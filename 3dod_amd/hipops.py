@@ -2153,12 +2153,30 @@ def nonfinite_flag(flat_grad, flag):
     _chk(lib.cr_nonfinite_flag(_ctx(flat_grad), _p(flat_grad), flat_grad.numel(), _p(flag)), "cr_nonfinite_flag")
 
 
-def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None, lr_scale_dev=None):
+def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None, lr_scale_dev=None, nesterov=False):
     """lr_scale_dev: optional device float; the step uses lr * lr_scale_dev[0] (read on the device -> graph-capturable)"""
     _p = _Args()
     lib = _lib.load()
-    _chk(lib.cr_sgd_step(_ctx(p), _p(p), _p(g), _p(m), p.numel(), float(lr), _p(lr_scale_dev), float(momentum),
-                         float(weight_decay), float(grad_scale), _p(skip_flag)), "cr_sgd_step")
+    fn = lib.cr_sgd_step_nesterov if nesterov else lib.cr_sgd_step
+    _chk(fn(_ctx(p), _p(p), _p(g), _p(m), p.numel(), float(lr), _p(lr_scale_dev), float(momentum),
+            float(weight_decay), float(grad_scale), _p(skip_flag)), "cr_sgd_step")
+
+
+def grad_clip_value(g, clip_value, grad_scale=1.0):
+    """SOLVER.CLIP_GRADIENTS, CLIP_TYPE 'value': g = clamp(g * grad_scale, -clip_value, clip_value) in place"""
+    _p = _Args()
+    _chk(_lib.load().cr_grad_clip_value(_ctx(g), _p(g), g.numel(), float(clip_value), float(grad_scale)), "cr_grad_clip_value")
+
+
+def grad_clip_norm(g, starts, counts, max_norm, norm_type=2.0, grad_scale=1.0, partial=None):
+    """CLIP_TYPE 'norm': every parameter (starts[i], counts[i] inside the flat gradient g) scaled on its own by
+    min(1, max_norm / (||g_i * grad_scale|| + 1e-6)), grad_scale folded in; partial: (len(starts) * 16,) float scratch"""
+    _p = _Args()
+    n = int(starts.numel())
+    if partial is None:
+        partial = torch.empty(n * 16, dtype=torch.float32, device=g.device)
+    _chk(_lib.load().cr_grad_clip_norm(_ctx(g), _p(g), _p(starts), _p(counts), n, float(max_norm), float(norm_type),
+                                       float(grad_scale), _p(partial)), "cr_grad_clip_norm")
 
 
 def adam_tick(step, skip_flag=None):

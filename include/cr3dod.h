@@ -583,6 +583,21 @@ int cr_nonfinite_flag(cr_ctx* ctx, const float* g, int64_t n, int* flag);
  * tools/train_net.py:410-414) is given, so a launch captured in a HIP graph follows the schedule. */
 int cr_sgd_step(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, const float* lr_scale_dev,
                 float momentum, float weight_decay, float grad_scale, const int* skip_flag);
+/* the same update with nesterov = True (SOLVER.NESTEROV, solver/build.py:50-56): p -= lr * (g' + momentum * m_new) */
+int cr_sgd_step_nesterov(cr_ctx* ctx, float* p, const float* g, float* m, int64_t n, float lr, const float* lr_scale_dev,
+                float momentum, float weight_decay, float grad_scale, const int* skip_flag);
+
+/* SOLVER.CLIP_GRADIENTS -- detectron2 maybe_add_gradient_clipping as called by cubercnn/solver/build.py:68 -- on the flat
+ * gradient in place, BEFORE the update; grad_scale (1 / world size after the all-reduce) is folded in, the update that follows
+ * runs with grad_scale 1.
+ *   cr_grad_clip_value: g = clamp(g * grad_scale, -clip_value, clip_value)                  (CLIP_TYPE "value")
+ *   cr_grad_clip_norm:  per parameter, norm = ||g * grad_scale||_norm_type (2, 1, inf or any p > 0),
+ *                       g = g * grad_scale * min(1, max_norm / (norm + 1e-6))                (CLIP_TYPE "norm")
+ *   starts / counts (nparam) int64 device arrays: offset and element count of every parameter inside g;
+ *   partial: nparam * 16 floats of device scratch (fixed-order two-pass reduction: bit-reproducible). */
+int cr_grad_clip_value(cr_ctx* ctx, float* g, int64_t n, float clip_value, float grad_scale);
+int cr_grad_clip_norm(cr_ctx* ctx, float* g, const int64_t* starts, const int64_t* counts, int nparam, float max_norm,
+                      float norm_type, float grad_scale, float* partial);
 /* torch.optim.Adam / AdamW with the reference's eps (cubercnn/solver/build.py:57-64: 'adam', 'adam+amsgrad', 'adamw',
  * 'adamw+amsgrad'), fused like cr_sgd_step: one launch per hyper-parameter segment of the flat buffers; decoupled = 1: AdamW.
  * max_exp_avg_sq: amsgrad state or NULL.  step: device float = number of applied updates, advanced by cr_adam_tick once per

@@ -264,14 +264,25 @@ def nonfinite_flag(flat_grad, flag):
         flag.fill_(1)
 
 
-def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None, lr_scale_dev=None):
+def sgd_step(p, g, m, lr, momentum, weight_decay, grad_scale=1.0, skip_flag=None, lr_scale_dev=None, nesterov=False):
     if skip_flag is not None and int(skip_flag.view(-1)[0]) != 0:
         return
     if lr_scale_dev is not None:
         lr = lr * float(lr_scale_dev.view(-1)[0])
     gg = g * grad_scale + weight_decay * p
     m.mul_(momentum).add_(gg)
-    p.sub_(lr * m)
+    p.sub_(lr * (gg + momentum * m if nesterov else m))
+
+
+def grad_clip_value(g, clip_value, grad_scale=1.0):
+    g.mul_(grad_scale).clamp_(-clip_value, clip_value)
+
+
+def grad_clip_norm(g, starts, counts, max_norm, norm_type=2.0, grad_scale=1.0, partial=None):
+    for a, n in zip(starts.tolist(), counts.tolist()):
+        v = g[a:a + n]
+        v.mul_(grad_scale)
+        v.mul_(min(1.0, max_norm / (float(torch.linalg.vector_norm(v, norm_type)) + 1e-6)))
 
 
 def cube_decode_loss(dxy, zr, dr, Ra, u, src_boxes, K4, v2r, prior_mean, gt2d, gtz, gtdims, gtR, allocentric=True,
