@@ -33,13 +33,16 @@ def cuboid_corners(box6, R):
 
 
 def cubes_project_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_pts=None,
-                        want=("corners", "boxes", "iou", "dim", "corner", "combined"), iou_boxes=None, fast=None, stats=None):
+                        want=("corners", "boxes", "iou", "dim", "corner", "combined"), iou_boxes=None, fast=None, stats=None,
+                        out=None):
     """Fused K17 (see cr_cubes_project_score).  Returns a dict with the requested
     planes plus `argmax` (N,) int64 and `best` (N,).  iou_boxes (N,4): the box of the IoU term when it is not
     ref_boxes (the GT-box branches of ROIHeads_Boxer score IoU against the projected ground-truth cube).
     fast: cr_cubes_project_score_fast (argmax / best bit-equal, planes to 1e-4).  None = fast exactly when no plane is
     requested -- then nothing that leaves the kernel differs (CR_GEO_EXACT=1: always the exact kernel).  stats: int64 (2,)
-    device tensor, fast kernel only: [0] += objects that took the exact sequence, [1] += re-evaluated candidates."""
+    device tensor, fast kernel only: [0] += objects that took the exact sequence, [1] += re-evaluated candidates.
+    out: the dict a previous call with the same shapes and `want` returned -- its tensors are written again instead of
+    allocating eight new ones."""
     if fast is None:
         fast = len(want) == 0 and os.environ.get("CR_GEO_EXACT", "0") != "1"
     cubes = _f32c(cubes, "cubes", (None, None, 15))
@@ -61,9 +64,15 @@ def cubes_project_score(cubes, K, im_wh, ref_boxes, prior_mu, prior_sigma, rect_
         iou_boxes = _f32c(iou_boxes, "iou_boxes", (N, 4))
     shapes = {"corners": (N, Pn, 8, 2), "boxes": (N, Pn, 4), "iou": (N, Pn), "dim": (N, Pn),
               "corner": (N, Pn), "combined": (N, Pn)}
-    out = {k: (torch.empty(shapes[k], dtype=f32, device=dev) if k in want else None) for k in shapes}
-    out["argmax"] = torch.empty((N,), dtype=torch.int64, device=dev)        # the kernel writes every object's entry
-    out["best"] = torch.empty((N,), dtype=f32, device=dev)
+    if out is not None:
+        ok = all((out.get(k) is None) == (k not in want) and (out.get(k) is None or (tuple(out[k].shape) == shapes[k] and
+                 out[k].dtype == f32 and out[k].device == dev and out[k].is_contiguous())) for k in shapes)
+        if not ok or tuple(out["argmax"].shape) != (N,) or tuple(out["best"].shape) != (N,) or out["argmax"].device != dev:
+            raise ValueError("out: not the result of a call with these shapes and this `want`")
+    else:
+        out = {k: (torch.empty(shapes[k], dtype=f32, device=dev) if k in want else None) for k in shapes}
+        out["argmax"] = torch.empty((N,), dtype=torch.int64, device=dev)        # the kernel writes every object's entry
+        out["best"] = torch.empty((N,), dtype=f32, device=dev)
     if N == 0:
         return out
     lib = _lib.load()

@@ -115,18 +115,40 @@ def bench_geometry(args, rank, world, dev, argmax_only=False, inp=None, cpu_base
         inp = geometry_inputs(n_obj, P, 1234 + rank, dev)
     want = () if argmax_only else ("corners", "boxes", "iou", "dim", "corner", "combined")
 
+    # the output planes are allocated once and written again by every launch (`out=`): eight allocations per call are ~37 us
+    # of host time, more than the fast kernel takes -- the loop would measure the host (scripts/geo_alloc_probe.py)
+    bufs = geo.cubes_project_score(inp["cubes"], inp["K"], inp["im_wh"], inp["ref"], inp["mu"], inp["sg"], inp["rect"],
+                                   want=want, fast=not exact)
+
     def step():
         return geo.cubes_project_score(inp["cubes"], inp["K"], inp["im_wh"], inp["ref"], inp["mu"], inp["sg"],
-                                       inp["rect"], want=want, fast=not exact)
+                                       inp["rect"], want=want, fast=not exact, out=bufs)
     for _ in range(args.warmup):
         step()
+    # the K launches are one HIP graph (CR_GRAPHS=none: K host launches): the wrapper's host time per call (~35 us of argument
+    # checks and ctypes marshalling) is about what the fast kernel takes, so a host loop would time whichever of the two is slower
+    graph = None
+    if os.environ.get("CR_GRAPHS", "dense") != "none":
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(args.steps):
+                    step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()                                  # one untimed replay
+        torch.cuda.synchronize()
     barrier(world)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        step()            # (the result is dropped before the next launch, like a consumer that is done with it: holding it
-                          # across the next call would keep two sets of output planes alive and alternate between them)
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(args.steps):
+            step()
     ev1.record()
     barrier(world)
     dt = time.perf_counter() - t0
@@ -146,7 +168,8 @@ def bench_geometry(args, rank, world, dev, argmax_only=False, inp=None, cpu_base
                                + ("argmax + best score only (60 B/cube)" if argmax_only else "full outputs (156 B/cube)") + ", one launch; "
                                + ("every plane bit-equal to the oracle" if exact else
                                   "argmax / best score bit-equal to the oracle, planes to 1e-4 (cr_cubes_project_score_fast)"),
-                   "objects_per_gpu": n_obj, "proposals": P, "parallelism": f"objects sharded x{world}, no collective"},
+                   "objects_per_gpu": n_obj, "proposals": P, "parallelism": f"objects sharded x{world}, no collective",
+                   "launch_mode": "the K launches replayed as one HIP graph" if graph is not None else "K host launches"},
         "roofline": {"bound": "hbm", "kernel": GEOMETRY_KERNEL[exact] + (" (no output planes)" if argmax_only else ""),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(GEOMETRY_PMC[(exact, argmax_only)], "k_project_score"),

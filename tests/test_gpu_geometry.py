@@ -386,3 +386,21 @@ def test_fast_sub_pixel_boxes_take_the_exact_sequence():
     check_fast(ex, fa)
     o = og.project_and_score(*case)
     assert (fa["argmax"] == o["argmax"]).all() and same_bits(fa["best"], o["best"])
+
+
+def test_out_buffers_are_reused():
+    case = random_case(3, 1000, seed=41, nasty=False)
+    cubes, K, im, ref, mu, sg, rect = case
+    a = (T(cubes), T(K), im, T(ref), T(mu), T(sg), T(rect))
+    first = geo.cubes_project_score(*a, fast=True)
+    ptrs = {k: v.data_ptr() for k, v in first.items() if v is not None}
+    keep = {k: v.clone() for k, v in first.items() if v is not None}
+    for v in first.values():
+        if v is not None:
+            v.zero_()
+    again = geo.cubes_project_score(*a, fast=True, out=first)
+    assert again is first and {k: v.data_ptr() for k, v in again.items() if v is not None} == ptrs
+    for k, v in keep.items():
+        assert torch.equal(again[k], v), k
+    with pytest.raises(ValueError):
+        geo.cubes_project_score(*a, fast=True, want=(), out=first)
