@@ -779,6 +779,53 @@ __global__ __launch_bounds__(GEO_T, (CPT <= 4 ? 4 : 1)) void k_project_score_fas
     // ---------------- exact re-evaluation of the candidates: 8 lanes per candidate, 32 candidates per round (the
     // objects resident on one CU start in different waves); results parked in the staging buffer, free by now
     const int slot = (tid + 64 * ((blockIdx.x >> 8) & 3)) & (GEO_T - 1);
+    if (ncand <= 8) {
+        // the usual case (3 candidates on average): ONE wave re-evaluates them, 8 lanes each, and reduces across its eight
+        // groups with shuffles -- no LDS round trip and none of the seven workgroup barriers of the general path below; the
+        // other three waves go straight to the plane stores
+        if (slot < 64) {
+            const int j = slot >> 3;
+            const bool act = j < ncand;
+            float e_iou = 0.0f, e_gauss = 0.0f, e_diff = 0.0f, e_s = 0.0f;
+            int cp = 0, cf = 0;
+            if (act) {
+                cp = s_cand[j] & 0xffff;
+                cf = s_cand[j] >> 16;
+                float cu[15];
+#pragma unroll
+                for (int k = 0; k < 15; ++k) cu[k] = cb[(size_t)cp * 15 + k];
+                cand_exact8(cu, slot & 7, o, a.cl, s_rect, e_iou, e_gauss, e_diff, e_s);
+            }
+            // torch.max semantics over the flagged candidates (block_max_nanprop): NaN if any NaN
+            const bool vd = act && (cf & 1), vs = act && (cf & 2);
+            float md = vd && e_diff == e_diff ? e_diff : -INFINITY, ms = vs && e_s == e_s ? e_s : -INFINITY;
+            int nd = vd && e_diff != e_diff, ns = vs && e_s != e_s;
+#pragma unroll
+            for (int m = 8; m < 64; m <<= 1) {
+                md = fmaxf(md, __shfl_xor(md, m, 64)); ms = fmaxf(ms, __shfl_xor(ms, m, 64));
+                nd |= __shfl_xor(nd, m, 64); ns |= __shfl_xor(ns, m, 64);
+            }
+            const float xmaxdiff = nd ? nan_f() : md, xmaxs = ns ? nan_f() : ms;
+            float bestv = 0.0f;
+            int besti = -1;
+            if (act && (cf & 4)) {
+                const float dim = (1.0f - e_diff / xmaxdiff) * e_gauss;
+                const float cor = 1.0f - e_s / xmaxs;
+                bestv = (e_iou * dim) * cor;
+                besti = cp;
+            }
+#pragma unroll
+            for (int m = 8; m < 64; m <<= 1) {
+                const float ov = __shfl_xor(bestv, m, 64);
+                const int oi = __shfl_xor(besti, m, 64);
+                if (arg_better(ov, oi, bestv, besti)) { bestv = ov; besti = oi; }
+            }
+            if (slot == 0) {
+                a.out_argmax[obj] = besti < 0 ? 0 : besti;
+                if (a.out_best) a.out_best[obj] = besti < 0 ? 0.0f : bestv;
+            }
+        }
+    } else {
 #pragma unroll 1
     for (int j0 = 0; j0 < ncand; j0 += GEO_T / 8) {
         const int j = j0 + (slot >> 3);
@@ -826,6 +873,7 @@ __global__ __launch_bounds__(GEO_T, (CPT <= 4 ? 4 : 1)) void k_project_score_fas
             if (arg_better(s_red[i], s_redi[i], bv, bi)) { bv = s_red[i]; bi = s_redi[i]; }
         a.out_argmax[obj] = bi < 0 ? 0 : bi;
         if (a.out_best) a.out_best[obj] = bi < 0 ? 0.0f : bv;
+    }
     }
     // ---------------- the four score planes, last: nothing waits for these stores
     if (a.out_iou || a.out_dim || a.out_corner || a.out_combined) {
