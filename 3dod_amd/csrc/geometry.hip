@@ -516,10 +516,11 @@ __device__ __forceinline__ void cand_exact8(const float* cu, const int i, const 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global store
 __device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// `scratch` must not be in use by an earlier reduction that slower waves may still be reading (no leading barrier: a
+// wave publishes its partial as soon as it is done with its own cubes; the one barrier waits for the slowest wave)
 __device__ __forceinline__ float block_max_plain(float v, float* scratch) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    barrier_lds_only();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     barrier_lds_only();
     float r = scratch[0];
@@ -528,13 +529,12 @@ __device__ __forceinline__ float block_max_plain(float v, float* scratch) {
     return r;
 }
 
-// maxima of three values at once (one barrier pair)
+// maxima of three values at once (same contract)
 __device__ __forceinline__ void block_max3_plain(float& a, float& b, float& c, float* scratch) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         a = fmaxf(a, __shfl_xor(a, off, 64)); b = fmaxf(b, __shfl_xor(b, off, 64)); c = fmaxf(c, __shfl_xor(c, off, 64));
     }
-    barrier_lds_only();
     if ((threadIdx.x & 63) == 0) {
         scratch[threadIdx.x >> 6] = a; scratch[GEO_W + (threadIdx.x >> 6)] = b; scratch[2 * GEO_W + (threadIdx.x >> 6)] = c;
     }
