@@ -461,18 +461,16 @@ __device__ __forceinline__ void dma16_f(__amdgpu_buffer_rsrc_t r, float* dst, un
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t cubes_rsrc(const float* cb, int P) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)cb, 0, P * 60, 0x00020000);
 }
-// asynchronous copy of chunk c (<= 256 cubes = 960 16-byte items; P % 4 == 0) of an object's cubes into s_cubes (16 KB);
-// the caller waits with vmcnt(0) + barrier
+// asynchronous copy of this WAVE's 64 cubes of chunk c (3 840 B = 240 16-byte items; P % 4 == 0) into the wave's own
+// 4 KB of s_cubes: no workgroup barrier in the staging loop, a wave waits for its own copies only (vmcnt).  Unconditional
+// (branches would let the scheduler sink the copies below the arithmetic they are meant to hide under): the 16 items past
+// the wave's cubes are the next wave's first bytes or, past the object's last cube, the zeros the buffer descriptor
+// returns out of range.
 __device__ __forceinline__ void stage_cubes_dma(__amdgpu_buffer_rsrc_t r, int c, float* s_cubes) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // unconditional (branches would let the scheduler sink the copies below the arithmetic they are meant to hide under):
-    // s_cubes holds 4 x 256 items, the 64 items past a full chunk are the next chunk's first bytes or, past the object's
-    // last cube, the zeros the buffer descriptor returns out of range
+    const unsigned src = (unsigned)(c * GEO_T + wave * 64) * 60u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i0 = k * GEO_T + wave * 64;                 // wave-uniform
-        dma16_f(r, s_cubes + i0 * 4, (unsigned)(c * (GEO_T * 60) + (i0 + lane) * 16));
-    }
+    for (int k = 0; k < 4; ++k) dma16_f(r, s_cubes + wave * 1024 + k * 256, src + (unsigned)(k * 64 + lane) * 16u);
 }
 
 // one candidate cube evaluated by 8 consecutive lanes (lane i = corner i) with the exact operation sequence of
@@ -629,10 +627,8 @@ __global__ __launch_bounds__(GEO_T, (CPT <= 4 ? 4 : 1)) void k_project_score_fas
         float cu[15];
         if (dma) {
             wait_dma_under_stores(c == 0 ? 0 : nstores);
-            barrier_lds_only();
-            lds_read_cube_asm(s_cubes, tid, cu);          // (rows past cnt: stale or zero bytes, never used)
-            barrier_lds_only();
-            if (base + GEO_T < P) stage_cubes_dma(rc, c + 1, s_cubes);
+            lds_read_cube_asm(s_cubes + (tid >> 6) * 1024, tid & 63, cu);      // (rows past cnt: zero bytes, never used)
+            if (base + GEO_T < P) stage_cubes_dma(rc, c + 1, s_cubes);         // the wave's own region: no barrier
             asm volatile("" ::: "memory");                // the plane stores below stay younger than the copies
         } else {
             stage_cubes(cb + (size_t)base * 15, cnt, s_cubes);
