@@ -451,6 +451,7 @@ __global__ __launch_bounds__(GEO_T) void k_project_score(const ScoreArgs a) {
 // differences.  Anything non-finite anywhere (a cube behind the camera plane hitting p2 = 0, a degenerate box, a zero
 // sigma ...) sends the whole object through the exact sequence: NaN / inf ordering is the reference's business.
 #define GEO_CAND 256
+#define GEO_STAGGER 8            // x 64 cycles between the first fetches of a workgroup's waves (4 ... 12 measure the same)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // one LDS-DMA: 64 lanes x 16 B from base + voff[lane] (0 past the descriptor's extent) to dst + 16 lane.  A plain function:
@@ -591,14 +592,20 @@ __global__ __launch_bounds__(GEO_T, (CPT <= 4 ? 4 : 1)) void k_project_score_fas
     // thing the kernel does: the per-object constants load under it.
     const bool dma = (P & 3) == 0 && ((uintptr_t)a.cubes & 15) == 0;
     const __amdgpu_buffer_rsrc_t rc = cubes_rsrc(cb, P);
-    if (dma) stage_cubes_dma(rc, 0, s_cubes);
+    // (the per-object constants are requested BEFORE anything with side effects: loads the compiler can prove unclobbered
+    // are scalar loads into SGPRs; behind an `s_sleep` or an asm statement they become vector loads and ~30 VGPRs)
     const bool have_rect = a.rect_pts != nullptr && a.rect_pts[obj * 8] == a.rect_pts[obj * 8];
+    ObjConst o;
+    load_obj(a, obj, o);
+    // the four waves ask for their first cubes GEO_STAGGER x 64 cycles apart: all 1 024 workgroups start together, and
+    // 16 MB requested in the same microsecond arrive together 4 us later -- staggered, wave 0 computes while 1..3 still wait
+    // (33.2 -> 32.5 us; staggering the four workgroups of a CU on top of it measured no better)
+    for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) __builtin_amdgcn_s_sleep(GEO_STAGGER);
+    if (dma) stage_cubes_dma(rc, 0, s_cubes);
     // without a rectangle the fallback one is a float64 mean of the EXACT boxes of all cubes: the exact sequence (its
     // first barrier waits for the copy above)
     bool exact_object = !have_rect;
     if (!exact_object) {
-    ObjConst o;
-    load_obj(a, obj, o);
     if (tid < 8) s_rect[tid] = a.rect_pts[obj * 8 + tid];
     if (tid == 0) s_cnt = 0;
     const float is0 = 1.0f / o.sg0, is1 = 1.0f / o.sg1, is2 = 1.0f / o.sg2;
