@@ -298,8 +298,17 @@ __device__ __forceinline__ void store_corners_transposed(const float* u, const f
 
 #define VAT(arr, c) arr[(c) * GEO_T]
 
-// the whole object with the exact sequence (body of k_project_score; the fast kernel's fallback)
-template <int CPT>
+// (defined with the fast kernel below)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cubes_rsrc(const float* cb, int P);
+__device__ __forceinline__ void stage_cubes_dma(__amdgpu_buffer_rsrc_t r, int c, float* s_cubes);
+__device__ __forceinline__ void lds_read_cube_asm(const float* s_cubes, int tid, float* cu);
+__device__ __forceinline__ void wait_dma_under_stores(int stores);
+
+// the whole object with the exact sequence (body of k_project_score; the fast kernel's fallback).  PIPE (k_project_score
+// only; L.s_cubes is 16 KB then): objects with a rectangle stream their cubes like the fast kernel -- every wave copies its
+// 64 cubes of the next chunk by LDS-DMA while it evaluates the current ones from registers, waits for its own copies only,
+// and never for the acknowledgement of its plane stores; no workgroup barrier in the chunk loop.
+template <int CPT, bool PIPE = false>
 __device__ __forceinline__ void score_object_exact(const ScoreArgs& a, const ScoreLds& L, const int obj) {
     const int tid = threadIdx.x;
     const int P = a.P;
@@ -319,6 +328,50 @@ __device__ __forceinline__ void score_object_exact(const ScoreArgs& a, const Sco
     float* const v_s = L.s_v + 3 * CPT * GEO_T + tid;
     double sum_mnx = 0, sum_mxx = 0, sum_mny = 0, sum_mxy = 0;
 
+    const bool piped = PIPE && have_rect && (P & 3) == 0 && ((uintptr_t)a.cubes & 15) == 0;     // block-uniform
+    if (piped) {
+        const __amdgpu_buffer_rsrc_t rc = cubes_rsrc(cb, P);
+        stage_cubes_dma(rc, 0, L.s_cubes);
+        __syncthreads();                                    // s_rect
+        float rect_r[8];                                    // (an LDS read inside the loop would wait for the copies in flight)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rect_r[i] = s_rect[i];
+        const int nstores = (a.out_corners ? 4 : 0) + (a.out_boxes ? 1 : 0);
+#pragma unroll 1
+        for (int c = 0; c < CPT; ++c) {
+            const int base = c * GEO_T;
+            if (base >= P) break;
+            const int cnt = min(GEO_T, P - base);
+            float cu[15];
+            wait_dma_under_stores(c == 0 ? 0 : nstores);
+            lds_read_cube_asm(L.s_cubes + (tid >> 6) * 1024, tid & 63, cu);
+            if (base + GEO_T < P) stage_cubes_dma(rc, c + 1, L.s_cubes);
+            asm volatile("" ::: "memory");
+            if (tid < cnt) {
+                float X[8], Y[8], Z[8], u[8], v[8];
+                cube_corners3d(cu, X, Y, Z);
+                project8(X, Y, Z, o.K, a.cl, u, v);
+                float b0, b1, b2, b3, iou, gauss, diff;
+                minmax8(u, b0, b2);
+                minmax8(v, b1, b3);
+                cube_scores_exact(cu, o, b0, b1, b2, b3, iou, gauss, diff);
+                const size_t gi = (size_t)obj * P + base + tid;
+                if (a.out_corners) {
+                    float4* oc = reinterpret_cast<float4*>(a.out_corners + gi * 16);
+                    oc[0] = make_float4(u[0], v[0], u[1], v[1]);
+                    oc[1] = make_float4(u[2], v[2], u[3], v[3]);
+                    oc[2] = make_float4(u[4], v[4], u[5], v[5]);
+                    oc[3] = make_float4(u[6], v[6], u[7], v[7]);
+                }
+                if (a.out_boxes) reinterpret_cast<float4*>(a.out_boxes)[gi] = make_float4(b0, b1, b2, b3);
+                VAT(v_iou, c) = iou;
+                VAT(v_gauss, c) = gauss;
+                VAT(v_diff, c) = diff;
+                VAT(v_s, c) = cube_chamfer_exact(u, v, rect_r);
+            }
+        }
+        __syncthreads();
+    } else
     // ---------------- pass A: corners, boxes, iou, gauss, ratio diff (+ chamfer if rect given)
     for (int pass = 0; pass < (have_rect ? 1 : 2); ++pass) {
         if (pass == 1) {
@@ -432,14 +485,14 @@ __device__ __forceinline__ void score_object_exact(const ScoreArgs& a, const Sco
 
 template <int CPT>
 __global__ __launch_bounds__(GEO_T) void k_project_score(const ScoreArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_cubes[GEO_T * 15];
+    __shared__ __attribute__((aligned(16))) float s_cubes[GEO_T * 16];
     __shared__ double s_red64[GEO_W * 4];
     __shared__ float s_red[GEO_W * 2];
     __shared__ int s_redi[GEO_W];
     __shared__ float s_rect[8];
     __shared__ float s_v[4 * CPT * GEO_T];
     const ScoreLds L = {s_cubes, s_red64, s_red, s_redi, s_rect, s_v};
-    score_object_exact<CPT>(a, L, blockIdx.x);
+    score_object_exact<CPT, true>(a, L, blockIdx.x);
 }
 
 // ---- fast variant ------------------------------------------------------------
