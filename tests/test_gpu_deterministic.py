@@ -44,4 +44,6 @@ def test_deterministic_mode_is_bit_reproducible():
     assert a[2] == 0 and b[2] == 0
     assert a[0] == b[0], "parameters after three steps differ between two runs in deterministic mode"
     c = _run(False)
-    assert abs(c[1] - a[1]) <= 1e-3 * max(1.0, abs(a[1]))          # same training, different summation order
+    # the default mode trains the same model with another (run-to-run varying) summation order of dW: after three SGD steps
+    # the third loss agrees to a few 1e-3 (measured 1e-4 ... 1.2e-3 over runs), not to rounding
+    assert abs(c[1] - a[1]) <= 1e-2 * max(1.0, abs(a[1]))
