@@ -677,43 +677,12 @@ __global__ __launch_bounds__(256) void k_ccl_best(int H, int W, const int* __res
 }
 
 #define RECT_T 256
-// dynamic LDS: int sx0[H], sx1[H], stack[2][H], hull_x[2H], hull_y[2H]
-__global__ __launch_bounds__(RECT_T) void k_mask_rect(int H, int W, const int* __restrict__ bbox, const int* __restrict__ labels,
-                                                      const unsigned long long* __restrict__ best, float* __restrict__ rects,
-                                                      unsigned char* __restrict__ valid) {
-    extern __shared__ int s_rect[];
-    int* sx0 = s_rect;
-    int* sx1 = sx0 + H;
-    int* stk = sx1 + H;
-    int* hx = stk + 2 * H;
-    int* hy = hx + 2 * H;
-    __shared__ int s_rows[2], s_cnt[3];
-    __shared__ double s_area[RECT_T / 64], s_ang[RECT_T / 64];
-    const int obj = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* out = rects + (size_t)obj * 8;
-    const unsigned long long key = best[obj];
-    if (key == 0ull) {                                                      // empty mask
-        if (tid < 8) out[tid] = __builtin_nanf("");                         // cr_cubes_project_score: fallback rectangle
-        if (tid == 0) valid[obj] = 0;
-        return;
-    }
-    const int root = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
-    const int* L = labels + (size_t)obj * H * W;
-    if (tid == 0) { s_rows[0] = H; s_rows[1] = -1; }
-    __syncthreads();
-    const int bx0 = bbox[4 * obj], by0 = bbox[4 * obj + 1], bx1 = bbox[4 * obj + 2], by1 = bbox[4 * obj + 3];
-    for (int r = by0 + wave; r <= by1; r += RECT_T / 64) {
-        int lo = W, hi = -1;
-        for (int x = bx0 + lane; x <= bx1; x += 64)
-            if (L[(size_t)r * W + x] == root) { lo = min(lo, x); hi = max(hi, x); }
-        for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-        if (lane == 0) {
-            sx0[r] = hi >= 0 ? lo : -1;
-            sx1[r] = hi;
-            if (hi >= 0) { atomicMin(&s_rows[0], r); atomicMax(&s_rows[1], r); }
-        }
-    }
-    __syncthreads();
+// row extremes of one component (sx0[r] = -1: the component has no pixel in row r) -> left / right convex chains ->
+// rotating calipers over the hull edges in f64 -> the four corners (cv2.boxPoints order).  Shared by the two mask kernels.
+__device__ __forceinline__ void rect_from_row_extremes(const int H, const int obj, int* sx0, int* sx1, int* stk, int* hx, int* hy,
+                                                       int* s_rows, int* s_cnt, double* s_area, double* s_ang,
+                                                       float* out, unsigned char* valid) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rmin = s_rows[0], rmax = s_rows[1];
     if (tid < 2) {                                                          // lane 0: left chain, lane 1: right chain
         int* st = stk + tid * H;
@@ -790,6 +759,183 @@ __global__ __launch_bounds__(RECT_T) void k_mask_rect(int H, int W, const int* _
     }
 }
 
+// dynamic LDS: int sx0[H], sx1[H], stack[2][H], hull_x[2H], hull_y[2H]
+__global__ __launch_bounds__(RECT_T) void k_mask_rect(int H, int W, const int* __restrict__ bbox, const int* __restrict__ labels,
+                                                      const unsigned long long* __restrict__ best, float* __restrict__ rects,
+                                                      unsigned char* __restrict__ valid) {
+    extern __shared__ int s_rect[];
+    int* sx0 = s_rect;
+    int* sx1 = sx0 + H;
+    int* stk = sx1 + H;
+    int* hx = stk + 2 * H;
+    int* hy = hx + 2 * H;
+    __shared__ int s_rows[2], s_cnt[3];
+    __shared__ double s_area[RECT_T / 64], s_ang[RECT_T / 64];
+    const int obj = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* out = rects + (size_t)obj * 8;
+    if (bbox[4 * obj + 2] == -2) return;                                    // k_mask_rect_runs has written this object
+    const unsigned long long key = best[obj];
+    if (key == 0ull) {                                                      // empty mask
+        if (tid < 8) out[tid] = __builtin_nanf("");                         // cr_cubes_project_score: fallback rectangle
+        if (tid == 0) valid[obj] = 0;
+        return;
+    }
+    const int root = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    const int* L = labels + (size_t)obj * H * W;
+    if (tid == 0) { s_rows[0] = H; s_rows[1] = -1; }
+    __syncthreads();
+    const int bx0 = bbox[4 * obj], by0 = bbox[4 * obj + 1], bx1 = bbox[4 * obj + 2], by1 = bbox[4 * obj + 3];
+    for (int r = by0 + wave; r <= by1; r += RECT_T / 64) {
+        int lo = W, hi = -1;
+        for (int x = bx0 + lane; x <= bx1; x += 64)
+            if (L[(size_t)r * W + x] == root) { lo = min(lo, x); hi = max(hi, x); }
+        for (int o = 32; o; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        if (lane == 0) {
+            sx0[r] = hi >= 0 ? lo : -1;
+            sx1[r] = hi;
+            if (hi >= 0) { atomicMin(&s_rows[0], r); atomicMax(&s_rows[1], r); }
+        }
+    }
+    __syncthreads();
+    rect_from_row_extremes(H, obj, sx0, sx1, stk, hx, hy, s_rows, s_cnt, s_area, s_ang, out, valid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same result from RUNS instead of pixel labels, one workgroup per object, everything in LDS: a row of an object mask
+// is a handful of runs, so the component labelling is a union-find over (rows x <= RUN_MAXR) run records with LDS atomics
+// instead of five passes over two int32 planes in global memory with L2 atomics (0.9 ms for 1 024 objects: latency of the
+// parent chains).  Objects with a row of more than RUN_MAXR runs (noise, combs) are left to the pixel-label kernels above:
+// this kernel marks the objects it has finished with bbox x1 = y1 = -2, which makes their window loops empty.
+//   1. runs of every window row (a wave per row: ballot over 64-pixel segments, run boundaries by bit scans)
+//   2. union of the runs of adjacent rows that touch 8-connectedly: [s - 1, e + 1] overlap (atomicMin on the parent)
+//   3. size[root] += run length;  4. best root = max (size, earliest first pixel);  5. row extremes of that component
+//   -> rect_from_row_extremes
+// ---------------------------------------------------------------------------------------------------------------------
+#define RUN_MAXR 4
+__device__ __forceinline__ int run_find(volatile int* P, int a) {
+    int p;
+    while ((p = P[a]) != a) a = p;
+    return a;
+}
+__device__ __forceinline__ void run_union(int* P, int a, int b) {
+    bool done = false;
+    while (!done) {
+        a = run_find(P, a);
+        b = run_find(P, b);
+        if (a < b) { const int old = atomicMin(P + b, a); done = old == b; b = old; }
+        else if (b < a) { const int old = atomicMin(P + a, b); done = old == a; a = old; }
+        else done = true;
+    }
+}
+
+// dynamic LDS, H rows: short rs[H][4], re[H][4]; int parent[4H], size[4H]; int rc[H]; then the 8H ints of k_mask_rect
+__global__ __launch_bounds__(RECT_T) void k_mask_rect_runs(MaskSrc src, int H, int W, int* __restrict__ bbox,
+                                                           float* __restrict__ rects, unsigned char* __restrict__ valid) {
+    extern __shared__ int s_dyn[];
+    short* rs = reinterpret_cast<short*>(s_dyn);
+    short* re = rs + RUN_MAXR * H;
+    int* parent = s_dyn + RUN_MAXR * H;                 // (2 x 4H shorts = 4H ints)
+    int* size = parent + RUN_MAXR * H;
+    int* rc = size + RUN_MAXR * H;
+    int* sx0 = rc + H;
+    int* sx1 = sx0 + H;
+    int* stk = sx1 + H;
+    int* hx = stk + 2 * H;
+    int* hy = hx + 2 * H;
+    __shared__ int s_rows[2], s_cnt[3], s_over;
+    __shared__ unsigned long long s_best;
+    __shared__ double s_area[RECT_T / 64], s_ang[RECT_T / 64];
+    const int obj = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* out = rects + (size_t)obj * 8;
+    const int bx0 = bbox[4 * obj], by0 = bbox[4 * obj + 1], bx1 = bbox[4 * obj + 2], by1 = bbox[4 * obj + 3];
+    if (bx1 < 0) {                                                           // empty mask
+        if (tid < 8) out[tid] = __builtin_nanf("");                         // cr_cubes_project_score: fallback rectangle
+        if (tid == 0) { valid[obj] = 0; bbox[4 * obj + 2] = -2; bbox[4 * obj + 3] = -2; }
+        return;
+    }
+    if (tid == 0) { s_over = 0; s_best = 0ull; s_rows[0] = H; s_rows[1] = -1; }
+    __syncthreads();
+    const unsigned char* m = src.of(obj, (size_t)H * W);
+    const int rows = by1 - by0 + 1;
+    // ---- 1. runs (every quantity below is wave-uniform: the bit scans run on the scalar unit)
+    for (int r = wave; r < rows; r += RECT_T / 64) {
+        const unsigned char* row = m + (size_t)(by0 + r) * W;
+        int cnt = 0, cur = -1;                                               // cur: start of a run still open at the segment end
+        for (int x0 = bx0; x0 <= bx1; x0 += 64) {
+            const int x = x0 + lane;
+            unsigned long long b = __ballot(x <= bx1 && row[x] != 0);
+            if (cur >= 0 && !(b & 1ull)) {                                   // the open run ended with the previous segment
+                if (cnt < RUN_MAXR && lane == 0) { rs[r * RUN_MAXR + cnt] = (short)cur; re[r * RUN_MAXR + cnt] = (short)(x0 - 1); }
+                ++cnt; cur = -1;
+            }
+            while (b) {
+                const int st = __ffsll((long long)b) - 1;
+                const unsigned long long rest = ~(b >> st);                  // zero bits above the run (and above bit 63 - st)
+                const int len = rest ? __ffsll((long long)rest) - 1 : 64 - st;
+                const int a = cur >= 0 ? cur : x0 + st;                      // (cur >= 0 implies st == 0 here)
+                if (st + len == 64) { cur = a; break; }                      // reaches the segment end: maybe continues
+                if (cnt < RUN_MAXR && lane == 0) { rs[r * RUN_MAXR + cnt] = (short)a; re[r * RUN_MAXR + cnt] = (short)(x0 + st + len - 1); }
+                ++cnt; cur = -1;
+                b &= ~(((len == 64 ? 0ull : (1ull << len)) - 1ull) << st);
+            }
+        }
+        if (cur >= 0) {
+            if (cnt < RUN_MAXR && lane == 0) { rs[r * RUN_MAXR + cnt] = (short)cur; re[r * RUN_MAXR + cnt] = (short)bx1; }
+            ++cnt;
+        }
+        if (lane == 0) {
+            rc[r] = min(cnt, RUN_MAXR);
+            if (cnt > RUN_MAXR) s_over = 1;
+        }
+    }
+    __syncthreads();
+    if (s_over) return;                                                      // left to the pixel-label kernels
+    for (int i = tid; i < rows * RUN_MAXR; i += RECT_T) { parent[i] = i; size[i] = 0; }
+    __syncthreads();
+    // ---- 2. unions between adjacent rows
+    for (int r = 1 + tid; r < rows; r += RECT_T)
+        for (int k = 0; k < rc[r]; ++k) {
+            const int s0 = rs[r * RUN_MAXR + k] - 1, e0 = re[r * RUN_MAXR + k] + 1;
+            for (int j = 0; j < rc[r - 1]; ++j)
+                if (rs[(r - 1) * RUN_MAXR + j] <= e0 && re[(r - 1) * RUN_MAXR + j] >= s0) run_union(parent, r * RUN_MAXR + k, (r - 1) * RUN_MAXR + j);
+        }
+    __syncthreads();
+    // ---- 3. sizes, 4. the largest component (ties: the one whose first pixel comes first in raster order)
+    for (int r = tid; r < rows; r += RECT_T)
+        for (int k = 0; k < rc[r]; ++k) {
+            const int root = run_find(parent, r * RUN_MAXR + k);
+            parent[r * RUN_MAXR + k] = root;                                 // (a root's entry stays itself)
+            atomicAdd(size + root, re[r * RUN_MAXR + k] - rs[r * RUN_MAXR + k] + 1);
+        }
+    __syncthreads();
+    for (int r = tid; r < rows; r += RECT_T)
+        for (int k = 0; k < rc[r]; ++k) {
+            const int i = r * RUN_MAXR + k;
+            if (parent[i] == i)
+                atomicMax(&s_best, ((unsigned long long)(unsigned)size[i] << 32) |
+                                   (unsigned long long)(0xFFFFFFFFu - (unsigned)((by0 + r) * W + rs[i])));
+        }
+    __syncthreads();
+    const unsigned long long key = s_best;
+    const int p0 = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));       // first pixel of the chosen component
+    const int root = (p0 / W - by0) * RUN_MAXR;                              // its first run is run 0..3 of that row: find which
+    int rootidx = -1;
+    for (int k = 0; k < RUN_MAXR; ++k)
+        if (k < rc[p0 / W - by0] && rs[root + k] == p0 % W) rootidx = root + k;
+    // ---- 5. row extremes of the chosen component (absolute rows, like k_mask_rect)
+    for (int r = tid; r < rows; r += RECT_T) {
+        int lo = W, hi = -1;
+        for (int k = 0; k < rc[r]; ++k)
+            if (parent[r * RUN_MAXR + k] == rootidx) { lo = min(lo, (int)rs[r * RUN_MAXR + k]); hi = max(hi, (int)re[r * RUN_MAXR + k]); }
+        sx0[by0 + r] = hi >= 0 ? lo : -1;
+        sx1[by0 + r] = hi;
+        if (hi >= 0) { atomicMin(&s_rows[0], by0 + r); atomicMax(&s_rows[1], by0 + r); }
+    }
+    if (tid == 0) { bbox[4 * obj + 2] = -2; bbox[4 * obj + 3] = -2; }        // finished: nothing left for the pixel-label kernels
+    __syncthreads();
+    rect_from_row_extremes(H, obj, sx0, sx1, stk, hx, hy, s_rows, s_cnt, s_area, s_ang, out, valid);
+}
+
 extern "C" int cr_mask_rects(cr_ctx* ctx, const unsigned char* masks, const unsigned char* const* mask_ptrs, int n, int H, int W,
                              int32_t* labels, int32_t* sizes, unsigned long long* best, int32_t* bbox, float* rects,
                              unsigned char* valid) {
@@ -804,6 +950,11 @@ extern "C" int cr_mask_rects(cr_ctx* ctx, const unsigned char* masks, const unsi
     const MaskSrc src{masks, mask_ptrs};
     const dim3 grid(CCL_ROWS, (unsigned)n), block(256);
     hipLaunchKernelGGL(k_mask_bbox, dim3((unsigned)cr_cdiv(H, 32), (unsigned)n), block, 0, ctx->stream, src, H, W, bbox);
+    // the run-based kernel first (LDS only; 21 ints of LDS per row); what it leaves goes through the pixel-label passes
+    const size_t run_lds = sizeof(int) * (size_t)H * (3 * RUN_MAXR + 1 + 8);
+    static const bool runs_on = []() { const char* e = getenv("CR_MASK_RUNS"); return !(e && e[0] == '0'); }();
+    if (runs_on && run_lds <= 64 * 1024 && W < 32768)
+        hipLaunchKernelGGL(k_mask_rect_runs, dim3((unsigned)n), dim3(RECT_T), run_lds, ctx->stream, src, H, W, bbox, rects, valid);
     hipLaunchKernelGGL(k_ccl_init, grid, block, 0, ctx->stream, src, H, W, (const int*)bbox, labels, sizes);
     hipLaunchKernelGGL(k_ccl_merge, grid, block, 0, ctx->stream, H, W, (const int*)bbox, labels);
     hipLaunchKernelGGL(k_ccl_sizes, grid, block, 0, ctx->stream, H, W, (const int*)bbox, labels, sizes);

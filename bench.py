@@ -315,7 +315,7 @@ def bench_boxnet(args, rank, world, dev):
                                                "bandwidth-bound; share of the step = kernel_ms / ms_per_step"}
     extra = {"roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        extra["cpu_baseline"] = cpu_baseline_boxnet(batch[0], n_obj)
+        extra["cpu_baseline"] = cpu_baseline_boxnet(batch[0], n_obj, seconds=getattr(args, "cpu_seconds", 12.0))
     return {**extra,
             "metric": "images/sec BoxNet 1000-cube proposal-and-scoring pipeline on GT boxes (BASELINE configs[2], end to end)",
             "value": B * world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -326,7 +326,7 @@ def bench_boxnet(args, rank, world, dev):
                        "cubes_per_s": nobj * 1000 * world * args.steps / dt, "parallelism": f"images sharded x{world}, no collective"}}
 
 
-def cpu_baseline_boxnet(sample, n_obj, P=1000):
+def cpu_baseline_boxnet(sample, n_obj, P=1000, seconds=12.0):
     """the oracle's stages of the same pipeline on ONE image (16 objects x 1000 cubes), numpy on one host core: ground-plane
     RANSAC on the back-projected ground pixels (oracle.geometry.ransac_plane), mask -> minimum-area rectangle
     (oracle.rect.rect_from_mask, scipy labelling), proposals from supplied draws (propose_from_draws), project + score +
@@ -342,9 +342,9 @@ def cpu_baseline_boxnet(sample, n_obj, P=1000):
     K = np.array([[f, 0, 256], [0, f, 256], [0, 0, 1]], dtype=np.float32)
     mu = rng.uniform(0.3, 1.1, (n_obj, 3)).astype(np.float32)
     sg = (0.2 * mu).astype(np.float32)
-    n_rep = 0                                                        # whole images for ~12 s of host work
+    n_rep = 0                                                        # whole images for ~`seconds` of host work
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 12.0:
+    while time.perf_counter() - t0 < seconds:
         n_rep += 1
         ys, xs = np.nonzero(ground)
         sel = rng.choice(len(ys), min(len(ys), 20000), replace=False)     # bounded: the 1000 x points distance matrix is host RAM
@@ -550,15 +550,17 @@ def main():
             res["cpu_baseline"] = bt.cpu_baseline_train(steps=2)
         if world == 1 and not args.train_only:
             # the other two workloads north_star names, in the SAME line (labelled keys; each with its own roofline and
-            # cpu_baseline): the 1000-cube geometry (BASELINE configs[2]; full outputs and the argmax-only AP path) and
-            # detector inference at 8 x 512 x 512 (configs[1]).  `value` above stays the train step.
+            # cpu_baseline): the 1000-cube geometry (BASELINE configs[2]; full outputs, the argmax-only AP path, the whole
+            # BoxNet proposal-and-scoring pipeline around it) and detector inference at 8 x 512 x 512 (configs[1]).
+            # `value` above stays the train step.
             sub = argparse.Namespace(**vars(args))
             keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "cpu_baseline")
             for key, fn, st, wu, kw in (("geometry", bench_geometry, 200, 20, {}),
                                         ("geometry_argmax_only", bench_geometry, 200, 20, {"argmax_only": True, "cpu_baseline": False}),
                                         ("geometry_exact_planes", bench_geometry, 200, 20, {"exact": True, "cpu_baseline": False}),
+                                        ("boxnet", bench_boxnet, 20, 5, {}),
                                         ("inference", bench_inference, 20, 5, {})):
-                sub.steps, sub.warmup, sub.cpu_steps = st, wu, 1
+                sub.steps, sub.warmup, sub.cpu_steps, sub.cpu_seconds = st, wu, 1, 4.0
                 try:
                     r = fn(sub, rank, world, dev, **kw)
                     res[key] = {k: r[k] for k in keep if k in r}
