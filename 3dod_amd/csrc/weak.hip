@@ -828,7 +828,7 @@ __device__ __forceinline__ void run_union(int* P, int a, int b) {
     }
 }
 
-// dynamic LDS, H rows: short rs[H][4], re[H][4]; int parent[4H], size[4H]; int rc[H]; then the 8H ints of k_mask_rect
+// dynamic LDS, H rows: short rs[H][4], re[H][4]; int parent[4H], size[4H]; int rc[H] (the 8H ints of the hull stage alias them)
 __global__ __launch_bounds__(RECT_T) void k_mask_rect_runs(MaskSrc src, int H, int W, int* __restrict__ bbox,
                                                            float* __restrict__ rects, unsigned char* __restrict__ valid) {
     extern __shared__ int s_dyn[];
@@ -837,11 +837,14 @@ __global__ __launch_bounds__(RECT_T) void k_mask_rect_runs(MaskSrc src, int H, i
     int* parent = s_dyn + RUN_MAXR * H;                 // (2 x 4H shorts = 4H ints)
     int* size = parent + RUN_MAXR * H;
     int* rc = size + RUN_MAXR * H;
-    int* sx0 = rc + H;
-    int* sx1 = sx0 + H;
-    int* stk = sx1 + H;
-    int* hx = stk + 2 * H;
-    int* hy = hx + 2 * H;
+    // the arrays of the hull stage live where records that are dead by then were: the row extremes on `size` (written after
+    // the best component is known), the chain stacks and hull vertices on the runs and parents (read last by step 5, a
+    // barrier before rect_from_row_extremes) -- 13 ints of LDS per row instead of 21: six workgroups per CU at H = 512
+    int* sx0 = size;
+    int* sx1 = size + H;
+    int* stk = s_dyn;
+    int* hx = s_dyn + 2 * H;
+    int* hy = parent;
     __shared__ int s_rows[2], s_cnt[3], s_over;
     __shared__ unsigned long long s_best;
     __shared__ double s_area[RECT_T / 64], s_ang[RECT_T / 64];
@@ -950,8 +953,8 @@ extern "C" int cr_mask_rects(cr_ctx* ctx, const unsigned char* masks, const unsi
     const MaskSrc src{masks, mask_ptrs};
     const dim3 grid(CCL_ROWS, (unsigned)n), block(256);
     hipLaunchKernelGGL(k_mask_bbox, dim3((unsigned)cr_cdiv(H, 32), (unsigned)n), block, 0, ctx->stream, src, H, W, bbox);
-    // the run-based kernel first (LDS only; 21 ints of LDS per row); what it leaves goes through the pixel-label passes
-    const size_t run_lds = sizeof(int) * (size_t)H * (3 * RUN_MAXR + 1 + 8);
+    // the run-based kernel first (LDS only; 13 ints of LDS per row); what it leaves goes through the pixel-label passes
+    const size_t run_lds = sizeof(int) * (size_t)H * (3 * RUN_MAXR + 1);
     static const bool runs_on = []() { const char* e = getenv("CR_MASK_RUNS"); return !(e && e[0] == '0'); }();
     if (runs_on && run_lds <= 64 * 1024 && W < 32768)
         hipLaunchKernelGGL(k_mask_rect_runs, dim3((unsigned)n), dim3(RECT_T), run_lds, ctx->stream, src, H, W, bbox, rects, valid);
