@@ -263,9 +263,9 @@ class RCNN3D(nn.Module):
             if bool(nonempty.all()):                                                              # the one host sync
                 out = []
                 for r, (h, w), bb in zip(instances, sizes, b.split(counts)):
-                    o = Instances((h, w), **r.get_fields())
-                    o.pred_boxes = Boxes(bb)
-                    out.append({"instances": o})
+                    f = dict(r.get_fields())
+                    f["pred_boxes"] = Boxes(bb)                    # the same rows, rescaled: lengths unchanged
+                    out.append({"instances": Instances._from_fields((h, w), f)})
                 return out
         return [{"instances": detector_postprocess(r, h, w)} for r, (h, w) in zip(instances, sizes)]
 

@@ -221,9 +221,9 @@ class ROIHeads_Boxer(StandardROIHeads):
             for i, (b, cls) in enumerate(zip(boxes, classes)):
                 n = counts[i]
                 sl = slice(off, off + n)
-                out_instances[i] = Instances(image_sizes[i], pred_boxes=b, scores=res["best"][sl], pred_classes=cls,
-                                             pred_bbox3D=verts[sl], pred_center_cam=ctr_cam[sl], pred_dimensions=dims[sl],
-                                             pred_pose=pose[sl], pred_center_2D=centers[sl])
+                out_instances[i] = Instances._from_fields(image_sizes[i], dict(
+                    pred_boxes=b, scores=res["best"][sl], pred_classes=cls, pred_bbox3D=verts[sl], pred_center_cam=ctr_cam[sl],
+                    pred_dimensions=dims[sl], pred_pose=pose[sl], pred_center_2D=centers[sl]))      # one slice: equal lengths
                 off += n
             if int(exhausted.item()) == 0:
                 return out_instances

@@ -116,6 +116,16 @@ class Instances:
         for k, v in kwargs.items():
             self.set(k, v)
 
+    @classmethod
+    def _from_fields(cls, image_size, fields):
+        """an Instances around `fields` WITHOUT the per-field length checks of set(): for results whose fields were cut with
+        one index / slice or moved as a whole (to, __getitem__, the packing loops of the heads), where the lengths agree by
+        construction -- set() costs two Python-level length queries per field and these run ~10 fields x 64 images per batch"""
+        ret = cls.__new__(cls)
+        object.__setattr__(ret, "_image_size", image_size)
+        object.__setattr__(ret, "_fields", fields)
+        return ret
+
     @property
     def image_size(self):
         return self._image_size
@@ -152,22 +162,15 @@ class Instances:
         return self._fields
 
     def to(self, *args, **kwargs):
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            if hasattr(v, "to"):
-                v = v.to(*args, **kwargs)
-            ret.set(k, v)
-        return ret
+        return Instances._from_fields(self._image_size, {k: (v.to(*args, **kwargs) if hasattr(v, "to") else v)
+                                                         for k, v in self._fields.items()})
 
     def __getitem__(self, item):
         if type(item) == int:
             if item >= len(self) or item < -len(self):
                 raise IndexError("Instances index out of range!")
             item = slice(item, None, len(self))
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            ret.set(k, v[item])
-        return ret
+        return Instances._from_fields(self._image_size, {k: v[item] for k, v in self._fields.items()})
 
     def __len__(self):
         for v in self._fields.values():
