@@ -503,7 +503,10 @@ def bench_depth(args, rank, world, dev):
     assert bool(torch.isfinite(d).all())
     gflop = depth_model_gflop(B, 24, 1024, [256, 512, 1024, 1024], 256, S // 14, S // 14)
     ach = gflop * B / (dt / args.steps) / 1e3
-    return {"metric": "images/sec Depth-Anything-V2 ViT-L forward (depth backbone of BASELINE configs[4])",
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        extra["cpu_baseline"] = cpu_baseline_depth(model, S)
+    return {**extra, "metric": "images/sec Depth-Anything-V2 ViT-L forward (depth backbone of BASELINE configs[4])",
             "value": B * world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -512,6 +515,25 @@ def bench_depth(args, rank, world, dev):
                        "global_batch": B * world, "parallelism": f"dp{world}", "gflop_per_image": gflop},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
                          "traffic": None, "scope": "whole forward (algorithmic flops / wall time)"}}
+
+
+def cpu_baseline_depth(model, S, seconds=15.0):
+    """oracle/depth_ref.py (plain torch float32 restatement of the reference's forward, pinned against the reference's own
+    output by tests/test_depth_oracle.py) with the SAME weights on the host cores: whole 518 x 518 images for ~15 s"""
+    from oracle import depth_ref
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    x = torch.randn(1, 3, S, S, generator=torch.Generator().manual_seed(99))
+    with torch.no_grad():
+        depth_ref.forward(sd, x, "vitl", model.max_depth)                  # warm-up (thread pool, allocator)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            depth_ref.forward(sd, x, "vitl", model.max_depth)
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x 1 image 518 x 518 through oracle/depth_ref.py (torch float32, {cores} threads), {dt:.1f} s"}
 
 
 def main():
