@@ -129,17 +129,22 @@ def bench_geometry(args, rank, world, dev, argmax_only=False, inp=None, cpu_base
     # checks and ctypes marshalling) is about what the fast kernel takes, so a host loop would time whichever of the two is slower
     graph = None
     if os.environ.get("CR_GRAPHS", "dense") != "none":
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                for _ in range(args.steps):
-                    step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph.replay()                                  # one untimed replay
-        torch.cuda.synchronize()
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(args.steps):
+                        step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph.replay()                                  # one untimed replay
+            torch.cuda.synchronize()
+        except Exception as e:                              # (a capture problem must not cost the measurement)
+            print(f"[bench] geometry: graph capture failed ({type(e).__name__}: {e}); timing host launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
     barrier(world)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
