@@ -217,14 +217,12 @@ class ROIHeads_Boxer(StandardROIHeads):
             best = cubes_t[torch.arange(cubes_t.shape[0], device=dev), idx]    # (Ntot,15)
             verts = geo.cuboid_corners(best[:, :6].contiguous(), best[:, 6:].reshape(-1, 3, 3).contiguous())
             ctr_cam, dims, pose = best[:, :3], best[:, 3:6], best[:, 6:].reshape(-1, 3, 3)
-            off = 0
+            # one split per field (six calls) instead of six slices per image; the pieces of one image have equal lengths
+            parts = [t.split(counts) for t in (res["best"], verts, ctr_cam, dims, pose, centers)]
             for i, (b, cls) in enumerate(zip(boxes, classes)):
-                n = counts[i]
-                sl = slice(off, off + n)
                 out_instances[i] = Instances._from_fields(image_sizes[i], dict(
-                    pred_boxes=b, scores=res["best"][sl], pred_classes=cls, pred_bbox3D=verts[sl], pred_center_cam=ctr_cam[sl],
-                    pred_dimensions=dims[sl], pred_pose=pose[sl], pred_center_2D=centers[sl]))      # one slice: equal lengths
-                off += n
+                    pred_boxes=b, scores=parts[0][i], pred_classes=cls, pred_bbox3D=parts[1][i], pred_center_cam=parts[2][i],
+                    pred_dimensions=parts[3][i], pred_pose=parts[4][i], pred_center_2D=parts[5][i]))
             if int(exhausted.item()) == 0:
                 return out_instances
             PN.note_exhausted()
