@@ -32,3 +32,13 @@ print("objects with a non-finite exact score:", int(pois.sum()), " best < 1e-6:"
       " boxes thinner than 1 px with overlap:", int((((ex["boxes"][..., 2] - ex["boxes"][..., 0]).clamp_max(1e9) < 1) & (ex["iou"] > 0)).any(1).sum()),
       " or flatter:", int((((ex["boxes"][..., 3] - ex["boxes"][..., 1]) < 1) & (ex["iou"] > 0)).any(1).sum()))
 print("argmax equal:", bool(torch.equal(ex["argmax"], fa["argmax"])))
+def t(fn, n=100):
+    for _ in range(10): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+o = orig(cubes, K, im, ref, mu, sg, rect, want=(), fast=True)
+print(f"argmax-only launch on these inputs: fast {t(lambda: orig(cubes, K, im, ref, mu, sg, rect, want=(), fast=True, out=o)):.1f} us, "
+      f"exact {t(lambda: orig(cubes, K, im, ref, mu, sg, rect, want=(), fast=False, out=o)):.1f} us")
