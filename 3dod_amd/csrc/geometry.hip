@@ -1266,10 +1266,14 @@ extern "C" int cr_propose_batched(cr_ctx* ctx, const float* boxes, const int32_t
 // their inliers over all points (points stay L2-resident: Q*12 B ~ 126 KB at 512^2).
 // ---------------------------------------------------------------------------
 #define RANSAC_TPB 8      // candidate planes per workgroup: every point read scores 8 hypotheses
+// compacted (optional): the eligible points of every image packed to the front of its (Q, 3) slab by k_ransac_compact, and
+// how many there are -- the count loop then runs over them alone (a ground mask covers ~40 % of the strided pixels)
 __global__ __launch_bounds__(GEO_T) void k_ransac_count(const float* __restrict__ pts, int Q,
                                                          const int32_t* __restrict__ triples, int T, float thresh,
                                                          float* __restrict__ eqs, int32_t* __restrict__ counts,
-                                                         const unsigned char* __restrict__ eligible) {
+                                                         const unsigned char* __restrict__ eligible,
+                                                         const float* __restrict__ compacted = nullptr,
+                                                         const int32_t* __restrict__ n_compacted = nullptr) {
     __shared__ int s_cnt[GEO_W][RANSAC_TPB];
     __shared__ float s_pl[RANSAC_TPB][5];   // cx, cy, cz, k, den
     const int t0 = blockIdx.x * RANSAC_TPB, tid = threadIdx.x;
@@ -1300,8 +1304,11 @@ __global__ __launch_bounds__(GEO_T) void k_ransac_count(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 5; ++j) pl[h][j] = s_pl[h < nh ? h : 0][j];
     }
-    for (int q = tid; q < Q; q += GEO_T) {
-        const float px = pts[q * 3], py = pts[q * 3 + 1], pz = pts[q * 3 + 2];
+    const float* lp = pts;
+    int Ql = Q;
+    if (compacted) { lp = compacted + (size_t)blockIdx.y * Q * 3; Ql = n_compacted[blockIdx.y]; eligible = nullptr; }
+    for (int q = tid; q < Ql; q += GEO_T) {
+        const float px = lp[q * 3], py = lp[q * 3 + 1], pz = lp[q * 3 + 2];
         const bool ok = !eligible || eligible[q];
 #pragma unroll
         for (int h = 0; h < RANSAC_TPB; ++h) {
@@ -1329,6 +1336,33 @@ __global__ __launch_bounds__(GEO_T) void k_ransac_count(const float* __restrict_
         counts[t] = c;
         eqs[t * 4] = s_pl[tid][0]; eqs[t * 4 + 1] = s_pl[tid][1]; eqs[t * 4 + 2] = s_pl[tid][2]; eqs[t * 4 + 3] = s_pl[tid][3];
     }
+}
+
+// ordered compaction of the eligible points of image blockIdx.x (ballots + running offset; order is irrelevant to the counts
+// but kept anyway): out (B, Q, 3), n_out (B)
+__global__ __launch_bounds__(GEO_T) void k_ransac_compact(const float* __restrict__ pts, const unsigned char* __restrict__ eligible,
+                                                           int Q, float* __restrict__ out, int32_t* __restrict__ n_out) {
+    __shared__ int s_w[GEO_W];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    pts += (size_t)b * Q * 3; eligible += (size_t)b * Q; out += (size_t)b * Q * 3;
+    int base = 0;
+    for (int q0 = 0; q0 < Q; q0 += GEO_T) {
+        const int q = q0 + tid;
+        const bool ok = q < Q && eligible[q];
+        const unsigned long long bal = __ballot(ok);
+        __syncthreads();
+        if (lane == 0) s_w[w] = __popcll(bal);
+        __syncthreads();
+        int off = base, tot = 0;
+#pragma unroll
+        for (int i = 0; i < GEO_W; ++i) { off += i < w ? s_w[i] : 0; tot += s_w[i]; }
+        if (ok) {
+            const int j = off + __popcll(bal & ((1ull << lane) - 1ull));
+            out[j * 3] = pts[q * 3]; out[j * 3 + 1] = pts[q * 3 + 1]; out[j * 3 + 2] = pts[q * 3 + 2];
+        }
+        base += tot;
+    }
+    if (tid == 0) n_out[b] = base;
 }
 
 __global__ __launch_bounds__(GEO_T) void k_ransac_pick(const float* __restrict__ eqs,
@@ -1387,6 +1421,15 @@ extern "C" int cr_ransac_plane_batched(cr_ctx* ctx, const float* pts, const unsi
     CR_CHECK_ARG(Q <= 0x7fffffff / 3 && (int64_t)B * T <= (int64_t)(ctx->ws_bytes / 16), "cr_ransac_plane_batched: too large");
     CR_CHECK_ARG(pts && triples && out_neg_eq && out_counts && out_best, "cr_ransac_plane_batched: NULL pointer");
     float* eqs = (float*)ctx->ws;
+    // workspace: plane equations (B, T, 4) | compacted points (B, Q, 3) | their counts (B)
+    const size_t off_c = ((size_t)B * T * 16 + 255) & ~(size_t)255, need = off_c + (size_t)B * Q * 12 + (size_t)B * 4;
+    if (eligible && need <= ctx->ws_bytes) {
+        float* cp = (float*)((char*)ctx->ws + off_c);
+        int32_t* cn = (int32_t*)(cp + (size_t)B * Q * 3);
+        hipLaunchKernelGGL(k_ransac_compact, dim3((unsigned)B), dim3(GEO_T), 0, ctx->stream, pts, eligible, (int)Q, cp, cn);
+        hipLaunchKernelGGL(k_ransac_count, dim3((unsigned)cr_cdiv(T, RANSAC_TPB), (unsigned)B), dim3(GEO_T), 0, ctx->stream, pts,
+                           (int)Q, triples, (int)T, thresh, eqs, out_counts, eligible, (const float*)cp, (const int32_t*)cn);
+    } else
     hipLaunchKernelGGL(k_ransac_count, dim3((unsigned)cr_cdiv(T, RANSAC_TPB), (unsigned)B), dim3(GEO_T), 0, ctx->stream, pts,
                        (int)Q, triples, (int)T, thresh, eqs, out_counts, eligible);
     CR_LAUNCH_CHECK();
