@@ -1685,6 +1685,36 @@ extern "C" int cr_conv2d_fwd_group(cr_ctx* ctx, int n, const void* const* xs, co
     return CR_OK;
 }
 
+// `batches` float32 GEMMs of one shape in ONE launch: y[b] (R,O) = x[b] (R,K) @ w[b] (O,K)^T, operands of batch b at
+// base + b * stride elements (the 16 products of a Winograd F(2x2,3x3) convolution: csrc/winograd.hip).  blockIdx.y = batch.
+__global__ __launch_bounds__(CONV_T) void k_gemm_batched_f32(ConvP p, long long sx, long long sw, long long sy, int count) {
+    const long long b = blockIdx.y;
+    p.x = (const float*)p.x + b * sx;
+    p.w = (const float*)p.w + b * sw;
+    p.y = (float*)p.y + b * sy;
+    conv_igemm_dma_body<128, 1, 0, float, 1, 128>(p, (int)blockIdx.x, count);
+}
+
+extern "C" int cr_gemm_batched_f32(cr_ctx* ctx, const float* x, const float* w, float* y, int R, int K, int O, int batches,
+                                   int64_t stride_x, int64_t stride_w, int64_t stride_y) {
+    CR_CHECK_ARG(ctx && x && w && y && R > 0 && batches >= 1 && batches <= 65535, "cr_gemm_batched_f32: bad args");
+    CR_CHECK_ARG(O % 128 == 0 && K % 32 == 0, "cr_gemm_batched_f32: O %% 128 == 0, K %% 32 == 0");
+    int rc = conv_common_checks("cr_gemm_batched_f32", 1, 1, R, K, O, 1, 1, 0, 1);
+    if (rc) return rc;
+    ConvP p;
+    p.x = x; p.w = w; p.y = y; p.res = nullptr; p.bias = nullptr; p.stats = nullptr;
+    p.N = 1; p.Hin = 1; p.Win = R; p.Cin = K; p.Cout = O; p.Hout = 1; p.Wout = R;
+    p.stride = 1; p.pad = 0; p.Kdim = K; p.M = R; p.cshift = 0; p.relu = 0; p.xcd = xcd_enabled(); p.f32 = 1;
+    p.part = nullptr; p.ksplit = 1; p.kstages = p.Kdim; p.cls = 0; p.Hfull = 1; p.Wfull = R; p.wstride = K;
+    p.x_bytes = (unsigned)((size_t)R * K * 4); p.w_bytes = (unsigned)((size_t)O * K * 4);
+    p.w3 = nullptr; p.w3_bytes = 0;
+    const int count = (int)(cr_cdiv(R, 128) * (O / 128));
+    hipLaunchKernelGGL(k_gemm_batched_f32, dim3((unsigned)count, (unsigned)batches), dim3(CONV_T), 0, ctx->stream, p,
+                       (long long)stride_x, (long long)stride_w, (long long)stride_y, count);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
 // dX_i = conv^T(dY_i) (+ accumulate_i).  wts: the [Cin][k*k*Cout] layouts (cr_weight_transpose); Cin % 128 == 0 here.
 extern "C" int cr_conv2d_bwd_data_group(cr_ctx* ctx, int n, const void* const* dys, const void* const* wts, void* const* dxs,
                                         const int* Ns, const int* Hs, const int* Ws, int Cin, int Cout, int ks, int pad,

@@ -300,6 +300,23 @@ int cr_fold_bn(cr_ctx* ctx, const float* w, const float* gamma, const float* bet
  * the same kernel from the dy tiles it stages anyway (dbias must be zeroed or hold the running gradient). */
 int cr_conv2d_bwd_weight_bias(cr_ctx* ctx, const void* dy, const void* x, float* dw, float* dbias, int N, int H, int W,
                               int Cin, int Cout, int ks, int stride, int pad, int accumulate, int act_f32);
+/* Winograd F(2x2, 3x3) transforms for stride-1, pad-1 3x3 convolutions on float32 NHWC maps (csrc/winograd.hip): the 16
+ * products over channels in between are 1x1 grouped convolutions (cr_conv2d_fwd_group) on V / U / M -- the arithmetic replaces
+ * torch.nn.functional.conv2d as called by detectron2's RPN head / FPN output convolutions in the reference's model.
+ *   cr_wino_filter  w (O,3,3,C) KRSC -> U (16,O,C) = G g G^T; backward != 0: U (16,C,O) of the 180-degree-rotated taps
+ *                   (backward-data = the same convolution with those filters on dY)
+ *   cr_wino_input   xs: n host-array pointers to (N_i,H_i,W_i,C) maps (H_i, W_i even) -> V (16,T,C), T = sum N_i H_i W_i / 4
+ *   cr_wino_output  M (16,T,O) -> ys[i] (N_i,H_i,W_i,O) = A^T M A + bias (O, or NULL), ReLU if relu, + accs[i] if given */
+int cr_wino_filter(cr_ctx* ctx, const float* w_krsc, float* U, int O, int C, int backward);
+/* the products in between as ONE launch: y[b] (R,O) = x[b] (R,K) @ w[b] (O,K)^T for b < batches, float32, operands of batch b
+ * at base + b * stride_* elements (O % 128 == 0, K % 32 == 0) */
+int cr_gemm_batched_f32(cr_ctx* ctx, const float* x, const float* w, float* y, int R, int K, int O, int batches,
+                        int64_t stride_x, int64_t stride_w, int64_t stride_y);
+int cr_wino_input(cr_ctx* ctx, int n, const float* const* xs, const int* Ns, const int* Hs, const int* Ws, int C,
+                  float* V, int64_t T);
+int cr_wino_output(cr_ctx* ctx, int n, const float* M, float* const* ys, const int* Ns, const int* Hs, const int* Ws,
+                   int O, int64_t T, const float* bias, int relu, const float* const* accs);
+
 /* Grouped launches: n <= 8 independent stride-1 convolutions of one geometry class (same k in {1,3}, pad, Cin, Cout, precision)
  * in ONE grid of 128 x 128 tiles (csrc/conv.hip: k_conv_igemm_dma_grp, k_conv_wgrad_f32_grp) -- the five pyramid levels of
  * detectron2's FPN output convolutions and of the RPN head's convolution (StandardRPNHead applies ONE conv to every level).

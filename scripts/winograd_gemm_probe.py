@@ -30,3 +30,18 @@ e1.record(); torch.cuda.synchronize()
 us1 = e0.elapsed_time(e1) / 20 * 1e3
 print(f"same flops as ONE launch ({16 * tiles} x 256 @ 256 x 256): {us1:.0f} us = {gf / us1 * 1e-3:.1f} TFLOP/s")
 print("the transforms are elementwise passes over 89 + 358 MB (input) and 358 + 89 MB (output): >= 150 us at 6 TB/s when not fused")
+# the same 16 products as TWO grouped 1x1 launches of 8 problems each (cr_conv2d_fwd_group, what a Winograd path would call)
+Vs = [v.view(1, 1, tiles, 256) for v in V]
+Us = [u.view(256, 256, 1, 1).contiguous(memory_format=torch.channels_last) for u in U]
+Ms = [torch.empty(1, 1, tiles, 256, device=dev) for _ in range(16)]
+def run2():
+    for h in (0, 8):
+        ops.conv_fwd_group_raw(Vs[h:h + 8], [u.view(256, 256) for u in U[h:h + 8]], Ms[h:h + 8], 256, 256, 1, 0, [None] * 8, False)
+for _ in range(5): run2()
+e0.record()
+for _ in range(20): run2()
+e1.record(); torch.cuda.synchronize()
+us2 = e0.elapsed_time(e1) / 20 * 1e3
+print(f"two grouped launches of 8: {us2:.0f} us = {gf / us2 * 1e-3:.1f} TFLOP/s")
+ref = V[3] @ U[3].t()
+print("max |grouped - matmul| / max:", float((Ms[3].view(tiles, 256) - ref).abs().max() / ref.abs().max()))
