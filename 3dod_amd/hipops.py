@@ -800,7 +800,7 @@ _WINO_BUF = {}
 
 
 def winograd_on():
-    return os.environ.get("CR_WINOGRAD", "0") == "1"
+    return os.environ.get("CR_WINOGRAD", "1") == "1"
 
 
 def _wino_buffers(T, C, O, dev):
@@ -816,8 +816,21 @@ def _wino_buffers(T, C, O, dev):
 
 def wino_supported(xs, weight, k, pad):
     return (winograd_on() and k == 3 and pad == 1 and xs[0].dtype == f32 and _ACT[0][1] == 1 and len(xs) <= 8
-            and weight.shape[0] % 128 == 0 and weight.shape[1] % 64 == 0
+            and weight.shape[0] % 128 == 0 and weight.shape[1] % 128 == 0       # (backward-data swaps the two)
             and all(x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 for x in xs))
+
+
+WINO_MIN_TILES = int(os.environ.get("CR_WINO_MIN_TILES", "4096"))
+
+
+def _wino_plan(xs, ws, bs, k, pad):
+    """"shared": every map through ONE Winograd pipeline (one weight and bias object for all); else per map True / False"""
+    n = len(xs)
+    if not wino_supported(xs, ws[0], k, pad):
+        return [False] * n
+    if all(w is ws[0] for w in ws) and all(b is bs[0] for b in bs):
+        return "shared"
+    return [x.shape[0] * (x.shape[1] // 2) * (x.shape[2] // 2) >= WINO_MIN_TILES for x in xs]
 
 
 def wino_conv3x3_group(srcs, w_krsc, dsts, bias, relu, accs, backward):
@@ -868,12 +881,19 @@ class _ConvBiasGroup(torch.autograd.Function):
         else:
             ys = [torch.empty(s, dtype=dt, device=x.device) for s, x in zip(shapes, xs)]
         bd = [None if b is None else b.detach() for b in bs]
-        # one weight over all maps (the RPN head) in float32: the Winograd route
-        ctx.wino = (all(w is ws[0] for w in ws) and all(b is bs[0] for b in bs) and wino_supported(xs, ws[0], k, pad))
-        if ctx.wino:
+        # float32 3x3: the Winograd route -- all maps in one pipeline when they share the weight (the RPN head), the big maps
+        # one by one otherwise (the FPN output convolutions; the small levels stay one direct grouped launch)
+        ctx.wino = plan = _wino_plan(xs, ws, bs, k, pad)
+        if plan == "shared":
             wino_conv3x3_group(xs, wbs[0], ys, bd[0], relu, None, False)
         else:
-            conv_fwd_group_raw(xs, wbs, ys, Cin, Cout, k, pad, bd, relu)
+            for i in range(n):
+                if plan[i]:
+                    wino_conv3x3_group([xs[i]], wbs[i], [ys[i]], bd[i], relu, None, False)
+            rest = [i for i in range(n) if not plan[i]]
+            if rest:
+                conv_fwd_group_raw([xs[i] for i in rest], [wbs[i] for i in rest], [ys[i] for i in rest], Cin, Cout, k, pad,
+                                   [bd[i] for i in rest], relu)
         ctx.cfg = (n, k, pad, relu)
         ctx.slots = slots
         ctx.refs = (ws, bs)
@@ -920,17 +940,24 @@ class _ConvBiasGroup(torch.autograd.Function):
             if i not in need_dx and ctx.slots[i][0] is not None and i in live:
                 raise RuntimeError("gradient slot registered for an input that needs no gradient")
         if need_dx:
-            wts = None if ctx.wino else [prepared_weights(ws[i], True, dt)[1] for i in need_dx]
+            plan = ctx.wino
             outs = [torch.empty_like(xs[i]) for i in need_dx]
             accs = []
             for i in need_dx:
                 slot, xi = ctx.slots[i]
                 a = None if slot is None else (_slot_take(slot) if xi <= 1 else _slot_fold(slot))
                 accs.append(None if a is None else a.to(dt).contiguous())
-            if ctx.wino:
+            if plan == "shared":
                 wino_conv3x3_group([gs[i] for i in need_dx], prepared_weights(ws[0], False, dt)[0], outs, None, False, accs, True)
             else:
-                conv_bwd_data_group_raw([gs[i] for i in need_dx], wts, outs, [xs[i].shape for i in need_dx], Cin, Cout, k, pad, accs)
+                for j, i in enumerate(need_dx):
+                    if plan[i]:
+                        wino_conv3x3_group([gs[i]], prepared_weights(ws[i], False, dt)[0], [outs[j]], None, False, [accs[j]], True)
+                rest = [j for j, i in enumerate(need_dx) if not plan[i]]
+                if rest:
+                    conv_bwd_data_group_raw([gs[need_dx[j]] for j in rest], [prepared_weights(ws[need_dx[j]], True, dt)[1] for j in rest],
+                                            [outs[j] for j in rest], [xs[need_dx[j]].shape for j in rest], Cin, Cout, k, pad,
+                                            [accs[j] for j in rest])
             for i, o in zip(need_dx, outs):
                 slot, xi = ctx.slots[i]
                 if slot is not None and xi > 1:
