@@ -833,6 +833,14 @@ def _wino_plan(xs, ws, bs, k, pad):
     return [x.shape[0] * (x.shape[1] // 2) * (x.shape[2] // 2) >= WINO_MIN_TILES for x in xs]
 
 
+def wino_gemm_raw(V, U, M, T, cin, cout):
+    """M[k] (T,cout) = V[k] (T,cin) @ U[k] (cout,cin)^T for the 16 transformed positions: one launch (module-level so that
+    bench.py can bracket it with events)"""
+    _p = _Args()
+    _chk(_lib.load().cr_gemm_batched_f32(_ctx(V), _p(V), _p(U), _p(M), T, cin, cout, 16, T * cin, cout * cin, T * cout),
+         "cr_gemm_batched_f32")
+
+
 def wino_conv3x3_group(srcs, w_krsc, dsts, bias, relu, accs, backward):
     """dsts[i] = conv3x3(srcs[i], w) (+ bias, ReLU, + accs[i]) for n maps sharing ONE weight: forward (w (O,3,3,C) applied to
     (N,H,W,C) maps) or, backward = True, the backward-data of that convolution (srcs = dY with O channels, dsts = dX with C)."""
@@ -849,7 +857,7 @@ def wino_conv3x3_group(srcs, w_krsc, dsts, bias, relu, accs, backward):
     _chk(lib.cr_wino_filter(ctx, _p(w_krsc), _p(U), O, C, int(backward)), "cr_wino_filter")
     Ns, Hs, Ws = _int_table([x.shape[0] for x in srcs]), _int_table([x.shape[1] for x in srcs]), _int_table([x.shape[2] for x in srcs])
     _chk(lib.cr_wino_input(ctx, len(srcs), cast(_ptr_table(srcs)), cast(Ns), cast(Hs), cast(Ws), cin, _p(V), T), "cr_wino_input")
-    _chk(lib.cr_gemm_batched_f32(ctx, _p(V), _p(U), _p(M), T, cin, cout, 16, T * cin, cout * cin, T * cout), "cr_gemm_batched_f32")
+    wino_gemm_raw(V, U, M, T, cin, cout)
     _chk(lib.cr_wino_output(ctx, len(dsts), _p(M), cast(_ptr_table(dsts)), cast(Ns), cast(Hs), cast(Ws), cout, T, _p(bias), int(relu),
                             cast(_ptr_table(accs)) if accs is not None else None), "cr_wino_output")
 

@@ -199,7 +199,7 @@ def _bench_train_mode(args, rank, world, dev, prec, is_main=True):
         # in the state the step leaves them in); the back-to-back micro-benchmark stays beside it
         if ins:
             def kname(kind):
-                key = {"fwd": "(fwd", "bwd-data": "(bwd-data", "wgrad": "wgrad"}[kind.replace("-group", "")]
+                key = {"fwd": "(fwd", "bwd-data": "(bwd-data", "wgrad": "wgrad", "wino-gemm": "k_gemm_batched"}[kind.replace("-group", "")]
                 c = [k for k in kern["all_directions"] if key in k]
                 return c[0] if c else kind
             worst = min(ins, key=lambda k: ins[k]["tflops"])
@@ -209,6 +209,7 @@ def _bench_train_mode(args, rank, world, dev, prec, is_main=True):
                         measured="HIP events around the kernel's launches inside train steps (dense region run eagerly for "
                                  "this measurement), mean over %d launches" % ins[worst]["launches"])
             kern["in_step"] = {kname(k): v for k, v in ins.items()}
+            kern["traffic"] = pmc_traffic_for(kern["kernel"], prec, IMS_PER_GPU)
     except Exception as e:           # never lose the headline to the instrumentation
         kern["in_step_error"] = f"{type(e).__name__}: {e}"
     note("roofline done")
@@ -314,7 +315,13 @@ def dominant_kernel_in_step(model, step, batches, dev, n_steps=3):
     find are those of the real step."""
     ops = importlib.import_module("3dod_amd.hipops")
     shape = (IMS_PER_GPU, 128, 128, 256)
-    recs = {"fwd": [], "bwd-data": [], "wgrad": [], "fwd-group": [], "bwd-data-group": [], "wgrad-group": []}
+    recs = {"fwd": [], "bwd-data": [], "wgrad": [], "fwd-group": [], "bwd-data-group": [], "wgrad-group": [], "wino-gemm": []}
+    T_all = IMS_PER_GPU * sum((h // 2) * (w // 2) for h, w in PYRAMID)
+    orig_w = getattr(ops, "wino_gemm_raw", None)
+
+    def wgemm(V, U, M, T, cin, cout):
+        f = lambda: orig_w(V, U, M, T, cin, cout)
+        return timed("wino-gemm", f) if (T == T_all and cin == 256 and cout == 256) else f()
     orig = (ops.conv_fwd_raw, ops.conv_bwd_data_raw, ops.conv_bwd_weight_raw)
     orig_g = (ops.conv_fwd_group_raw, ops.conv_bwd_data_group_raw, ops.conv_bwd_weight_group_raw)
 
@@ -358,6 +365,8 @@ def dominant_kernel_in_step(model, step, batches, dev, n_steps=3):
     model._graphed, model._graphed_cache, model._graphed_max = None, None, 0
     ops.conv_fwd_raw, ops.conv_bwd_data_raw, ops.conv_bwd_weight_raw = fwd, bwd, wg
     ops.conv_fwd_group_raw, ops.conv_bwd_data_group_raw, ops.conv_bwd_weight_group_raw = gfwd, gbwd, gwg
+    if orig_w is not None:
+        ops.wino_gemm_raw = wgemm
     try:
         for i in range(n_steps):
             step(batches[i % len(batches)])
@@ -365,13 +374,15 @@ def dominant_kernel_in_step(model, step, batches, dev, n_steps=3):
     finally:
         ops.conv_fwd_raw, ops.conv_bwd_data_raw, ops.conv_bwd_weight_raw = orig
         ops.conv_fwd_group_raw, ops.conv_bwd_data_group_raw, ops.conv_bwd_weight_group_raw = orig_g
+        if orig_w is not None:
+            ops.wino_gemm_raw = orig_w
         model._graphed, model._graphed_cache, model._graphed_max = saved
     flop1, flopg = 2.0 * IMS_PER_GPU * 128 * 128 * 256 * 9 * 256, pyramid_flop()
     out = {}
     for kind, ev in recs.items():
         if ev:
             ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-            fl = flopg if kind.endswith("-group") else flop1
+            fl = 2.0 * 16 * T_all * 256 * 256 if kind == "wino-gemm" else (flopg if kind.endswith("-group") else flop1)
             out[kind] = {"ms": ms, "tflops": fl / ms / 1e9, "launches": len(ev), "flop_per_launch": fl}
     return out
 
@@ -406,6 +417,23 @@ def cpu_baseline_train(inference=False, steps=None, weak=False):
         return {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
 
+def pmc_traffic_for(kernel, prec, N):
+    """memory-side traffic per launch of `kernel` from the committed PMC passes of the same kernel and shapes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction applied: profiles/r0N_pmc_*traffic*.json); None if absent"""
+    try:
+        if N != IMS_PER_GPU:
+            raise KeyError("the committed PMC passes are for 4 images")
+        here = os.path.dirname(os.path.abspath(__file__))
+        fn = {"fp32": "r03_pmc_conv_traffic_fp32.json", "fp32x3": "r02_pmc_conv_traffic_fp32x3.json"}.get(prec, "r01_pmc_conv_traffic.json")
+        if kernel.startswith("k_gemm_batched_f32"):
+            fn = "r03_pmc_wino_gemm_traffic.json"
+        pmc = json.load(open(os.path.join(here, "profiles", fn)))
+        key = kernel.split(" ")[0].replace(",", ", ").rstrip(">")
+        return [v["traffic_bytes"] for k, v in pmc["kernels"].items() if k.replace(" ", "").startswith(key.replace(" ", ""))][0]
+    except Exception:
+        return None
+
+
 def dominant_kernel_roofline(dev, prec="fp32", reps=20, images=IMS_PER_GPU):
     """the dominant launches of the step (profiles/: the implicit-GEMM convolutions) timed live with HIP events on the stream
     they are launched on: the grouped 3x3 256->256 convolution over the five pyramid levels of IMS_PER_GPU 512 x 512 images
@@ -428,7 +456,22 @@ def dominant_kernel_roofline(dev, prec="fp32", reps=20, images=IMS_PER_GPU):
     ig1 = {"fp32": "k_conv_igemm_dma<128,3,%d,float>", "fp32x3": "k_conv_igemm_dma_s3<128,3,%d>", "bf16": "k_conv_igemm_dma<128,3,%d>"}[prec]
     tname = "float" if prec == "fp32" else "u16"
     cases = []
-    if grouped:
+    wino = grouped and prec == "fp32" and ops.wino_supported(xs, w, 3, 1)
+    if wino:
+        # float32 default: forward and backward-data of these layers run the Winograd F(2x2,3x3) route -- their matrix work is
+        # the batched GEMM of the 16 transformed positions (RPN head: all five levels in one launch)
+        T = sum(x.shape[0] * (x.shape[1] // 2) * (x.shape[2] // 2) for x in xs)
+        V = torch.randn(16, T, C, generator=g).to(dev)
+        U = (torch.randn(16, C, C, generator=g) * 0.02).to(dev)
+        Mo = torch.empty(16, T, C, device=dev)
+        lib = importlib.import_module("3dod_amd._lib")
+
+        def gemm16():
+            lib.check(lib.load().cr_gemm_batched_f32(lib.ctx_for(V.device), lib.ptr(V), lib.ptr(U), lib.ptr(Mo), T, C, C, 16,
+                                                     T * C, C * C, T * C), "cr_gemm_batched_f32")
+        cases.append(("k_gemm_batched_f32 (the 16 Winograd products of the RPN head conv, fwd / bwd-data, 5 levels)",
+                      2.0 * 16 * T * C * C, gemm16))
+    elif grouped:
         ys = [torch.empty_like(x) for x in xs]
         dxs = [torch.empty_like(x) for x in xs]
         cases.append(("k_conv_igemm_dma_grp<3,0,%s> (fwd, 5 levels)" % tname, flopg,
@@ -457,20 +500,11 @@ def dominant_kernel_roofline(dev, prec="fp32", reps=20, images=IMS_PER_GPU):
     worst = min(out, key=lambda k: out[k]["tflops"])
     # memory-side traffic per launch from the committed PMC passes of the same kernel and shapes (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction applied: profiles/r0N_pmc_conv_traffic*.json)
-    traffic = None
-    try:
-        if N != IMS_PER_GPU:
-            raise KeyError("the committed PMC passes are for 4 images")
-        here = os.path.dirname(os.path.abspath(__file__))
-        fn = {"fp32": "r03_pmc_conv_traffic_fp32.json", "fp32x3": "r02_pmc_conv_traffic_fp32x3.json"}.get(prec, "r01_pmc_conv_traffic.json")
-        pmc = json.load(open(os.path.join(here, "profiles", fn)))
-        key = worst.split(" ")[0].replace(",", ", ").rstrip(">")
-        traffic = [v["traffic_bytes"] for k, v in pmc["kernels"].items() if k.replace(" ", "").startswith(key.replace(" ", ""))][0]
-    except Exception:
-        pass
+    traffic = pmc_traffic_for(worst, prec, N)
     return {"bound": "mfma", "kernel": worst,
             "shape": ((f"3x3 conv 256->256 on the five pyramid levels of {N} x 512 x 512 images ({N}x128x128 ... {N}x8x8; FPN output convs / "
                        "RPN head conv), one grouped launch, ") if "levels" in worst else f"3x3 conv 256->256 on {N}x128x128 (FPN p2 output), ")
+                     + ("Winograd F(2x2,3x3): 16 GEMMs (tiles x 256) @ (256 x 256) in one launch, " if worst.startswith("k_gemm_batched") else "")
                      + {"fp32": "f32 in / f32 acc", "fp32x3": "f32 in (3 x bf16 split, 6 MFMAs per term) / f32 acc", "bf16": "bf16 in / f32 acc"}[prec],
             "achieved": out[worst]["tflops"], "peak": peak, "unit": "TFLOP/s",
             "frac": out[worst]["tflops"] / peak, "traffic": traffic,
