@@ -3070,6 +3070,46 @@ extern "C" int cr_conv2d_bwd_weight_bias(cr_ctx* ctx, const void* dy, const void
 
 // dW_i += dY_i^T X_i (f32 mode, k in {1, 3}, stride 1, Cout % 128 == 0) for n convolutions in one launch; dws may repeat a
 // pointer (shared weights: the contributions are summed); dbiases (or entries) may be NULL.  ALWAYS accumulates.
+// `batches` float32 weight-gradient GEMMs of one shape in ONE launch: dw[b] (O,K) += dy[b] (R,O)^T x[b] (R,K) (f32 atomics over
+// the pixel splits), operands of batch b at base + b * stride elements -- the 16 products of a Winograd weight gradient
+// (csrc/winograd.hip).  One launch lets a block keep a long pixel range (12 splits instead of 170 per product: the atomics of a
+// 128 x 128 tile are paid 14 times less often).  dw must be zeroed (or hold what is to be added to).
+__global__ __launch_bounds__(CONV_T) void k_wgrad_batched_f32(WgP p, long long sdy, long long sx, long long sdw, int count) {
+    const long long b = blockIdx.y;
+    p.dy = (const float*)p.dy + b * sdy;
+    p.x = (const float*)p.x + b * sx;
+    p.dw = p.dw + b * sdw;
+    conv_wgrad_f32_body<128, 1>(p, (int)blockIdx.x, count);
+}
+
+extern "C" int cr_wgrad_batched_f32(cr_ctx* ctx, const float* dy, const float* x, float* dw, int R, int K, int O, int batches,
+                                    int64_t stride_dy, int64_t stride_x, int64_t stride_dw) {
+    CR_CHECK_ARG(ctx && dy && x && dw && R > 0 && batches >= 1 && batches <= 65535, "cr_wgrad_batched_f32: bad args");
+    CR_CHECK_ARG(O % 128 == 0 && K % 32 == 0, "cr_wgrad_batched_f32: O %% 128 == 0, K %% 32 == 0");
+    WgP p;
+    p.dbg = 0; p.cshift_w = 0; p.cshift_hw = -1; p.slab = nullptr; p.bslab = nullptr; p.slab_stride = 0;
+    p.dy = dy; p.x = x; p.dw = dw; p.dbias = nullptr;
+    p.N = 1; p.Hin = 1; p.Win = R; p.Cin = K; p.Cout = O; p.Hout = 1; p.Wout = R;
+    p.stride = 1; p.pad = 0; p.Kdim = K; p.M = R; p.cshift = 0;
+    p.x_bytes = (unsigned)((size_t)R * K * 4); p.dy_bytes = (unsigned)((size_t)R * O * 4);
+    const int nsteps = (R + 15) / 16;
+    const int tm = O / 128, tn = (int)cr_cdiv(K, 128);
+    const int tiles = tm * tn * batches;
+    int splits = 768 / tiles;
+    const int max_splits = nsteps / 8 > 1 ? nsteps / 8 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.steps_per_split = (nsteps + splits - 1) / splits;
+    p.steps_per_split = (p.steps_per_split + 1) & ~1;
+    splits = (nsteps + p.steps_per_split - 1) / p.steps_per_split;
+    p.tm = tm; p.tn = tn; p.xcd = xcd_enabled();
+    const int count = tm * tn * splits;
+    hipLaunchKernelGGL(k_wgrad_batched_f32, dim3((unsigned)count, (unsigned)batches), dim3(CONV_T), 0, ctx->stream, p,
+                       (long long)stride_dy, (long long)stride_x, (long long)stride_dw, count);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
 extern "C" int cr_conv2d_bwd_weight_group(cr_ctx* ctx, int n, const void* const* dys, const void* const* xs, float* const* dws,
                                           float* const* dbiases, const int* Ns, const int* Hs, const int* Ws, int Cin, int Cout,
                                           int ks, int pad, int act_f32) {

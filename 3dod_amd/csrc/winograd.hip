@@ -125,6 +125,71 @@ __global__ __launch_bounds__(256) void k_wino_filter(const float* __restrict__ w
     }
 }
 
+// the adjoint of the output transform for the weight gradient: dM = A dY A^T of every 2 x 2 tile of dY (16 planes (T, C)), and,
+// when db is given, db[c] += sum of dY (f32 atomics: one per workgroup and channel)
+__global__ __launch_bounds__(256) void k_wino_dy(WinoGeo g, float* __restrict__ dM, float* __restrict__ db) {
+    __shared__ float s_sum[4][64];
+    const int mi = wino_find(g, (int)blockIdx.x);
+    const WinoMap& m = g.m[mi];
+    const int C = g.C, cgs = C >> 6;
+    const int local = (int)blockIdx.x - m.blk0;
+    const int cg = local % cgs, row = local / cgs;
+    const int th = m.H >> 1, tw = m.W >> 1;
+    const int n = row / th, ty = row % th;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = cg * 64 + lane;
+    const size_t plane = (size_t)g.T * C;
+    float acc = 0.f;
+    for (int tx = wave; tx < tw; tx += 4) {
+        const size_t p = (((size_t)n * m.H + 2 * ty) * m.W + 2 * tx) * C + c;
+        const float d00 = m.src[p], d01 = m.src[p + C], d10 = m.src[p + (size_t)m.W * C], d11 = m.src[p + (size_t)m.W * C + C];
+        acc += (d00 + d01) + (d10 + d11);
+        const float t[4][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {d00 - d10, d01 - d11}, {-d10, -d11}};
+        const size_t o = ((size_t)m.tbase + ((size_t)n * th + ty) * tw + tx) * C + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dM[(i * 4 + 0) * plane + o] = t[i][0];
+            dM[(i * 4 + 1) * plane + o] = t[i][0] + t[i][1];
+            dM[(i * 4 + 2) * plane + o] = t[i][0] - t[i][1];
+            dM[(i * 4 + 3) * plane + o] = -t[i][1];
+        }
+    }
+    if (db) {
+        s_sum[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0) atomicAdd(db + c, (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]));
+    }
+}
+
+// dW[o][r][s][c] += (G^T dU G)[r][s] from dU (16, O, C): the weight gradient back from the transformed domain, added into the
+// flat-gradient view of the (O,3,3,C) weight (one thread per (o, c): no atomics)
+__global__ __launch_bounds__(256) void k_wino_filter_grad(const float* __restrict__ dU, float* __restrict__ dw, int O, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= O * C) return;
+    const int o = idx / C, c = idx - o * C;
+    const size_t plane = (size_t)O * C;
+    float u[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[i][j] = dU[(i * 4 + j) * plane + idx];
+    float t[3][4];                                       // G^T u : G^T = [[1, .5, .5, 0], [0, .5, -.5, 0], [0, .5, .5, 1]]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+        t[1][j] = 0.5f * (u[1][j] - u[2][j]);
+        t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float g0 = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+        const float g1 = 0.5f * (t[r][1] - t[r][2]);
+        const float g2 = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+        float* d = dw + ((size_t)(o * 3 + r) * 3) * C + c;
+        d[0] += g0; d[C] += g1; d[2 * C] += g2;
+    }
+}
+
 static int wino_geo(const char* who, WinoGeo& g, int n, const float* const* srcs, float* const* dsts, const float* const* accs,
                     const int* Ns, const int* Hs, const int* Ws, int C, int64_t T, unsigned* blocks) {
     CR_CHECK_ARG(n >= 1 && n <= WINO_MAX_MAPS, "%s: 1..%d maps", who, WINO_MAX_MAPS);
@@ -173,6 +238,27 @@ extern "C" int cr_wino_output(cr_ctx* ctx, int n, const float* M, float* const* 
     int rc = wino_geo("cr_wino_output", g, n, nullptr, ys, accs, Ns, Hs, Ws, O, T, &blocks);
     if (rc) return rc;
     hipLaunchKernelGGL(k_wino_output, dim3(blocks), dim3(256), 0, ctx->stream, g, M, bias, relu);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// dys: n host-array pointers to (N_i,H_i,W_i,O) maps -> dM (16,T,O) = A dY A^T; db (O) += per-channel sums of dY when given
+extern "C" int cr_wino_dy(cr_ctx* ctx, int n, const float* const* dys, const int* Ns, const int* Hs, const int* Ws, int O,
+                          float* dM, int64_t T, float* db) {
+    CR_CHECK_ARG(ctx && dys && Ns && Hs && Ws && dM, "cr_wino_dy: NULL pointer");
+    WinoGeo g;
+    unsigned blocks = 0;
+    int rc = wino_geo("cr_wino_dy", g, n, dys, nullptr, nullptr, Ns, Hs, Ws, O, T, &blocks);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_wino_dy, dim3(blocks), dim3(256), 0, ctx->stream, g, dM, db);
+    CR_LAUNCH_CHECK();
+    return CR_OK;
+}
+
+// dw (O,3,3,C) += G^T dU G, dU (16,O,C) = sum over tiles of dM^T V per transformed position
+extern "C" int cr_wino_filter_grad(cr_ctx* ctx, const float* dU, float* dw, int O, int C) {
+    CR_CHECK_ARG(ctx && dU && dw && O > 0 && C > 0, "cr_wino_filter_grad: bad args");
+    hipLaunchKernelGGL(k_wino_filter_grad, dim3((unsigned)cr_cdiv((int64_t)O * C, 256)), dim3(256), 0, ctx->stream, dU, dw, O, C);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

@@ -316,6 +316,16 @@ int cr_wino_input(cr_ctx* ctx, int n, const float* const* xs, const int* Ns, con
                   float* V, int64_t T);
 int cr_wino_output(cr_ctx* ctx, int n, const float* M, float* const* ys, const int* Ns, const int* Hs, const int* Ws,
                    int O, int64_t T, const float* bias, int relu, const float* const* accs);
+/* weight gradient the same way: dU[k] (O,C) = dM[k]^T V[k] over the tiles (cr_linear_bwd_weight per position), with
+ *   cr_wino_dy           dys: n maps (N_i,H_i,W_i,O) -> dM (16,T,O) = A dY A^T; db (O) += channel sums of dY when given
+ *   cr_wino_filter_grad  dw (O,3,3,C) += G^T dU G from dU (16,O,C) */
+int cr_wino_dy(cr_ctx* ctx, int n, const float* const* dys, const int* Ns, const int* Hs, const int* Ws, int O,
+               float* dM, int64_t T, float* db);
+int cr_wino_filter_grad(cr_ctx* ctx, const float* dU, float* dw, int O, int C);
+/* dw[b] (O,K) += dy[b] (R,O)^T x[b] (R,K) for b < batches in one launch (float32, f32 atomics over the pixel splits; dw zeroed
+ * by the caller or holding what is added to); operands of batch b at base + b * stride_* elements */
+int cr_wgrad_batched_f32(cr_ctx* ctx, const float* dy, const float* x, float* dw, int R, int K, int O, int batches,
+                         int64_t stride_dy, int64_t stride_x, int64_t stride_dw);
 
 /* Grouped launches: n <= 8 independent stride-1 convolutions of one geometry class (same k in {1,3}, pad, Cin, Cout, precision)
  * in ONE grid of 128 x 128 tiles (csrc/conv.hip: k_conv_igemm_dma_grp, k_conv_wgrad_f32_grp) -- the five pyramid levels of

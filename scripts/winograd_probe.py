@@ -43,3 +43,16 @@ refb = [torch.nn.functional.conv_transpose2d(g.permute(0, 3, 1, 2).double(), w.d
 for name, ys in (("direct", dd), ("winograd", dw_)):
     print(name, "backward-data max err / max:", max(float((y.double() - r).abs().max() / r.abs().max()) for y, r in zip(ys, refb)))
 print(f"backward-data: direct {t(directb):.0f} us, winograd {t(winob):.0f} us")
+# weight gradient
+sink_d = torch.zeros(O, C, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+sink_w = torch.zeros(O, C, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+bd_, bw_ = torch.zeros(O, device=dev), torch.zeros(O, device=dev)
+directw = lambda: ops.conv_bwd_weight_group_raw(gs, xs, [sink_d] * 5, [bd_] * 5, C, O, 3, 1)
+winow = lambda: ops.wino_wgrad_group(gs, xs, sink_w, bw_)
+directw(); winow(); torch.cuda.synchronize()
+refw = sum(torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), w.shape, g.permute(0, 3, 1, 2).double(), padding=1) for x, g in zip(xs, gs))
+refb = sum(g.double().sum((0, 1, 2)) for g in gs)
+print("weight gradient max err / max: direct", float((sink_d.double() - refw).abs().max() / refw.abs().max()),
+      "winograd", float((sink_w.double() - refw).abs().max() / refw.abs().max()),
+      "| bias: direct", float((bd_.double() - refb).abs().max() / refb.abs().max()), "winograd", float((bw_.double() - refb).abs().max() / refb.abs().max()))
+print(f"weight gradient: direct {t(directw):.0f} us, winograd {t(winow):.0f} us")

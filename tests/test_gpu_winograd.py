@@ -76,3 +76,54 @@ def test_odd_maps_stay_on_the_direct_route():
     xs, w, b = make([(15, 16), (8, 8)], 128, 128, seed=3)
     assert not ops.wino_supported(xs, w, 3, 1)
     assert ops.wino_supported(xs[1:], w, 3, 1) == (os.environ.get("CR_WINOGRAD", "1") == "1" and ops.precision() == "fp32")
+
+
+@pytest.mark.parametrize("sizes,C,O", [([(16, 24), (8, 8), (2, 6)], 128, 128), ([(64, 64)], 128, 256), ([(12, 20), (6, 10)], 256, 128)])
+def test_weight_gradient_against_float64(sizes, C, O):
+    """dW += G^T (dM^T V) G and db += sum dY (cr_wino_dy, cr_wgrad_batched_f32, cr_wino_filter_grad), accumulated INTO the sinks"""
+    xs, w, b = make(sizes, C, O, seed=len(sizes) * 10 + O)
+    gs = [torch.randn(x.shape[0], x.shape[1], x.shape[2], O, device=DEV) for x in xs]
+    w0 = (torch.randn(O, C, 3, 3, device=DEV) * 0.5).contiguous(memory_format=torch.channels_last)
+    b0 = torch.randn(O, device=DEV)
+    sink, bsink = w0.clone(memory_format=torch.preserve_format), b0.clone()
+    ops.wino_wgrad_group(gs, xs, sink, bsink)
+    refw = sum(torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).to(f64), w.shape, g.permute(0, 3, 1, 2).to(f64), padding=1)
+               for x, g in zip(xs, gs))
+    refb = sum(g.to(f64).sum((0, 1, 2)) for g in gs)
+    assert float(((sink - w0).double() - refw).abs().max() / refw.abs().max()) < 5e-6
+    assert float(((bsink - b0).double() - refb).abs().max() / refb.abs().max()) < 5e-6
+    sink2 = torch.zeros_like(sink)
+    ops.wino_wgrad_group(gs, xs, sink2, None)                       # no bias sink: weights only
+    assert rel(sink2, refw) < 5e-6
+
+
+def test_autograd_weight_gradient_into_sinks(monkeypatch):
+    """parameters with gradient sinks (what FlatSGD attaches): the op's weight / bias gradients land in the sinks, Winograd route
+    and direct route (CR_WINO_WGRAD=0) agreeing to float32 rounding; CR_DETERMINISTIC=1 keeps the direct kernels"""
+    if ops.precision() != "fp32":
+        pytest.skip("float32 route")
+    monkeypatch.setattr(ops, "WINO_MIN_TILES", 1024)
+    sizes = [(64, 64), (32, 32), (16, 16)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CR_WINO_WGRAD", mode)
+        assert ops.wino_wgrad_on() == (mode == "1")
+        for shared in (True, False):
+            xs, w, b = make(sizes, 128, 128, seed=11)
+            ws = [w.clone().requires_grad_() for _ in sizes]
+            bs = [b.clone().requires_grad_() for _ in sizes]
+            if shared:
+                ws, bs = [ws[0]] * 3, [bs[0]] * 3
+            for p in set(ws) | set(bs):
+                p._cr_grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+            ys = ops.conv_bias_act_group(xs, ws, bs, pad=1, relu=True)
+            sum((y * torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)).sum() for y in ys).backward()
+            assert all(p.grad is None for p in ws + bs)
+            res[(mode, shared)] = [p._cr_grad for p in ws + bs]
+    for shared in (True, False):
+        for a, b_ in zip(res[("0", shared)], res[("1", shared)]):
+            assert float(a.abs().max()) > 0
+            assert float((a - b_).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-6
+    monkeypatch.setenv("CR_WINO_WGRAD", "1")
+    monkeypatch.setenv("CR_DETERMINISTIC", "1")
+    assert not ops.wino_wgrad_on()
