@@ -841,9 +841,11 @@ def wino_gemm_raw(V, U, M, T, cin, cout):
          "cr_gemm_batched_f32")
 
 
-def wino_conv3x3_group(srcs, w_krsc, dsts, bias, relu, accs, backward):
+def wino_conv3x3_group(srcs, w_krsc, dsts, bias, relu, accs, backward, keep_v=False):
     """dsts[i] = conv3x3(srcs[i], w) (+ bias, ReLU, + accs[i]) for n maps sharing ONE weight: forward (w (O,3,3,C) applied to
-    (N,H,W,C) maps) or, backward = True, the backward-data of that convolution (srcs = dY with O channels, dsts = dX with C)."""
+    (N,H,W,C) maps) or, backward = True, the backward-data of that convolution (srcs = dY with O channels, dsts = dX with C).
+    keep_v: the transformed input goes to a tensor of its own, which is returned (the weight gradient multiplies the same
+    planes: wino_wgrad_group(v_saved=...)), instead of the shared planes the next Winograd convolution overwrites."""
     cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
     lib = _lib.load()
     _p = _Args()
@@ -853,6 +855,8 @@ def wino_conv3x3_group(srcs, w_krsc, dsts, bias, relu, accs, backward):
     dev = srcs[0].device
     T = sum(x.shape[0] * (x.shape[1] // 2) * (x.shape[2] // 2) for x in srcs)
     V, M, U = _wino_buffers(T, cin, cout, dev)
+    if keep_v:
+        V = torch.empty((16, T, cin), dtype=f32, device=dev)
     ctx = _ctx(srcs[0])
     _chk(lib.cr_wino_filter(ctx, _p(w_krsc), _p(U), O, C, int(backward)), "cr_wino_filter")
     Ns, Hs, Ws = _int_table([x.shape[0] for x in srcs]), _int_table([x.shape[1] for x in srcs]), _int_table([x.shape[2] for x in srcs])
@@ -860,6 +864,7 @@ def wino_conv3x3_group(srcs, w_krsc, dsts, bias, relu, accs, backward):
     wino_gemm_raw(V, U, M, T, cin, cout)
     _chk(lib.cr_wino_output(ctx, len(dsts), _p(M), cast(_ptr_table(dsts)), cast(Ns), cast(Hs), cast(Ws), cout, T, _p(bias), int(relu),
                             cast(_ptr_table(accs)) if accs is not None else None), "cr_wino_output")
+    return V if keep_v else None
 
 
 def wino_wgrad_on():
@@ -868,7 +873,7 @@ def wino_wgrad_on():
     return os.environ.get("CR_WINO_WGRAD", "1") != "0" and os.environ.get("CR_DETERMINISTIC", "0") in ("", "0")
 
 
-def wino_wgrad_group(gs, xs, w_sink, b_sink):
+def wino_wgrad_group(gs, xs, w_sink, b_sink, v_saved=None):
     """weight (and bias) gradient of ONE 3x3 weight applied to n maps, the Winograd way: dM = A dY A^T and V = B^T x B as for
     the forward pass, dU[k] = dM[k]^T V[k] per transformed position (cr_linear_bwd_weight), dW += G^T dU G into the flat
     gradient; db += channel sums of dY.  45.8 instead of 103 GFLOP for the five pyramid levels of 4 images."""
@@ -881,7 +886,11 @@ def wino_wgrad_group(gs, xs, w_sink, b_sink):
     V, M, U = _wino_buffers(T, C, O, dev)
     ctx = _ctx(xs[0])
     Ns, Hs, Ws = _int_table([x.shape[0] for x in xs]), _int_table([x.shape[1] for x in xs]), _int_table([x.shape[2] for x in xs])
-    _chk(lib.cr_wino_input(ctx, len(xs), cast(_ptr_table(xs)), cast(Ns), cast(Hs), cast(Ws), C, _p(V), T), "cr_wino_input")
+    if v_saved is not None:                 # the forward pass kept B^T x B of exactly these maps
+        assert v_saved.shape == (16, T, C)
+        V = v_saved
+    else:
+        _chk(lib.cr_wino_input(ctx, len(xs), cast(_ptr_table(xs)), cast(Ns), cast(Hs), cast(Ws), C, _p(V), T), "cr_wino_input")
     _chk(lib.cr_wino_dy(ctx, len(gs), cast(_ptr_table(gs)), cast(Ns), cast(Hs), cast(Ws), O, _p(M), T, _p(b_sink)), "cr_wino_dy")
     U.zero_()
     _chk(lib.cr_wgrad_batched_f32(ctx, _p(M), _p(V), _p(U), T, C, O, 16, T * O, T * C, O * C), "cr_wgrad_batched_f32")
@@ -918,12 +927,16 @@ class _ConvBiasGroup(torch.autograd.Function):
         # float32 3x3: the Winograd route -- all maps in one pipeline when they share the weight (the RPN head), the big maps
         # one by one otherwise (the FPN output convolutions; the small levels stay one direct grouped launch)
         ctx.wino = plan = _wino_plan(xs, ws, bs, k, pad)
+        # the transformed input is kept for the weight gradient when that will take the Winograd route too
+        keep = lambda i: (ctx.needs_input_grad[4 + n + i] and grad_sink(ws[i]) is not None and wino_wgrad_on()
+                          and os.environ.get("CR_WINO_KEEP_V", "1") != "0")
+        ctx.wino_v = {}
         if plan == "shared":
-            wino_conv3x3_group(xs, wbs[0], ys, bd[0], relu, None, False)
+            ctx.wino_v["shared"] = wino_conv3x3_group(xs, wbs[0], ys, bd[0], relu, None, False, keep(0))
         else:
             for i in range(n):
                 if plan[i]:
-                    wino_conv3x3_group([xs[i]], wbs[i], [ys[i]], bd[i], relu, None, False)
+                    ctx.wino_v[i] = wino_conv3x3_group([xs[i]], wbs[i], [ys[i]], bd[i], relu, None, False, keep(i))
             rest = [i for i in range(n) if not plan[i]]
             if rest:
                 conv_fwd_group_raw([xs[i] for i in rest], [wbs[i] for i in rest], [ys[i] for i in rest], Cin, Cout, k, pad,
@@ -1007,12 +1020,13 @@ class _ConvBiasGroup(torch.autograd.Function):
         if wl and wplan == "shared":
             # one weight over all maps: dU[k] = dM[k]^T V[k] for the 16 transformed positions in one batched launch
             want_db = bs[0] is not None and ctx.needs_input_grad[4 + 2 * n + wl[0]]
-            wino_wgrad_group([gs[i] for i in wl], [xs[i] for i in wl], grad_sink(ws[0]), grad_sink(bs[0]) if want_db else None)
+            wino_wgrad_group([gs[i] for i in wl], [xs[i] for i in wl], grad_sink(ws[0]), grad_sink(bs[0]) if want_db else None,
+                             ctx.wino_v.get("shared") if len(wl) == n else None)
             wl = []
         elif wl and wplan is not None and any(wplan[i] for i in wl):
             for i in [i for i in wl if wplan[i]]:
                 want_db = bs[i] is not None and ctx.needs_input_grad[4 + 2 * n + i]
-                wino_wgrad_group([gs[i]], [xs[i]], grad_sink(ws[i]), grad_sink(bs[i]) if want_db else None)
+                wino_wgrad_group([gs[i]], [xs[i]], grad_sink(ws[i]), grad_sink(bs[i]) if want_db else None, ctx.wino_v.get(i))
             wl = [i for i in wl if not wplan[i]]
         if wl and sinks_ok and len(wl) > 1:
             dwt = [grad_sink(ws[i]) for i in wl]

@@ -124,6 +124,15 @@ def test_autograd_weight_gradient_into_sinks(monkeypatch):
         for a, b_ in zip(res[("0", shared)], res[("1", shared)]):
             assert float(a.abs().max()) > 0
             assert float((a - b_).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-6
+    # the forward pass kept B^T x B for the weight gradient (CR_WINO_KEEP_V, default on): bit-equal to transforming again
     monkeypatch.setenv("CR_WINO_WGRAD", "1")
+    monkeypatch.setenv("CR_WINO_KEEP_V", "0")
+    xs, w, b = make(sizes, 128, 128, seed=11)
+    w.requires_grad_()
+    w._cr_grad = torch.zeros_like(w, memory_format=torch.preserve_format)
+    ys = ops.conv_bias_act_group(xs, [w] * 3, [b] * 3, pad=1, relu=True)
+    sum((y * torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)).sum() for y in ys).backward()
+    # atomics order differs run to run: float32 rounding only
+    assert float((w._cr_grad - res[("1", True)][0]).abs().max()) <= 2e-5 * float(w._cr_grad.abs().max())
     monkeypatch.setenv("CR_DETERMINISTIC", "1")
     assert not ops.wino_wgrad_on()
