@@ -70,7 +70,7 @@ SIGNATURES = {
     "cr_wino_input": [P, c_int, P, P, P, P, c_int, P, c_int64],
     "cr_wino_output": [P, c_int, P, P, P, P, P, c_int, c_int64, P, c_int, P],
     "cr_wino_dy": [P, c_int, P, P, P, P, c_int, P, c_int64, P],
-    "cr_wino_filter_grad": [P, P, P, c_int, c_int],
+    "cr_wino_filter_grad": [P, P, P, c_int, c_int, P, P],
     "cr_wgrad_batched_f32": [P, P, P, P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64],
     "cr_conv2d_bwd_data_group": [P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "cr_conv2d_bwd_weight_group": [P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int],

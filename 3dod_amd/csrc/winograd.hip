@@ -22,76 +22,100 @@ __device__ __forceinline__ int wino_find(const WinoGeo& g, int blk) {
     return i;
 }
 
-// grid: per map N * (H/2) * (C/64) blocks; block 256 = 4 waves, wave w takes tile columns w, w+4, ...; lane = channel
-__global__ __launch_bounds__(256) void k_wino_input(WinoGeo g, float* __restrict__ V) {
-    const int mi = wino_find(g, (int)blockIdx.x);
-    const WinoMap& m = g.m[mi];
-    const int C = g.C, cgs = C >> 6;
+// The three map-side transforms share one decomposition: a wave owns one 2 x 2 output tile at a time and its 64 lanes cover
+// 64 * VEC consecutive channels with VEC floats each (16-byte accesses for C % 256 == 0: whole 1 KB channel rows per wave
+// instruction); a block of 4 waves takes TPB consecutive tiles of one map and one channel group.
+typedef float vf1 __attribute__((ext_vector_type(1)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
+typedef float vf4 __attribute__((ext_vector_type(4)));
+#define WINO_TPB 8          // tiles per block of the input / output transforms
+#define WINO_TPB_DY 16      // ... of the dY transform (fewer bias atomics)
+#define WINO_DB_SLOTS 16    // partial bias-gradient rows the dY transform spreads its atomics over
+
+struct WinoTile { int n, ty, tx, c; bool ok; };
+template <int VEC>
+__device__ __forceinline__ WinoTile wino_tile(const WinoGeo& g, const WinoMap& m, int tile_in_block, int tpb) {
+    const int cgs = g.C / (64 * VEC);
     const int local = (int)blockIdx.x - m.blk0;
-    const int cg = local % cgs, row = local / cgs;
+    const int cg = local % cgs, chunk = local / cgs;
     const int th = m.H >> 1, tw = m.W >> 1;
-    const int n = row / th, ty = row % th;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = cg * 64 + lane;
+    const int t = chunk * tpb + tile_in_block;
+    WinoTile w;
+    w.ok = t < m.N * th * tw;
+    w.n = t / (th * tw);
+    const int r = t - w.n * (th * tw);
+    w.ty = r / tw; w.tx = r - w.ty * tw;
+    w.c = (cg * 64 + (threadIdx.x & 63)) * VEC;
+    return w;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_wino_input(WinoGeo g, float* __restrict__ V) {
+    constexpr int VEC = sizeof(VT) / 4;
+    const WinoMap& m = g.m[wino_find(g, (int)blockIdx.x)];
+    const int C = g.C, th = m.H >> 1, tw = m.W >> 1;
     const size_t plane = (size_t)g.T * C;
-    for (int tx = wave; tx < tw; tx += 4) {
-        float d[4][4];
+    for (int k = threadIdx.x >> 6; k < WINO_TPB; k += 4) {
+        const WinoTile w = wino_tile<VEC>(g, m, k, WINO_TPB);
+        if (!w.ok) break;
+        VT d[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int y = 2 * ty - 1 + i;
+            const int y = 2 * w.ty - 1 + i;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int x = 2 * tx - 1 + j;
+                const int x = 2 * w.tx - 1 + j;
                 d[i][j] = ((unsigned)y < (unsigned)m.H && (unsigned)x < (unsigned)m.W)
-                              ? m.src[(((size_t)n * m.H + y) * m.W + x) * C + c] : 0.f;
+                              ? *(const VT*)(m.src + (((size_t)w.n * m.H + y) * m.W + x) * C + w.c) : (VT)(0.f);
             }
         }
-        float t[4][4];
+        VT t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
         }
-        const size_t o = ((size_t)m.tbase + ((size_t)n * th + ty) * tw + tx) * C + c;
+        float* o = V + ((size_t)m.tbase + ((size_t)w.n * th + w.ty) * tw + w.tx) * C + w.c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            V[(i * 4 + 0) * plane + o] = t[i][0] - t[i][2];
-            V[(i * 4 + 1) * plane + o] = t[i][1] + t[i][2];
-            V[(i * 4 + 2) * plane + o] = t[i][2] - t[i][1];
-            V[(i * 4 + 3) * plane + o] = t[i][1] - t[i][3];
+            *(VT*)(o + (i * 4 + 0) * plane) = t[i][0] - t[i][2];
+            *(VT*)(o + (i * 4 + 1) * plane) = t[i][1] + t[i][2];
+            *(VT*)(o + (i * 4 + 2) * plane) = t[i][2] - t[i][1];
+            *(VT*)(o + (i * 4 + 3) * plane) = t[i][1] - t[i][3];
         }
     }
 }
 
+template <typename VT>
 __global__ __launch_bounds__(256) void k_wino_output(WinoGeo g, const float* __restrict__ M, const float* __restrict__ bias, int relu) {
-    const int mi = wino_find(g, (int)blockIdx.x);
-    const WinoMap& m = g.m[mi];
-    const int C = g.C, cgs = C >> 6;                    // C: OUTPUT channels of the product here
-    const int local = (int)blockIdx.x - m.blk0;
-    const int cg = local % cgs, row = local / cgs;
-    const int th = m.H >> 1, tw = m.W >> 1;
-    const int n = row / th, ty = row % th;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = cg * 64 + lane;
+    constexpr int VEC = sizeof(VT) / 4;
+    const WinoMap& m = g.m[wino_find(g, (int)blockIdx.x)];
+    const int C = g.C, th = m.H >> 1, tw = m.W >> 1;     // C: OUTPUT channels of the product here
     const size_t plane = (size_t)g.T * C;
-    const float b = bias ? bias[c] : 0.f;
-    for (int tx = wave; tx < tw; tx += 4) {
-        const size_t o = ((size_t)m.tbase + ((size_t)n * th + ty) * tw + tx) * C + c;
-        float q[4][4];
+    for (int k = threadIdx.x >> 6; k < WINO_TPB; k += 4) {
+        const WinoTile w = wino_tile<VEC>(g, m, k, WINO_TPB);
+        if (!w.ok) break;
+        VT b = (VT)(0.f);                               // (a parameter may sit at any 4-byte offset of a flat buffer)
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) b[e] = bias[w.c + e];
+        }
+        const float* o = M + ((size_t)m.tbase + ((size_t)w.n * th + w.ty) * tw + w.tx) * C + w.c;
+        VT q[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) q[i][j] = M[(i * 4 + j) * plane + o];
-        float s[2][4];
+            for (int j = 0; j < 4; ++j) q[i][j] = *(const VT*)(o + (i * 4 + j) * plane);
+        VT s[2][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s[0][j] = (q[0][j] + q[1][j]) + q[2][j]; s[1][j] = (q[1][j] - q[2][j]) - q[3][j]; }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            float y0 = (s[i][0] + s[i][1]) + s[i][2] + b, y1 = (s[i][1] - s[i][2]) - s[i][3] + b;
-            const size_t p = (((size_t)n * m.H + 2 * ty + i) * m.W + 2 * tx) * C + c;
-            if (relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
-            if (m.acc) { y0 += m.acc[p]; y1 += m.acc[p + C]; }
-            m.dst[p] = y0;
-            m.dst[p + C] = y1;
+            VT y0 = (s[i][0] + s[i][1]) + s[i][2] + b, y1 = (s[i][1] - s[i][2]) - s[i][3] + b;
+            const size_t p = (((size_t)w.n * m.H + 2 * w.ty + i) * m.W + 2 * w.tx) * C + w.c;
+            if (relu) { y0 = __builtin_elementwise_max(y0, (VT)(0.f)); y1 = __builtin_elementwise_max(y1, (VT)(0.f)); }
+            if (m.acc) { y0 += *(const VT*)(m.acc + p); y1 += *(const VT*)(m.acc + p + C); }
+            *(VT*)(m.dst + p) = y0;
+            *(VT*)(m.dst + p + C) = y1;
         }
     }
 }
@@ -126,47 +150,58 @@ __global__ __launch_bounds__(256) void k_wino_filter(const float* __restrict__ w
 }
 
 // the adjoint of the output transform for the weight gradient: dM = A dY A^T of every 2 x 2 tile of dY (16 planes (T, C)), and,
-// when db is given, db[c] += sum of dY (f32 atomics: one per workgroup and channel)
+// when db_part (WINO_DB_SLOTS, C) is given, db_part[block % slots][c] += sum of dY (f32 atomics, one per workgroup and channel,
+// spread over the slots: thousands of atomics on ONE address serialise in L2); k_wino_filter_grad folds the slots into db
+template <typename VT>
 __global__ __launch_bounds__(256) void k_wino_dy(WinoGeo g, float* __restrict__ dM, float* __restrict__ db) {
-    __shared__ float s_sum[4][64];
-    const int mi = wino_find(g, (int)blockIdx.x);
-    const WinoMap& m = g.m[mi];
-    const int C = g.C, cgs = C >> 6;
-    const int local = (int)blockIdx.x - m.blk0;
-    const int cg = local % cgs, row = local / cgs;
-    const int th = m.H >> 1, tw = m.W >> 1;
-    const int n = row / th, ty = row % th;
+    constexpr int VEC = sizeof(VT) / 4;
+    __shared__ VT s_sum[4][64];
+    const WinoMap& m = g.m[wino_find(g, (int)blockIdx.x)];
+    const int C = g.C, th = m.H >> 1, tw = m.W >> 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = cg * 64 + lane;
     const size_t plane = (size_t)g.T * C;
-    float acc = 0.f;
-    for (int tx = wave; tx < tw; tx += 4) {
-        const size_t p = (((size_t)n * m.H + 2 * ty) * m.W + 2 * tx) * C + c;
-        const float d00 = m.src[p], d01 = m.src[p + C], d10 = m.src[p + (size_t)m.W * C], d11 = m.src[p + (size_t)m.W * C + C];
+    VT acc = (VT)(0.f);
+    int c = wino_tile<VEC>(g, m, 0, WINO_TPB_DY).c;
+    for (int k = wave; k < WINO_TPB_DY; k += 4) {
+        const WinoTile w = wino_tile<VEC>(g, m, k, WINO_TPB_DY);
+        if (!w.ok) break;
+        const float* p = m.src + (((size_t)w.n * m.H + 2 * w.ty) * m.W + 2 * w.tx) * C + w.c;
+        const VT d00 = *(const VT*)p, d01 = *(const VT*)(p + C), d10 = *(const VT*)(p + (size_t)m.W * C),
+                 d11 = *(const VT*)(p + (size_t)m.W * C + C);
         acc += (d00 + d01) + (d10 + d11);
-        const float t[4][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {d00 - d10, d01 - d11}, {-d10, -d11}};
-        const size_t o = ((size_t)m.tbase + ((size_t)n * th + ty) * tw + tx) * C + c;
+        const VT t[4][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {d00 - d10, d01 - d11}, {-d10, -d11}};
+        float* o = dM + ((size_t)m.tbase + ((size_t)w.n * th + w.ty) * tw + w.tx) * C + w.c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            dM[(i * 4 + 0) * plane + o] = t[i][0];
-            dM[(i * 4 + 1) * plane + o] = t[i][0] + t[i][1];
-            dM[(i * 4 + 2) * plane + o] = t[i][0] - t[i][1];
-            dM[(i * 4 + 3) * plane + o] = -t[i][1];
+            *(VT*)(o + (i * 4 + 0) * plane) = t[i][0];
+            *(VT*)(o + (i * 4 + 1) * plane) = t[i][0] + t[i][1];
+            *(VT*)(o + (i * 4 + 2) * plane) = t[i][0] - t[i][1];
+            *(VT*)(o + (i * 4 + 3) * plane) = -t[i][1];
         }
     }
     if (db) {
         s_sum[wave][lane] = acc;
         __syncthreads();
-        if (wave == 0) atomicAdd(db + c, (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]));
+        if (wave == 0) {
+            const VT v = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) atomicAdd(db + (size_t)(blockIdx.x % WINO_DB_SLOTS) * C + c + e, v[e]);
+        }
     }
 }
 
 // dW[o][r][s][c] += (G^T dU G)[r][s] from dU (16, O, C): the weight gradient back from the transformed domain, added into the
 // flat-gradient view of the (O,3,3,C) weight (one thread per (o, c): no atomics)
-__global__ __launch_bounds__(256) void k_wino_filter_grad(const float* __restrict__ dU, float* __restrict__ dw, int O, int C) {
+__global__ __launch_bounds__(256) void k_wino_filter_grad(const float* __restrict__ dU, float* __restrict__ dw, int O, int C,
+                                                          const float* __restrict__ db_part, float* __restrict__ db) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= O * C) return;
     const int o = idx / C, c = idx - o * C;
+    if (db && c == 0) {                                  // fixed-order sum of the partial bias-gradient rows
+        float sum = 0.f;
+        for (int k = 0; k < WINO_DB_SLOTS; ++k) sum += db_part[(size_t)k * O + o];
+        db[o] += sum;
+    }
     const size_t plane = (size_t)O * C;
     float u[4][4];
 #pragma unroll
@@ -191,17 +226,19 @@ __global__ __launch_bounds__(256) void k_wino_filter_grad(const float* __restric
 }
 
 static int wino_geo(const char* who, WinoGeo& g, int n, const float* const* srcs, float* const* dsts, const float* const* accs,
-                    const int* Ns, const int* Hs, const int* Ws, int C, int64_t T, unsigned* blocks) {
+                    const int* Ns, const int* Hs, const int* Ws, int C, int64_t T, int tpb, unsigned* blocks, int* vec) {
     CR_CHECK_ARG(n >= 1 && n <= WINO_MAX_MAPS, "%s: 1..%d maps", who, WINO_MAX_MAPS);
     CR_CHECK_ARG(C > 0 && C % 64 == 0, "%s: channels %% 64", who);
     g.n = n; g.C = C; g.T = (int)T;
+    const int v = C % 256 == 0 ? 4 : C % 128 == 0 ? 2 : 1;           // floats per lane: 16-byte accesses when the channels allow
+    *vec = v;
     int tb = 0, blk = 0;
     for (int i = 0; i < n; ++i) {
         CR_CHECK_ARG(Ns[i] > 0 && Hs[i] > 0 && Ws[i] > 0 && Hs[i] % 2 == 0 && Ws[i] % 2 == 0, "%s: map %d needs even H and W", who, i);
         g.m[i].src = srcs ? srcs[i] : nullptr; g.m[i].dst = dsts ? dsts[i] : nullptr; g.m[i].acc = accs ? accs[i] : nullptr;
         g.m[i].N = Ns[i]; g.m[i].H = Hs[i]; g.m[i].W = Ws[i]; g.m[i].tbase = tb; g.m[i].blk0 = blk;
         tb += Ns[i] * (Hs[i] / 2) * (Ws[i] / 2);
-        blk += Ns[i] * (Hs[i] / 2) * (C / 64);
+        blk += (int)cr_cdiv((int64_t)Ns[i] * (Hs[i] / 2) * (Ws[i] / 2), tpb) * (C / (64 * v));
     }
     CR_CHECK_ARG(tb == T && (int64_t)T * C * 16 < (1ll << 40), "%s: T = %lld does not match the maps (%d tiles)", who, (long long)T, tb);
     for (int i = n; i < WINO_MAX_MAPS; ++i) g.m[i] = g.m[n - 1];
@@ -222,9 +259,12 @@ extern "C" int cr_wino_input(cr_ctx* ctx, int n, const float* const* xs, const i
     CR_CHECK_ARG(ctx && xs && Ns && Hs && Ws && V, "cr_wino_input: NULL pointer");
     WinoGeo g;
     unsigned blocks = 0;
-    int rc = wino_geo("cr_wino_input", g, n, xs, nullptr, nullptr, Ns, Hs, Ws, C, T, &blocks);
+    int vec = 1;
+    int rc = wino_geo("cr_wino_input", g, n, xs, nullptr, nullptr, Ns, Hs, Ws, C, T, WINO_TPB, &blocks, &vec);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_wino_input, dim3(blocks), dim3(256), 0, ctx->stream, g, V);
+    if (vec == 4) hipLaunchKernelGGL(k_wino_input<vf4>, dim3(blocks), dim3(256), 0, ctx->stream, g, V);
+    else if (vec == 2) hipLaunchKernelGGL(k_wino_input<vf2>, dim3(blocks), dim3(256), 0, ctx->stream, g, V);
+    else hipLaunchKernelGGL(k_wino_input<vf1>, dim3(blocks), dim3(256), 0, ctx->stream, g, V);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
@@ -235,30 +275,39 @@ extern "C" int cr_wino_output(cr_ctx* ctx, int n, const float* M, float* const* 
     CR_CHECK_ARG(ctx && M && ys && Ns && Hs && Ws, "cr_wino_output: NULL pointer");
     WinoGeo g;
     unsigned blocks = 0;
-    int rc = wino_geo("cr_wino_output", g, n, nullptr, ys, accs, Ns, Hs, Ws, O, T, &blocks);
+    int vec = 1;
+    int rc = wino_geo("cr_wino_output", g, n, nullptr, ys, accs, Ns, Hs, Ws, O, T, WINO_TPB, &blocks, &vec);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_wino_output, dim3(blocks), dim3(256), 0, ctx->stream, g, M, bias, relu);
+    if (vec == 4) hipLaunchKernelGGL(k_wino_output<vf4>, dim3(blocks), dim3(256), 0, ctx->stream, g, M, bias, relu);
+    else if (vec == 2) hipLaunchKernelGGL(k_wino_output<vf2>, dim3(blocks), dim3(256), 0, ctx->stream, g, M, bias, relu);
+    else hipLaunchKernelGGL(k_wino_output<vf1>, dim3(blocks), dim3(256), 0, ctx->stream, g, M, bias, relu);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
 
-// dys: n host-array pointers to (N_i,H_i,W_i,O) maps -> dM (16,T,O) = A dY A^T; db (O) += per-channel sums of dY when given
+// dys: n host-array pointers to (N_i,H_i,W_i,O) maps -> dM (16,T,O) = A dY A^T; db_part (16,O), zeroed by the caller, += partial
+// per-channel sums of dY when given (cr_wino_filter_grad adds their total to the bias gradient)
 extern "C" int cr_wino_dy(cr_ctx* ctx, int n, const float* const* dys, const int* Ns, const int* Hs, const int* Ws, int O,
                           float* dM, int64_t T, float* db) {
     CR_CHECK_ARG(ctx && dys && Ns && Hs && Ws && dM, "cr_wino_dy: NULL pointer");
     WinoGeo g;
     unsigned blocks = 0;
-    int rc = wino_geo("cr_wino_dy", g, n, dys, nullptr, nullptr, Ns, Hs, Ws, O, T, &blocks);
+    int vec = 1;
+    int rc = wino_geo("cr_wino_dy", g, n, dys, nullptr, nullptr, Ns, Hs, Ws, O, T, WINO_TPB_DY, &blocks, &vec);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_wino_dy, dim3(blocks), dim3(256), 0, ctx->stream, g, dM, db);
+    if (vec == 4) hipLaunchKernelGGL(k_wino_dy<vf4>, dim3(blocks), dim3(256), 0, ctx->stream, g, dM, db);
+    else if (vec == 2) hipLaunchKernelGGL(k_wino_dy<vf2>, dim3(blocks), dim3(256), 0, ctx->stream, g, dM, db);
+    else hipLaunchKernelGGL(k_wino_dy<vf1>, dim3(blocks), dim3(256), 0, ctx->stream, g, dM, db);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }
 
-// dw (O,3,3,C) += G^T dU G, dU (16,O,C) = sum over tiles of dM^T V per transformed position
-extern "C" int cr_wino_filter_grad(cr_ctx* ctx, const float* dU, float* dw, int O, int C) {
-    CR_CHECK_ARG(ctx && dU && dw && O > 0 && C > 0, "cr_wino_filter_grad: bad args");
-    hipLaunchKernelGGL(k_wino_filter_grad, dim3((unsigned)cr_cdiv((int64_t)O * C, 256)), dim3(256), 0, ctx->stream, dU, dw, O, C);
+// dw (O,3,3,C) += G^T dU G, dU (16,O,C) = sum over tiles of dM^T V per transformed position; db (O) += the column sums of
+// db_part (16,O) from cr_wino_dy when both are given
+extern "C" int cr_wino_filter_grad(cr_ctx* ctx, const float* dU, float* dw, int O, int C, const float* db_part, float* db) {
+    CR_CHECK_ARG(ctx && dU && dw && O > 0 && C > 0 && (!db == !db_part), "cr_wino_filter_grad: bad args");
+    hipLaunchKernelGGL(k_wino_filter_grad, dim3((unsigned)cr_cdiv((int64_t)O * C, 256)), dim3(256), 0, ctx->stream, dU, dw, O, C,
+                       db_part, db);
     CR_LAUNCH_CHECK();
     return CR_OK;
 }

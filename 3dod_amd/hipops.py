@@ -809,8 +809,10 @@ def _wino_buffers(T, C, O, dev):
     if ent is None:
         if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
             raise _lib.CrError("winograd: the V / M planes must be allocated before the graph capture (run one eager pass first)")
+        # U (16, O, C) is the head of a flat buffer whose 16 * O tail holds the partial bias gradients of the weight-gradient
+        # route (one zero-fill covers both)
         ent = _WINO_BUF[key] = (torch.empty((16, T, C), dtype=f32, device=dev), torch.empty((16, T, O), dtype=f32, device=dev),
-                                torch.empty((16, O, C), dtype=f32, device=dev))
+                                torch.empty((16 * O * C + 16 * O,), dtype=f32, device=dev))
     return ent
 
 
@@ -855,6 +857,7 @@ def wino_conv3x3_group(srcs, w_krsc, dsts, bias, relu, accs, backward, keep_v=Fa
     dev = srcs[0].device
     T = sum(x.shape[0] * (x.shape[1] // 2) * (x.shape[2] // 2) for x in srcs)
     V, M, U = _wino_buffers(T, cin, cout, dev)
+    U = U[:16 * O * C]
     if keep_v:
         V = torch.empty((16, T, cin), dtype=f32, device=dev)
     ctx = _ctx(srcs[0])
@@ -891,10 +894,11 @@ def wino_wgrad_group(gs, xs, w_sink, b_sink, v_saved=None):
         V = v_saved
     else:
         _chk(lib.cr_wino_input(ctx, len(xs), cast(_ptr_table(xs)), cast(Ns), cast(Hs), cast(Ws), C, _p(V), T), "cr_wino_input")
-    _chk(lib.cr_wino_dy(ctx, len(gs), cast(_ptr_table(gs)), cast(Ns), cast(Hs), cast(Ws), O, _p(M), T, _p(b_sink)), "cr_wino_dy")
     U.zero_()
+    part = U[16 * O * C:] if b_sink is not None else None
+    _chk(lib.cr_wino_dy(ctx, len(gs), cast(_ptr_table(gs)), cast(Ns), cast(Hs), cast(Ws), O, _p(M), T, _p(part)), "cr_wino_dy")
     _chk(lib.cr_wgrad_batched_f32(ctx, _p(M), _p(V), _p(U), T, C, O, 16, T * O, T * C, O * C), "cr_wgrad_batched_f32")
-    _chk(lib.cr_wino_filter_grad(ctx, _p(U), _p(w_sink), O, C), "cr_wino_filter_grad")
+    _chk(lib.cr_wino_filter_grad(ctx, _p(U), _p(w_sink), O, C, _p(part), _p(b_sink)), "cr_wino_filter_grad")
 
 
 class _ConvBiasGroup(torch.autograd.Function):

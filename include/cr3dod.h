@@ -316,12 +316,13 @@ int cr_wino_input(cr_ctx* ctx, int n, const float* const* xs, const int* Ns, con
                   float* V, int64_t T);
 int cr_wino_output(cr_ctx* ctx, int n, const float* M, float* const* ys, const int* Ns, const int* Hs, const int* Ws,
                    int O, int64_t T, const float* bias, int relu, const float* const* accs);
-/* weight gradient the same way: dU[k] (O,C) = dM[k]^T V[k] over the tiles (cr_linear_bwd_weight per position), with
- *   cr_wino_dy           dys: n maps (N_i,H_i,W_i,O) -> dM (16,T,O) = A dY A^T; db (O) += channel sums of dY when given
- *   cr_wino_filter_grad  dw (O,3,3,C) += G^T dU G from dU (16,O,C) */
+/* weight gradient the same way: dU[k] (O,C) = dM[k]^T V[k] over the tiles (cr_wgrad_batched_f32: the 16 positions in one launch), with
+ *   cr_wino_dy           dys: n maps (N_i,H_i,W_i,O) -> dM (16,T,O) = A dY A^T; db_part (16,O), zeroed by the caller, +=
+ *                        partial channel sums of dY when given (atomics spread over 16 rows)
+ *   cr_wino_filter_grad  dw (O,3,3,C) += G^T dU G from dU (16,O,C); db (O) += column sums of db_part when both given */
 int cr_wino_dy(cr_ctx* ctx, int n, const float* const* dys, const int* Ns, const int* Hs, const int* Ws, int O,
-               float* dM, int64_t T, float* db);
-int cr_wino_filter_grad(cr_ctx* ctx, const float* dU, float* dw, int O, int C);
+               float* dM, int64_t T, float* db_part);
+int cr_wino_filter_grad(cr_ctx* ctx, const float* dU, float* dw, int O, int C, const float* db_part, float* db);
 /* dw[b] (O,K) += dy[b] (R,O)^T x[b] (R,K) for b < batches in one launch (float32, f32 atomics over the pixel splits; dw zeroed
  * by the caller or holding what is added to); operands of batch b at base + b * stride_* elements */
 int cr_wgrad_batched_f32(cr_ctx* ctx, const float* dy, const float* x, float* dw, int R, int K, int O, int batches,
