@@ -481,7 +481,19 @@ def dominant_kernel_roofline(dev, prec="fp32", reps=20, images=IMS_PER_GPU):
     else:
         cases.append((ig1 % 0 + " (fwd)", flop1, lambda: ops.conv_fwd_raw(xs[0], wb, C, 3, 1, 1)))
         cases.append((ig1 % 1 + " (bwd-data)", flop1, lambda: ops.conv_bwd_data_raw(dys[0], wt, xs[0].shape, 3, 1, 1)))
-    if grouped and prec == "fp32":
+    if wino and ops.wino_wgrad_on():
+        # ... and so does their weight gradient: dU[k] = dM[k]^T V[k] for the 16 positions in one launch (f32 atomics over 12
+        # pixel splits into a zeroed dU; the zero-fill is part of what is timed)
+        dM = torch.randn(16, T, C, generator=g).to(dev)
+        dU = torch.empty(16, C, C, device=dev)
+
+        def wgrad16():
+            dU.zero_()
+            lib.check(lib.load().cr_wgrad_batched_f32(lib.ctx_for(V.device), lib.ptr(dM), lib.ptr(V), lib.ptr(dU), T, C, C, 16,
+                                                      T * C, T * C, C * C), "cr_wgrad_batched_f32")
+        cases.append(("k_wgrad_batched_f32 (the 16 Winograd weight-gradient products of the RPN head conv, 5 levels)",
+                      2.0 * 16 * T * C * C, wgrad16))
+    elif grouped and prec == "fp32":
         cases.append(("k_conv_wgrad_f32_grp<3> (wgrad, 5 levels)", flopg,
                       lambda: ops.conv_bwd_weight_group_raw(dys, xs, [sink] * 5, [None] * 5, C, C, 3, 1)))
     else:
