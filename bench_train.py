@@ -425,7 +425,7 @@ def pmc_traffic_for(kernel, prec, N):
             raise KeyError("the committed PMC passes are for 4 images")
         here = os.path.dirname(os.path.abspath(__file__))
         fn = {"fp32": "r03_pmc_conv_traffic_fp32.json", "fp32x3": "r02_pmc_conv_traffic_fp32x3.json"}.get(prec, "r01_pmc_conv_traffic.json")
-        if kernel.startswith("k_gemm_batched_f32"):
+        if kernel.startswith(("k_gemm_batched_f32", "k_wgrad_batched_f32")):
             fn = "r03_pmc_wino_gemm_traffic.json"
         pmc = json.load(open(os.path.join(here, "profiles", fn)))
         key = kernel.split(" ")[0].replace(",", ", ").rstrip(">")
