@@ -232,7 +232,10 @@ def _bench_train_mode(args, rank, world, dev, prec, is_main=True):
                    "comm": comm},
         "roofline": dict(kern, whole_step={"achieved": achieved_tf, "unit": "TFLOP/s",
                                            "frac": achieved_tf / peak,
-                                           "algorithmic_gflop_per_step": TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU}),
+                                           "algorithmic_gflop_per_step": TRAIN_GFLOP_PER_IMAGE * IMS_PER_GPU,
+                                           "note": "direct-form flops of the step / wall time: an effective rate -- in float32 the "
+                                                   "pyramid heads' 3x3 layers execute 2.25x fewer multiplies (Winograd); the "
+                                                   "per-kernel figures above count the flops the kernel executes"}),
     }
     if eager is not None:
         res["eager"] = eager
