@@ -1602,16 +1602,29 @@ static int group_tail_split(cr_ctx* ctx, ConvGroup& g, int* counts, int n, bool*
     int total = 0;
     for (int i = 0; i < n; ++i) total += counts[i];
     const int full = (total / slots) * slots, rem = total - full;
-    if (full == 0 || rem < slots / 16 || rem > (slots * 7) / 8) return 0;        // nothing to win / the last round is nearly full anyway
     int bulk = 0, nsplit = 0;
     size_t need = 0;
-    for (int i = 0; i < n; ++i) {                                                 // problems arrive largest first
-        if (bulk + counts[i] <= full) { bulk += counts[i]; continue; }
-        split[i] = true;
-        need += (size_t)g.p[i].M * g.p[i].Cout * sizeof(float);
-        ++nsplit;
-    }
     int S = S_env;
+    if (total * 2 <= slots) {
+        // a group that fills less than half of ONE round (the three small FPN levels: 88 tiles on 256 CUs): every problem is
+        // split along k, as many ways as still fit the resident slots
+        static const int S_small = env_int("CR_GRP_KSPLIT_SMALL", 3);
+        S = S_small < slots / total ? S_small : slots / total;
+        if (S < 2) return 0;
+        for (int i = 0; i < n; ++i) {
+            split[i] = true;
+            need += (size_t)g.p[i].M * g.p[i].Cout * sizeof(float);
+            ++nsplit;
+        }
+    } else {
+        if (full == 0 || rem < slots / 16 || rem > (slots * 7) / 8) return 0;    // nothing to win / the last round is nearly full anyway
+        for (int i = 0; i < n; ++i) {                                             // problems arrive largest first
+            if (bulk + counts[i] <= full) { bulk += counts[i]; continue; }
+            split[i] = true;
+            need += (size_t)g.p[i].M * g.p[i].Cout * sizeof(float);
+            ++nsplit;
+        }
+    }
     while (S >= 2 && need * S > ctx->ws_bytes) --S;
     if (S < 2) { for (int i = 0; i < n; ++i) split[i] = false; return 0; }
     size_t off = 0;
